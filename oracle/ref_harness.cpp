@@ -1,0 +1,153 @@
+// oracle/ref_harness.cpp -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+//
+// Thin extern "C" driver around the UNMODIFIED reference sources, compiled in place
+// from /root/reference/src by oracle/Makefile into oracle/_ref/libfslic_ref.so.
+// It exists so that (1) the C restatement in oracle/slic_oracle.c can be validated
+// against the real reference stage by stage, (2) tests/golden/ fixtures can be
+// generated, and (3) bench.py can time the real reference (SlicAvx2 + OpenMP) as
+// cpu_baseline.kind == "reference".
+//
+// Stage access: the reference keeps quad_image / assignment / S protected
+// (src/context.h:37-52).  We include every std header context.h needs FIRST and
+// then re-define `protected`/`private` for the reference headers only, so the
+// reference .cpp files themselves are compiled untouched.
+#include <vector>
+#include <chrono>
+#include <cassert>
+#include <cstring>
+#include <string>
+#include <memory>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <iostream>
+#include <iomanip>
+#include <sstream>
+#include <map>
+#include <limits>
+#include <stdexcept>
+#include <cstdlib>
+
+#define protected public
+#define private public
+#include "context.h"
+#include "lsc.h"
+#include "cca.h"
+#undef protected
+#undef private
+#include "parallel.h"
+
+namespace {
+template <typename Ctx>
+void configure(Ctx* c, float compactness, float min_size_factor, int subsample_stride,
+               int convert_to_lab, int manhattan, int num_threads) {
+    // mirrors cfast_slic.pyx:179-187
+    c->num_threads = num_threads;
+    c->compactness = compactness;
+    c->min_size_factor = min_size_factor;
+    c->subsample_stride_config = (int16_t)subsample_stride;
+    c->convert_to_lab = convert_to_lab != 0;
+    c->preemptive = false;
+    c->preemptive_thres = 0.05f;
+    c->manhattan_spatial_dist = manhattan != 0;
+    c->debug_mode = false;
+}
+thread_local std::string g_timing;
+}
+
+extern "C" {
+
+// cfast_slic.pyx:359-369
+int ref_supports_arch(const char* arch) {
+    fslic::ContextBuilder b(arch);
+    return b.is_supported_arch() ? 1 : 0;
+}
+
+// cfast_slic.pyx:124-147 (SlicModel.initialize)
+int ref_initialize_clusters(const char* arch, int H, int W, int K, const uint8_t* rgb, Cluster* clusters) {
+    fslic::ContextBuilder b(arch);
+    if (!b.is_supported_arch()) return -1;
+    fslic::Context* c = b.build(H, W, K, rgb, clusters);
+    c->initialize_clusters();
+    delete c;
+    return 0;
+}
+
+// cfast_slic.pyx:150-260 (SlicModel.iterate, integer SLIC path) with optional stage dumps:
+//   lab_out      : H*W*4 bytes (L,a,b,0) copied from quad_image            (may be NULL)
+//   prelabels_out: H*W u16, labels after full_assign, before connectivity  (may be NULL)
+//   labels_out   : H*W u16, final labels (0xFFFF possible)
+int ref_slic_iterate(const char* arch, int H, int W, int K, const uint8_t* rgb, Cluster* clusters,
+                     int max_iter, float compactness, float min_size_factor, int subsample_stride,
+                     int convert_to_lab, int manhattan, int num_threads,
+                     uint16_t* labels_out, uint8_t* lab_out, uint16_t* prelabels_out) {
+    fslic::ContextBuilder b(arch);
+    if (!b.is_supported_arch()) return -1;
+    fslic::Context* c = b.build(H, W, K, rgb, clusters);
+    configure(c, compactness, min_size_factor, subsample_stride, convert_to_lab, manhattan, num_threads);
+    c->initialize_state();
+    c->iterate(labels_out, max_iter);
+    g_timing = c->get_timing_report();
+    if (lab_out) {
+        for (int i = 0; i < H; i++)
+            for (int j = 0; j < W; j++)
+                for (int ch = 0; ch < 4; ch++)
+                    lab_out[(size_t)(i * W + j) * 4 + ch] = c->quad_image.get(i, 4 * j + ch);
+    }
+    if (prelabels_out) {
+        for (int i = 0; i < H; i++)
+            for (int j = 0; j < W; j++)
+                prelabels_out[(size_t)i * W + j] = c->assignment.get(i, j);
+    }
+    delete c;
+    return 0;
+}
+
+// LSC path: cfast_slic.pyx:207-216 -> src/lsc-builder.cpp
+int ref_lsc_iterate(const char* arch, int H, int W, int K, const uint8_t* rgb, Cluster* clusters,
+                    int max_iter, float compactness, float min_size_factor, int subsample_stride,
+                    int convert_to_lab, int manhattan, int num_threads,
+                    uint16_t* labels_out, uint16_t* prelabels_out) {
+    fslic::ContextLSCBuilder b(arch);
+    if (!b.is_supported_arch()) return -1;
+    fslic::ContextLSC* c = b.build(H, W, K, rgb, clusters);
+    configure(c, compactness, min_size_factor, subsample_stride, convert_to_lab, manhattan, num_threads);
+    c->initialize_state();
+    c->iterate(labels_out, max_iter);
+    g_timing = c->get_timing_report();
+    if (prelabels_out) {
+        for (int i = 0; i < H; i++)
+            for (int j = 0; j < W; j++)
+                prelabels_out[(size_t)i * W + j] = c->assignment.get(i, j);
+    }
+    delete c;
+    return 0;
+}
+
+const char* ref_last_timing_report() { return g_timing.c_str(); }
+
+// cfast_slic.pyx:371-396 (module-level enforce_connectivity): K = max label + 1 is computed by the caller.
+int ref_enforce_connectivity(uint16_t* labels, int H, int W, int K, int min_threshold, int num_threads) {
+    fsparallel::Scope scope(num_threads);
+    cca::ConnectivityEnforcer ce(labels, H, W, K, min_threshold);
+    ce.execute(labels);
+    return 0;
+}
+
+// src/cielab.h:286-333 tables, for digest checks
+int ref_lab_tables(int* gamma256, int* lab8193);
+
+int ref_S(int H, int W, int K) {
+    Cluster dummy[1];
+    (void)dummy;
+    return (int)(int16_t)sqrt(H * W / K);   // src/context.h:60
+}
+
+}  // extern "C"
+
+#include "cielab.h"
+extern "C" int ref_lab_tables(int* gamma256, int* lab8193) {
+    for (int i = 0; i < 256; i++) gamma256[i] = fast_cielab_cvt.srgb_gamma_tbl[i];
+    for (int i = 0; i <= 8192; i++) lab8193[i] = fast_cielab_cvt.lab_tbl[i];
+    return 0;
+}

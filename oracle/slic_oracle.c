@@ -1,0 +1,424 @@
+/* oracle/slic_oracle.c -- TEST INFRASTRUCTURE ONLY.  Never imported, linked or executed by the
+ * product (fast_slic_amd/, include/, the C-ABI library).  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it, and only as the checker.
+ *
+ * Plain-C, single-threaded restatement of the reference's fast_slic.Slic.iterate() hot path
+ * (Algy/fast-slic v0.4.0).  Every function cites the reference file:line it follows; paths are
+ * relative to /root/reference.  This is a restatement, not a copy: the reference's padded
+ * AlignedArray halo, OpenMP phase scheduling and AVX2 blends are replaced by their observable
+ * semantics (in-image pixels only; global visit order (phase, k)).
+ *
+ * PARITY PIN: the reference's own golden PNGs are stale so parity is pinned
+ * against the reference itself, compiled unmodified into oracle/_ref/libfslic_ref.so by
+ * oracle/Makefile and compared stage by stage in tests/test_oracle_vs_ref.py, plus the committed
+ * fixtures under tests/golden/ (generated from that library by tests/golden/make_golden.py).
+ *
+ * Third-party algorithm on the path: std::partial_sort (src/cca.cpp:226) from libstdc++
+ * (GCC 11.4, bits/stl_algo.h __heap_select + bits/stl_heap.h __make_heap/__pop_heap/
+ * __adjust_heap/__push_heap).  Only the *set* of the first K elements is observable (they are
+ * re-sorted by leader afterwards), so orc_heap_select() restates __heap_select exactly.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {            /* src/fast-slic-common.h:10-23 */
+    float y, x, r, g, b, a;
+    uint16_t number;
+    uint8_t is_active, is_updatable;
+    uint32_t num_members;
+} OrcCluster;
+
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* ---------------------------------------------------------------------------------------------
+ * RGB -> CIELAB fixed-point tables.  src/cielab.h:11-20 (gamma formula in the header comment),
+ * :296-305 (table construction), :327-332 (lab_nonlin).
+ * ------------------------------------------------------------------------------------------- */
+static int g_gamma[256];
+static int g_labtbl[8193];
+static int g_cb[9];
+static int g_tables_ready = 0;
+
+static void build_tables(void) {
+    static const float C[9] = {                     /* src/cielab.h:288-292 */
+        0.43395633f, 0.37621531f, 0.18984309f,
+        0.2126729f,  0.7151522f,  0.072175f,
+        0.01775782f, 0.1094756f,  0.87283638f };
+    if (g_tables_ready) return;
+    for (int i = 0; i < 256; i++) {
+        double v = i / 255.0;                        /* src/cielab.h:12-18 */
+        double X = (v <= 0.04045) ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4);
+        float Xf = (float)X;                         /* stored as float (src/cielab.h:22) */
+        g_gamma[i] = (int)(Xf * 8192);               /* src/cielab.h:298-299 */
+    }
+    for (int i = 0; i < 9; i++) g_cb[i] = (int)roundf(C[i] * 65536); /* :300-301 */
+    for (int i = 0; i <= 8192; i++) {                /* :302-304, :327-332 */
+        float v = (float)i / 8192;
+        float lo = 7.787f * v + 0.137931f;
+        float hi = powf(v, 0.333333f);
+        float f = (v > 0.008856f) ? hi : lo;
+        g_labtbl[i] = (int)roundf(f * 8192);
+    }
+    g_tables_ready = 1;
+}
+
+void orc_lab_tables(int* gamma256, int* lab8193, int* cb9) {
+    build_tables();
+    memcpy(gamma256, g_gamma, sizeof g_gamma);
+    memcpy(lab8193, g_labtbl, sizeof g_labtbl);
+    if (cb9) memcpy(cb9, g_cb, sizeof g_cb);
+}
+
+/* src/cielab.h:309-325 FastCIELabCvt::convert */
+static void lab_convert(uint8_t R, uint8_t G, uint8_t B, uint8_t* l, uint8_t* a, uint8_t* b) {
+    int sr = g_gamma[R], sg = g_gamma[G], sb = g_gamma[B];
+    int xr = (g_cb[0] * sr + g_cb[1] * sg + g_cb[2] * sb) >> 16;
+    int yr = (g_cb[3] * sr + g_cb[4] * sg + g_cb[5] * sb) >> 16;
+    int zr = (g_cb[6] * sr + g_cb[7] * sg + g_cb[8] * sb) >> 16;
+    int fx = g_labtbl[xr], fy = g_labtbl[yr], fz = g_labtbl[zr];
+    int ciel = 116 * fy - (16 << 13);
+    int ciea = 500 * (fx - fy) + (128 << 13);
+    int cieb = 200 * (fy - fz) + (128 << 13);
+    *l = (uint8_t)clampi((int)((unsigned)ciel >> 12), 0, 255);
+    *a = (uint8_t)clampi((int)((unsigned)ciea >> 12) - 128, 0, 255);
+    *b = (uint8_t)clampi((int)((unsigned)cieb >> 12) - 128, 0, 255);
+}
+
+/* src/cielab.h:337-353 rgb_to_cielab; output 4 B/px (L,a,b,0) like quad_image */
+void orc_rgb_to_lab(const uint8_t* rgb, int H, int W, uint8_t* lab4) {
+    build_tables();
+    for (int p = 0; p < H * W; p++) {
+        lab_convert(rgb[3 * p], rgb[3 * p + 1], rgb[3 * p + 2],
+                    &lab4[4 * p], &lab4[4 * p + 1], &lab4[4 * p + 2]);
+        lab4[4 * p + 3] = 0;
+    }
+}
+
+/* src/context.cpp:42-97 BaseContext::initialize_clusters */
+void orc_initialize_clusters(int H, int W, int K, const uint8_t* rgb, OrcCluster* cl) {
+    if (H <= 0 || W <= 0 || K <= 0) return;
+    int n_y = (int)sqrt((double)K);
+    int* n_xs = (int*)malloc(sizeof(int) * n_y);
+    for (int i = 0; i < n_y; i++) n_xs[i] = K / n_y;
+    int remainder = K % n_y, row = 0;
+    while (remainder-- > 0) {
+        n_xs[row]++;
+        row += 2;
+        if (row >= n_y) row = 1 % n_y;
+    }
+    int h = (H + n_y - 1) / n_y;
+    int acc_k = 0;
+    for (int i = 0; i < H; i += h) {
+        int r = i / h; if (r > n_y - 1) r = n_y - 1;
+        int w = (W + n_xs[r] - 1) / n_xs[r];
+        for (int j = 0; j < W; j += w) {
+            if (acc_k >= K) break;
+            int cy = clampi(i + h / 2, 0, H - 1), cx = clampi(j + w / 2, 0, W - 1);
+            cl[acc_k].y = (float)cy; cl[acc_k].x = (float)cx;
+            cl[acc_k].is_active = 1; cl[acc_k].is_updatable = 1;
+            acc_k++;
+        }
+    }
+    while (acc_k < K) {
+        cl[acc_k].is_active = 1; cl[acc_k].is_updatable = 1;
+        cl[acc_k].y = (float)(H / 2); cl[acc_k].x = (float)(W / 2);
+        acc_k++;
+    }
+    for (int k = 0; k < K; k++) {
+        int base = W * (int)cl[k].y + (int)cl[k].x;
+        cl[k].r = rgb[3 * base]; cl[k].g = rgb[3 * base + 1]; cl[k].b = rgb[3 * base + 2];
+        cl[k].number = (uint16_t)k;
+        cl[k].num_members = 0;
+    }
+    free(n_xs);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Connectivity / min-size pass.  src/cca.cpp:178-265 (execute), :33-101 (union), :103-173 (flatten).
+ * ------------------------------------------------------------------------------------------- */
+static int uf_find(int* parent, int i) {
+    int r = i;
+    while (parent[r] != r) r = parent[r];
+    while (parent[i] != r) { int n = parent[i]; parent[i] = r; i = n; }
+    return r;
+}
+/* src/cca.h:36-57 DisjointSet::merge always redirects the larger parent to the smaller one, so a
+ * component's root is its minimum raster index ("leader").  Any union-by-min-index gives the same
+ * partition and the same roots. */
+static void uf_union(int* parent, int a, int b) {
+    a = uf_find(parent, a); b = uf_find(parent, b);
+    if (a == b) return;
+    if (a < b) parent[b] = a; else parent[a] = b;
+}
+
+/* libstdc++ bits/stl_heap.h (GCC 11): __push_heap / __adjust_heap / __make_heap / __pop_heap and
+ * bits/stl_algo.h __heap_select, specialised for comp(l, r) = area[l] > area[r]
+ * (areacmpcls, src/cca.cpp:180-186). */
+static int cmp_area(const int* area, int l, int r) { return area[l] > area[r]; }
+static void push_heap_(int* first, int hole, int top, int value, const int* area) {
+    int parent = (hole - 1) / 2;
+    while (hole > top && cmp_area(area, first[parent], value)) {
+        first[hole] = first[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    first[hole] = value;
+}
+static void adjust_heap_(int* first, int hole, int len, int value, const int* area) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (cmp_area(area, first[child], first[child - 1])) child--;
+        first[hole] = first[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        first[hole] = first[child - 1];
+        hole = child - 1;
+    }
+    push_heap_(first, hole, top, value, area);
+}
+/* After the call the first `middle` entries of comps[] are the set std::partial_sort keeps
+ * (order not meaningful: the caller re-sorts by leader, src/cca.cpp:229). */
+void orc_heap_select(int* comps, int middle, int n, const int* area) {
+    if (middle >= 2) {                                 /* __make_heap */
+        int parent = (middle - 2) / 2;
+        for (;;) {
+            int value = comps[parent];
+            adjust_heap_(comps, parent, middle, value, area);
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    for (int i = middle; i < n; i++) {                 /* __heap_select loop */
+        if (cmp_area(area, comps[i], comps[0])) {      /* __pop_heap(first, middle, i) */
+            int value = comps[i];
+            comps[i] = comps[0];
+            adjust_heap_(comps, 0, middle, value, area);
+        }
+    }
+}
+
+static int cmp_int(const void* a, const void* b) {
+    int x = *(const int*)a, y = *(const int*)b;
+    return (x > y) - (x < y);
+}
+
+/* src/cca.cpp:178-265 ConnectivityEnforcer::execute, in place on labels[H*W]. */
+void orc_enforce_connectivity(uint16_t* labels, int H, int W, int K, int min_threshold) {
+    int N = H * W;
+    if (N <= 0) return;
+    int* parent = (int*)malloc(sizeof(int) * N);
+    int* comp_of = (int*)malloc(sizeof(int) * N);
+    for (int i = 0; i < N; i++) parent[i] = i;
+    /* src/cca.cpp:33-101: 4-connected unions of equal labels (0xFFFF is a label like any other) */
+    for (int i = 0; i < H; i++)
+        for (int j = 0; j < W; j++) {
+            int p = i * W + j;
+            if (j > 0 && labels[p - 1] == labels[p]) uf_union(parent, p - 1, p);
+            if (i > 0 && labels[p - W] == labels[p]) uf_union(parent, p - W, p);
+        }
+    /* src/cca.cpp:103-173 flatten: component_no = rank of root (leader) in raster order */
+    int ncomp = 0;
+    for (int i = 0; i < N; i++) if (parent[i] == i) ncomp++;
+    int* leader = (int*)malloc(sizeof(int) * (ncomp > 0 ? ncomp : 1));
+    int* area = (int*)calloc(ncomp > 0 ? ncomp : 1, sizeof(int));
+    int c = 0;
+    for (int i = 0; i < N; i++) if (parent[i] == i) { comp_of[i] = c; leader[c] = i; c++; }
+    for (int i = 0; i < N; i++) {
+        int r = uf_find(parent, i);
+        comp_of[i] = comp_of[r];
+        area[comp_of[i]]++;
+    }
+    /* src/cca.cpp:205-217 threshold_by_area */
+    uint16_t* substitute = (uint16_t*)malloc(sizeof(uint16_t) * (ncomp > 0 ? ncomp : 1));
+    for (int i = 0; i < ncomp; i++) substitute[i] = 0xFFFF;
+    int* comps = (int*)malloc(sizeof(int) * (ncomp > 0 ? ncomp : 1));
+    int ncomps = 0;
+    for (int i = 0; i < ncomp; i++) if (area[i] >= min_threshold) comps[ncomps++] = i;
+    /* src/cca.cpp:222-230 partial_sort top-K by area, then sort by leader (== by component no) */
+    if ((size_t)K < (size_t)ncomps) {
+        orc_heap_select(comps, K, ncomps, area);
+        ncomps = K;
+    }
+    qsort(comps, ncomps, sizeof(int), cmp_int);
+    /* src/cca.cpp:233-255 substitute */
+    uint16_t next_label = 0;
+    for (int i = 0; i < ncomps; i++) substitute[comps[i]] = next_label++;
+    if (ncomp > 0 && substitute[0] == 0xFFFF) substitute[0] = 0;
+    for (int i = 0; i < ncomp; i++) {
+        if (substitute[i] != 0xFFFF) continue;
+        int li = leader[i];
+        uint16_t s;
+        if (li % W > 0) s = substitute[comp_of[li - 1]];
+        else s = substitute[comp_of[li - W]];
+        if (s == 0xFFFF) s = 0;
+        substitute[i] = s;
+    }
+    /* src/cca.cpp:258-264 output */
+    for (int i = 0; i < N; i++) labels[i] = substitute[comp_of[i]];
+    free(parent); free(comp_of); free(leader); free(area); free(substitute); free(comps);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * The iterate() driver.  src/context.cpp:108-197.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int H, W, K, S;
+    int stride, rem;
+    const uint8_t* lab;        /* 4 B/px */
+    uint16_t* assignment;      /* H*W, persistent across iterations (src/context.cpp:138-145) */
+    uint16_t* min_dists;
+    uint16_t* patch;           /* (2S+1)^2 */
+    OrcCluster* cl;
+} Ctx;
+
+/* src/context.cpp:22-40 set_spatial_patch */
+static void set_spatial_patch(Ctx* c, float compactness, int color_shift, int manhattan) {
+    int S = c->S, P = 2 * S + 1;
+    float coef = 1.0f / ((float)S / compactness);
+    coef *= (1 << color_shift);
+    for (int i = 0; i < P; i++)
+        for (int j = 0; j < P; j++) {
+            if (manhattan)
+                c->patch[i * P + j] = (uint16_t)(coef * (abs(i - S) + abs(j - S)));
+            else
+                c->patch[i * P + j] = (uint16_t)(coef * hypotf((float)(i - S), (float)(j - S)));
+        }
+}
+
+/* src/context.cpp:258-298 assign_clusters for ONE cluster, restricted to in-image pixels
+ * (the reference writes into an S-pixel halo that is never read back). */
+static void assign_one(Ctx* c, const OrcCluster* cluster) {
+    int S = c->S, P = 2 * S + 1, W = c->W, H = c->H;
+    int16_t cy = (int16_t)cluster->y, cx = (int16_t)cluster->x;
+    int16_t cr = (int16_t)cluster->r, cg = (int16_t)cluster->g, cb = (int16_t)cluster->b;
+    uint16_t no = cluster->number;
+    for (int i_off = 0, i = cy - S; i_off < P; i_off++, i++) {
+        if (i < 0 || i >= H) continue;
+        if (i % c->stride != c->rem) continue;            /* src/context.h:89-91 */
+        for (int j_off = 0, j = cx - S; j_off < P; j_off++, j++) {
+            if (j < 0 || j >= W) continue;
+            const uint8_t* px = &c->lab[4 * (i * W + j)];
+            uint16_t color = (uint16_t)(abs(px[0] - cr) + abs(px[1] - cg) + abs(px[2] - cb));
+            uint16_t d = (uint16_t)(c->patch[i_off * P + j_off] + color);   /* u16 wrap */
+            if (c->min_dists[i * W + j] > d) {             /* strict >: first visitor wins ties */
+                c->min_dists[i * W + j] = d;
+                c->assignment[i * W + j] = no;
+            }
+        }
+    }
+}
+
+/* src/context.cpp:199-243 assign(): min_dists reset, centre clamp, T-cell binning in k order,
+ * 4 colour phases.  Cells of one phase are >= T = 2S+32 apart so their +-S windows never overlap:
+ * the per-pixel visit order is (phase, k). */
+static void assign(Ctx* c) {
+    int H = c->H, W = c->W, K = c->K, S = c->S;
+    for (int i = 0; i < H * W; i++) c->min_dists[i] = 0xFFFF;
+    for (int k = 0; k < K; k++) {
+        c->cl[k].x = clampf(c->cl[k].x, 0, (float)(W - 1));
+        c->cl[k].y = clampf(c->cl[k].y, 0, (float)(H - 1));
+    }
+    int T = 2 * S + 32;
+    int cell_W = (W + T - 1) / T, cell_H = (H + T - 1) / T;
+    for (int phase = 0; phase < 4; phase++)
+        for (int ci = phase / 2; ci < cell_H; ci += 2)
+            for (int cj = phase % 2; cj < cell_W; cj += 2)
+                for (int k = 0; k < K; k++) {
+                    if (!c->cl[k].is_active) continue;
+                    int y = (int)c->cl[k].y, x = (int)c->cl[k].x;
+                    if (y / T == ci && x / T == cj) assign_one(c, &c->cl[k]);
+                }
+}
+
+/* src/context.cpp:301-387 update() (preemptive off, centroid quantisation on) */
+static void update(Ctx* c) {
+    int H = c->H, W = c->W, K = c->K;
+    int32_t* n = (int32_t*)calloc(K, sizeof(int32_t));
+    int32_t* acc = (int32_t*)calloc((size_t)K * 5, sizeof(int32_t));
+    for (int i = c->rem; i < H; i += c->stride)           /* fit_to_stride(0) == rem */
+        for (int j = 0; j < W; j++) {
+            uint16_t k = c->assignment[i * W + j];
+            if (k == 0xFFFF) continue;
+            const uint8_t* px = &c->lab[4 * (i * W + j)];
+            n[k]++;
+            acc[5 * k + 0] = (int32_t)((uint32_t)acc[5 * k + 0] + (uint32_t)i);
+            acc[5 * k + 1] = (int32_t)((uint32_t)acc[5 * k + 1] + (uint32_t)j);
+            acc[5 * k + 2] += px[0]; acc[5 * k + 3] += px[1]; acc[5 * k + 4] += px[2];
+        }
+    for (int k = 0; k < K; k++) {
+        OrcCluster* cl = &c->cl[k];
+        if (!cl->is_updatable) continue;
+        int32_t m = n[k];
+        cl->num_members = (uint32_t)m;
+        if (m == 0) continue;
+        /* round_int, src/fast-slic-common.h:62-65 */
+        cl->y = (float)((acc[5 * k + 0] + m / 2) / m);
+        cl->x = (float)((acc[5 * k + 1] + m / 2) / m);
+        cl->r = (float)((acc[5 * k + 2] + m / 2) / m);
+        cl->g = (float)((acc[5 * k + 3] + m / 2) / m);
+        cl->b = (float)((acc[5 * k + 4] + m / 2) / m);
+    }
+    free(n); free(acc);
+}
+
+/* src/context.cpp:108-197 iterate().  lab_out / prelabels_out may be NULL. */
+int orc_slic_iterate(int H, int W, int K, const uint8_t* rgb, OrcCluster* clusters,
+                     int max_iter, float compactness, float min_size_factor, int subsample_stride,
+                     int convert_to_lab, int manhattan,
+                     uint16_t* labels_out, uint8_t* lab_out, uint16_t* prelabels_out) {
+    if (H <= 0 || W <= 0 || K <= 0) return -1;
+    build_tables();
+    Ctx c;
+    c.H = H; c.W = W; c.K = K; c.cl = clusters;
+    c.S = (int)(int16_t)sqrt(H * W / K);                 /* src/context.h:60 */
+    int S = c.S, N = H * W;
+    uint8_t* lab = (uint8_t*)calloc((size_t)N * 4, 1);
+    c.lab = lab;
+    c.assignment = (uint16_t*)malloc(sizeof(uint16_t) * N);
+    c.min_dists = (uint16_t*)malloc(sizeof(uint16_t) * N);
+    c.patch = (uint16_t*)malloc(sizeof(uint16_t) * (2 * S + 1) * (2 * S + 1));
+    int color_shift;
+    if (convert_to_lab) {                                /* src/context.cpp:114-116 */
+        orc_rgb_to_lab(rgb, H, W, lab);
+        color_shift = 1;                                 /* src/cielab.h:284,352 */
+    } else {                                             /* :117-127 */
+        for (int p = 0; p < N; p++) { lab[4*p] = rgb[3*p]; lab[4*p+1] = rgb[3*p+1]; lab[4*p+2] = rgb[3*p+2]; }
+        color_shift = 0;
+    }
+    for (int k = 0; k < K; k++) {                        /* :128-135 colour resample */
+        int y = clampi((int)clusters[k].y, 0, H - 1), x = clampi((int)clusters[k].x, 0, W - 1);
+        clusters[k].r = lab[4 * (y * W + x)];
+        clusters[k].g = lab[4 * (y * W + x) + 1];
+        clusters[k].b = lab[4 * (y * W + x) + 2];
+    }
+    for (int p = 0; p < N; p++) c.assignment[p] = 0xFFFF; /* :138-145, once per call */
+    set_spatial_patch(&c, compactness, color_shift, manhattan);
+    c.rem = 0; c.stride = subsample_stride;              /* :149-150 */
+    for (int k = 0; k < K; k++) clusters[k].is_updatable = 2;  /* src/preemptive.h:59-67 */
+    for (int it = 0; it < max_iter; it++) {              /* :158-175 */
+        assign(&c);
+        update(&c);
+        c.rem = (c.rem + 1) % c.stride;
+    }
+    for (int k = 0; k < K; k++) clusters[k].is_active = 1;     /* src/preemptive.h:69-74 */
+    c.stride = 1; c.rem = 0;                             /* full_assign :246-256 */
+    assign(&c);
+    if (lab_out) memcpy(lab_out, lab, (size_t)N * 4);
+    if (prelabels_out) memcpy(prelabels_out, c.assignment, sizeof(uint16_t) * N);
+    memcpy(labels_out, c.assignment, sizeof(uint16_t) * N);    /* write_back :182-190 */
+    {                                                    /* enforce_connectivity :14-20 */
+        int thres = (int)round((double)(S * S) * (double)min_size_factor);
+        orc_enforce_connectivity(labels_out, H, W, K, thres);
+    }
+    free(lab); free(c.assignment); free(c.min_dists); free(c.patch);
+    return 0;
+}
+
+int orc_S(int H, int W, int K) { return (int)(int16_t)sqrt(H * W / K); }
