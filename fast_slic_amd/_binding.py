@@ -1,0 +1,349 @@
+"""ctypes binding of the C ABI in include/fslic_hip.h.
+
+Plays the role cfast_slic.pyx plays in the reference: `SlicModel` owns the Cluster[K] block, forwards
+`initialize` / `iterate` to the engine and converts the uint16 label map to the int16 map the
+reference returns (cfast_slic.pyx:258-260).  Only the arch "hip/gfx950" exists here; the reference's
+CPU archs stay in the reference.  There is deliberately NO CPU fallback: if the HIP library is
+missing or no GPU is visible, constructing a SlicModel raises.
+"""
+import ctypes as C
+import os
+import subprocess
+import threading
+
+import numpy as np
+
+ARCH_NAME = "hip/gfx950"
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libfslic_hip.so")
+
+CLUSTER_DTYPE = np.dtype([
+    ("y", "<f4"), ("x", "<f4"), ("r", "<f4"), ("g", "<f4"), ("b", "<f4"), ("a", "<f4"),
+    ("number", "<u2"), ("is_active", "u1"), ("is_updatable", "u1"), ("num_members", "<u4"),
+])  # src/fast-slic-common.h:10-23
+assert CLUSTER_DTYPE.itemsize == 32
+
+FSLIC_OK, FSLIC_E_INVALID, FSLIC_E_UNSUPPORTED, FSLIC_E_HIP, FSLIC_E_INTERNAL = range(5)
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("max_iter", C.c_int32), ("compactness", C.c_float), ("min_size_factor", C.c_float),
+        ("subsample_stride", C.c_int32), ("convert_to_lab", C.c_int32),
+        ("manhattan_spatial_dist", C.c_int32), ("preemptive", C.c_int32),
+        ("preemptive_thres", C.c_float), ("num_threads", C.c_int32), ("debug_mode", C.c_int32),
+        ("force_generic", C.c_int32), ("reserved", C.c_int32 * 5),
+    ]
+
+
+EXPORTS = [
+    "fslic_hip_device_count", "fslic_hip_create", "fslic_hip_destroy", "fslic_hip_initialize_clusters",
+    "fslic_hip_iterate", "fslic_hip_iterate_device", "fslic_hip_iterate_batch", "fslic_hip_rgb_to_lab",
+    "fslic_hip_enforce_connectivity", "fslic_hip_last_prelabels", "fslic_hip_last_timing_report",
+    "fslic_hip_last_device_times", "fslic_hip_last_path", "fslic_hip_last_error", "fslic_hip_version",
+]
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def build_library(force=False):
+    """Compile fast_slic_amd/libfslic_hip.so for gfx950 with hipcc (in-tree, see csrc/Makefile)."""
+    csrc = os.path.join(_HERE, "csrc")
+    args = ["make", "-s", "-C", csrc]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return _LIB_PATH
+
+
+def load_library():
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(_LIB_PATH):
+            raise ImportError(
+                "fast_slic_amd: %s is missing; build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C fast_slic_amd/csrc` (there is no CPU fallback)" % _LIB_PATH)
+        lib = C.CDLL(_LIB_PATH)
+        vp, i32 = C.c_void_p, C.c_int
+        lib.fslic_hip_device_count.restype = i32
+        lib.fslic_hip_create.argtypes = [i32, i32, C.POINTER(vp)]
+        lib.fslic_hip_destroy.argtypes = [vp]
+        lib.fslic_hip_destroy.restype = None
+        lib.fslic_hip_initialize_clusters.argtypes = [i32, i32, i32, vp, vp]
+        lib.fslic_hip_iterate.argtypes = [vp, C.POINTER(Params), i32, i32, i32, vp, vp, vp]
+        lib.fslic_hip_iterate_device.argtypes = [vp, i32, C.POINTER(Params), i32, i32, i32, vp, vp, vp]
+        lib.fslic_hip_iterate_batch.argtypes = [vp, C.POINTER(Params), i32, i32, i32, i32, vp, vp, vp, i32]
+        lib.fslic_hip_rgb_to_lab.argtypes = [vp, i32, i32, vp, i32, vp]
+        lib.fslic_hip_enforce_connectivity.argtypes = [vp, vp, i32, i32, i32, i32]
+        lib.fslic_hip_last_prelabels.argtypes = [vp, i32, vp]
+        lib.fslic_hip_last_timing_report.argtypes = [vp]
+        lib.fslic_hip_last_timing_report.restype = C.c_char_p
+        lib.fslic_hip_last_device_times.argtypes = [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        lib.fslic_hip_last_path.argtypes = [vp, i32]
+        lib.fslic_hip_last_error.restype = C.c_char_p
+        lib.fslic_hip_version.restype = C.c_char_p
+        _lib = lib
+        return lib
+
+
+def _raise(rc):
+    msg = load_library().fslic_hip_last_error().decode("utf-8", "replace")
+    if rc == FSLIC_E_INVALID:
+        raise ValueError(msg)
+    if rc == FSLIC_E_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise RuntimeError(msg)
+
+
+def _check(rc):
+    if rc != FSLIC_OK:
+        _raise(rc)
+
+
+class Engine(object):
+    """One GPU, `n_slots` frames in flight.  Thin owner of an fslic_engine handle."""
+
+    def __init__(self, device=0, n_slots=1):
+        lib = load_library()
+        h = C.c_void_p()
+        _check(lib.fslic_hip_create(int(device), int(n_slots), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+        self.n_slots = int(n_slots)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().fslic_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- stage entry points -------------------------------------------------------------
+    def rgb_to_lab(self, image, convert=True):
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        H, W, ch = image.shape
+        if ch != 3:
+            raise ValueError("nchan != 3")
+        out = np.empty((H, W, 4), np.uint8)
+        _check(load_library().fslic_hip_rgb_to_lab(self._h, H, W, image.ctypes.data, int(bool(convert)), out.ctypes.data))
+        return out
+
+    def enforce_connectivity(self, labels_u16, K, min_threshold):
+        out = np.ascontiguousarray(labels_u16, dtype=np.uint16).copy()
+        H, W = out.shape
+        _check(load_library().fslic_hip_enforce_connectivity(self._h, out.ctypes.data, H, W, int(K), int(min_threshold)))
+        return out
+
+    def iterate(self, image, clusters, params):
+        """Host numpy in, host numpy out (uint16 labels); clusters (CLUSTER_DTYPE[K]) updated in place."""
+        H, W, _ = image.shape
+        labels = np.empty((H, W), np.uint16)
+        _check(load_library().fslic_hip_iterate(self._h, C.byref(params), H, W, clusters.shape[0],
+                                                image.ctypes.data, clusters.ctypes.data, labels.ctypes.data))
+        return labels
+
+    def iterate_device(self, d_rgb_ptr, d_labels_ptr, H, W, clusters, params, slot=0):
+        """Frame and label map resident in HBM (raw device pointers, e.g. torch tensor.data_ptr())."""
+        _check(load_library().fslic_hip_iterate_device(self._h, int(slot), C.byref(params), H, W, clusters.shape[0],
+                                                       C.c_void_p(d_rgb_ptr), clusters.ctypes.data, C.c_void_p(d_labels_ptr)))
+
+    def iterate_batch(self, rgb_ptrs, cluster_arrays, label_ptrs, H, W, params, device_ptrs):
+        n = len(rgb_ptrs)
+        K = cluster_arrays[0].shape[0]
+        PA = C.c_void_p * n
+        a_rgb = PA(*[C.c_void_p(int(p)) for p in rgb_ptrs])
+        a_cl = PA(*[C.c_void_p(c.ctypes.data) for c in cluster_arrays])
+        a_lab = PA(*[C.c_void_p(int(p)) for p in label_ptrs])
+        _check(load_library().fslic_hip_iterate_batch(self._h, C.byref(params), H, W, K, n,
+                                                      C.cast(a_rgb, C.c_void_p), C.cast(a_cl, C.c_void_p),
+                                                      C.cast(a_lab, C.c_void_p), int(bool(device_ptrs))))
+
+    def last_prelabels(self, H, W, slot=0):
+        out = np.empty((H, W), np.uint16)
+        _check(load_library().fslic_hip_last_prelabels(self._h, int(slot), out.ctypes.data))
+        return out
+
+    def last_timing_report(self):
+        return load_library().fslic_hip_last_timing_report(self._h).decode("utf-8")
+
+    def last_device_times(self, slot=0):
+        t, f = C.c_float(), C.c_float()
+        _check(load_library().fslic_hip_last_device_times(self._h, int(slot), C.byref(t), C.byref(f)))
+        return t.value, f.value
+
+    def last_path(self, slot=0):
+        return load_library().fslic_hip_last_path(self._h, int(slot))
+
+
+_default_engines = {}
+_engine_lock = threading.Lock()
+
+
+def default_engine(device=0):
+    with _engine_lock:
+        e = _default_engines.get(device)
+        if e is None:
+            e = Engine(device, 1)
+            _default_engines[device] = e
+        return e
+
+
+def device_count():
+    return load_library().fslic_hip_device_count()
+
+
+def is_supported_arch(arch_name):
+    """cfast_slic.is_supported_arch (cfast_slic.pyx:354-357) for the one arch this package provides."""
+    return arch_name == ARCH_NAME
+
+
+def get_supported_archs():
+    """cfast_slic.get_supported_archs (cfast_slic.pyx:359-369)."""
+    return [ARCH_NAME]
+
+
+def make_params(max_iter, compactness, min_size_factor, subsample_stride, convert_to_lab=True,
+                manhattan_spatial_dist=True, preemptive=False, preemptive_thres=0.05, num_threads=-1,
+                debug_mode=False, force_generic=False):
+    p = Params()
+    p.max_iter = int(max_iter)
+    p.compactness = float(compactness)
+    p.min_size_factor = float(min_size_factor)
+    p.subsample_stride = int(subsample_stride)
+    p.convert_to_lab = int(bool(convert_to_lab))
+    p.manhattan_spatial_dist = int(bool(manhattan_spatial_dist))
+    p.preemptive = int(bool(preemptive))
+    p.preemptive_thres = float(preemptive_thres)
+    p.num_threads = int(num_threads)
+    p.debug_mode = int(bool(debug_mode))
+    p.force_generic = int(bool(force_generic))
+    return p
+
+
+class SlicModel(object):
+    """Mirror of cfast_slic.SlicModel (cfast_slic.pyx:14-328) for arch "hip/gfx950"."""
+
+    def __init__(self, num_components, arch_name=ARCH_NAME, real_dist=False, device=0):
+        if isinstance(arch_name, bytes):
+            arch_name = arch_name.decode("utf-8")
+        if not is_supported_arch(arch_name):
+            raise NotImplementedError("Unsupported arch " + repr(arch_name))      # pyx:21-22
+        if num_components >= 65534:
+            raise ValueError("num_components cannot exceed 65534")                # pyx:24-25
+        elif num_components <= 0:
+            raise ValueError("num_components should be a non-negative integer")   # pyx:26-27
+        self.num_components = int(num_components)
+        self.num_threads = -1
+        self.arch_name = arch_name
+        self.real_dist = real_dist
+        self.real_dist_type = "standard"
+        self.convert_to_lab = False
+        self.float_color = True
+        self.debug_mode = False
+        self.initialized = False
+        self.preemptive = False
+        self.preemptive_thres = 0.05
+        self.manhattan_spatial_dist = True
+        self.last_timing_report = ""
+        self.last_recorder_report = ""
+        self.force_generic = False
+        self.device = int(device)
+        self._clusters = np.zeros(self.num_components, CLUSTER_DTYPE)              # pyx:38-39
+        self._engine = default_engine(self.device)   # raises when no GPU / library: no CPU fallback
+
+    def copy(self):
+        # cfast_slic.pyx:45-49 drops arch_name; here the arch is preserved.
+        result = SlicModel(self.num_components, self.arch_name, device=self.device)
+        result._clusters[:] = self._clusters
+        result.initialized = self.initialized
+        return result
+
+    @property
+    def clusters(self):                                                            # pyx:51-66
+        out = []
+        for c in self._clusters:
+            out.append(dict(
+                number=int(c["number"]),
+                yx=(float(c["y"]), float(c["x"])),
+                color=(float(c["r"]), float(c["g"]), float(c["b"])),
+                num_members=int(c["num_members"]),
+            ))
+        return out
+
+    @clusters.setter
+    def clusters(self, clusters):                                                  # pyx:68-98
+        n = len(clusters)
+        new = np.zeros(n, CLUSTER_DTYPE)
+        for i, d in enumerate(clusters):
+            y, x = d["yx"]
+            r, g, b = d["color"]
+            new[i]["number"] = i
+            new[i]["y"] = np.uint16(y)
+            new[i]["x"] = np.uint16(x)
+            new[i]["r"] = np.uint8(r)
+            new[i]["g"] = np.uint8(g)
+            new[i]["b"] = np.uint8(b)
+            new[i]["num_members"] = np.uint32(d["num_members"])
+        self._clusters = new
+        self.num_components = n
+        self.initialized = True
+
+    @property
+    def cluster_array(self):
+        """The raw Cluster[K] block (structured numpy view); not part of the reference surface."""
+        return self._clusters
+
+    def to_yxmrgb(self):                                                           # pyx:100-113
+        c = self._clusters
+        return np.stack([c["y"], c["x"], c["num_members"].astype(np.float64), c["r"], c["g"], c["b"]], 1).astype(np.float64)
+
+    @staticmethod
+    def _check_image(image):
+        image = np.asarray(image)
+        if image.dtype != np.uint8 or image.ndim != 3 or not image.flags["C_CONTIGUOUS"]:
+            raise ValueError("image must be a C-contiguous uint8 array of shape [H, W, 3]")
+        if image.shape[2] != 3:
+            raise ValueError("nchan != 3")                                         # pyx:125-126
+        return image
+
+    def initialize(self, image):                                                   # pyx:124-147
+        image = self._check_image(image)
+        H, W, _ = image.shape
+        _check(load_library().fslic_hip_initialize_clusters(H, W, self.num_components, image.ctypes.data,
+                                                            self._clusters.ctypes.data))
+        self.initialized = True
+
+    def iterate(self, image, max_iter, compactness, min_size_factor, subsample_stride):   # pyx:150-260
+        if not self.initialized:
+            raise RuntimeError("Slic model is not initialized")                    # pyx:151-152
+        image = self._check_image(image)
+        if self.real_dist:
+            raise NotImplementedError("real_dist variants are not implemented on " + ARCH_NAME)
+        p = make_params(max_iter, compactness, min_size_factor, subsample_stride, self.convert_to_lab,
+                        self.manhattan_spatial_dist, self.preemptive, self.preemptive_thres,
+                        self.num_threads, self.debug_mode, self.force_generic)
+        labels = self._engine.iterate(image, self._clusters, p)
+        self.last_timing_report = self._engine.last_timing_report()
+        result = labels.astype(np.int16)                                           # pyx:258-260
+        result[labels == 0xFFFF] = -1
+        return result
+
+
+def enforce_connectivity(assignments, min_threshold, device=0):
+    """cfast_slic.enforce_connectivity (cfast_slic.pyx:371-396): in place on an int16 [H, W] array."""
+    a = np.asarray(assignments)
+    if a.dtype != np.int16 or a.ndim != 2 or not a.flags["C_CONTIGUOUS"]:
+        raise ValueError("assignments must be a C-contiguous int16 array of shape [H, W]")
+    u = a.view(np.uint16)
+    valid = u[u != 0xFFFF]
+    K = (int(valid.max()) if valid.size else 0) + 1
+    out = default_engine(device).enforce_connectivity(u, K, min_threshold)
+    u[...] = out
+    return assignments

@@ -1,0 +1,733 @@
+// engine.cpp -- host side of the MI355X SLIC engine and its C ABI (include/fslic_hip.h).
+//
+// The engine replaces, for the arch "hip/gfx950", what SlicModel.iterate builds per call in the
+// reference: a Context (src/context.h:59-66), initialize_state(), iterate() (src/context.cpp:108-197)
+// and its teardown (cfast_slic.pyx:171-197).  Device and pinned buffers are owned here and cached
+// across calls; the only state that carries over between calls is the caller's Cluster[K].
+#include "kernels.h"
+#include "../../include/fslic_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <vector>
+
+using namespace fslic;
+
+static_assert(sizeof(fslic_cluster) == 32, "Cluster ABI (src/fast-slic-common.h:10-23)");
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                            \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess)                                                                  \
+            return fail(FSLIC_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));       \
+    } while (0)
+
+// ---- RGB->LAB tables, built exactly like FastCIELabCvt's constructor (src/cielab.h:296-305) ----
+// The gamma table is the sRGB transfer function given in the header comment (src/cielab.h:11-20),
+// evaluated in double and stored as float like _srgb_gamma_tbl.  lab_tbl depends on the host libm's
+// powf (src/cielab.h:327-332), so it is built on the host and uploaded, never recomputed on device.
+struct HostTables {
+    uint16_t gamma[256];
+    uint16_t lab[8194];
+    int cb[9];
+};
+HostTables g_tables;
+std::once_flag g_tables_once;
+
+void build_host_tables() {
+    static const float C[9] = {0.43395633f, 0.37621531f, 0.18984309f, 0.2126729f, 0.7151522f,
+                               0.072175f,   0.01775782f, 0.1094756f,  0.87283638f};
+    for (int i = 0; i < 256; i++) {
+        const double v = i / 255.0;
+        const double X = (v <= 0.04045) ? v / 12.92 : std::pow((v + 0.055) / 1.055, 2.4);
+        const float Xf = (float)X;
+        g_tables.gamma[i] = (uint16_t)(int)(Xf * 8192);
+    }
+    for (int i = 0; i < 9; i++) g_tables.cb[i] = (int)roundf(C[i] * 65536);
+    for (int i = 0; i <= 8192; i++) {
+        const float v = (float)i / 8192;
+        const float lo = 7.787f * v + 0.137931f;
+        const float hi = powf(v, 0.333333f);
+        g_tables.lab[i] = (uint16_t)(int)roundf(((v > 0.008856f) ? hi : lo) * 8192);
+    }
+    g_tables.lab[8193] = 0;
+}
+
+inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+inline float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// src/context.cpp:22-40 set_spatial_patch (host, float arithmetic identical to the reference)
+void build_patch(int S, float compactness, int color_shift, bool manhattan, std::vector<uint16_t>& patch) {
+    const int P = 2 * S + 1;
+    patch.resize((size_t)P * P);
+    float coef = 1.0f / ((float)S / compactness);
+    coef *= (1 << color_shift);
+    for (int i = 0; i < P; i++)
+        for (int j = 0; j < P; j++) {
+            if (manhattan)
+                patch[(size_t)i * P + j] = (uint16_t)(coef * (std::abs(i - S) + std::abs(j - S)));
+            else
+                patch[(size_t)i * P + j] = (uint16_t)(coef * hypotf((float)(i - S), (float)(j - S)));
+        }
+}
+
+// The Manhattan patch is a function of d = |di| + |dj| only.  Find M with (d*M)>>16 == lut[d] for every
+// d in [0, 2S] so the kernel can form the spatial term with one 24-bit multiply and fold it into the
+// packed key.  Returns false when no such multiplier exists (the generic kernel then uses the patch).
+bool find_multiplier(int S, const std::vector<uint16_t>& patch, uint32_t& M, uint32_t& max_spatial) {
+    const int P = 2 * S + 1;
+    uint64_t lo = 0, hi = (1ull << 24) - 1;
+    max_spatial = 0;
+    for (int d = 0; d <= 2 * S; d++) {
+        // element of the patch with |di|+|dj| == d: (S - min(d,S), S + (d - min(d,S)))
+        const int di = std::min(d, S), dj = d - di;
+        const uint64_t L = patch[(size_t)(S - di) * P + (S + dj)];
+        max_spatial = std::max<uint32_t>(max_spatial, (uint32_t)L);
+        if (d == 0) {
+            if (L != 0) return false;
+            continue;
+        }
+        lo = std::max<uint64_t>(lo, (L * 65536 + d - 1) / d);
+        hi = std::min<uint64_t>(hi, ((L + 1) * 65536 - 1) / d);
+    }
+    if (lo > hi) return false;
+    M = (uint32_t)lo;
+    if ((uint64_t)(2 * S) * M >= (1ull << 30)) return false;
+    return true;
+}
+
+struct Slot {
+    hipStream_t st = nullptr;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // device
+    char* arena = nullptr;
+    size_t arena_cap = 0;
+    FrameDev f{};
+    CcaDev c{};
+    char* zero_block = nullptr;
+    size_t zero_bytes = 0;
+    uint8_t* d_rgb_stage = nullptr;
+    uint16_t* d_out_stage = nullptr;
+    uint16_t* d_patch = nullptr;
+    int32_t* d_keep_leader = nullptr;
+    uint16_t* d_keep_label = nullptr;
+    uint32_t* d_err = nullptr;
+    // pinned host
+    uint32_t* h_cl = nullptr;        // [0,K) yx in; out: 4K words (yx, lab, n, moved)
+    uint32_t* h_misc = nullptr;      // [0] roots, [1] candidates, [2] err flag
+    int32_t* h_keep_leader = nullptr;
+    uint16_t* h_keep_label = nullptr;
+    uint16_t* h_patch = nullptr;
+    size_t h_patch_cap = 0;
+    int32_t* h_cand_leader = nullptr;
+    uint32_t* h_cand_area = nullptr;
+    size_t h_cand_cap = 0;
+    int hK = 0;
+    int keyH = 0, keyW = 0, keyK = 0;
+    // per-call state
+    int H = 0, W = 0, K = 0, S = 0;
+    bool generic = false;
+    fslic_params p{};
+    fslic_cluster* clusters = nullptr;
+    uint16_t* d_out = nullptr;
+    float total_ms = 0, fa_ms = 0, lab_ms = 0, loop_ms = 0, cca_ms = 0;
+    int last_path = 0;
+    bool have_pre = false;
+};
+
+}  // namespace
+
+struct fslic_engine {
+    int device = 0;
+    std::vector<Slot> slots;
+    uint16_t* d_gamma = nullptr;
+    uint16_t* d_labtbl = nullptr;
+    LabTables tables{};
+    std::string timing;
+};
+
+namespace {
+
+void free_slot(Slot& s) {
+    if (s.arena) hipFree(s.arena);
+    if (s.h_cl) hipHostFree(s.h_cl);
+    if (s.h_misc) hipHostFree(s.h_misc);
+    if (s.h_keep_leader) hipHostFree(s.h_keep_leader);
+    if (s.h_keep_label) hipHostFree(s.h_keep_label);
+    if (s.h_patch) hipHostFree(s.h_patch);
+    if (s.h_cand_leader) hipHostFree(s.h_cand_leader);
+    if (s.h_cand_area) hipHostFree(s.h_cand_area);
+    for (auto& e : s.ev) if (e) hipEventDestroy(e);
+    if (s.st) hipStreamDestroy(s.st);
+    s = Slot();
+}
+
+// (Re)allocate the slot's buffers for an H x W frame with K clusters and carve the device arena.
+int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S) {
+    const size_t N = (size_t)H * W;
+    const int sh = [&] { int v = 2; while ((1 << (v + 1)) <= S) v++; return v; }();
+    const int ncx = (W + (1 << sh) - 1) >> sh, ncy = (H + (1 << sh) - 1) >> sh;
+    const size_t ncell = (size_t)ncx * ncy;
+    const size_t P = (size_t)(2 * S + 1);
+
+    if (s.hK < K) {
+        if (s.h_cl) { hipHostFree(s.h_cl); hipHostFree(s.h_keep_leader); hipHostFree(s.h_keep_label); }
+        HIPCHK(hipHostMalloc((void**)&s.h_cl, sizeof(uint32_t) * 4 * (size_t)K));
+        HIPCHK(hipHostMalloc((void**)&s.h_keep_leader, sizeof(int32_t) * (size_t)K));
+        HIPCHK(hipHostMalloc((void**)&s.h_keep_label, sizeof(uint16_t) * (size_t)K));
+        s.hK = K;
+    }
+    if (!s.h_misc) HIPCHK(hipHostMalloc((void**)&s.h_misc, 64));
+    if (s.h_patch_cap < P * P) {
+        if (s.h_patch) hipHostFree(s.h_patch);
+        HIPCHK(hipHostMalloc((void**)&s.h_patch, sizeof(uint16_t) * P * P));
+        s.h_patch_cap = P * P;
+    }
+
+    // ---- carve ----
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_lab = take(N * 4), o_labels = take(N * 2);
+    const size_t o_cl = take((size_t)K * 4 * 5);                     // yx, lab, n, moved, tag (contiguous)
+    const size_t o_zero = off;
+    const size_t o_sums = take((size_t)K * 6 * 4);
+    const size_t o_cc0 = take(ncell * 4), o_cc1 = take(ncell * 4);
+    const size_t o_misc = take(256);                                 // ovf_cnt[2], err, cca counters
+    const size_t zero_bytes = off - o_zero;
+    const size_t o_ci0 = take(ncell * kCellCap * sizeof(ClusterRec)), o_ci1 = take(ncell * kCellCap * sizeof(ClusterRec));
+    const size_t o_ov0 = take((size_t)K * sizeof(ClusterRec)), o_ov1 = take((size_t)K * sizeof(ClusterRec));
+    const size_t o_patch = take(P * P * 2);
+    const size_t o_parent = take(N * 4), o_area = take(N * 4), o_final = take(N * 2), o_roots = take(N * 4);
+    const size_t o_candl = take(N * 4), o_canda = take(N * 4);
+    const size_t o_keepl = take((size_t)K * 4), o_keepb = take((size_t)K * 2);
+    const size_t o_rgb = take(N * 3), o_out = take(N * 2);
+    const size_t total = off;
+
+    if (s.arena_cap < total) {
+        if (s.arena) { hipFree(s.arena); s.arena = nullptr; s.arena_cap = 0; }
+        HIPCHK(hipMalloc((void**)&s.arena, total));
+        s.arena_cap = total;
+    }
+    char* b = s.arena;
+    FrameDev& f = s.f;
+    f.H = H; f.W = W; f.N = (int)N; f.K = K; f.S = S; f.T = 2 * S + 32;
+    f.cs_shift = sh; f.ncx = ncx; f.ncy = ncy; f.ncell = (int)ncell;
+    f.lab = (uint32_t*)(b + o_lab);
+    f.labels = (uint16_t*)(b + o_labels);
+    uint32_t* cl = (uint32_t*)(b + o_cl);
+    f.cl_yx = cl; f.cl_lab = cl + K; f.cl_n = cl + 2 * (size_t)K; f.cl_moved = cl + 3 * (size_t)K; f.cl_tag = cl + 4 * (size_t)K;
+    f.sums = (uint32_t*)(b + o_sums);
+    f.cell_cnt[0] = (uint32_t*)(b + o_cc0); f.cell_cnt[1] = (uint32_t*)(b + o_cc1);
+    uint32_t* misc = (uint32_t*)(b + o_misc);
+    f.ovf_cnt[0] = misc + 0; f.ovf_cnt[1] = misc + 1; f.err_flag = misc + 2;
+    f.cell_items[0] = (ClusterRec*)(b + o_ci0); f.cell_items[1] = (ClusterRec*)(b + o_ci1);
+    f.ovf_items[0] = (ClusterRec*)(b + o_ov0); f.ovf_items[1] = (ClusterRec*)(b + o_ov1);
+    s.d_patch = (uint16_t*)(b + o_patch);
+    f.patch2d = s.d_patch;
+    s.d_err = misc + 2;
+    s.zero_block = b + o_zero; s.zero_bytes = zero_bytes;
+    CcaDev& c = s.c;
+    c.H = H; c.W = W; c.N = (int)N; c.K = K;
+    c.parent = (int32_t*)(b + o_parent); c.area = (uint32_t*)(b + o_area);
+    c.final_lab = (uint16_t*)(b + o_final); c.roots = (int32_t*)(b + o_roots);
+    c.counters = misc + 4;
+    c.cand_leader = (int32_t*)(b + o_candl); c.cand_area = (uint32_t*)(b + o_canda);
+    s.d_keep_leader = (int32_t*)(b + o_keepl); s.d_keep_label = (uint16_t*)(b + o_keepb);
+    s.d_rgb_stage = (uint8_t*)(b + o_rgb); s.d_out_stage = (uint16_t*)(b + o_out);
+    s.keyH = H; s.keyW = W; s.keyK = K;
+    (void)e;
+    return FSLIC_OK;
+}
+
+int validate(const fslic_params* p, int H, int W, int K, int& S) {
+    if (!p) return fail(FSLIC_E_INVALID, "params is NULL");
+    if (H <= 0 || W <= 0) return fail(FSLIC_E_INVALID, "H and W must be positive");
+    if (H > 32767 || W > 32767) return fail(FSLIC_E_INVALID, "H and W must fit int16 (src/context.cpp:262)");
+    if ((long long)H * W >= (1ll << 31)) return fail(FSLIC_E_INVALID, "H*W must fit int32");
+    if (K <= 0 || K >= 65534) return fail(FSLIC_E_INVALID, "num_components must be in [1, 65533] (cfast_slic.pyx:24-27)");
+    if (p->subsample_stride < 1 || p->subsample_stride > 255) return fail(FSLIC_E_INVALID, "subsample_stride must be in [1, 255]");
+    if (p->max_iter < 0) return fail(FSLIC_E_INVALID, "max_iter must be >= 0");
+    if (p->preemptive) return fail(FSLIC_E_UNSUPPORTED, "preemptive=True is not implemented on hip/gfx950");
+    if (!(p->compactness > 0.0f) || !std::isfinite(p->compactness)) return fail(FSLIC_E_INVALID, "compactness must be a positive finite number");
+    S = (int)(int16_t)sqrt(H * W / K);   // src/context.h:60
+    if (S < 1) return fail(FSLIC_E_INVALID, "num_components exceeds the number of pixels (S == 0)");
+    return FSLIC_OK;
+}
+
+// ---- the top-K / ranking step of ConnectivityEnforcer::execute (src/cca.cpp:205-237) on the host ----
+// Input: candidates (components with area >= threshold) in arbitrary order.  Output: kept leaders in
+// ascending order; label = position.  libstdc++'s std::partial_sort decides ties at the cut exactly as it
+// does for the reference (same library, same input order: ascending component number == ascending leader).
+int select_kept(Slot& s, uint32_t M, int K, uint32_t& n_keep) {
+    std::vector<uint32_t> order(M);
+    std::iota(order.begin(), order.end(), 0u);
+    const int32_t* leader = s.h_cand_leader;
+    const uint32_t* area = s.h_cand_area;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return leader[a] < leader[b]; });
+    if ((size_t)K < order.size()) {
+        std::partial_sort(order.begin(), order.begin() + K, order.end(),
+                          [&](uint32_t a, uint32_t b) { return area[a] > area[b]; });
+        order.resize(K);
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return leader[a] < leader[b]; });
+    }
+    n_keep = (uint32_t)order.size();
+    for (uint32_t i = 0; i < n_keep; i++) {
+        s.h_keep_leader[i] = leader[order[i]];
+        s.h_keep_label[i] = (uint16_t)i;
+    }
+    return FSLIC_OK;
+}
+
+int ensure_cand_capacity(Slot& s, size_t M) {
+    if (s.h_cand_cap >= M) return FSLIC_OK;
+    if (s.h_cand_leader) { hipHostFree(s.h_cand_leader); hipHostFree(s.h_cand_area); s.h_cand_leader = nullptr; s.h_cand_area = nullptr; }
+    const size_t cap = std::max<size_t>(M, 16384);
+    HIPCHK(hipHostMalloc((void**)&s.h_cand_leader, sizeof(int32_t) * cap));
+    HIPCHK(hipHostMalloc((void**)&s.h_cand_area, sizeof(uint32_t) * cap));
+    s.h_cand_cap = cap;
+    return FSLIC_OK;
+}
+
+// Connectivity pass on the slot's stream: phase 1 (device), host top-K, phase 2 (device).
+int cca_enqueue_phase1(Slot& s, const uint16_t* d_in, uint16_t* d_out, int K, int min_threshold) {
+    CcaDev& c = s.c;
+    c.in = d_in; c.out = d_out; c.K = K; c.min_threshold = min_threshold;
+    launch_cca_phase1(c, s.st);
+    HIPCHK(hipMemcpyAsync(s.h_misc, c.counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.st));
+    return FSLIC_OK;
+}
+int cca_host_and_phase2(Slot& s) {
+    CcaDev& c = s.c;
+    HIPCHK(hipStreamSynchronize(s.st));
+    const uint32_t M = s.h_misc[1];
+    uint32_t n_keep = 0;
+    if (M > 0) {
+        int rc = ensure_cand_capacity(s, M);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(s.h_cand_leader, c.cand_leader, sizeof(int32_t) * M, hipMemcpyDeviceToHost, s.st));
+        HIPCHK(hipMemcpyAsync(s.h_cand_area, c.cand_area, sizeof(uint32_t) * M, hipMemcpyDeviceToHost, s.st));
+        HIPCHK(hipStreamSynchronize(s.st));
+        select_kept(s, M, c.K, n_keep);
+        HIPCHK(hipMemcpyAsync(s.d_keep_leader, s.h_keep_leader, sizeof(int32_t) * n_keep, hipMemcpyHostToDevice, s.st));
+        HIPCHK(hipMemcpyAsync(s.d_keep_label, s.h_keep_label, sizeof(uint16_t) * n_keep, hipMemcpyHostToDevice, s.st));
+        launch_cca_set_kept(c, s.d_keep_leader, s.d_keep_label, (int)n_keep, s.st);
+    }
+    launch_cca_phase2(c, s.st);
+    return FSLIC_OK;
+}
+
+// Everything of iterate() up to and including the device half of the connectivity pass.
+int frame_enqueue_phase1(fslic_engine* e, Slot& s, const fslic_params* p, int H, int W, int K,
+                         const uint8_t* d_rgb, fslic_cluster* clusters, uint16_t* d_out, bool generic) {
+    int S = 0;
+    int rc = validate(p, H, W, K, S);
+    if (rc) return rc;
+    if (!clusters || !d_rgb || !d_out) return fail(FSLIC_E_INVALID, "NULL pointer argument");
+    if (s.keyH != H || s.keyW != W || s.keyK != K) {
+        HIPCHK(hipStreamSynchronize(s.st));
+        rc = prepare(e, s, H, W, K, S);
+        if (rc) return rc;
+    }
+    s.H = H; s.W = W; s.K = K; s.S = S; s.p = *p; s.clusters = clusters; s.d_out = d_out;
+    FrameDev& f = s.f;
+    f.rgb = d_rgb;
+
+    const int color_shift = p->convert_to_lab ? 1 : 0;   // src/cielab.h:284,352 ; src/context.cpp:126
+    const bool manhattan = p->manhattan_spatial_dist != 0;
+    std::vector<uint16_t> patch;
+    build_patch(S, p->compactness, color_shift, manhattan, patch);
+    uint32_t M = 0, max_sp = 0;
+    bool tiled_ok = manhattan && find_multiplier(S, patch, M, max_sp) && (max_sp + 765u < 16384u) && S >= 8;
+    if (generic || p->force_generic) tiled_ok = false;
+    s.generic = !tiled_ok;
+    f.M = M;
+    if (s.generic) {
+        std::memcpy(s.h_patch, patch.data(), patch.size() * sizeof(uint16_t));
+        HIPCHK(hipMemcpyAsync(s.d_patch, s.h_patch, patch.size() * sizeof(uint16_t), hipMemcpyHostToDevice, s.st));
+    }
+    // cluster centres: integer part of the clamped position (src/context.cpp:129-131,208-211,262)
+    for (int k = 0; k < K; k++) {
+        const int y = clampi((int)clusters[k].y, 0, H - 1), x = clampi((int)clusters[k].x, 0, W - 1);
+        s.h_cl[k] = ((uint32_t)y << 16) | (uint32_t)x;
+    }
+    HIPCHK(hipMemcpyAsync(f.cl_yx, s.h_cl, sizeof(uint32_t) * (size_t)K, hipMemcpyHostToDevice, s.st));
+    HIPCHK(hipMemsetAsync(s.zero_block, 0, s.zero_bytes, s.st));
+    HIPCHK(hipMemsetAsync(f.cl_n, 0, sizeof(uint32_t) * 2 * (size_t)K, s.st));   // cl_n, cl_moved
+
+    HIPCHK(hipEventRecord(s.ev[0], s.st));
+    launch_rgb_to_lab(d_rgb, f.lab, f.N, p->convert_to_lab, e->tables, s.st);
+    launch_fill_u16(f.labels, f.N, 0xFFFFu, s.st);             // src/context.cpp:138-145
+    HIPCHK(hipEventRecord(s.ev[1], s.st));
+    launch_bin_clusters(f, 0, 0, s.st);
+    const int stride = p->subsample_stride;
+    int rem = 0;
+    for (int it = 0; it < p->max_iter; it++) {                  // src/context.cpp:158-175
+        if (s.generic) launch_assign_generic(f, rem, stride, it & 1, true, s.st);
+        else launch_assign(f, rem, stride, it & 1, true, s.st);
+        launch_bin_clusters(f, 1, (it + 1) & 1, s.st);
+        rem = (rem + 1) % stride;
+    }
+    HIPCHK(hipEventRecord(s.ev[2], s.st));
+    // full_assign: stride 1, rem 0, no update afterwards (src/context.cpp:246-256)
+    if (s.generic) launch_assign_generic(f, 0, 1, p->max_iter & 1, false, s.st);
+    else launch_assign(f, 0, 1, p->max_iter & 1, false, s.st);
+    HIPCHK(hipEventRecord(s.ev[3], s.st));
+    // cluster state + overflow flag back to the host
+    HIPCHK(hipMemcpyAsync(s.h_cl, f.cl_yx, sizeof(uint32_t) * 4 * (size_t)K, hipMemcpyDeviceToHost, s.st));
+    HIPCHK(hipMemcpyAsync(s.h_misc + 2, s.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s.st));
+    // enforce_connectivity, src/context.cpp:14-20
+    const int thres = (int)round((double)(S * S) * (double)p->min_size_factor);
+    rc = cca_enqueue_phase1(s, f.labels, d_out, K, thres);
+    if (rc) return rc;
+    s.have_pre = true;
+    s.last_path = s.generic ? 1 : 0;
+    return FSLIC_OK;
+}
+
+int frame_phase2(Slot& s) {
+    int rc = cca_host_and_phase2(s);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(s.ev[4], s.st));
+    return FSLIC_OK;
+}
+
+// returns 1 when the tiled kernel overflowed an LDS candidate list and the frame must be redone
+int frame_finish(Slot& s, bool& redo) {
+    HIPCHK(hipStreamSynchronize(s.st));
+    redo = (!s.generic && s.h_misc[2] != 0);
+    if (redo) return FSLIC_OK;
+    hipEventElapsedTime(&s.total_ms, s.ev[0], s.ev[4]);
+    hipEventElapsedTime(&s.lab_ms, s.ev[0], s.ev[1]);
+    hipEventElapsedTime(&s.loop_ms, s.ev[1], s.ev[2]);
+    hipEventElapsedTime(&s.fa_ms, s.ev[2], s.ev[3]);
+    hipEventElapsedTime(&s.cca_ms, s.ev[3], s.ev[4]);
+    // write the cluster state back the way the reference leaves it
+    const int K = s.K, H = s.H, W = s.W;
+    const uint32_t* yx = s.h_cl;
+    const uint32_t* lab = s.h_cl + K;
+    const uint32_t* n = s.h_cl + 2 * (size_t)K;
+    const uint32_t* moved = s.h_cl + 3 * (size_t)K;
+    fslic_cluster* cl = s.clusters;
+    for (int k = 0; k < K; k++) {
+        cl[k].r = (float)(lab[k] & 255u);                 // src/context.cpp:132-134 / :370-372
+        cl[k].g = (float)((lab[k] >> 8) & 255u);
+        cl[k].b = (float)((lab[k] >> 16) & 255u);
+        if (moved[k]) {                                    // src/context.cpp:368-369
+            cl[k].y = (float)(yx[k] >> 16);
+            cl[k].x = (float)(yx[k] & 0xFFFFu);
+        } else {                                           // assign() safeguard, src/context.cpp:208-211
+            cl[k].x = clampf(cl[k].x, 0.0f, (float)(W - 1));
+            cl[k].y = clampf(cl[k].y, 0.0f, (float)(H - 1));
+        }
+        if (s.p.max_iter > 0) cl[k].num_members = n[k];   // src/context.cpp:362
+        cl[k].is_updatable = 2;                            // src/preemptive.h:59-67
+        cl[k].is_active = 1;                               // src/preemptive.h:69-74
+    }
+    return FSLIC_OK;
+}
+
+int run_frame(fslic_engine* e, Slot& s, const fslic_params* p, int H, int W, int K, const uint8_t* d_rgb,
+              fslic_cluster* clusters, uint16_t* d_out) {
+    bool generic = false;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        int rc = frame_enqueue_phase1(e, s, p, H, W, K, d_rgb, clusters, d_out, generic);
+        if (rc) return rc;
+        rc = frame_phase2(s);
+        if (rc) return rc;
+        bool redo = false;
+        rc = frame_finish(s, redo);
+        if (rc) return rc;
+        if (!redo) return FSLIC_OK;
+        generic = true;
+    }
+    return fail(FSLIC_E_INTERNAL, "generic path reported a candidate overflow");
+}
+
+void make_timing_report(fslic_engine* e, const Slot& s) {
+    char buf[1024];
+    auto us = [](float ms) { return (long long)(ms * 1000.0f); };
+    snprintf(buf, sizeof buf,
+             "{\"name\": \"iterate\", \"duration\": %lld, \"children\": ["
+             "{\"name\": \"cielab_conversion\", \"duration\": %lld, \"children\": []},"
+             "{\"name\": \"assign_update_loop\", \"duration\": %lld, \"children\": []},"
+             "{\"name\": \"full_assign\", \"duration\": %lld, \"children\": []},"
+             "{\"name\": \"enforce_connectivity\", \"duration\": %lld, \"children\": []}]}",
+             us(s.total_ms), us(s.lab_ms), us(s.loop_ms), us(s.fa_ms), us(s.cca_ms));
+    e->timing = buf;
+}
+
+}  // namespace
+
+// ================================= C ABI ==========================================================
+extern "C" {
+
+const char* fslic_hip_last_error(void) { return g_err.c_str(); }
+const char* fslic_hip_version(void) { return "fast_slic_amd 0.1 (gfx950)"; }
+
+int fslic_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int fslic_hip_create(int device, int n_slots, fslic_engine** out) {
+    if (!out) return fail(FSLIC_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (n_slots < 1 || n_slots > 64) return fail(FSLIC_E_INVALID, "n_slots must be in [1, 64]");
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(FSLIC_E_HIP, "no such HIP device");
+    HIPCHK(hipSetDevice(device));
+    std::call_once(g_tables_once, build_host_tables);
+    fslic_engine* e = new fslic_engine();
+    e->device = device;
+    e->slots.resize(n_slots);
+    for (auto& s : e->slots) {
+        if (hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) { fslic_hip_destroy(e); return fail(FSLIC_E_HIP, "hipStreamCreate failed"); }
+        for (auto& ev : s.ev)
+            if (hipEventCreate(&ev) != hipSuccess) { fslic_hip_destroy(e); return fail(FSLIC_E_HIP, "hipEventCreate failed"); }
+    }
+    if (hipMalloc((void**)&e->d_gamma, sizeof g_tables.gamma) != hipSuccess ||
+        hipMalloc((void**)&e->d_labtbl, sizeof g_tables.lab) != hipSuccess) { fslic_hip_destroy(e); return fail(FSLIC_E_HIP, "hipMalloc(tables) failed"); }
+    if (hipMemcpy(e->d_gamma, g_tables.gamma, sizeof g_tables.gamma, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(e->d_labtbl, g_tables.lab, sizeof g_tables.lab, hipMemcpyHostToDevice) != hipSuccess) { fslic_hip_destroy(e); return fail(FSLIC_E_HIP, "table upload failed"); }
+    e->tables.gamma = e->d_gamma;
+    e->tables.labtbl = e->d_labtbl;
+    for (int i = 0; i < 9; i++) e->tables.cb[i] = g_tables.cb[i];
+    *out = e;
+    return FSLIC_OK;
+}
+
+void fslic_hip_destroy(fslic_engine* e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    for (auto& s : e->slots) {
+        if (s.st) hipStreamSynchronize(s.st);
+        free_slot(s);
+    }
+    if (e->d_gamma) hipFree(e->d_gamma);
+    if (e->d_labtbl) hipFree(e->d_labtbl);
+    delete e;
+}
+
+// BaseContext::initialize_clusters, src/context.cpp:42-97 (host, serial, O(K)).
+int fslic_hip_initialize_clusters(int H, int W, int K, const uint8_t* rgb, fslic_cluster* cl) {
+    if (!rgb || !cl) return fail(FSLIC_E_INVALID, "NULL pointer argument");
+    if (H <= 0 || W <= 0 || K <= 0) return FSLIC_OK;   // the reference returns silently (:43)
+    const int n_y = (int)sqrt((double)K);
+    std::vector<int> n_xs(n_y, K / n_y);
+    int remainder = K % n_y, row = 0;
+    while (remainder-- > 0) {
+        n_xs[row]++;
+        row += 2;
+        if (row >= n_y) row = 1 % n_y;
+    }
+    const int h = (H + n_y - 1) / n_y;
+    int acc = 0;
+    for (int i = 0; i < H; i += h) {
+        const int w = (W + n_xs[std::min(i / h, n_y - 1)] - 1) / n_xs[std::min(i / h, n_y - 1)];
+        for (int j = 0; j < W; j += w) {
+            if (acc >= K) break;
+            cl[acc].y = (float)clampi(i + h / 2, 0, H - 1);
+            cl[acc].x = (float)clampi(j + w / 2, 0, W - 1);
+            cl[acc].is_active = 1;
+            cl[acc].is_updatable = 1;
+            acc++;
+        }
+    }
+    for (; acc < K; acc++) {            // leftovers pile up on the image centre (:80-86)
+        cl[acc].is_active = 1;
+        cl[acc].is_updatable = 1;
+        cl[acc].y = (float)(H / 2);
+        cl[acc].x = (float)(W / 2);
+    }
+    for (int k = 0; k < K; k++) {
+        const size_t base = (size_t)W * (int)cl[k].y + (int)cl[k].x;
+        cl[k].r = rgb[3 * base];
+        cl[k].g = rgb[3 * base + 1];
+        cl[k].b = rgb[3 * base + 2];
+        cl[k].number = (uint16_t)k;
+        cl[k].num_members = 0;
+    }
+    return FSLIC_OK;
+}
+
+int fslic_hip_iterate_device(fslic_engine* e, int slot, const fslic_params* p, int H, int W, int K,
+                             const uint8_t* d_rgb, fslic_cluster* clusters, uint16_t* d_labels) {
+    if (!e) return fail(FSLIC_E_INVALID, "engine is NULL");
+    if (slot < 0 || slot >= (int)e->slots.size()) return fail(FSLIC_E_INVALID, "slot out of range");
+    HIPCHK(hipSetDevice(e->device));
+    Slot& s = e->slots[slot];
+    int rc = run_frame(e, s, p, H, W, K, d_rgb, clusters, d_labels);
+    if (rc == FSLIC_OK && slot == 0) make_timing_report(e, s);
+    return rc;
+}
+
+int fslic_hip_iterate(fslic_engine* e, const fslic_params* p, int H, int W, int K, const uint8_t* rgb,
+                      fslic_cluster* clusters, uint16_t* labels) {
+    if (!e) return fail(FSLIC_E_INVALID, "engine is NULL");
+    if (!rgb || !labels || !clusters) return fail(FSLIC_E_INVALID, "NULL pointer argument");
+    HIPCHK(hipSetDevice(e->device));
+    Slot& s = e->slots[0];
+    int S = 0;
+    int rc = validate(p, H, W, K, S);
+    if (rc) return rc;
+    if (s.keyH != H || s.keyW != W || s.keyK != K) {
+        HIPCHK(hipStreamSynchronize(s.st));
+        rc = prepare(e, s, H, W, K, S);
+        if (rc) return rc;
+    }
+    const size_t N = (size_t)H * W;
+    HIPCHK(hipMemcpyAsync(s.d_rgb_stage, rgb, N * 3, hipMemcpyHostToDevice, s.st));
+    rc = run_frame(e, s, p, H, W, K, s.d_rgb_stage, clusters, s.d_out_stage);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(labels, s.d_out_stage, N * 2, hipMemcpyDeviceToHost, s.st));
+    HIPCHK(hipStreamSynchronize(s.st));
+    make_timing_report(e, s);
+    return FSLIC_OK;
+}
+
+int fslic_hip_iterate_batch(fslic_engine* e, const fslic_params* p, int H, int W, int K, int n_frames,
+                            const uint8_t* const* rgb, fslic_cluster* const* clusters,
+                            uint16_t* const* labels, int device_ptrs) {
+    if (!e) return fail(FSLIC_E_INVALID, "engine is NULL");
+    if (n_frames < 0 || (n_frames > 0 && (!rgb || !clusters || !labels))) return fail(FSLIC_E_INVALID, "bad batch arguments");
+    HIPCHK(hipSetDevice(e->device));
+    const int ns = (int)e->slots.size();
+    const size_t N = (size_t)H * W;
+    int S = 0;
+    int rc = validate(p, H, W, K, S);
+    if (rc) return rc;
+    for (int base = 0; base < n_frames; base += ns) {
+        const int cnt = std::min(ns, n_frames - base);
+        // enqueue the device half of every frame of the group, then serve the host top-K step of each
+        // while the other slots' kernels keep the GPU busy
+        for (int i = 0; i < cnt; i++) {
+            Slot& s = e->slots[i];
+            const uint8_t* d_rgb = rgb[base + i];
+            uint16_t* d_out = labels[base + i];
+            if (!device_ptrs) {
+                if (s.keyH != H || s.keyW != W || s.keyK != K) {
+                    HIPCHK(hipStreamSynchronize(s.st));
+                    rc = prepare(e, s, H, W, K, S);
+                    if (rc) return rc;
+                }
+                HIPCHK(hipMemcpyAsync(s.d_rgb_stage, rgb[base + i], N * 3, hipMemcpyHostToDevice, s.st));
+                d_rgb = s.d_rgb_stage;
+                d_out = s.d_out_stage;
+            }
+            rc = frame_enqueue_phase1(e, s, p, H, W, K, d_rgb, clusters[base + i], d_out, false);
+            if (rc) return rc;
+        }
+        for (int i = 0; i < cnt; i++) {
+            rc = frame_phase2(e->slots[i]);
+            if (rc) return rc;
+        }
+        for (int i = 0; i < cnt; i++) {
+            Slot& s = e->slots[i];
+            bool redo = false;
+            rc = frame_finish(s, redo);
+            if (rc) return rc;
+            if (redo) {
+                rc = frame_enqueue_phase1(e, s, p, H, W, K, s.f.rgb, clusters[base + i], s.d_out, true);
+                if (rc) return rc;
+                rc = frame_phase2(s);
+                if (rc) return rc;
+                rc = frame_finish(s, redo);
+                if (rc) return rc;
+            }
+            if (!device_ptrs) {
+                HIPCHK(hipMemcpyAsync(labels[base + i], s.d_out_stage, N * 2, hipMemcpyDeviceToHost, s.st));
+                HIPCHK(hipStreamSynchronize(s.st));
+            }
+        }
+    }
+    return FSLIC_OK;
+}
+
+int fslic_hip_rgb_to_lab(fslic_engine* e, int H, int W, const uint8_t* rgb, int convert, uint8_t* lab4) {
+    if (!e || !rgb || !lab4) return fail(FSLIC_E_INVALID, "NULL pointer argument");
+    if (H <= 0 || W <= 0 || (long long)H * W >= (1ll << 31)) return fail(FSLIC_E_INVALID, "bad image size");
+    HIPCHK(hipSetDevice(e->device));
+    const size_t N = (size_t)H * W;
+    uint8_t* d_rgb = nullptr;
+    uint32_t* d_lab = nullptr;
+    HIPCHK(hipMalloc((void**)&d_rgb, N * 3));
+    if (hipMalloc((void**)&d_lab, N * 4) != hipSuccess) { hipFree(d_rgb); return fail(FSLIC_E_HIP, "hipMalloc failed"); }
+    hipStream_t st = e->slots[0].st;
+    hipMemcpyAsync(d_rgb, rgb, N * 3, hipMemcpyHostToDevice, st);
+    launch_rgb_to_lab(d_rgb, d_lab, (int)N, convert, e->tables, st);
+    hipMemcpyAsync(lab4, d_lab, N * 4, hipMemcpyDeviceToHost, st);
+    hipError_t err = hipStreamSynchronize(st);
+    hipFree(d_rgb);
+    hipFree(d_lab);
+    if (err != hipSuccess) return fail(FSLIC_E_HIP, hipGetErrorString(err));
+    return FSLIC_OK;
+}
+
+int fslic_hip_enforce_connectivity(fslic_engine* e, uint16_t* labels, int H, int W, int K, int min_threshold) {
+    if (!e || !labels) return fail(FSLIC_E_INVALID, "NULL pointer argument");
+    if (H <= 0 || W <= 0 || (long long)H * W >= (1ll << 31)) return fail(FSLIC_E_INVALID, "bad image size");
+    if (K <= 0) return FSLIC_OK;   // src/context.cpp:16
+    HIPCHK(hipSetDevice(e->device));
+    Slot& s = e->slots[0];
+    const int Kb = std::min(std::max(K, 1), 65536);
+    // any S works for the connectivity buffers; reuse the frame carve
+    int S = (int)sqrt((double)H * W / Kb);
+    if (S < 1) S = 1;
+    HIPCHK(hipStreamSynchronize(s.st));
+    int rc = prepare(e, s, H, W, Kb, S);
+    if (rc) return rc;
+    s.keyH = s.keyW = s.keyK = 0;   // the carve above is not a frame configuration
+    const size_t N = (size_t)H * W;
+    HIPCHK(hipMemsetAsync(s.zero_block, 0, s.zero_bytes, s.st));
+    HIPCHK(hipMemcpyAsync(s.d_out_stage, labels, N * 2, hipMemcpyHostToDevice, s.st));
+    rc = cca_enqueue_phase1(s, s.d_out_stage, s.d_out_stage, K, min_threshold);
+    if (rc) return rc;
+    rc = cca_host_and_phase2(s);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(labels, s.d_out_stage, N * 2, hipMemcpyDeviceToHost, s.st));
+    HIPCHK(hipStreamSynchronize(s.st));
+    return FSLIC_OK;
+}
+
+int fslic_hip_last_prelabels(fslic_engine* e, int slot, uint16_t* prelabels) {
+    if (!e || !prelabels) return fail(FSLIC_E_INVALID, "NULL pointer argument");
+    if (slot < 0 || slot >= (int)e->slots.size()) return fail(FSLIC_E_INVALID, "slot out of range");
+    Slot& s = e->slots[slot];
+    if (!s.have_pre || s.keyH == 0) return fail(FSLIC_E_INVALID, "no frame has been processed on this slot");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpy(prelabels, s.f.labels, (size_t)s.f.N * 2, hipMemcpyDeviceToHost));
+    return FSLIC_OK;
+}
+
+const char* fslic_hip_last_timing_report(fslic_engine* e) { return e ? e->timing.c_str() : ""; }
+
+int fslic_hip_last_device_times(fslic_engine* e, int slot, float* total_ms, float* full_assign_ms) {
+    if (!e || slot < 0 || slot >= (int)e->slots.size()) return fail(FSLIC_E_INVALID, "bad engine/slot");
+    if (total_ms) *total_ms = e->slots[slot].total_ms;
+    if (full_assign_ms) *full_assign_ms = e->slots[slot].fa_ms;
+    return FSLIC_OK;
+}
+
+int fslic_hip_last_path(fslic_engine* e, int slot) {
+    if (!e || slot < 0 || slot >= (int)e->slots.size()) return -1;
+    return e->slots[slot].last_path;
+}
+
+}  // extern "C"

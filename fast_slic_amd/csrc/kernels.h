@@ -1,0 +1,93 @@
+// kernels.h -- launch interface between the host engine (engine.cpp) and the gfx950 kernels
+// (kernels.hip).  Internal to the library; the public boundary is include/fslic_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fslic {
+
+// ---- compile-time geometry ---------------------------------------------------------------
+constexpr int kTileW = 64;          // assign tile width  = one wavefront of columns
+constexpr int kWavesPerBlock = 4;   // assign block = 4 wavefronts stacked vertically
+constexpr int kRowsPerWave = 8;     // visited rows per wavefront
+constexpr int kCellCap = 8;         // cluster records per coarse cell before spilling to overflow
+constexpr int kMaxRaw = 1024;       // gathered candidate records per block (LDS)
+constexpr int kMaxList = 256;       // sorted + de-duplicated candidates per block (LDS)
+constexpr int kAccSlots = 32;       // candidates with LDS-privatised centroid sums
+constexpr int kAccCopies = 8;       // privatised copies per (slot, quantity)
+constexpr uint32_t kHuge = 0x40000000u;   // out-of-window marker added to the distance key
+constexpr int kCcaTile = 64;        // connectivity tile: 64 x 64 pixels, one block of 256 threads
+
+// One cluster as the kernels see it (16 B, one ds_read_b128 / global_load_dwordx4).
+//   yx  = y << 16 | x          (integer centre, src/context.cpp:262 casts to int16)
+//   lab = L | a << 8 | b << 16 (integer colour, always <= 255 per channel)
+//   tag = phase << 16 | k      visit order of the reference's scatter (src/context.cpp:214-242)
+struct ClusterRec {
+    uint32_t yx, lab, tag, pad;
+};
+
+// Per-frame device state that every kernel of the frame shares.
+struct FrameDev {
+    // geometry
+    int H, W, N, K, S;
+    int T;               // 2S + 32, phase cell side (src/context.cpp:213)
+    int cs_shift;        // coarse bin side = 1 << cs_shift
+    int ncx, ncy, ncell;
+    uint32_t M;          // spatial fixed point: patch[d] == (d * M) >> 16 for d in [0, 2S]
+    // image planes
+    const uint8_t* rgb;  // N*3
+    uint32_t* lab;       // N, L|a<<8|b<<16
+    uint16_t* labels;    // N, pre-connectivity assignment (persists across iterations)
+    // cluster state (SoA)
+    uint32_t* cl_yx;     // K
+    uint32_t* cl_lab;    // K
+    uint32_t* cl_tag;    // K  phase << 16 | k of the current centres
+    uint32_t* cl_n;      // K  num_members of the last update
+    uint32_t* cl_moved;  // K  1 once an update with n > 0 has moved the cluster
+    uint32_t* sums;      // K*6: count, sum y, sum x, sum L, sum a, sum b (zero between iterations)
+    // coarse bins, double buffered by iteration parity
+    uint32_t* cell_cnt[2];     // ncell
+    ClusterRec* cell_items[2]; // ncell * kCellCap
+    uint32_t* ovf_cnt[2];      // 1
+    ClusterRec* ovf_items[2];  // K
+    uint32_t* err_flag;        // != 0: a block overflowed its LDS candidate list -> host reruns generic
+    // generic-path tables
+    const uint16_t* patch2d;   // (2S+1)^2, src/context.cpp:22-40
+};
+
+struct CcaDev {
+    int H, W, N, K;
+    int min_threshold;
+    const uint16_t* in;   // N labels
+    uint16_t* out;        // N labels (may alias in)
+    int32_t* parent;      // N
+    uint32_t* area;       // N (sparse: valid at tile-local roots)
+    uint16_t* final_lab;  // N (sparse: valid at global roots)
+    int32_t* roots;       // N  list of tile-local roots
+    uint32_t* counters;   // [0] = #roots, [1] = #candidates (area >= threshold)
+    int32_t* cand_leader; // N
+    uint32_t* cand_area;  // N
+};
+
+struct LabTables {
+    const uint16_t* gamma;   // 256   src/cielab.h:298-299
+    const uint16_t* labtbl;  // 8193  src/cielab.h:302-304
+    int cb[9];               //       src/cielab.h:300-301
+};
+
+// ---- launches (all asynchronous on `st`) ----------------------------------------------------
+void launch_rgb_to_lab(const uint8_t* rgb, uint32_t* lab, int N, int convert, const LabTables& t, hipStream_t st);
+void launch_fill_u16(uint16_t* p, int n, uint16_t v, hipStream_t st);
+// mode 0: resample colours at the current centres (src/context.cpp:128-135) and bin;
+// mode 1: integer centroid update from `sums` (src/context.cpp:356-373), zero sums, and bin.
+void launch_bin_clusters(const FrameDev& f, int mode, int buf, hipStream_t st);
+// One assign pass over rows == rem (mod stride); fuse_update also accumulates the centroid sums
+// of src/context.cpp:301-354 for the same rows.
+void launch_assign(const FrameDev& f, int rem, int stride, int buf, bool fuse_update, hipStream_t st);
+void launch_assign_generic(const FrameDev& f, int rem, int stride, int buf, bool fuse_update, hipStream_t st);
+// connectivity
+void launch_cca_phase1(const CcaDev& c, hipStream_t st);   // local CCL, border merge, compress, collect
+void launch_cca_set_kept(const CcaDev& c, const int32_t* d_leaders, const uint16_t* d_labels, int n, hipStream_t st);
+void launch_cca_phase2(const CcaDev& c, hipStream_t st);   // chain resolution + relabel
+
+}  // namespace fslic

@@ -1,0 +1,727 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the SLIC hot path.
+//
+// Nothing here is a translation of the reference's AVX2/NEON code.  The reference *scatters*:
+// each cluster min-updates a (2S+1)^2 window, clusters visited in (phase, k) order
+// (src/context.cpp:199-298, src/arch/x64/avx2.h:89-187).  These kernels *gather*: every pixel
+// takes the lexicographic minimum of (distance, phase, k) over the clusters whose window covers
+// it, which is the same function of the inputs and needs no min_dists plane in memory.
+//
+// All arithmetic on this path is integer, so the results are bit-identical to the reference.
+#include "kernels.h"
+
+namespace fslic {
+
+#define LANE() (threadIdx.x & 63)
+
+static __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// =============================================================================================
+// RGB -> CIELAB prepass.  Restates FastCIELabCvt::convert (src/cielab.h:309-325) with both lookup
+// tables staged in LDS (16.5 KB); 4 pixels per thread: 3 dword loads in, one 16-byte store out.
+// Algorithmic traffic: 3 B read + 4 B written per pixel.
+// =============================================================================================
+struct LabConst { int cb[9]; };
+
+static __device__ __forceinline__ uint32_t lab_px(uint32_t R, uint32_t G, uint32_t B,
+                                                  const uint16_t* sg, const uint16_t* sl, const LabConst& k) {
+    const int sr = sg[R], sgv = sg[G], sb = sg[B];
+    const int xr = (k.cb[0] * sr + k.cb[1] * sgv + k.cb[2] * sb) >> 16;
+    const int yr = (k.cb[3] * sr + k.cb[4] * sgv + k.cb[5] * sb) >> 16;
+    const int zr = (k.cb[6] * sr + k.cb[7] * sgv + k.cb[8] * sb) >> 16;
+    const int fx = sl[xr], fy = sl[yr], fz = sl[zr];
+    const int ciel = 116 * fy - (16 << 13);
+    const int ciea = 500 * (fx - fy) + (128 << 13);
+    const int cieb = 200 * (fy - fz) + (128 << 13);
+    int l = (int)((unsigned)ciel >> 12);
+    int a = (int)((unsigned)ciea >> 12) - 128;
+    int b = (int)((unsigned)cieb >> 12) - 128;
+    l = min(max(l, 0), 255);
+    a = min(max(a, 0), 255);
+    b = min(max(b, 0), 255);
+    return (uint32_t)l | ((uint32_t)a << 8) | ((uint32_t)b << 16);
+}
+
+template <bool CONVERT>
+__global__ __launch_bounds__(1024) void k_rgb_to_lab(const uint8_t* __restrict__ rgb, uint32_t* __restrict__ lab,
+                                                     int N, const uint16_t* __restrict__ g_gamma,
+                                                     const uint16_t* __restrict__ g_labtbl, LabConst kc, int aligned4) {
+    __shared__ uint16_t s_gamma[256];
+    __shared__ uint16_t s_lab[8194];
+    if (CONVERT) {
+        for (int i = threadIdx.x; i < 128; i += blockDim.x)
+            reinterpret_cast<uint32_t*>(s_gamma)[i] = reinterpret_cast<const uint32_t*>(g_gamma)[i];
+        for (int i = threadIdx.x; i < 4097; i += blockDim.x)   // 8194 entries (last one padding)
+            reinterpret_cast<uint32_t*>(s_lab)[i] = reinterpret_cast<const uint32_t*>(g_labtbl)[i];
+        __syncthreads();
+    }
+    const int nquad = aligned4 ? (N >> 2) : 0;
+    const int gstride = gridDim.x * blockDim.x;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += gstride) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(rgb) + 3 * (size_t)q;
+        const uint32_t w0 = src[0], w1 = src[1], w2 = src[2];
+        uint32_t r0 = w0 & 255, g0 = (w0 >> 8) & 255, b0 = (w0 >> 16) & 255;
+        uint32_t r1 = w0 >> 24, g1 = w1 & 255, b1 = (w1 >> 8) & 255;
+        uint32_t r2 = (w1 >> 16) & 255, g2 = w1 >> 24, b2 = w2 & 255;
+        uint32_t r3 = (w2 >> 8) & 255, g3 = (w2 >> 16) & 255, b3 = w2 >> 24;
+        uint4 o;
+        if (CONVERT) {
+            o.x = lab_px(r0, g0, b0, s_gamma, s_lab, kc);
+            o.y = lab_px(r1, g1, b1, s_gamma, s_lab, kc);
+            o.z = lab_px(r2, g2, b2, s_gamma, s_lab, kc);
+            o.w = lab_px(r3, g3, b3, s_gamma, s_lab, kc);
+        } else {   // raw copy, src/context.cpp:117-127
+            o.x = r0 | (g0 << 8) | (b0 << 16);
+            o.y = r1 | (g1 << 8) | (b1 << 16);
+            o.z = r2 | (g2 << 8) | (b2 << 16);
+            o.w = r3 | (g3 << 8) | (b3 << 16);
+        }
+        reinterpret_cast<uint4*>(lab)[q] = o;
+    }
+    // tail (and the whole image when the source pointer is not 4-byte aligned)
+    for (int p = (nquad << 2) + blockIdx.x * blockDim.x + threadIdx.x; p < N; p += gstride) {
+        const uint32_t r = rgb[3 * (size_t)p], g = rgb[3 * (size_t)p + 1], b = rgb[3 * (size_t)p + 2];
+        lab[p] = CONVERT ? lab_px(r, g, b, s_gamma, s_lab, kc) : (r | (g << 8) | (b << 16));
+    }
+}
+
+void launch_rgb_to_lab(const uint8_t* rgb, uint32_t* lab, int N, int convert, const LabTables& t, hipStream_t st) {
+    LabConst kc;
+    for (int i = 0; i < 9; i++) kc.cb[i] = t.cb[i];
+    const int aligned4 = ((reinterpret_cast<uintptr_t>(rgb) & 3) == 0) ? 1 : 0;
+    int blocks = (N / 4 + 1023) / 1024;
+    if (blocks > 256) blocks = 256;   // one resident block per CU, grid-stride: tables are staged once per block
+    if (blocks < 1) blocks = 1;
+    if (convert)
+        hipLaunchKernelGGL(k_rgb_to_lab<true>, dim3(blocks), dim3(1024), 0, st, rgb, lab, N, t.gamma, t.labtbl, kc, aligned4);
+    else
+        hipLaunchKernelGGL(k_rgb_to_lab<false>, dim3(blocks), dim3(1024), 0, st, rgb, lab, N, t.gamma, t.labtbl, kc, aligned4);
+}
+
+__global__ void k_fill_u16(uint32_t* p, int nwords, uint32_t v, uint16_t* tailp, int tail) {
+    const int gstride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += gstride) p[i] = v;
+    if (tail && blockIdx.x == 0 && threadIdx.x == 0) *tailp = (uint16_t)v;
+}
+void launch_fill_u16(uint16_t* p, int n, uint16_t v, hipStream_t st) {
+    const int nwords = n >> 1;
+    int blocks = (nwords + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_fill_u16, dim3(blocks), dim3(256), 0, st, reinterpret_cast<uint32_t*>(p), nwords,
+                       (uint32_t)v | ((uint32_t)v << 16), p + (n - 1), n & 1);
+}
+
+// =============================================================================================
+// Cluster pass (K threads): centroid finalisation + coarse binning.
+//   mode 0: colour resample at the centre, src/context.cpp:128-135
+//   mode 1: integer mean of the accumulated sums, src/context.cpp:356-373 (round_int,
+//           src/fast-slic-common.h:62-65), num_members written even when it is 0 (:362-364)
+// Then every cluster record {yx, lab, phase<<16|k} is appended to the coarse cell containing
+// its centre (spill list when a cell is full).  The other parity's counters are cleared for the
+// next iteration, so no per-iteration memset launch is needed.
+// =============================================================================================
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, int buf) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < f.ncell) f.cell_cnt[buf ^ 1][k] = 0;
+    if (k == 0) *f.ovf_cnt[buf ^ 1] = 0;
+    if (k >= f.K) return;
+    uint32_t yx = f.cl_yx[k];
+    int y = (int)(yx >> 16), x = (int)(yx & 0xFFFF);
+    uint32_t lab;
+    if (MODE == 0) {
+        lab = f.lab[(size_t)y * f.W + x] & 0x00FFFFFFu;
+        f.cl_lab[k] = lab;
+    } else {
+        lab = f.cl_lab[k];
+        uint32_t* s = f.sums + 6 * (size_t)k;
+        const int32_t n = (int32_t)s[0];
+        f.cl_n[k] = (uint32_t)n;
+        if (n != 0) {
+            const int32_t h = n / 2;
+            y = ((int32_t)s[1] + h) / n;
+            x = ((int32_t)s[2] + h) / n;
+            const int32_t L = ((int32_t)s[3] + h) / n;
+            const int32_t a = ((int32_t)s[4] + h) / n;
+            const int32_t b = ((int32_t)s[5] + h) / n;
+            yx = ((uint32_t)y << 16) | (uint32_t)(x & 0xFFFF);
+            lab = (uint32_t)(L & 255) | ((uint32_t)(a & 255) << 8) | ((uint32_t)(b & 255) << 16);
+            f.cl_yx[k] = yx;
+            f.cl_lab[k] = lab;
+            f.cl_moved[k] = 1;
+        }
+        s[0] = 0; s[1] = 0; s[2] = 0; s[3] = 0; s[4] = 0; s[5] = 0;
+    }
+    // visit order of the reference scatter: phase = 2*((cy/T)&1) + ((cx/T)&1), then k
+    const uint32_t phase = (uint32_t)(2 * ((y / f.T) & 1) + ((x / f.T) & 1));
+    ClusterRec rec;
+    rec.yx = yx; rec.lab = lab; rec.tag = (phase << 16) | (uint32_t)k; rec.pad = 0;
+    f.cl_tag[k] = rec.tag;
+    const int cell = (y >> f.cs_shift) * f.ncx + (x >> f.cs_shift);
+    const uint32_t slot = atomicAdd(&f.cell_cnt[buf][cell], 1u);
+    if (slot < (uint32_t)kCellCap) {
+        f.cell_items[buf][(size_t)cell * kCellCap + slot] = rec;
+    } else {
+        const uint32_t o = atomicAdd(f.ovf_cnt[buf], 1u);
+        f.ovf_items[buf][o] = rec;
+    }
+}
+
+void launch_bin_clusters(const FrameDev& f, int mode, int buf, hipStream_t st) {
+    const int n = f.K > f.ncell ? f.K : f.ncell;
+    const int blocks = (n + 255) / 256;
+    if (mode == 0) hipLaunchKernelGGL(k_bin_clusters<0>, dim3(blocks), dim3(256), 0, st, f, buf);
+    else hipLaunchKernelGGL(k_bin_clusters<1>, dim3(blocks), dim3(256), 0, st, f, buf);
+}
+
+// =============================================================================================
+// Assign kernel (the roofline kernel).  One block = 64 columns x (4 wavefronts x R visited rows).
+// Lane = column, so |x - cx| and the x window test are per-lane-per-candidate, while |y - cy| and
+// the y window test are wave-uniform per row and live in SGPRs.  Per pixel-candidate the VALU does
+//     a   = A + B                      (spatial term, 16 fractional bits, window folded in as kHuge)
+//     w   = v_sad_hi_u8(pix, clab, a)  ((|dL|+|da|+|db|) << 16) + a
+//     key = (w & 0xffff0000) | idx     idx = rank of the candidate in (phase, k) order
+//     best = min(best, key)
+// so `best` ends up as the lexicographic minimum of (distance, phase, k).  Pixels that no window
+// covers are not written: the previous label persists (src/context.cpp:138-145 clears the
+// assignment plane once per call, not per iteration).
+// Algorithmic traffic: 4 B read + 2 B written per visited pixel; min-distances never leave VGPRs.
+// With FUSE the centroid sums of update() (src/context.cpp:301-354) for the same rows are
+// accumulated in LDS (privatised copies) and flushed with one global atomic per (candidate,
+// quantity) and block.
+// =============================================================================================
+static __device__ __forceinline__ void global_accumulate(uint32_t* sums, uint32_t k, uint32_t y, uint32_t x, uint32_t pix) {
+    uint32_t* s = sums + 6 * (size_t)k;
+    atomicAdd(s + 0, 1u);
+    atomicAdd(s + 1, y);
+    atomicAdd(s + 2, x);
+    atomicAdd(s + 3, pix & 255u);
+    atomicAdd(s + 4, (pix >> 8) & 255u);
+    atomicAdd(s + 5, (pix >> 16) & 255u);
+}
+
+template <int R, bool FUSE>
+__global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride, int Hv, int buf) {
+    // raw gather arrays are dead once the sorted list exists; the centroid accumulators reuse them
+    __shared__ uint32_t s_raw[3 * kMaxRaw];
+    __shared__ uint4 s_list[kMaxList];
+    __shared__ uint8_t s_dup[kMaxRaw];
+    __shared__ uint32_t s_cnt[2];
+    uint32_t* const s_raw_yx = s_raw;
+    uint32_t* const s_raw_lab = s_raw + kMaxRaw;
+    uint32_t* const s_raw_tag = s_raw + 2 * kMaxRaw;
+    uint32_t* const s_acc = s_raw;   // kAccSlots * 6 * kAccCopies words (after the list is built)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = (int)rfl((uint32_t)(tid >> 6));
+    const int W = f.W, S = f.S;
+    const int x0 = blockIdx.x * kTileW;
+    const int x = x0 + lane;
+    const int vrow_b0 = blockIdx.y * (kWavesPerBlock * R);
+    const int vrow_w0 = vrow_b0 + wave * R;
+    const int yw_lo = rem + vrow_w0 * stride;
+    const bool okx = x < W;
+
+    if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
+
+    // 1. issue the pixel loads first; they do not depend on the candidate list
+    uint32_t pix[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const bool ok = okx && (vrow_w0 + r) < Hv;
+        pix[r] = ok ? f.lab[(size_t)(yw_lo + r * stride) * W + x] : 0u;
+    }
+    __syncthreads();
+
+    // 2. gather the clusters whose window can touch this block from the coarse cells
+    {
+        const int vlast = min(vrow_b0 + kWavesPerBlock * R - 1, Hv - 1);
+        const int yb_lo = rem + vrow_b0 * stride, yb_hi = rem + vlast * stride;
+        const int xb_hi = min(x0 + kTileW - 1, W - 1);
+        const int wy_lo = yb_lo - S, wy_hi = yb_hi + S, wx_lo = x0 - S, wx_hi = xb_hi + S;
+        const int sh = f.cs_shift;
+        const int cxa = max(wx_lo, 0) >> sh, cxb = min(wx_hi, W - 1) >> sh;
+        const int cya = max(wy_lo, 0) >> sh, cyb = min(wy_hi, f.H - 1) >> sh;
+        const int ncxr = cxb - cxa + 1, ncyr = cyb - cya + 1;
+        const int total = ncxr * ncyr * kCellCap;
+        const uint32_t* __restrict__ ccnt = f.cell_cnt[buf];
+        const ClusterRec* __restrict__ citems = f.cell_items[buf];
+        for (int i = tid; i < total; i += 256) {
+            const int slot = i & (kCellCap - 1);
+            const int c = i / kCellCap;
+            const int cyi = c / ncxr;
+            const int cell = (cya + cyi) * f.ncx + cxa + (c - cyi * ncxr);
+            const uint32_t cnt = ccnt[cell];
+            if ((uint32_t)slot < cnt) {
+                const ClusterRec rec = citems[(size_t)cell * kCellCap + slot];
+                const int cy = (int)(rec.yx >> 16), cx = (int)(rec.yx & 0xFFFF);
+                if (cy >= wy_lo && cy <= wy_hi && cx >= wx_lo && cx <= wx_hi) {
+                    const uint32_t pos = atomicAdd(&s_cnt[0], 1u);
+                    if (pos < (uint32_t)kMaxRaw) { s_raw_yx[pos] = rec.yx; s_raw_lab[pos] = rec.lab; s_raw_tag[pos] = rec.tag; }
+                }
+            }
+        }
+        const uint32_t novf = *f.ovf_cnt[buf];
+        const ClusterRec* __restrict__ oitems = f.ovf_items[buf];
+        for (uint32_t i = tid; i < novf; i += 256) {
+            const ClusterRec rec = oitems[i];
+            const int cy = (int)(rec.yx >> 16), cx = (int)(rec.yx & 0xFFFF);
+            if (cy >= wy_lo && cy <= wy_hi && cx >= wx_lo && cx <= wx_hi) {
+                const uint32_t pos = atomicAdd(&s_cnt[0], 1u);
+                if (pos < (uint32_t)kMaxRaw) { s_raw_yx[pos] = rec.yx; s_raw_lab[pos] = rec.lab; s_raw_tag[pos] = rec.tag; }
+            }
+        }
+    }
+    __syncthreads();
+    int nraw = (int)s_cnt[0];
+    if (nraw > kMaxRaw) { nraw = kMaxRaw; if (tid == 0) *f.err_flag = 1u; }
+
+    // 3a. exact prune: a cluster with the same integer (y, x, L, a, b) as an earlier-ordered one has the
+    //     same distance everywhere and loses every tie, so it can never win a pixel.
+    for (int i = tid; i < nraw; i += 256) {
+        const uint32_t yx = s_raw_yx[i], lb = s_raw_lab[i], tg = s_raw_tag[i];
+        uint32_t dup = 0;
+        for (int j = 0; j < nraw; ++j)
+            dup |= (uint32_t)(s_raw_tag[j] < tg && s_raw_yx[j] == yx && s_raw_lab[j] == lb);
+        s_dup[i] = (uint8_t)dup;
+    }
+    __syncthreads();
+    // 3b. rank the survivors by (phase, k): list index order == visit order of the reference
+    for (int i = tid; i < nraw; i += 256) {
+        if (s_dup[i]) continue;
+        const uint32_t tg = s_raw_tag[i];
+        int rank = 0;
+        for (int j = 0; j < nraw; ++j) rank += (int)(s_raw_tag[j] < tg && !s_dup[j]);
+        if (rank < kMaxList) s_list[rank] = make_uint4(s_raw_yx[i], s_raw_lab[i], tg & 0xFFFFu, 0u);
+        atomicAdd(&s_cnt[1], 1u);
+    }
+    __syncthreads();
+    int n = (int)s_cnt[1];
+    if (n > kMaxList) { n = kMaxList; if (tid == 0) *f.err_flag = 1u; }
+    if (FUSE) {
+        for (int i = tid; i < kAccSlots * 6 * kAccCopies; i += 256) s_acc[i] = 0u;
+        __syncthreads();
+    }
+
+    // 4. the argmin
+    uint32_t best[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) best[r] = 0xFFFFFFFFu;
+    const uint32_t M = f.M;
+    const int yw_hi = yw_lo + (R - 1) * stride;
+#pragma unroll 1
+    for (int c = 0; c < n; ++c) {
+        const uint4 rec = s_list[c];
+        const uint32_t cyx = rfl(rec.x);
+        const uint32_t clab = rfl(rec.y);
+        const int cy = (int)(cyx >> 16), cx = (int)(cyx & 0xFFFFu);
+        if (cy + S < yw_lo || cy - S > yw_hi) continue;   // wave-uniform cull
+        const int dx = x - cx;
+        const uint32_t ux = (uint32_t)(dx < 0 ? -dx : dx);
+        const uint32_t A = ux <= (uint32_t)S ? __umul24(ux, M) : kHuge;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int dy = yw_lo + r * stride - cy;
+            const uint32_t uy = (uint32_t)(dy < 0 ? -dy : dy);
+            const uint32_t B = uy <= (uint32_t)S ? uy * M : kHuge;   // SALU
+            const uint32_t w = __builtin_amdgcn_sad_hi_u8(pix[r], clab, A + B);
+            const uint32_t key = (w & 0xFFFF0000u) | (uint32_t)c;
+            best[r] = min(best[r], key);
+        }
+    }
+
+    // 5. write labels (+ fused centroid sums)
+    uint32_t slot[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int y = yw_lo + r * stride;
+        const bool ok = okx && (vrow_w0 + r) < Hv;
+        const bool found = best[r] < kHuge;
+        const uint32_t idx = found ? (best[r] & 0xFFFFu) : 0u;
+        const uint32_t k = s_list[idx].z;
+        slot[r] = 0xFFFFFFFFu;
+        if (ok) {
+            const size_t p = (size_t)y * W + x;
+            if (found) {
+                f.labels[p] = (uint16_t)k;
+                if (FUSE) {
+                    if (idx < (uint32_t)kAccSlots) slot[r] = idx;
+                    else global_accumulate(f.sums, k, (uint32_t)y, (uint32_t)x, pix[r]);
+                }
+            } else if (FUSE) {
+                const uint32_t old = f.labels[p];     // stale label still takes part in update()
+                if (old != 0xFFFFu) global_accumulate(f.sums, old, (uint32_t)y, (uint32_t)x, pix[r]);
+            }
+        }
+    }
+    if (FUSE) {
+        bool uni = slot[0] != 0xFFFFFFFFu;
+#pragma unroll
+        for (int r = 1; r < R; ++r) uni = uni && (slot[r] == slot[0]);
+        const uint32_t copy = (uint32_t)lane & (kAccCopies - 1);
+        if (uni) {   // whole column in one superpixel: one set of LDS atomics for R pixels
+            uint32_t sL = 0, sa = 0, sb = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { sL += pix[r] & 255u; sa += (pix[r] >> 8) & 255u; sb += (pix[r] >> 16) & 255u; }
+            uint32_t* a = s_acc + (slot[0] * 6) * kAccCopies + copy;
+            atomicAdd(a + 0 * kAccCopies, (uint32_t)R);
+            atomicAdd(a + 1 * kAccCopies, (uint32_t)(R * yw_lo + stride * (R * (R - 1) / 2)));
+            atomicAdd(a + 2 * kAccCopies, (uint32_t)(R * x));
+            atomicAdd(a + 3 * kAccCopies, sL);
+            atomicAdd(a + 4 * kAccCopies, sa);
+            atomicAdd(a + 5 * kAccCopies, sb);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (slot[r] != 0xFFFFFFFFu) {
+                    uint32_t* a = s_acc + (slot[r] * 6) * kAccCopies + copy;
+                    atomicAdd(a + 0 * kAccCopies, 1u);
+                    atomicAdd(a + 1 * kAccCopies, (uint32_t)(yw_lo + r * stride));
+                    atomicAdd(a + 2 * kAccCopies, (uint32_t)x);
+                    atomicAdd(a + 3 * kAccCopies, pix[r] & 255u);
+                    atomicAdd(a + 4 * kAccCopies, (pix[r] >> 8) & 255u);
+                    atomicAdd(a + 5 * kAccCopies, (pix[r] >> 16) & 255u);
+                }
+            }
+        }
+        __syncthreads();
+        const int nacc = min(n, kAccSlots) * 6;
+        for (int i = tid; i < nacc; i += 256) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int c = 0; c < kAccCopies; ++c) v += s_acc[i * kAccCopies + c];
+            if (v) {
+                const int sl = i / 6;
+                atomicAdd(f.sums + 6 * (size_t)s_list[sl].z + (i - sl * 6), v);
+            }
+        }
+    }
+}
+
+void launch_assign(const FrameDev& f, int rem, int stride, int buf, bool fuse_update, hipStream_t st) {
+    const int Hv = (f.H - rem + stride - 1) / stride;
+    if (Hv <= 0) return;
+    constexpr int R = kRowsPerWave;
+    dim3 grid((f.W + kTileW - 1) / kTileW, (Hv + kWavesPerBlock * R - 1) / (kWavesPerBlock * R));
+    if (fuse_update) hipLaunchKernelGGL((k_assign<R, true>), grid, dim3(256), 0, st, f, rem, stride, Hv, buf);
+    else hipLaunchKernelGGL((k_assign<R, false>), grid, dim3(256), 0, st, f, rem, stride, Hv, buf);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic gather: one thread per visited pixel, candidates read straight from the coarse cells,
+// 64-bit key (u16 distance << 32 | phase << 16 | k), spatial term from the (2S+1)^2 patch itself and
+// the distance wrapped to 16 bits exactly like src/context.cpp:285-286.  It is the fallback for inputs
+// the tiled kernel does not take (candidate-list overflow, S < 8, non-Manhattan patch, no exact
+// fixed-point multiplier) and an independent cross-check of the tiled kernel in the tests.
+// ---------------------------------------------------------------------------------------------
+static __device__ __forceinline__ void generic_test(const ClusterRec& rec, int y, int x, int S, int P, uint32_t pix,
+                                                    const uint16_t* __restrict__ patch, unsigned long long& best) {
+    const int dy = y - (int)(rec.yx >> 16), dx = x - (int)(rec.yx & 0xFFFFu);
+    if (dy < -S || dy > S || dx < -S || dx > S) return;
+    const uint32_t sp = patch[(dy + S) * P + (dx + S)];
+    const uint32_t d = (sp + __builtin_amdgcn_sad_u8(pix, rec.lab, 0u)) & 0xFFFFu;
+    const unsigned long long key = ((unsigned long long)d << 32) | rec.tag;
+    best = key < best ? key : best;
+}
+
+template <bool FUSE>
+__global__ __launch_bounds__(256) void k_assign_generic(FrameDev f, int rem, int stride, int Hv, int buf) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)Hv * f.W) return;
+    const int v = (int)(i / f.W), x = (int)(i - (size_t)v * f.W);
+    const int y = rem + v * stride;
+    const size_t p = (size_t)y * f.W + x;
+    const uint32_t pix = f.lab[p];
+    const int S = f.S, P = 2 * S + 1, sh = f.cs_shift;
+    unsigned long long best = ~0ull;
+    const int cxa = max(x - S, 0) >> sh, cxb = min(x + S, f.W - 1) >> sh;
+    const int cya = max(y - S, 0) >> sh, cyb = min(y + S, f.H - 1) >> sh;
+    for (int cyi = cya; cyi <= cyb; ++cyi)
+        for (int cxi = cxa; cxi <= cxb; ++cxi) {
+            const int cell = cyi * f.ncx + cxi;
+            const uint32_t cnt = min(f.cell_cnt[buf][cell], (uint32_t)kCellCap);
+            for (uint32_t s = 0; s < cnt; ++s)
+                generic_test(f.cell_items[buf][(size_t)cell * kCellCap + s], y, x, S, P, pix, f.patch2d, best);
+        }
+    const uint32_t novf = *f.ovf_cnt[buf];
+    for (uint32_t s = 0; s < novf; ++s) generic_test(f.ovf_items[buf][s], y, x, S, P, pix, f.patch2d, best);
+    uint32_t lbl;
+    if (best != ~0ull) { lbl = (uint32_t)(best & 0xFFFFull); f.labels[p] = (uint16_t)lbl; }
+    else lbl = f.labels[p];
+    if (FUSE && lbl != 0xFFFFu) global_accumulate(f.sums, lbl, (uint32_t)y, (uint32_t)x, pix);
+}
+
+void launch_assign_generic(const FrameDev& f, int rem, int stride, int buf, bool fuse_update, hipStream_t st) {
+    const int Hv = (f.H - rem + stride - 1) / stride;
+    if (Hv <= 0) return;
+    const size_t n = (size_t)Hv * f.W;
+    const int blocks = (int)((n + 255) / 256);
+    if (fuse_update) hipLaunchKernelGGL(k_assign_generic<true>, dim3(blocks), dim3(256), 0, st, f, rem, stride, Hv, buf);
+    else hipLaunchKernelGGL(k_assign_generic<false>, dim3(blocks), dim3(256), 0, st, f, rem, stride, Hv, buf);
+}
+
+// =============================================================================================
+// Connectivity / min-size pass (src/cca.cpp).  GPU union-find whose roots are the minimum raster
+// index of each component, exactly the "leader" the reference ends up with (src/cca.h:36-57).
+//   k_cca_local    64x64 tiles resolved entirely in LDS (row runs by ballot, vertical unions by LDS
+//                  atomicMin), writes parent[p] = global index of the tile-local root, tile-local
+//                  areas, and appends tile-local roots to a list
+//   k_cca_border   unions across tile borders (global atomicMin)
+//   k_cca_compress tile-local roots -> global roots, areas summed into the global root
+//   k_cca_collect  global roots with area >= threshold -> candidate list for the top-K step
+//   (host)         std::partial_sort / ranking of <= few thousand (leader, area) pairs
+//   k_cca_chain    every other component takes the final label of the component left of (or
+//                  above) its leader, src/cca.cpp:240-254, resolved by chasing toward smaller leaders
+//   k_cca_relabel  out[p] = final[root(p)]
+// =============================================================================================
+// find with path halving.  The halving store races with concurrent atomicMin hooks, which is safe:
+// it only ever replaces a parent by one of its ancestors (cf. ECL-CC style concurrent union-find).
+static __device__ __forceinline__ uint32_t lds_find(volatile uint32_t* par, uint32_t x) {
+    for (;;) {
+        const uint32_t p = par[x];
+        if (p == x) return x;
+        const uint32_t gp = par[p];
+        if (gp == p) return p;
+        par[x] = gp;
+        x = gp;
+    }
+}
+static __device__ __forceinline__ void lds_union(volatile uint32_t* par, uint32_t a, uint32_t b) {
+    for (;;) {
+        a = lds_find(par, a);
+        b = lds_find(par, b);
+        if (a == b) return;
+        if (a < b) { const uint32_t t = a; a = b; b = t; }
+        const uint32_t old = atomicMin(const_cast<uint32_t*>(par) + a, b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cca_local(CcaDev c) {
+    constexpr int T = kCcaTile;
+    __shared__ uint16_t s_lbl[T * T];
+    __shared__ uint32_t s_par[T * T];
+    __shared__ uint32_t s_area[T * T];
+    const int lane = LANE(), wave = threadIdx.x >> 6;
+    const int tx0 = blockIdx.x * T, ty0 = blockIdx.y * T;
+    const int x = tx0 + lane;
+    const bool okx = x < c.W;
+    // pass 1: labels -> LDS, horizontal runs: parent = first lane of the run
+    for (int ly = wave * (T / 4); ly < (wave + 1) * (T / 4); ++ly) {
+        const int y = ty0 + ly;
+        const bool ok = okx && y < c.H;
+        const uint32_t lbl = ok ? (uint32_t)c.in[(size_t)y * c.W + x] : 0x10000u;
+        const uint32_t left = __shfl_up(lbl, 1);
+        const bool start = (lane == 0) || (lbl != left) || !ok;
+        const unsigned long long m = __ballot(start);
+        const unsigned long long lower = m & ((2ull << lane) - 1ull);
+        const int rs = 63 - __clzll(lower);
+        s_lbl[ly * T + lane] = (uint16_t)lbl;
+        s_par[ly * T + lane] = (uint32_t)(ly * T + rs);
+        s_area[ly * T + lane] = 0u;
+    }
+    __syncthreads();
+    // pass 2: vertical unions, one per horizontal overlap of two runs
+    for (int ly = wave * (T / 4); ly < (wave + 1) * (T / 4); ++ly) {
+        if (ly == 0) continue;
+        const int y = ty0 + ly;
+        const bool ok = okx && y < c.H;
+        if (!ok) continue;
+        const int p = ly * T + lane;
+        const uint16_t lbl = s_lbl[p];
+        if (s_lbl[p - T] == lbl) {
+            const bool first = (lane == 0) || s_lbl[p - 1] != lbl || s_lbl[p - T - 1] != lbl;
+            if (first) lds_union(s_par, (uint32_t)p, (uint32_t)(p - T));
+        }
+    }
+    __syncthreads();
+    // pass 3: flatten, publish parent, count members per run
+    for (int ly = wave * (T / 4); ly < (wave + 1) * (T / 4); ++ly) {
+        const int y = ty0 + ly;
+        const bool ok = okx && y < c.H;
+        const int p = ly * T + lane;
+        uint32_t r = 0xFFFFFFFFu;
+        if (ok) {
+            r = lds_find(s_par, (uint32_t)p);
+            s_par[p] = r;
+            c.parent[(size_t)y * c.W + x] = (int32_t)((size_t)(ty0 + (int)(r / T)) * c.W + tx0 + (int)(r % T));
+        }
+        const uint32_t rl = __shfl_up(r, 1);
+        const bool start = (lane == 0) || (r != rl) || !ok;
+        const unsigned long long m = __ballot(start);
+        if (ok && start) {
+            const unsigned long long higher = (lane == 63) ? 0ull : (m >> (lane + 1));
+            const int len = higher ? (__ffsll((long long)higher)) : (64 - lane);
+            atomicAdd(&s_area[r], (uint32_t)len);
+        }
+    }
+    __syncthreads();
+    // pass 4: tile-local roots -> area plane + root list (one global atomic per wavefront row)
+    for (int ly = wave * (T / 4); ly < (wave + 1) * (T / 4); ++ly) {
+        const int y = ty0 + ly;
+        const bool ok = okx && y < c.H;
+        const int p = ly * T + lane;
+        const bool isroot = ok && s_par[p] == (uint32_t)p;
+        const unsigned long long m = __ballot(isroot);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&c.counters[0], (uint32_t)__popcll(m));
+            base = __shfl(base, leader);
+            if (isroot) {
+                const int32_t g = (int32_t)((size_t)y * c.W + x);
+                c.area[g] = s_area[p];
+                c.roots[base + __popcll(m & ((1ull << lane) - 1ull))] = g;
+            }
+        }
+    }
+}
+
+static __device__ __forceinline__ int32_t g_load(int32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static __device__ __forceinline__ int32_t g_find(int32_t* parent, int32_t x) {
+    for (;;) {
+        const int32_t p = g_load(parent + x);
+        if (p == x) return x;
+        const int32_t gp = g_load(parent + p);
+        if (gp == p) return p;
+        __hip_atomic_store(parent + x, gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x = gp;
+    }
+}
+static __device__ __forceinline__ void g_union(int32_t* parent, int32_t a, int32_t b) {
+    for (;;) {
+        a = g_find(parent, a);
+        b = g_find(parent, b);
+        if (a == b) return;
+        if (a < b) { const int32_t t = a; a = b; b = t; }
+        const int32_t old = atomicMin(parent + a, b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cca_border(CcaDev c, int nh, int nv) {
+    constexpr int T = kCcaTile;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int W = c.W, H = c.H;
+    if (i < nh) {            // pixel on the first row of a tile row, merge with the pixel above
+        const int by = i / W + 1, x = i - (by - 1) * W;
+        const int p = by * T * W + x;
+        const uint16_t lbl = c.in[p];
+        if (c.in[p - W] == lbl) {
+            const bool first = (x % T == 0) || c.in[p - 1] != lbl || c.in[p - W - 1] != lbl;
+            if (first) g_union(c.parent, p, p - W);
+        }
+    } else if (i < nh + nv) { // pixel on the first column of a tile column, merge with the pixel to the left
+        const int j = i - nh;
+        const int bx = j / H + 1, y = j - (bx - 1) * H;
+        const int p = y * W + bx * T;
+        const uint16_t lbl = c.in[p];
+        if (c.in[p - 1] == lbl) {
+            const bool first = (y % T == 0) || c.in[p - W] != lbl || c.in[p - W - 1] != lbl;
+            if (first) g_union(c.parent, p, p - 1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cca_compress(CcaDev c) {
+    const uint32_t n = c.counters[0];
+    const uint32_t gstride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gstride) {
+        const int32_t r = c.roots[i];
+        const int32_t g = g_find(c.parent, r);
+        if (g != r) {
+            c.parent[r] = g;
+            atomicAdd(&c.area[g], c.area[r]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cca_collect(CcaDev c) {
+    const uint32_t n = c.counters[0];
+    const uint32_t gstride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gstride) {
+        const int32_t r = c.roots[i];
+        if (c.parent[r] != r) continue;
+        c.final_lab[r] = 0xFFFFu;
+        const uint32_t a = c.area[r];
+        if ((int64_t)a >= (int64_t)c.min_threshold) {     // src/cca.cpp:213-217
+            const uint32_t pos = atomicAdd(&c.counters[1], 1u);
+            c.cand_leader[pos] = r;
+            c.cand_area[pos] = a;
+        }
+    }
+}
+
+void launch_cca_phase1(const CcaDev& c, hipStream_t st) {
+    constexpr int T = kCcaTile;
+    const int tx = (c.W + T - 1) / T, ty = (c.H + T - 1) / T;
+    hipLaunchKernelGGL(k_cca_local, dim3(tx, ty), dim3(256), 0, st, c);
+    const int nh = (ty - 1) * c.W, nv = (tx - 1) * c.H;
+    if (nh + nv > 0)
+        hipLaunchKernelGGL(k_cca_border, dim3((nh + nv + 255) / 256), dim3(256), 0, st, c, nh, nv);
+    hipLaunchKernelGGL(k_cca_compress, dim3(1024), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_cca_collect, dim3(1024), dim3(256), 0, st, c);
+}
+
+__global__ void k_cca_set_kept(CcaDev c, const int32_t* __restrict__ leaders, const uint16_t* __restrict__ labels, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) c.final_lab[leaders[i]] = labels[i];
+}
+void launch_cca_set_kept(const CcaDev& c, const int32_t* d_leaders, const uint16_t* d_labels, int n, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_cca_set_kept, dim3((n + 255) / 256), dim3(256), 0, st, c, d_leaders, d_labels, n);
+}
+
+__global__ __launch_bounds__(256) void k_cca_chain(CcaDev c) {
+    const uint32_t n = c.counters[0];
+    const uint32_t gstride = gridDim.x * blockDim.x;
+    const int W = c.W;
+    volatile uint16_t* fin = c.final_lab;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gstride) {
+        const int32_t r = c.roots[i];
+        if (c.parent[r] != r) continue;
+        if (fin[r] != 0xFFFFu) continue;          // kept component
+        int32_t cur = r;
+        uint32_t f;
+        for (;;) {
+            if (cur == 0) { f = 0; break; }        // src/cca.cpp:238
+            const int32_t t = (cur % W > 0) ? cur - 1 : cur - W;   // src/cca.cpp:243-248
+            const int32_t g = c.parent[c.parent[t]];
+            f = fin[g];
+            if (f != 0xFFFFu) break;
+            cur = g;
+        }
+        fin[r] = (uint16_t)f;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cca_relabel(CcaDev c) {
+    const int gstride = gridDim.x * blockDim.x;
+    const int nquad = c.N >> 2;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += gstride) {
+        const int4 lr = reinterpret_cast<const int4*>(c.parent)[q];
+        const uint32_t a = c.final_lab[c.parent[lr.x]], b = c.final_lab[c.parent[lr.y]];
+        const uint32_t d = c.final_lab[c.parent[lr.z]], e = c.final_lab[c.parent[lr.w]];
+        uint2 o;
+        o.x = a | (b << 16);
+        o.y = d | (e << 16);
+        reinterpret_cast<uint2*>(c.out)[q] = o;
+    }
+    for (int p = (nquad << 2) + blockIdx.x * blockDim.x + threadIdx.x; p < c.N; p += gstride)
+        c.out[p] = c.final_lab[c.parent[c.parent[p]]];
+}
+
+void launch_cca_phase2(const CcaDev& c, hipStream_t st) {
+    hipLaunchKernelGGL(k_cca_chain, dim3(1024), dim3(256), 0, st, c);
+    int blocks = (c.N / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_cca_relabel, dim3(blocks), dim3(256), 0, st, c);
+}
+
+}  // namespace fslic

@@ -1,0 +1,135 @@
+/* fslic_hip.h -- C ABI of the MI355X (gfx950) SLIC superpixel engine.
+ *
+ * This is the drop-in boundary for ONE hot path of Algy/fast-slic: fast_slic.Slic.iterate()
+ * (RGB->CIELAB prepass, subsampled assign/update loop, full assign, connectivity/min-size pass).
+ * Every entry point names the reference interface it replaces; paths are relative to the
+ * reference repository root.  Plain C types only: no C++ or torch types cross this boundary.
+ *
+ * Threading (cfast_slic.pyx:188-193 releases the GIL around the calls replaced here): calls on one
+ * engine handle are serialised by the caller; different handles (one per GPU) may be driven from
+ * different threads.  The library never calls into Python.
+ *
+ * All functions returning int return 0 on success and a non-zero FSLIC_E_* code on failure;
+ * fslic_hip_last_error() then returns a thread-local human-readable message.  No exception
+ * crosses the ABI (the reference maps C++ exceptions through Cython `except +`, cfast_slic.pxd:47,51).
+ */
+#ifndef FSLIC_HIP_H
+#define FSLIC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FSLIC_HIP_ARCH_NAME "hip/gfx950"   /* new entry for archtbl[], src/context-impl.cpp:15-24 */
+
+enum {
+    FSLIC_OK = 0,
+    FSLIC_E_INVALID = 1,       /* bad argument (maps to ValueError in the binding)             */
+    FSLIC_E_UNSUPPORTED = 2,   /* option outside the implemented surface (NotImplementedError) */
+    FSLIC_E_HIP = 3,           /* HIP runtime failure: no device, OOM, launch error            */
+    FSLIC_E_INTERNAL = 4
+};
+
+/* Bit-compatible with `Cluster`, src/fast-slic-common.h:10-23 (32 bytes; Cython mirror
+ * cfast_slic.pxd:8-18).  r,g,b hold L,a,b when convert_to_lab is set.  `a` is never written. */
+typedef struct fslic_cluster {
+    float y, x, r, g, b, a;
+    uint16_t number;
+    uint8_t is_active;
+    uint8_t is_updatable;
+    uint32_t num_members;
+} fslic_cluster;
+
+/* The public configuration fields of BaseContext (src/context.h:26-36) as set by
+ * SlicModel.iterate (cfast_slic.pyx:179-187), plus max_iter (context.iterate's argument). */
+typedef struct fslic_params {
+    int32_t max_iter;              /* BaseContext::iterate(assignment, max_iter), src/context.cpp:108 */
+    float compactness;             /* src/context.h:28 */
+    float min_size_factor;         /* src/context.h:29 */
+    int32_t subsample_stride;      /* subsample_stride_config, src/context.h:26 (>= 1) */
+    int32_t convert_to_lab;        /* src/context.h:30 */
+    int32_t manhattan_spatial_dist;/* src/context.h:35; 0 (hypotf patch) takes the generic kernel */
+    int32_t preemptive;            /* src/context.h:32; must be 0 (FSLIC_E_UNSUPPORTED otherwise) */
+    float preemptive_thres;        /* ignored while preemptive == 0 */
+    int32_t num_threads;           /* src/context.h:27; ignored on the GPU */
+    int32_t debug_mode;            /* src/context.h:36; ignored (no recorder report) */
+    int32_t force_generic;         /* testing aid: run the brute-force gather kernel instead of the tiled one */
+    int32_t reserved[5];
+} fslic_params;
+
+typedef struct fslic_engine fslic_engine;
+
+/* Number of visible HIP devices (0 when none / runtime unusable). */
+int fslic_hip_device_count(void);
+
+/* Create / destroy an engine bound to one GPU.  The engine owns every device and pinned-host
+ * buffer and caches them across calls keyed by (H, W, K); the reference re-allocates per call
+ * (BaseContext ctor, src/context.h:59-66, invoked from cfast_slic.pyx:171-177).
+ * n_slots >= 1 is the number of frames that may be in flight at once (one HIP stream each). */
+int fslic_hip_create(int device, int n_slots, fslic_engine** out);
+void fslic_hip_destroy(fslic_engine* e);
+
+/* Replaces BaseContext::initialize_clusters (src/context.cpp:42-97) as called by
+ * SlicModel.initialize (cfast_slic.pyx:124-147).  Pure host code, O(K); `rgb` is a host pointer
+ * to C-contiguous uint8[H][W][3]. */
+int fslic_hip_initialize_clusters(int H, int W, int K, const uint8_t* rgb, fslic_cluster* clusters);
+
+/* Replaces Context construction + initialize_state() + iterate() + delete for the integer SLIC path
+ * (cfast_slic.pyx:171-197 -> src/context.cpp:108-197).
+ *   rgb      : HOST pointer, borrowed, C-contiguous uint8[H][W][3]
+ *   clusters : HOST pointer to K clusters, updated in place exactly like the reference does
+ *   labels   : HOST pointer to uint16[H][W]; all H*W entries are written (0xFFFF possible);
+ *              the caller applies astype(int16) / 0xFFFF -> -1 (cfast_slic.pyx:258-260). */
+int fslic_hip_iterate(fslic_engine* e, const fslic_params* p, int H, int W, int K,
+                      const uint8_t* rgb, fslic_cluster* clusters, uint16_t* labels);
+
+/* Same computation with the frame already resident in HBM (NEW surface, absent in the reference;
+ * SURVEY.md section 8f-4).  d_rgb / d_labels are DEVICE pointers on the engine's GPU; clusters stays a
+ * host pointer (K*32 bytes).  `slot` selects the in-flight slot / stream (0 <= slot < n_slots).
+ * The call returns after the slot's stream has been synchronised. */
+int fslic_hip_iterate_device(fslic_engine* e, int slot, const fslic_params* p, int H, int W, int K,
+                             const uint8_t* d_rgb, fslic_cluster* clusters, uint16_t* d_labels);
+
+/* Independent frames, round-robin over the engine's slots (NEW surface; BASELINE.json config 4).
+ * rgb[i] / labels[i] are host pointers when device_ptrs == 0 and device pointers otherwise;
+ * clusters[i] are host pointers, each K clusters. */
+int fslic_hip_iterate_batch(fslic_engine* e, const fslic_params* p, int H, int W, int K, int n_frames,
+                            const uint8_t* const* rgb, fslic_cluster* const* clusters,
+                            uint16_t* const* labels, int device_ptrs);
+
+/* Stage entry points (used by the parity tests; each mirrors one stage of iterate()). */
+
+/* rgb_to_cielab, src/cielab.h:337-353 (convert != 0) or the raw copy of src/context.cpp:117-127
+ * (convert == 0).  Host pointers; lab4 is uint8[H][W][4] = (L, a, b, 0). */
+int fslic_hip_rgb_to_lab(fslic_engine* e, int H, int W, const uint8_t* rgb, int convert, uint8_t* lab4);
+
+/* cca::ConnectivityEnforcer(labels,H,W,K,min_threshold).execute(labels), src/cca.cpp:178-265, as
+ * exposed by cfast_slic.enforce_connectivity (cfast_slic.pyx:371-396).  In place, host pointer. */
+int fslic_hip_enforce_connectivity(fslic_engine* e, uint16_t* labels, int H, int W, int K, int min_threshold);
+
+/* Labels after full_assign and before the connectivity pass (BaseContext::assignment,
+ * src/context.cpp:182-190) of the last fslic_hip_iterate*() call on `slot`; host pointer, H*W. */
+int fslic_hip_last_prelabels(fslic_engine* e, int slot, uint16_t* prelabels);
+
+/* Replaces BaseContext::get_timing_report (src/context.h:74): JSON with the fstimer schema
+ * {"name","duration"(us),"children"} (src/timer.cpp:4-18), durations from HIP events of the last
+ * call on slot 0.  Pointer valid until the next call on the engine. */
+const char* fslic_hip_last_timing_report(fslic_engine* e);
+
+/* Device time (ms, HIP events on the slot's stream) of the last iterate*() on `slot`:
+ * whole pipeline, and the full-assign kernel alone (the roofline kernel).  */
+int fslic_hip_last_device_times(fslic_engine* e, int slot, float* total_ms, float* full_assign_ms);
+
+/* Which kernel family served the last call on `slot`: 0 = tiled (LDS candidate lists), 1 = generic. */
+int fslic_hip_last_path(fslic_engine* e, int slot);
+
+const char* fslic_hip_last_error(void);
+const char* fslic_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FSLIC_HIP_H */

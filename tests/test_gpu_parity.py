@@ -1,0 +1,250 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C ABI
+(fast_slic_amd._binding -> libfslic_hip.so) and is compared bit-for-bit with the plain-C oracle on the
+same seeded inputs, and with the committed reference fixtures / digests."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from fast_slic_amd import _binding as B
+from fast_slic_amd import Slic, SlicModel, make_params
+from fast_slic_amd.synth import variant
+from util import digest, small_case_names, cca_case_names, case_kwargs, describe_mismatch, cluster_fields_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def run_hip(engine, img, cl0, force_generic=False, max_iter=10, compactness=10.0, min_size_factor=0.25,
+            subsample_stride=3, convert_to_lab=True, manhattan=True):
+    cl = cl0.copy()
+    p = make_params(max_iter, compactness, min_size_factor, subsample_stride, convert_to_lab, manhattan,
+                    force_generic=force_generic)
+    labels = engine.iterate(np.ascontiguousarray(img), cl, p)
+    pre = engine.last_prelabels(img.shape[0], img.shape[1])
+    return labels, cl, pre, engine.last_path()
+
+
+def assert_same(tag, hip, ora):
+    labels, cl, pre = hip
+    o_labels, o_cl, o_pre = ora
+    assert np.array_equal(pre, o_pre), describe_mismatch(tag + "/prelabels", pre, o_pre)
+    msgs = cluster_fields_equal(cl, o_cl)
+    assert not msgs, tag + ": " + "; ".join(msgs)
+    assert np.array_equal(labels, o_labels), describe_mismatch(tag + "/labels", labels, o_labels)
+
+
+# ---- stage: RGB -> LAB -----------------------------------------------------------------------
+def test_lab_whole_rgb_cube(engine):
+    # every one of the 2^24 colours, as a 4096 x 4096 frame
+    v = np.arange(1 << 24, dtype=np.uint32)
+    img = np.stack([(v >> 16) & 255, (v >> 8) & 255, v & 255], 1).astype(np.uint8).reshape(4096, 4096, 3)
+    got = engine.rgb_to_lab(img)
+    exp = orc.rgb_to_lab(img)
+    assert np.array_equal(got, exp), describe_mismatch("lab cube", got, exp)
+
+
+@pytest.mark.parametrize("H,W", [(1, 1), (3, 5), (97, 131), (480, 640)])
+def test_lab_ragged_sizes_and_raw_copy(engine, H, W):
+    img = variant("C", H, W)
+    assert np.array_equal(engine.rgb_to_lab(img), orc.rgb_to_lab(img))
+    raw = engine.rgb_to_lab(img, convert=False)
+    assert np.array_equal(raw[..., :3], img) and (raw[..., 3] == 0).all()
+
+
+# ---- stage: connectivity ---------------------------------------------------------------------
+def test_connectivity_golden_cases(engine, golden_small):
+    for name in cca_case_names(golden_small):
+        K, thr = (10, 0) if name.startswith("kat") else (int(golden_small[name + "/K"]), int(golden_small[name + "/thr"]))
+        got = engine.enforce_connectivity(golden_small[name + "/in"], K, thr)
+        exp = golden_small[name + "/out"]
+        assert np.array_equal(got, exp), describe_mismatch(name, got, exp)
+
+
+@pytest.mark.parametrize("case", ["noise", "stripes", "single", "holes", "checker", "blocks", "ties"])
+def test_connectivity_adversarial(engine, case):
+    rng = np.random.default_rng(11)
+    H, W = 203, 331
+    if case == "noise":
+        lab = rng.integers(0, 3, (H, W)).astype(np.uint16); K, thr = 50, 4
+    elif case == "stripes":      # long vertical chains across many 64x64 tiles
+        lab = (np.arange(W)[None, :] // 3 % 2 + np.zeros((H, 1), int)).astype(np.uint16); K, thr = 500, 0
+    elif case == "single":
+        lab = np.zeros((H, W), np.uint16); K, thr = 5, 10
+    elif case == "holes":
+        lab = rng.integers(0, 4, (H, W)).astype(np.uint16); lab[rng.random((H, W)) < 0.2] = 0xFFFF; K, thr = 30, 3
+    elif case == "checker":      # every pixel its own component: more components than K, all area 1
+        lab = ((np.arange(H)[:, None] + np.arange(W)[None, :]) % 2).astype(np.uint16); K, thr = 20, 1
+    elif case == "blocks":
+        lab = np.kron(rng.integers(0, 6, (H // 16 + 1, W // 16 + 1)), np.ones((16, 16), int))[:H, :W].astype(np.uint16); K, thr = 40, 64
+    else:                        # equal-area components at the top-K cut
+        lab = np.kron(np.arange(13 * 21).reshape(13, 21), np.ones((16, 16), int))[:H, :W].astype(np.uint16); K, thr = 100, 16
+    got = engine.enforce_connectivity(lab, K, thr)
+    exp = orc.enforce_connectivity(lab, K, thr)
+    assert np.array_equal(got, exp), describe_mismatch(case, got, exp)
+
+
+# ---- whole path: small golden fixtures (reference outputs) -----------------------------------------
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_small_golden_cases(engine, golden_small, force_generic):
+    for name in small_case_names(golden_small):
+        img = golden_small[name + "/image"]
+        cl0 = golden_small[name + "/clusters0"]
+        kw = case_kwargs(golden_small, name)
+        labels, cl, pre, path = run_hip(engine, img, cl0, force_generic=force_generic, **kw)
+        lab = engine.rgb_to_lab(img, convert=kw.get("convert_to_lab", True))
+        assert np.array_equal(lab, golden_small[name + "/lab"]), name
+        assert_same(name, (labels, cl, pre), (golden_small[name + "/labels"], golden_small[name + "/clusters"],
+                                              golden_small[name + "/prelabels"]))
+
+
+# ---- whole path: BASELINE.json sizes, tiled kernel, against the oracle and the reference digests -------
+@pytest.mark.parametrize("name", ["C1_480x640_k200", "C2_720x1280_k1600", "C3_2160x3840_k6000",
+                                  "C3b_2160x3840_k1600", "B_720x1280_k1600", "C_480x640_k200", "D_480x640_k100"])
+def test_baseline_sizes(engine, golden_digests, name):
+    d = golden_digests[name]
+    img = variant(d["variant"], d["H"], d["W"])
+    cl0 = orc.initialize_clusters(img, d["K"])
+    labels, cl, pre, path = run_hip(engine, img, cl0)
+    assert path == 0, "expected the tiled kernel family"
+    o_labels, o_cl, o_lab, o_pre = orc.slic_iterate(img, cl0, stages=True)
+    assert_same(name, (labels, cl, pre), (o_labels, o_cl, o_pre))
+    assert digest(pre) == d["prelabels"]
+    assert digest(orc.to_int16(labels)) == d["labels_int16"]
+    assert digest(orc.cluster_table(cl)) == d["clusters_f32"]
+
+
+@pytest.mark.parametrize("kw", [
+    dict(max_iter=0), dict(max_iter=1), dict(max_iter=2), dict(subsample_stride=1), dict(subsample_stride=5),
+    dict(compactness=1.0), dict(compactness=100.0), dict(min_size_factor=0.0), dict(min_size_factor=1.0),
+    dict(convert_to_lab=False), dict(manhattan=False),
+])
+def test_option_coverage_against_oracle(engine, kw):
+    img = variant("A", 300, 420, seed=5)
+    cl0 = orc.initialize_clusters(img, 96)
+    labels, cl, pre, path = run_hip(engine, img, cl0, **kw)
+    o_labels, o_cl, o_lab, o_pre = orc.slic_iterate(img, cl0, stages=True, **kw)
+    assert_same(str(kw), (labels, cl, pre), (o_labels, o_cl, o_pre))
+    if kw.get("manhattan", True) is False:
+        assert path == 1
+
+
+@pytest.mark.parametrize("H,W,K", [(64, 64, 1), (33, 47, 6), (65, 129, 11), (200, 200, 2), (100, 100, 625), (480, 640, 3000)])
+def test_ragged_and_extreme_shapes(engine, H, W, K):
+    img = variant("A", H, W, seed=2)
+    cl0 = orc.initialize_clusters(img, K)
+    labels, cl, pre, path = run_hip(engine, img, cl0)
+    o_labels, o_cl, o_lab, o_pre = orc.slic_iterate(img, cl0, stages=True)
+    assert_same("%dx%d K=%d path=%d" % (H, W, K, path), (labels, cl, pre), (o_labels, o_cl, o_pre))
+
+
+def test_generic_equals_tiled_at_720p(engine):
+    img = variant("A", 720, 1280, seed=3)
+    cl0 = orc.initialize_clusters(img, 1600)
+    a = run_hip(engine, img, cl0)
+    b = run_hip(engine, img, cl0, force_generic=True)
+    assert a[3] == 0 and b[3] == 1
+    assert_same("generic-vs-tiled", a[:3], b[:3])
+
+
+def test_pileup_of_identical_clusters_is_pruned_exactly(engine):
+    # 4K / K=6000 piles 225 clusters on one pixel; here the same effect at a small size:
+    # all clusters start on two pixels with identical colours
+    img = variant("B", 256, 256)
+    K = 400
+    cl0 = orc.initialize_clusters(img, K)
+    cl0["y"][100:] = 128; cl0["x"][100:] = 128
+    labels, cl, pre, path = run_hip(engine, img, cl0)
+    o_labels, o_cl, o_lab, o_pre = orc.slic_iterate(img, cl0, stages=True)
+    assert_same("pileup path=%d" % path, (labels, cl, pre), (o_labels, o_cl, o_pre))
+
+
+def test_warm_start_second_frame(engine):
+    img1, img2 = variant("A", 240, 320, 0), variant("A", 240, 320, 1)
+    cl0 = orc.initialize_clusters(img1, 150)
+    _, cl_h, _, _ = run_hip(engine, img1, cl0)
+    _, cl_o = orc.slic_iterate(img1, cl0)
+    l_h, cl_h2, pre_h, _ = run_hip(engine, img2, cl_h)
+    l_o, cl_o2, _, pre_o = orc.slic_iterate(img2, cl_o, stages=True)
+    assert_same("warm", (l_h, cl_h2, pre_h), (l_o, cl_o2, pre_o))
+
+
+# ---- the Python surface, mirroring the reference's test/test_slic.py:41-65 ----------------------------
+def test_slic_model_clusters():
+    x = np.zeros([480, 640, 3], np.uint8)
+    slic = Slic(num_components=100)
+    slic.iterate(x)
+    for i, cluster in enumerate(slic.slic_model.clusters):
+        assert cluster['number'] == i
+        assert isinstance(cluster, dict)
+        assert len(cluster['yx']) == 2
+        assert isinstance(cluster['yx'], tuple)
+        assert len(cluster['color']) == 3
+        assert isinstance(cluster['color'], tuple)
+        assert isinstance(cluster['num_members'], int)
+
+
+def test_slic_model_clusters_setter():
+    x = np.zeros([480, 640, 3], np.uint8)
+    slic = Slic(num_components=100)
+    slic.iterate(x)
+    orig_clusters = slic.slic_model.clusters
+    slic.slic_model.clusters = orig_clusters[:10]
+    assert len(slic.slic_model.clusters) == 10
+    assert slic.slic_model.clusters == orig_clusters[:10]
+    assert slic.slic_model.num_components == 10
+    assert slic.num_components == 10
+
+
+def test_python_surface_equals_oracle_on_zeros_frame():
+    # all-zero frame: every distance ties, the result is decided by the (phase, k) visit order alone
+    x = np.zeros([480, 640, 3], np.uint8)
+    slic = Slic(num_components=100)
+    got = slic.iterate(x)
+    assert got.dtype == np.int16 and got.shape == (480, 640)
+    cl0 = orc.initialize_clusters(x, 100)
+    o_labels, o_cl = orc.slic_iterate(x, cl0)
+    assert np.array_equal(got, orc.to_int16(o_labels))
+    assert slic.slic_model.cluster_array.tobytes() == o_cl.tobytes()
+    assert '"name": "iterate"' in slic.slic_model.last_timing_report
+
+
+def test_errors_surface_like_the_reference():
+    slic = Slic(num_components=10)
+    with pytest.raises(ValueError):
+        slic.iterate(np.zeros([10, 10, 4], np.uint8))              # nchan != 3, cfast_slic.pyx:125-126
+    m = SlicModel(10)
+    with pytest.raises(RuntimeError):
+        m.iterate(np.zeros([10, 10, 3], np.uint8), 10, 10.0, 0.25, 3)   # not initialised, pyx:151-152
+    with pytest.raises(NotImplementedError):
+        Slic(num_components=10, preemptive=True).iterate(np.zeros([64, 64, 3], np.uint8))
+
+
+# ---- device-resident and batched entry points ------------------------------------------------------
+def test_device_resident_and_batch_entry_points(engine):
+    import torch
+    H, W, K, n = 240, 320, 150, 6
+    frames = [variant("A", H, W, seed=s) for s in range(n)]
+    p = make_params(10, 10.0, 0.25, 3)
+    exp = []
+    for f in frames:
+        cl0 = orc.initialize_clusters(f, K)
+        exp.append(orc.slic_iterate(f, cl0))
+    d_rgb = [torch.from_numpy(f).cuda() for f in frames]
+    d_lab = [torch.empty((H, W), dtype=torch.int16, device="cuda") for _ in frames]
+    cls = [orc.initialize_clusters(f, K) for f in frames]
+    torch.cuda.synchronize()
+    # one frame, explicit slot
+    engine.iterate_device(d_rgb[0].data_ptr(), d_lab[0].data_ptr(), H, W, cls[0], p, slot=1)
+    assert np.array_equal(d_lab[0].cpu().numpy().view(np.uint16), exp[0][0])
+    assert cls[0].tobytes() == exp[0][1].tobytes()
+    # batch over device pointers
+    cls = [orc.initialize_clusters(f, K) for f in frames]
+    engine.iterate_batch([t.data_ptr() for t in d_rgb], cls, [t.data_ptr() for t in d_lab], H, W, p, device_ptrs=True)
+    for i in range(n):
+        assert np.array_equal(d_lab[i].cpu().numpy().view(np.uint16), exp[i][0]), i
+        assert cls[i].tobytes() == exp[i][1].tobytes(), i
+    # batch over host pointers
+    cls = [orc.initialize_clusters(f, K) for f in frames]
+    outs = [np.empty((H, W), np.uint16) for _ in frames]
+    engine.iterate_batch([f.ctypes.data for f in frames], cls, [o.ctypes.data for o in outs], H, W, p, device_ptrs=False)
+    for i in range(n):
+        assert np.array_equal(outs[i], exp[i][0]), i
