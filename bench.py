@@ -1,0 +1,222 @@
+#!/usr/bin/env python
+"""bench.py -- megapixels/sec of the SLIC hot path on MI355X (BASELINE.json's metric).
+
+One *step* = one pass of fast_slic.Slic.iterate() (max_iter=10, defaults) over one batch of synthetic
+frames per GPU: 8 frames of 1280x720 RGB, K=1600 (BASELINE.json configs[1]; 8 frames/GPU is the sharding of
+configs[3], so --gpus 8 is exactly the 64-frame batch).  Frames and label maps are resident in HBM when the
+timed region starts (torch tensors; the C ABI gets raw device pointers).  One process per GPU, frames are
+independent so there is no data-path collective; torch.distributed (RCCL) carries only the barrier and the
+max-over-ranks of the elapsed time.
+
+Prints ONE JSON line on rank 0.  Extra keys: "roofline" (dominant kernel = the full-assign launch, HIP-event
+timed on its own stream inside the engine), "cpu_baseline" (the unmodified reference, SlicAvx2 + OpenMP, on
+this host's cores; the plain-C port if oracle/_ref is absent), "roofline_4k" (the north-star kernel:
+full-assign at 3840x2160, K=1600, measured after the timed region, not part of `value`).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+ASSIGN_BYTES_PER_PX = 6.0      # 4 B LAB read + 2 B label write per visited pixel
+
+WORKLOADS = {
+    "720p": dict(H=720, W=1280, K=1600, name="1280x720 RGB, K=1600, 10 iters (configs[1]), 8 frames/GPU"),
+    "4k": dict(H=2160, W=3840, K=1600, name="3840x2160 RGB, K=1600, 10 iters, 2 frames/GPU"),
+    "4k6000": dict(H=2160, W=3840, K=6000, name="3840x2160 RGB, K=6000, 10 iters (configs[2]), 2 frames/GPU"),
+}
+
+
+def cpu_baseline(H, W, K, budget_s=8.0):
+    """Reference timed on this host: iterate(img, 10) only, fresh clusters per frame (the reference
+    re-allocates its context per call anyway), frames of the same synthetic stream as the GPU leg.
+    The OpenMP thread count is chosen by a short sweep (the reference's per-iteration `omp critical`
+    merges collapse when every hardware thread of a big host is used); `cores` is the count used."""
+    from fast_slic_amd.synth import variant
+    from oracle import ref, oracle as orc
+    ncores = os.cpu_count() or 1
+    frames = [variant("A", H, W, seed=s) for s in range(4)]
+    if ref.available() and ref.supports_arch("x64/avx2"):
+        kind = "reference"
+        what = "fast_slic.avx2.SlicAvx2 + OpenMP (oracle/_ref, unmodified reference)"
+        init = lambda img: ref.initialize_clusters(img, K)
+        cls = [init(f) for f in frames]
+        best_t, cores = None, 1
+        for nt in [1, 2, 4, 8, 16, 32, 64, 128, 256]:
+            if nt > ncores:
+                break
+            ref.slic_iterate(frames[0], cls[0], num_threads=nt, arch="x64/avx2")   # warm-up (thread pool)
+            t = time.perf_counter()
+            ref.slic_iterate(frames[1], cls[1], num_threads=nt, arch="x64/avx2")
+            t = time.perf_counter() - t
+            if best_t is None or t < best_t:
+                best_t, cores = t, nt
+            elif t > 3.0 * best_t:
+                break
+        run = lambda img, cl: ref.slic_iterate(img, cl, num_threads=cores, arch="x64/avx2")
+    else:
+        kind, cores = "port", 1
+        what = "plain-C scalar port (oracle/slic_oracle.c)"
+        init = lambda img: orc.initialize_clusters(img, K)
+        cls = [init(f) for f in frames]
+        run = lambda img, cl: orc.slic_iterate(img, cl)
+    run(frames[0], cls[0])   # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    best = 1e9
+    while True:
+        i = n % len(frames)
+        t = time.perf_counter()
+        run(frames[i], cls[i])
+        best = min(best, time.perf_counter() - t)
+        n += 1
+        if time.perf_counter() - t0 > budget_s and n >= 4:
+            break
+    elapsed = time.perf_counter() - t0
+    return dict(value=round(H * W * n / elapsed / 1e6, 2), unit="megapixels/sec", cores=cores, kind=kind,
+                host_threads_available=ncores, best_frame_ms=round(best * 1e3, 3),
+                sample="%d frames of %dx%d K=%d, iterate(img,10) only, %s, %d OpenMP threads (best of a 1..%d sweep), %.1f s wall"
+                       % (n, W, H, K, what, cores, ncores, elapsed))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="720p", choices=sorted(WORKLOADS))
+    ap.add_argument("--frames-per-gpu", type=int, default=0)
+    ap.add_argument("--slots", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-4k", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from fast_slic_amd import Engine, make_params, CLUSTER_DTYPE
+    from fast_slic_amd import _binding as B
+    from fast_slic_amd.synth import variant
+
+    wl = WORKLOADS[args.workload]
+    H, W, K = wl["H"], wl["W"], wl["K"]
+    fpg = args.frames_per_gpu or (8 if args.workload == "720p" else 2)
+    eng = Engine(local_rank, max(1, min(args.slots, fpg)))
+    params = make_params(10, 10.0, 0.25, 3)
+
+    # this rank's shard of the synthetic frame stream: frames are independent, rank r owns seeds r*fpg .. r*fpg+fpg-1
+    seeds = [rank * fpg + i for i in range(fpg)]
+    frames = [variant("A", H, W, seed=s) for s in seeds]
+    d_rgb = [torch.from_numpy(f).cuda() for f in frames]
+    d_lab = [torch.empty((H, W), dtype=torch.int16, device="cuda") for _ in frames]
+    cl0 = []
+    for f in frames:
+        c = np.zeros(K, CLUSTER_DTYPE)
+        B.load_library().fslic_hip_initialize_clusters(H, W, K, f.ctypes.data, c.ctypes.data)
+        cl0.append(c)
+    rgb_ptrs = [t.data_ptr() for t in d_rgb]
+    lab_ptrs = [t.data_ptr() for t in d_lab]
+    torch.cuda.synchronize()
+
+    def step():
+        cls = [c.copy() for c in cl0]        # every step is a cold iterate() from the grid seeding
+        eng.iterate_batch(rgb_ptrs, cls, lab_ptrs, H, W, params, device_ptrs=True)
+        return cls
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fa_ms, tot_ms = [], []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for s in range(eng.n_slots):
+            t, f = eng.last_device_times(s)
+            tot_ms.append(t)
+            fa_ms.append(f)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        total_px = float(H) * W * fpg * world * args.steps
+        fa_avg_ms = float(np.mean(fa_ms))
+        achieved = ASSIGN_BYTES_PER_PX * H * W / (fa_avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "megapixels/sec @10 iters (1280x720 & 4K, K=1600); % HBM roofline",
+            "value": round(total_px / elapsed / 1e6, 2),
+            "unit": "megapixels/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/u16/i32 (integer SLIC)", "data": "synthetic",
+            "config": {"workload": wl["name"], "frames_per_gpu": fpg, "global_frames": fpg * world,
+                       "slots_per_gpu": eng.n_slots, "inputs": "device-resident uint8 RGB, device int16 labels",
+                       "parallelism": "frames sharded across GPUs, no collective"},
+            "device_ms_per_frame": round(float(np.mean(tot_ms)), 4),
+            "roofline": {"kernel": "k_assign<8,false> (full_assign launch, %dx%d)" % (W, H), "bound": "hbm",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "bytes_per_launch": ASSIGN_BYTES_PER_PX * H * W, "avg_launch_ms": round(fa_avg_ms, 5)},
+        }
+        if not args.no_4k and args.workload == "720p":
+            # the north-star kernel: full-assign at 3840x2160, K=1600, same engine, after the timed region
+            H4, W4, K4 = 2160, 3840, 1600
+            img = variant("A", H4, W4)
+            d4 = torch.from_numpy(img).cuda()
+            l4 = torch.empty((H4, W4), dtype=torch.int16, device="cuda")
+            c4 = np.zeros(K4, CLUSTER_DTYPE)
+            B.load_library().fslic_hip_initialize_clusters(H4, W4, K4, img.ctypes.data, c4.ctypes.data)
+            torch.cuda.synchronize()
+            f4, t4 = [], []
+            for i in range(8):
+                eng.iterate_device(d4.data_ptr(), l4.data_ptr(), H4, W4, c4.copy(), params, slot=0)
+                if i >= 2:
+                    t, f = eng.last_device_times(0)
+                    t4.append(t)
+                    f4.append(f)
+            a4 = ASSIGN_BYTES_PER_PX * H4 * W4 / (float(np.mean(f4)) * 1e-3) / 1e9
+            out["roofline_4k"] = {"kernel": "k_assign<8,false> (full_assign launch, 3840x2160, K=1600)", "bound": "hbm",
+                                  "achieved": round(a4, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(a4 / HBM_PEAK_GBS, 4), "traffic": None,
+                                  "avg_launch_ms": round(float(np.mean(f4)), 5),
+                                  "device_ms_per_frame": round(float(np.mean(t4)), 4),
+                                  "single_frame_megapixels_per_sec": round(H4 * W4 / (float(np.mean(t4)) * 1e-3) / 1e6, 1)}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(H, W, K)
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

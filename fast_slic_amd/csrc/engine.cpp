@@ -86,30 +86,44 @@ void build_patch(int S, float compactness, int color_shift, bool manhattan, std:
         }
 }
 
-// The Manhattan patch is a function of d = |di| + |dj| only.  Find M with (d*M)>>16 == lut[d] for every
-// d in [0, 2S] so the kernel can form the spatial term with one 24-bit multiply and fold it into the
-// packed key.  Returns false when no such multiplier exists (the generic kernel then uses the patch).
-bool find_multiplier(int S, const std::vector<uint16_t>& patch, uint32_t& M, uint32_t& max_spatial) {
+// The Manhattan patch is a function of d = |di| + |dj| only.  Find (M, C) with (d*M + C) >> 16 == lut[d]
+// for every d in [0, 2S] so the kernel can form the spatial term with one 24-bit multiply-add and fold it
+// into the packed key.  The offset C absorbs the float rounding of coef*d in set_spatial_patch (e.g. S=22,
+// compactness=10: lut[11] == 10 although coef < 10/11).  Returns false when no pair exists (the generic
+// kernel then reads the patch itself).
+bool find_multiplier(int S, float coef, const std::vector<uint16_t>& patch, uint32_t& M, uint32_t& C, uint32_t& max_spatial) {
     const int P = 2 * S + 1;
-    uint64_t lo = 0, hi = (1ull << 24) - 1;
+    std::vector<int64_t> L(2 * S + 1);
     max_spatial = 0;
     for (int d = 0; d <= 2 * S; d++) {
         // element of the patch with |di|+|dj| == d: (S - min(d,S), S + (d - min(d,S)))
         const int di = std::min(d, S), dj = d - di;
-        const uint64_t L = patch[(size_t)(S - di) * P + (S + dj)];
-        max_spatial = std::max<uint32_t>(max_spatial, (uint32_t)L);
-        if (d == 0) {
-            if (L != 0) return false;
-            continue;
-        }
-        lo = std::max<uint64_t>(lo, (L * 65536 + d - 1) / d);
-        hi = std::min<uint64_t>(hi, ((L + 1) * 65536 - 1) / d);
+        L[d] = patch[(size_t)(S - di) * P + (S + dj)];
+        max_spatial = std::max<uint32_t>(max_spatial, (uint32_t)L[d]);
     }
-    if (lo > hi) return false;
-    M = (uint32_t)lo;
-    if ((uint64_t)(2 * S) * M >= (1ull << 30)) return false;
-    return true;
+    if (L[0] != 0) return false;
+    const int64_t M0 = (int64_t)llround((double)coef * 65536.0);
+    for (int64_t delta = 0; delta <= 512; delta++) {
+        for (int sgn = 0; sgn < 2; sgn++) {
+            const int64_t m = M0 + (sgn ? -delta : delta);
+            if (m < 0 || m >= (1 << 24) || (sgn && delta == 0)) continue;
+            int64_t lo = 0, hi = 65535;
+            for (int d = 1; d <= 2 * S && lo <= hi; d++) {
+                lo = std::max<int64_t>(lo, L[d] * 65536 - d * m);
+                hi = std::min<int64_t>(hi, (L[d] + 1) * 65536 - 1 - d * m);
+            }
+            if (lo <= hi) {
+                if ((int64_t)(2 * S) * m + lo >= (1ll << 30)) return false;
+                M = (uint32_t)m;
+                C = (uint32_t)lo;
+                return true;
+            }
+        }
+    }
+    return false;
 }
+
+constexpr size_t kLutMaxWords = 12288;   // 48 KB of LDS for the spatial table at most
 
 struct Slot {
     hipStream_t st = nullptr;
@@ -124,6 +138,8 @@ struct Slot {
     uint8_t* d_rgb_stage = nullptr;
     uint16_t* d_out_stage = nullptr;
     uint16_t* d_patch = nullptr;
+    uint32_t* d_lut = nullptr;
+    uint32_t* h_lut = nullptr;
     int32_t* d_keep_leader = nullptr;
     uint16_t* d_keep_label = nullptr;
     uint32_t* d_err = nullptr;
@@ -167,6 +183,7 @@ void free_slot(Slot& s) {
     if (s.arena) hipFree(s.arena);
     if (s.h_cl) hipHostFree(s.h_cl);
     if (s.h_misc) hipHostFree(s.h_misc);
+    if (s.h_lut) hipHostFree(s.h_lut);
     if (s.h_keep_leader) hipHostFree(s.h_keep_leader);
     if (s.h_keep_label) hipHostFree(s.h_keep_label);
     if (s.h_patch) hipHostFree(s.h_patch);
@@ -193,6 +210,7 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S) {
         s.hK = K;
     }
     if (!s.h_misc) HIPCHK(hipHostMalloc((void**)&s.h_misc, 64));
+    if (!s.h_lut) HIPCHK(hipHostMalloc((void**)&s.h_lut, kLutMaxWords * 4));
     if (s.h_patch_cap < P * P) {
         if (s.h_patch) hipHostFree(s.h_patch);
         HIPCHK(hipHostMalloc((void**)&s.h_patch, sizeof(uint16_t) * P * P));
@@ -212,6 +230,7 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S) {
     const size_t o_ci0 = take(ncell * kCellCap * sizeof(ClusterRec)), o_ci1 = take(ncell * kCellCap * sizeof(ClusterRec));
     const size_t o_ov0 = take((size_t)K * sizeof(ClusterRec)), o_ov1 = take((size_t)K * sizeof(ClusterRec));
     const size_t o_patch = take(P * P * 2);
+    const size_t o_lut = take(kLutMaxWords * 4);
     const size_t o_parent = take(N * 4), o_area = take(N * 4), o_final = take(N * 2), o_roots = take(N * 4);
     const size_t o_candl = take(N * 4), o_canda = take(N * 4);
     const size_t o_keepl = take((size_t)K * 4), o_keepb = take((size_t)K * 2);
@@ -239,6 +258,7 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S) {
     f.ovf_items[0] = (ClusterRec*)(b + o_ov0); f.ovf_items[1] = (ClusterRec*)(b + o_ov1);
     s.d_patch = (uint16_t*)(b + o_patch);
     f.patch2d = s.d_patch;
+    s.d_lut = (uint32_t*)(b + o_lut);
     s.d_err = misc + 2;
     s.zero_block = b + o_zero; s.zero_bytes = zero_bytes;
     CcaDev& c = s.c;
@@ -351,11 +371,44 @@ int frame_enqueue_phase1(fslic_engine* e, Slot& s, const fslic_params* p, int H,
     const bool manhattan = p->manhattan_spatial_dist != 0;
     std::vector<uint16_t> patch;
     build_patch(S, p->compactness, color_shift, manhattan, patch);
-    uint32_t M = 0, max_sp = 0;
-    bool tiled_ok = manhattan && find_multiplier(S, patch, M, max_sp) && (max_sp + 765u < 16384u) && S >= 8;
+    uint32_t M = 0, Coff = 0, max_sp = 0;
+    float coef = 1.0f / ((float)S / p->compactness);
+    coef *= (1 << color_shift);
+    const bool have_mc = manhattan && find_multiplier(S, coef, patch, M, Coff, max_sp);
+    for (uint16_t v : patch) max_sp = std::max<uint32_t>(max_sp, v);
+    bool tiled_ok = (max_sp + 765u < 16384u) && S >= 8;
+    f.lut_words = 0; f.lut_row = 0; f.lut_oow = 0; f.lut = s.d_lut;
+    if (tiled_ok && !have_mc) {
+        // LDS table mode.  Manhattan: 1-D in d = ux + uy (out-of-window -> 2S+1, so any index > 2S is huge).
+        // Otherwise 2-D in (uy, ux) with one extra out-of-window row and column.
+        const size_t Pp = (size_t)(2 * S + 1);
+        if (manhattan) {
+            const int oow = 2 * S + 1, words = 4 * S + 3;
+            if ((size_t)words > kLutMaxWords) tiled_ok = false;
+            else {
+                for (int d = 0; d < words; d++) {
+                    if (d <= 2 * S) { const int di = std::min(d, S), dj = d - di; s.h_lut[d] = (uint32_t)patch[(size_t)(S - di) * Pp + (S + dj)] << 16; }
+                    else s.h_lut[d] = kHuge;
+                }
+                f.lut_words = words; f.lut_row = 1; f.lut_oow = oow;
+            }
+        } else {
+            const int row = S + 2, words = row * row;
+            if ((size_t)words > kLutMaxWords) tiled_ok = false;
+            else {
+                for (int uy = 0; uy < row; uy++)
+                    for (int ux = 0; ux < row; ux++)
+                        s.h_lut[uy * row + ux] = (uy > S || ux > S) ? kHuge : ((uint32_t)patch[(size_t)(S + uy) * Pp + (S + ux)] << 16);
+                f.lut_words = words; f.lut_row = row; f.lut_oow = S + 1;
+            }
+        }
+    }
     if (generic || p->force_generic) tiled_ok = false;
     s.generic = !tiled_ok;
     f.M = M;
+    f.C = Coff;
+    if (tiled_ok && f.lut_words > 0)
+        HIPCHK(hipMemcpyAsync(s.d_lut, s.h_lut, (size_t)f.lut_words * 4, hipMemcpyHostToDevice, s.st));
     if (s.generic) {
         std::memcpy(s.h_patch, patch.data(), patch.size() * sizeof(uint16_t));
         HIPCHK(hipMemcpyAsync(s.d_patch, s.h_patch, patch.size() * sizeof(uint16_t), hipMemcpyHostToDevice, s.st));

@@ -33,7 +33,7 @@ struct FrameDev {
     int T;               // 2S + 32, phase cell side (src/context.cpp:213)
     int cs_shift;        // coarse bin side = 1 << cs_shift
     int ncx, ncy, ncell;
-    uint32_t M;          // spatial fixed point: patch[d] == (d * M) >> 16 for d in [0, 2S]
+    uint32_t M, C;       // spatial fixed point: patch[d] == (d * M + C) >> 16 for d in [0, 2S]
     // image planes
     const uint8_t* rgb;  // N*3
     uint32_t* lab;       // N, L|a<<8|b<<16
@@ -51,6 +51,9 @@ struct FrameDev {
     uint32_t* ovf_cnt[2];      // 1
     ClusterRec* ovf_items[2];  // K
     uint32_t* err_flag;        // != 0: a block overflowed its LDS candidate list -> host reruns generic
+    // LDS spatial table of the tiled kernel (lut_words == 0: fixed-point mode, no table)
+    const uint32_t* lut;       // lut_words entries: patch value << 16, or kHuge for out-of-window indices
+    int lut_words, lut_row, lut_oow;   // index = ux' + uy' * lut_row, ux'/uy' = |d| if <= S else lut_oow
     // generic-path tables
     const uint16_t* patch2d;   // (2S+1)^2, src/context.cpp:22-40
 };

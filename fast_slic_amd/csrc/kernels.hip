@@ -200,8 +200,14 @@ static __device__ __forceinline__ void global_accumulate(uint32_t* sums, uint32_
     atomicAdd(s + 5, (pix >> 16) & 255u);
 }
 
-template <int R, bool FUSE>
+// LUT == false: spatial term = (d*M + C) >> 16 formed in VALU (exact multiplier found by the host).
+// LUT == true : spatial term read from an LDS table indexed by ux' + uy'*lut_row (Manhattan patches the
+//               fixed point cannot express because of the float rounding in set_spatial_patch, and the
+//               hypotf patch of manhattan_spatial_dist=False); entries are pre-shifted by 16, out-of-window
+//               indices hold kHuge.
+template <int R, bool FUSE, bool LUT>
 __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride, int Hv, int buf) {
+    extern __shared__ uint32_t s_lut[];
     // raw gather arrays are dead once the sorted list exists; the centroid accumulators reuse them
     __shared__ uint32_t s_raw[3 * kMaxRaw];
     __shared__ uint4 s_list[kMaxList];
@@ -224,6 +230,9 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
     const bool okx = x < W;
 
     if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
+    if (LUT) {
+        for (int i = tid; i < f.lut_words; i += 256) s_lut[i] = f.lut[i];
+    }
 
     // 1. issue the pixel loads first; they do not depend on the candidate list
     uint32_t pix[R];
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
         }
     }
     __syncthreads();
-    int nraw = (int)s_cnt[0];
+    int nraw = (int)rfl(s_cnt[0]);
     if (nraw > kMaxRaw) { nraw = kMaxRaw; if (tid == 0) *f.err_flag = 1u; }
 
     // 3a. exact prune: a cluster with the same integer (y, x, L, a, b) as an earlier-ordered one has the
@@ -297,7 +306,7 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
         atomicAdd(&s_cnt[1], 1u);
     }
     __syncthreads();
-    int n = (int)s_cnt[1];
+    int n = (int)rfl(s_cnt[1]);
     if (n > kMaxList) { n = kMaxList; if (tid == 0) *f.err_flag = 1u; }
     if (FUSE) {
         for (int i = tid; i < kAccSlots * 6 * kAccCopies; i += 256) s_acc[i] = 0u;
@@ -308,7 +317,7 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
     uint32_t best[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) best[r] = 0xFFFFFFFFu;
-    const uint32_t M = f.M;
+    const uint32_t M = f.M, Coff = f.C;
     const int yw_hi = yw_lo + (R - 1) * stride;
 #pragma unroll 1
     for (int c = 0; c < n; ++c) {
@@ -319,15 +328,27 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
         if (cy + S < yw_lo || cy - S > yw_hi) continue;   // wave-uniform cull
         const int dx = x - cx;
         const uint32_t ux = (uint32_t)(dx < 0 ? -dx : dx);
-        const uint32_t A = ux <= (uint32_t)S ? __umul24(ux, M) : kHuge;
+        if (LUT) {
+            const uint32_t A = ux <= (uint32_t)S ? ux : (uint32_t)f.lut_oow;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int dy = yw_lo + r * stride - cy;
-            const uint32_t uy = (uint32_t)(dy < 0 ? -dy : dy);
-            const uint32_t B = uy <= (uint32_t)S ? uy * M : kHuge;   // SALU
-            const uint32_t w = __builtin_amdgcn_sad_hi_u8(pix[r], clab, A + B);
-            const uint32_t key = (w & 0xFFFF0000u) | (uint32_t)c;
-            best[r] = min(best[r], key);
+            for (int r = 0; r < R; ++r) {
+                const int dy = yw_lo + r * stride - cy;
+                const uint32_t uy = (uint32_t)(dy < 0 ? -dy : dy);
+                const uint32_t B = (uy <= (uint32_t)S ? uy : (uint32_t)f.lut_oow) * (uint32_t)f.lut_row;   // SALU
+                const uint32_t w = __builtin_amdgcn_sad_hi_u8(pix[r], clab, s_lut[A + B]);
+                best[r] = min(best[r], w | (uint32_t)c);
+            }
+        } else {
+            const uint32_t A = ux <= (uint32_t)S ? __umul24(ux, M) + Coff : kHuge;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int dy = yw_lo + r * stride - cy;
+                const uint32_t uy = (uint32_t)(dy < 0 ? -dy : dy);
+                const uint32_t B = uy <= (uint32_t)S ? uy * M : kHuge;   // SALU
+                const uint32_t w = __builtin_amdgcn_sad_hi_u8(pix[r], clab, A + B);
+                const uint32_t key = (w & 0xFFFF0000u) | (uint32_t)c;
+                best[r] = min(best[r], key);
+            }
         }
     }
 
@@ -404,8 +425,14 @@ void launch_assign(const FrameDev& f, int rem, int stride, int buf, bool fuse_up
     if (Hv <= 0) return;
     constexpr int R = kRowsPerWave;
     dim3 grid((f.W + kTileW - 1) / kTileW, (Hv + kWavesPerBlock * R - 1) / (kWavesPerBlock * R));
-    if (fuse_update) hipLaunchKernelGGL((k_assign<R, true>), grid, dim3(256), 0, st, f, rem, stride, Hv, buf);
-    else hipLaunchKernelGGL((k_assign<R, false>), grid, dim3(256), 0, st, f, rem, stride, Hv, buf);
+    if (f.lut_words > 0) {
+        const size_t lds = (size_t)f.lut_words * sizeof(uint32_t);
+        if (fuse_update) hipLaunchKernelGGL((k_assign<R, true, true>), grid, dim3(256), lds, st, f, rem, stride, Hv, buf);
+        else hipLaunchKernelGGL((k_assign<R, false, true>), grid, dim3(256), lds, st, f, rem, stride, Hv, buf);
+    } else {
+        if (fuse_update) hipLaunchKernelGGL((k_assign<R, true, false>), grid, dim3(256), 0, st, f, rem, stride, Hv, buf);
+        else hipLaunchKernelGGL((k_assign<R, false, false>), grid, dim3(256), 0, st, f, rem, stride, Hv, buf);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

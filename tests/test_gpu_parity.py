@@ -90,6 +90,8 @@ def test_small_golden_cases(engine, golden_small, force_generic):
         cl0 = golden_small[name + "/clusters0"]
         kw = case_kwargs(golden_small, name)
         labels, cl, pre, path = run_hip(engine, img, cl0, force_generic=force_generic, **kw)
+        S = orc.S_of(img.shape[0], img.shape[1], int(golden_small[name + "/K"]))
+        assert path == (1 if (force_generic or S < 8) else 0), (name, S, path)
         lab = engine.rgb_to_lab(img, convert=kw.get("convert_to_lab", True))
         assert np.array_equal(lab, golden_small[name + "/lab"]), name
         assert_same(name, (labels, cl, pre), (golden_small[name + "/labels"], golden_small[name + "/clusters"],
@@ -123,8 +125,7 @@ def test_option_coverage_against_oracle(engine, kw):
     labels, cl, pre, path = run_hip(engine, img, cl0, **kw)
     o_labels, o_cl, o_lab, o_pre = orc.slic_iterate(img, cl0, stages=True, **kw)
     assert_same(str(kw), (labels, cl, pre), (o_labels, o_cl, o_pre))
-    if kw.get("manhattan", True) is False:
-        assert path == 1
+    assert path == 0, "every option here is served by the tiled kernel family"
 
 
 @pytest.mark.parametrize("H,W,K", [(64, 64, 1), (33, 47, 6), (65, 129, 11), (200, 200, 2), (100, 100, 625), (480, 640, 3000)])
