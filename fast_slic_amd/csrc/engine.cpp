@@ -154,6 +154,7 @@ struct Slot {
     uint32_t* h_cand_area = nullptr;
     size_t h_cand_cap = 0;
     int hK = 0;
+    uint32_t gen_counter = 0;
     int keyH = 0, keyW = 0, keyK = 0;
     // per-call state
     int H = 0, W = 0, K = 0, S = 0;
@@ -271,6 +272,9 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S) {
     s.d_rgb_stage = (uint8_t*)(b + o_rgb); s.d_out_stage = (uint16_t*)(b + o_out);
     s.keyH = H; s.keyW = W; s.keyK = K;
     (void)e;
+    // Bin slots are validated by a generation stamp (ClusterRec::pad == FrameDev::gen, gen >= 1 and strictly
+    // increasing per slot), so a freshly carved region must not contain bytes that could pass for a stamp.
+    HIPCHK(hipMemsetAsync(b + o_ci0, 0, (o_ov0 - o_ci0), s.st));
     return FSLIC_OK;
 }
 
@@ -423,15 +427,16 @@ int frame_enqueue_phase1(fslic_engine* e, Slot& s, const fslic_params* p, int H,
     HIPCHK(hipMemsetAsync(f.cl_n, 0, sizeof(uint32_t) * 2 * (size_t)K, s.st));   // cl_n, cl_moved
 
     HIPCHK(hipEventRecord(s.ev[0], s.st));
-    launch_rgb_to_lab(d_rgb, f.lab, f.N, p->convert_to_lab, e->tables, s.st);
-    launch_fill_u16(f.labels, f.N, 0xFFFFu, s.st);             // src/context.cpp:138-145
+    launch_rgb_to_lab(d_rgb, f.lab, f.N, p->convert_to_lab, e->tables, f.labels, s.st);   // + labels <- 0xFFFF
     HIPCHK(hipEventRecord(s.ev[1], s.st));
+    f.gen = ++s.gen_counter;
     launch_bin_clusters(f, 0, 0, s.st);
     const int stride = p->subsample_stride;
     int rem = 0;
     for (int it = 0; it < p->max_iter; it++) {                  // src/context.cpp:158-175
         if (s.generic) launch_assign_generic(f, rem, stride, it & 1, true, s.st);
         else launch_assign(f, rem, stride, it & 1, true, s.st);
+        f.gen = ++s.gen_counter;
         launch_bin_clusters(f, 1, (it + 1) & 1, s.st);
         rem = (rem + 1) % stride;
     }
@@ -724,7 +729,7 @@ int fslic_hip_rgb_to_lab(fslic_engine* e, int H, int W, const uint8_t* rgb, int 
     if (hipMalloc((void**)&d_lab, N * 4) != hipSuccess) { hipFree(d_rgb); return fail(FSLIC_E_HIP, "hipMalloc failed"); }
     hipStream_t st = e->slots[0].st;
     hipMemcpyAsync(d_rgb, rgb, N * 3, hipMemcpyHostToDevice, st);
-    launch_rgb_to_lab(d_rgb, d_lab, (int)N, convert, e->tables, st);
+    launch_rgb_to_lab(d_rgb, d_lab, (int)N, convert, e->tables, nullptr, st);
     hipMemcpyAsync(lab4, d_lab, N * 4, hipMemcpyDeviceToHost, st);
     hipError_t err = hipStreamSynchronize(st);
     hipFree(d_rgb);

@@ -33,6 +33,7 @@ struct FrameDev {
     int T;               // 2S + 32, phase cell side (src/context.cpp:213)
     int cs_shift;        // coarse bin side = 1 << cs_shift
     int ncx, ncy, ncell;
+    uint32_t gen;        // generation stamp of the bin pass that filled cell_items[buf] (ClusterRec::pad)
     uint32_t M, C;       // spatial fixed point: patch[d] == (d * M + C) >> 16 for d in [0, 2S]
     // image planes
     const uint8_t* rgb;  // N*3
@@ -79,7 +80,8 @@ struct LabTables {
 };
 
 // ---- launches (all asynchronous on `st`) ----------------------------------------------------
-void launch_rgb_to_lab(const uint8_t* rgb, uint32_t* lab, int N, int convert, const LabTables& t, hipStream_t st);
+// labels_init != nullptr: also fill the N-entry label plane with 0xFFFF (src/context.cpp:138-145)
+void launch_rgb_to_lab(const uint8_t* rgb, uint32_t* lab, int N, int convert, const LabTables& t, uint16_t* labels_init, hipStream_t st);
 void launch_fill_u16(uint16_t* p, int n, uint16_t v, hipStream_t st);
 // mode 0: resample colours at the current centres (src/context.cpp:128-135) and bin;
 // mode 1: integer centroid update from `sums` (src/context.cpp:356-373), zero sums, and bin.

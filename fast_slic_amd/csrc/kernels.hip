@@ -44,7 +44,8 @@ static __device__ __forceinline__ uint32_t lab_px(uint32_t R, uint32_t G, uint32
 template <bool CONVERT>
 __global__ __launch_bounds__(1024) void k_rgb_to_lab(const uint8_t* __restrict__ rgb, uint32_t* __restrict__ lab,
                                                      int N, const uint16_t* __restrict__ g_gamma,
-                                                     const uint16_t* __restrict__ g_labtbl, LabConst kc, int aligned4) {
+                                                     const uint16_t* __restrict__ g_labtbl, LabConst kc, int aligned4,
+                                                     uint16_t* __restrict__ labels_init) {
     __shared__ uint16_t s_gamma[256];
     __shared__ uint16_t s_lab[8194];
     if (CONVERT) {
@@ -76,15 +77,18 @@ __global__ __launch_bounds__(1024) void k_rgb_to_lab(const uint8_t* __restrict__
             o.w = r3 | (g3 << 8) | (b3 << 16);
         }
         reinterpret_cast<uint4*>(lab)[q] = o;
+        // assignment plane <- 0xFFFF once per call (src/context.cpp:138-145)
+        if (labels_init) reinterpret_cast<uint2*>(labels_init)[q] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
     }
     // tail (and the whole image when the source pointer is not 4-byte aligned)
     for (int p = (nquad << 2) + blockIdx.x * blockDim.x + threadIdx.x; p < N; p += gstride) {
         const uint32_t r = rgb[3 * (size_t)p], g = rgb[3 * (size_t)p + 1], b = rgb[3 * (size_t)p + 2];
         lab[p] = CONVERT ? lab_px(r, g, b, s_gamma, s_lab, kc) : (r | (g << 8) | (b << 16));
+        if (labels_init) labels_init[p] = 0xFFFFu;
     }
 }
 
-void launch_rgb_to_lab(const uint8_t* rgb, uint32_t* lab, int N, int convert, const LabTables& t, hipStream_t st) {
+void launch_rgb_to_lab(const uint8_t* rgb, uint32_t* lab, int N, int convert, const LabTables& t, uint16_t* labels_init, hipStream_t st) {
     LabConst kc;
     for (int i = 0; i < 9; i++) kc.cb[i] = t.cb[i];
     const int aligned4 = ((reinterpret_cast<uintptr_t>(rgb) & 3) == 0) ? 1 : 0;
@@ -92,9 +96,9 @@ void launch_rgb_to_lab(const uint8_t* rgb, uint32_t* lab, int N, int convert, co
     if (blocks > 256) blocks = 256;   // one resident block per CU, grid-stride: tables are staged once per block
     if (blocks < 1) blocks = 1;
     if (convert)
-        hipLaunchKernelGGL(k_rgb_to_lab<true>, dim3(blocks), dim3(1024), 0, st, rgb, lab, N, t.gamma, t.labtbl, kc, aligned4);
+        hipLaunchKernelGGL(k_rgb_to_lab<true>, dim3(blocks), dim3(1024), 0, st, rgb, lab, N, t.gamma, t.labtbl, kc, aligned4, labels_init);
     else
-        hipLaunchKernelGGL(k_rgb_to_lab<false>, dim3(blocks), dim3(1024), 0, st, rgb, lab, N, t.gamma, t.labtbl, kc, aligned4);
+        hipLaunchKernelGGL(k_rgb_to_lab<false>, dim3(blocks), dim3(1024), 0, st, rgb, lab, N, t.gamma, t.labtbl, kc, aligned4, labels_init);
 }
 
 __global__ void k_fill_u16(uint32_t* p, int nwords, uint32_t v, uint16_t* tailp, int tail) {
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, int buf) {
     // visit order of the reference scatter: phase = 2*((cy/T)&1) + ((cx/T)&1), then k
     const uint32_t phase = (uint32_t)(2 * ((y / f.T) & 1) + ((x / f.T) & 1));
     ClusterRec rec;
-    rec.yx = yx; rec.lab = lab; rec.tag = (phase << 16) | (uint32_t)k; rec.pad = 0;
+    rec.yx = yx; rec.lab = lab; rec.tag = (phase << 16) | (uint32_t)k; rec.pad = f.gen;
     f.cl_tag[k] = rec.tag;
     const int cell = (y >> f.cs_shift) * f.ncx + (x >> f.cs_shift);
     const uint32_t slot = atomicAdd(&f.cell_cnt[buf][cell], 1u);
@@ -208,15 +212,14 @@ static __device__ __forceinline__ void global_accumulate(uint32_t* sums, uint32_
 template <int R, bool FUSE, bool LUT>
 __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride, int Hv, int buf) {
     extern __shared__ uint32_t s_lut[];
-    // raw gather arrays are dead once the sorted list exists; the centroid accumulators reuse them
     __shared__ uint32_t s_raw[3 * kMaxRaw];
     __shared__ uint4 s_list[kMaxList];
     __shared__ uint8_t s_dup[kMaxRaw];
     __shared__ uint32_t s_cnt[2];
+    __shared__ uint32_t s_acc[FUSE ? kAccSlots * 6 * kAccCopies : 1];
     uint32_t* const s_raw_yx = s_raw;
     uint32_t* const s_raw_lab = s_raw + kMaxRaw;
     uint32_t* const s_raw_tag = s_raw + 2 * kMaxRaw;
-    uint32_t* const s_acc = s_raw;   // kAccSlots * 6 * kAccCopies words (after the list is built)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -230,8 +233,12 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
     const bool okx = x < W;
 
     if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
+    const uint32_t novf = *f.ovf_cnt[buf];        // issued early, consumed after the cell gather
     if (LUT) {
         for (int i = tid; i < f.lut_words; i += 256) s_lut[i] = f.lut[i];
+    }
+    if (FUSE) {
+        for (int i = tid; i < kAccSlots * 6 * kAccCopies; i += 256) s_acc[i] = 0u;
     }
 
     // 1. issue the pixel loads first; they do not depend on the candidate list
@@ -243,7 +250,8 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
     }
     __syncthreads();
 
-    // 2. gather the clusters whose window can touch this block from the coarse cells
+    // 2. gather the clusters whose window can touch this block from the coarse cells.  A slot is live
+    //    when its generation stamp equals this pass's, so one round trip fetches count and payload.
     {
         const int vlast = min(vrow_b0 + kWavesPerBlock * R - 1, Hv - 1);
         const int yb_lo = rem + vrow_b0 * stride, yb_hi = rem + vlast * stride;
@@ -254,24 +262,19 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
         const int cya = max(wy_lo, 0) >> sh, cyb = min(wy_hi, f.H - 1) >> sh;
         const int ncxr = cxb - cxa + 1, ncyr = cyb - cya + 1;
         const int total = ncxr * ncyr * kCellCap;
-        const uint32_t* __restrict__ ccnt = f.cell_cnt[buf];
         const ClusterRec* __restrict__ citems = f.cell_items[buf];
         for (int i = tid; i < total; i += 256) {
             const int slot = i & (kCellCap - 1);
             const int c = i / kCellCap;
             const int cyi = c / ncxr;
             const int cell = (cya + cyi) * f.ncx + cxa + (c - cyi * ncxr);
-            const uint32_t cnt = ccnt[cell];
-            if ((uint32_t)slot < cnt) {
-                const ClusterRec rec = citems[(size_t)cell * kCellCap + slot];
-                const int cy = (int)(rec.yx >> 16), cx = (int)(rec.yx & 0xFFFF);
-                if (cy >= wy_lo && cy <= wy_hi && cx >= wx_lo && cx <= wx_hi) {
-                    const uint32_t pos = atomicAdd(&s_cnt[0], 1u);
-                    if (pos < (uint32_t)kMaxRaw) { s_raw_yx[pos] = rec.yx; s_raw_lab[pos] = rec.lab; s_raw_tag[pos] = rec.tag; }
-                }
+            const ClusterRec rec = citems[(size_t)cell * kCellCap + slot];
+            const int cy = (int)(rec.yx >> 16), cx = (int)(rec.yx & 0xFFFF);
+            if (rec.pad == f.gen && cy >= wy_lo && cy <= wy_hi && cx >= wx_lo && cx <= wx_hi) {
+                const uint32_t pos = atomicAdd(&s_cnt[0], 1u);
+                if (pos < (uint32_t)kMaxRaw) { s_raw_yx[pos] = rec.yx; s_raw_lab[pos] = rec.lab; s_raw_tag[pos] = rec.tag; }
             }
         }
-        const uint32_t novf = *f.ovf_cnt[buf];
         const ClusterRec* __restrict__ oitems = f.ovf_items[buf];
         for (uint32_t i = tid; i < novf; i += 256) {
             const ClusterRec rec = oitems[i];
@@ -286,32 +289,54 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
     int nraw = (int)rfl(s_cnt[0]);
     if (nraw > kMaxRaw) { nraw = kMaxRaw; if (tid == 0) *f.err_flag = 1u; }
 
-    // 3a. exact prune: a cluster with the same integer (y, x, L, a, b) as an earlier-ordered one has the
-    //     same distance everywhere and loses every tie, so it can never win a pixel.
-    for (int i = tid; i < nraw; i += 256) {
-        const uint32_t yx = s_raw_yx[i], lb = s_raw_lab[i], tg = s_raw_tag[i];
-        uint32_t dup = 0;
-        for (int j = 0; j < nraw; ++j)
-            dup |= (uint32_t)(s_raw_tag[j] < tg && s_raw_yx[j] == yx && s_raw_lab[j] == lb);
-        s_dup[i] = (uint8_t)dup;
-    }
-    __syncthreads();
-    // 3b. rank the survivors by (phase, k): list index order == visit order of the reference
-    for (int i = tid; i < nraw; i += 256) {
-        if (s_dup[i]) continue;
-        const uint32_t tg = s_raw_tag[i];
-        int rank = 0;
-        for (int j = 0; j < nraw; ++j) rank += (int)(s_raw_tag[j] < tg && !s_dup[j]);
-        if (rank < kMaxList) s_list[rank] = make_uint4(s_raw_yx[i], s_raw_lab[i], tg & 0xFFFFu, 0u);
-        atomicAdd(&s_cnt[1], 1u);
-    }
-    __syncthreads();
-    int n = (int)rfl(s_cnt[1]);
-    if (n > kMaxList) { n = kMaxList; if (tid == 0) *f.err_flag = 1u; }
-    if (FUSE) {
-        for (int i = tid; i < kAccSlots * 6 * kAccCopies; i += 256) s_acc[i] = 0u;
+    // 3. exact prune + rank.  A cluster with the same integer (y, x, L, a, b) as an earlier-ordered one has
+    //    the same distance everywhere and loses every tie, so it can never win a pixel: drop it.  The
+    //    survivors are ranked by (phase, k): list index order == visit order of the reference scatter.
+    int n;
+    if (nraw <= 64) {
+        // one record per lane; every wavefront does the pair tests with readlane broadcasts, no LDS traffic
+        const bool act = lane < nraw;
+        const uint32_t yx_j = act ? s_raw_yx[lane] : 0u;
+        const uint32_t lab_j = act ? s_raw_lab[lane] : 0u;
+        const uint32_t tag_j = act ? s_raw_tag[lane] : 0xFFFFFFFFu;
+        bool dup = false;
+        for (int i = 0; i < nraw; ++i) {
+            const uint32_t ty = __builtin_amdgcn_readlane(yx_j, i);
+            const uint32_t tl = __builtin_amdgcn_readlane(lab_j, i);
+            const uint32_t tt = __builtin_amdgcn_readlane(tag_j, i);
+            dup = dup || (act && (tt < tag_j) && (ty == yx_j) && (tl == lab_j));
+        }
+        const unsigned long long dupmask = __ballot(dup);
+        for (int i = wave; i < nraw; i += kWavesPerBlock) {
+            if ((dupmask >> i) & 1ull) continue;
+            const uint32_t tt = __builtin_amdgcn_readlane(tag_j, i);
+            const int rank = __popcll(__ballot(act && !dup && tag_j < tt));
+            if (lane == 0)
+                s_list[rank] = make_uint4(__builtin_amdgcn_readlane(yx_j, i), __builtin_amdgcn_readlane(lab_j, i), tt & 0xFFFFu, 0u);
+        }
+        n = nraw - __popcll(dupmask);
+    } else {
+        for (int i = tid; i < nraw; i += 256) {
+            const uint32_t yx = s_raw_yx[i], lb = s_raw_lab[i], tg = s_raw_tag[i];
+            uint32_t dup = 0;
+            for (int j = 0; j < nraw; ++j)
+                dup |= (uint32_t)(s_raw_tag[j] < tg && s_raw_yx[j] == yx && s_raw_lab[j] == lb);
+            s_dup[i] = (uint8_t)dup;
+        }
         __syncthreads();
+        for (int i = tid; i < nraw; i += 256) {
+            if (s_dup[i]) continue;
+            const uint32_t tg = s_raw_tag[i];
+            int rank = 0;
+            for (int j = 0; j < nraw; ++j) rank += (int)(s_raw_tag[j] < tg && !s_dup[j]);
+            if (rank < kMaxList) s_list[rank] = make_uint4(s_raw_yx[i], s_raw_lab[i], tg & 0xFFFFu, 0u);
+            atomicAdd(&s_cnt[1], 1u);
+        }
+        __syncthreads();
+        n = (int)rfl(s_cnt[1]);
+        if (n > kMaxList) { n = kMaxList; if (tid == 0) *f.err_flag = 1u; }
     }
+    __syncthreads();
 
     // 4. the argmin
     uint32_t best[R];
@@ -319,9 +344,11 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
     for (int r = 0; r < R; ++r) best[r] = 0xFFFFFFFFu;
     const uint32_t M = f.M, Coff = f.C;
     const int yw_hi = yw_lo + (R - 1) * stride;
+    uint2 nxt = *reinterpret_cast<const uint2*>(&s_list[0]);
 #pragma unroll 1
     for (int c = 0; c < n; ++c) {
-        const uint4 rec = s_list[c];
+        const uint2 rec = nxt;
+        nxt = *reinterpret_cast<const uint2*>(&s_list[min(c + 1, kMaxList - 1)]);   // prefetch: hides the LDS latency
         const uint32_t cyx = rfl(rec.x);
         const uint32_t clab = rfl(rec.y);
         const int cy = (int)(cyx >> 16), cx = (int)(cyx & 0xFFFFu);
@@ -424,9 +451,19 @@ void launch_assign(const FrameDev& f, int rem, int stride, int buf, bool fuse_up
     const int Hv = (f.H - rem + stride - 1) / stride;
     if (Hv <= 0) return;
     constexpr int R = kRowsPerWave;
-    dim3 grid((f.W + kTileW - 1) / kTileW, (Hv + kWavesPerBlock * R - 1) / (kWavesPerBlock * R));
+    const int tiles_x = (f.W + kTileW - 1) / kTileW;
+    dim3 grid(tiles_x, (Hv + kWavesPerBlock * R - 1) / (kWavesPerBlock * R));
+    const size_t lds = (size_t)f.lut_words * sizeof(uint32_t);
+    // Every block pays a fixed candidate-list prologue; when the 8-row grid would need more than one wave of
+    // resident blocks (256 CUs x ~6), the un-fused pass uses 16 rows per wavefront to stay at one wave.
+    if (!fuse_update && (int)(grid.x * grid.y) > 1536) {
+        constexpr int R2 = 2 * kRowsPerWave;
+        dim3 grid2(tiles_x, (Hv + kWavesPerBlock * R2 - 1) / (kWavesPerBlock * R2));
+        if (f.lut_words > 0) hipLaunchKernelGGL((k_assign<R2, false, true>), grid2, dim3(256), lds, st, f, rem, stride, Hv, buf);
+        else hipLaunchKernelGGL((k_assign<R2, false, false>), grid2, dim3(256), 0, st, f, rem, stride, Hv, buf);
+        return;
+    }
     if (f.lut_words > 0) {
-        const size_t lds = (size_t)f.lut_words * sizeof(uint32_t);
         if (fuse_update) hipLaunchKernelGGL((k_assign<R, true, true>), grid, dim3(256), lds, st, f, rem, stride, Hv, buf);
         else hipLaunchKernelGGL((k_assign<R, false, true>), grid, dim3(256), lds, st, f, rem, stride, Hv, buf);
     } else {
@@ -526,71 +563,112 @@ static __device__ __forceinline__ void lds_union(volatile uint32_t* par, uint32_
     }
 }
 
+// read-only find (no halving stores), unrolled for the flatten pass
+static __device__ __forceinline__ uint32_t lds_find_ro(const volatile uint32_t* par, uint32_t x) {
+    uint32_t p = par[x];
+    while (p != x) { x = p; p = par[x]; }
+    return x;
+}
+
+// One block = one 64x64 tile = 4 wavefronts x 16 rows.  Lane = column.
+//  A  each wavefront resolves its own 16-row strip top-down: horizontal runs by ballot, one LDS union per
+//     horizontal overlap with the row above; the (possibly stale) root of the pixel above travels in a VGPR,
+//     so a row costs a handful of dependent LDS operations instead of chain walks
+//  B  the three strip seams inside the tile are merged in LDS
+//  C  flatten: every pixel -> tile-local root (min raster index), parent plane written, run lengths added
+//     to the root's area
+//  D  tile-local roots appended to the root list (one global atomic per wavefront row)
 __global__ __launch_bounds__(256) void k_cca_local(CcaDev c) {
     constexpr int T = kCcaTile;
+    constexpr int RW = T / 4;
     __shared__ uint16_t s_lbl[T * T];
     __shared__ uint32_t s_par[T * T];
     __shared__ uint32_t s_area[T * T];
-    const int lane = LANE(), wave = threadIdx.x >> 6;
+    const int lane = LANE();
+    const int wave = (int)rfl((uint32_t)(threadIdx.x >> 6));
     const int tx0 = blockIdx.x * T, ty0 = blockIdx.y * T;
     const int x = tx0 + lane;
     const bool okx = x < c.W;
-    // pass 1: labels -> LDS, horizontal runs: parent = first lane of the run
-    for (int ly = wave * (T / 4); ly < (wave + 1) * (T / 4); ++ly) {
-        const int y = ty0 + ly;
-        const bool ok = okx && y < c.H;
-        const uint32_t lbl = ok ? (uint32_t)c.in[(size_t)y * c.W + x] : 0x10000u;
-        const uint32_t left = __shfl_up(lbl, 1);
-        const bool start = (lane == 0) || (lbl != left) || !ok;
+    const int ly0 = wave * RW;
+    const unsigned long long lowmask = (2ull << lane) - 1ull;
+
+    uint32_t lbl[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int y = ty0 + ly0 + i;
+        lbl[i] = (okx && y < c.H) ? (uint32_t)c.in[(size_t)y * c.W + x] : 0x10000u;
+    }
+    // ---- A ----
+    uint32_t up_root = 0;
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int ly = ly0 + i;
+        const bool ok = okx && (ty0 + ly) < c.H;
+        const int p = ly * T + lane;
+        const uint32_t l = lbl[i];
+        const uint32_t left = __shfl_up(l, 1);
+        const bool start = (lane == 0) || (l != left) || !ok;
         const unsigned long long m = __ballot(start);
-        const unsigned long long lower = m & ((2ull << lane) - 1ull);
-        const int rs = 63 - __clzll(lower);
-        s_lbl[ly * T + lane] = (uint16_t)lbl;
-        s_par[ly * T + lane] = (uint32_t)(ly * T + rs);
-        s_area[ly * T + lane] = 0u;
+        const uint32_t node = (uint32_t)(ly * T + (63 - __clzll(m & lowmask)));
+        s_lbl[p] = (uint16_t)l;
+        s_area[p] = 0u;
+        s_par[p] = node;
+        uint32_t cur_root = node;
+        if (i > 0) {
+            const uint32_t u = lbl[i - 1];
+            const uint32_t upl = __shfl_up(u, 1);
+            const bool first = ok && (u == l) && ((lane == 0) || (left != l) || (upl != l));
+            if (first) lds_union(s_par, node, up_root);
+            if (ok) cur_root = lds_find(s_par, node);
+        }
+        up_root = cur_root;
     }
     __syncthreads();
-    // pass 2: vertical unions, one per horizontal overlap of two runs
-    for (int ly = wave * (T / 4); ly < (wave + 1) * (T / 4); ++ly) {
-        if (ly == 0) continue;
-        const int y = ty0 + ly;
-        const bool ok = okx && y < c.H;
-        if (!ok) continue;
-        const int p = ly * T + lane;
-        const uint16_t lbl = s_lbl[p];
-        if (s_lbl[p - T] == lbl) {
-            const bool first = (lane == 0) || s_lbl[p - 1] != lbl || s_lbl[p - T - 1] != lbl;
+    // ---- B ----
+    if (wave > 0) {
+        const int p = ly0 * T + lane;
+        const bool ok = okx && (ty0 + ly0) < c.H;
+        const uint32_t l = lbl[0];
+        const uint32_t left = __shfl_up(l, 1);
+        if (ok && (uint32_t)s_lbl[p - T] == l) {
+            const bool first = (lane == 0) || (left != l) || ((uint32_t)s_lbl[p - T - 1] != l);
             if (first) lds_union(s_par, (uint32_t)p, (uint32_t)(p - T));
         }
     }
     __syncthreads();
-    // pass 3: flatten, publish parent, count members per run
-    for (int ly = wave * (T / 4); ly < (wave + 1) * (T / 4); ++ly) {
+    // ---- C ----
+    uint32_t root[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) root[i] = s_par[(ly0 + i) * T + lane];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) root[i] = s_par[root[i]];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) root[i] = lds_find_ro(s_par, root[i]);
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int ly = ly0 + i;
         const int y = ty0 + ly;
         const bool ok = okx && y < c.H;
-        const int p = ly * T + lane;
-        uint32_t r = 0xFFFFFFFFu;
-        if (ok) {
-            r = lds_find(s_par, (uint32_t)p);
-            s_par[p] = r;
-            c.parent[(size_t)y * c.W + x] = (int32_t)((size_t)(ty0 + (int)(r / T)) * c.W + tx0 + (int)(r % T));
-        }
+        const uint32_t r = ok ? root[i] : 0xFFFFFFFFu;
+        if (ok) c.parent[(size_t)y * c.W + x] = (int32_t)((size_t)(ty0 + (int)(r / T)) * c.W + tx0 + (int)(r % T));
         const uint32_t rl = __shfl_up(r, 1);
         const bool start = (lane == 0) || (r != rl) || !ok;
         const unsigned long long m = __ballot(start);
         if (ok && start) {
             const unsigned long long higher = (lane == 63) ? 0ull : (m >> (lane + 1));
-            const int len = higher ? (__ffsll((long long)higher)) : (64 - lane);
+            const int len = higher ? __ffsll((long long)higher) : (64 - lane);
             atomicAdd(&s_area[r], (uint32_t)len);
         }
     }
     __syncthreads();
-    // pass 4: tile-local roots -> area plane + root list (one global atomic per wavefront row)
-    for (int ly = wave * (T / 4); ly < (wave + 1) * (T / 4); ++ly) {
+    // ---- D ----
+#pragma unroll 4
+    for (int i = 0; i < RW; ++i) {
+        const int ly = ly0 + i;
         const int y = ty0 + ly;
         const bool ok = okx && y < c.H;
         const int p = ly * T + lane;
-        const bool isroot = ok && s_par[p] == (uint32_t)p;
+        const bool isroot = ok && root[i] == (uint32_t)p;
         const unsigned long long m = __ballot(isroot);
         if (m) {
             const int leader = __ffsll((long long)m) - 1;
