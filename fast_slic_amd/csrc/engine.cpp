@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <mutex>
 #include <numeric>
 #include <string>
@@ -155,6 +156,7 @@ struct Slot {
     size_t h_cand_cap = 0;
     int hK = 0;
     uint32_t gen_counter = 0;
+    unsigned long long* d_dbg = nullptr;
     int keyH = 0, keyW = 0, keyK = 0;
     // per-call state
     int H = 0, W = 0, K = 0, S = 0;
@@ -440,11 +442,35 @@ int frame_enqueue_phase1(fslic_engine* e, Slot& s, const fslic_params* p, int H,
         launch_bin_clusters(f, 1, (it + 1) & 1, s.st);
         rem = (rem + 1) % stride;
     }
+    if (getenv("FSLIC_DEBUG_TIMING")) {
+        if (!s.d_dbg) HIPCHK(hipMalloc((void**)&s.d_dbg, sizeof(unsigned long long) * 8 * 65536));
+        f.dbg = s.d_dbg;
+    } else f.dbg = nullptr;
     HIPCHK(hipEventRecord(s.ev[2], s.st));
     // full_assign: stride 1, rem 0, no update afterwards (src/context.cpp:246-256)
     if (s.generic) launch_assign_generic(f, 0, 1, p->max_iter & 1, false, s.st);
     else launch_assign(f, 0, 1, p->max_iter & 1, false, s.st);
     HIPCHK(hipEventRecord(s.ev[3], s.st));
+    if (f.dbg) {   // bring-up aid: average per-phase cycles of the full-assign launch, printed to stderr
+        HIPCHK(hipStreamSynchronize(s.st));
+        const int R2 = 16, R1 = 8;
+        const int tiles_x = (W + kTileW - 1) / kTileW;
+        int ty = (H + 4 * R1 - 1) / (4 * R1);
+        if (tiles_x * ty > 1536) ty = (H + 4 * R2 - 1) / (4 * R2);
+        const int nb = std::min(tiles_x * ty, 65536);
+        std::vector<unsigned long long> h((size_t)nb * 8);
+        HIPCHK(hipMemcpy(h.data(), s.d_dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        double ph[5] = {0, 0, 0, 0, 0}, nr = 0, nn = 0;
+        unsigned long long tmin = ~0ull, tmax = 0;
+        for (int b = 0; b < nb; b++) {
+            for (int q = 0; q < 5; q++) ph[q] += (double)(h[(size_t)b * 8 + q + 1] - h[(size_t)b * 8 + q]);
+            nr += (double)h[(size_t)b * 8 + 6]; nn += (double)h[(size_t)b * 8 + 7];
+            tmin = std::min(tmin, h[(size_t)b * 8]); tmax = std::max(tmax, h[(size_t)b * 8 + 5]);
+        }
+        fprintf(stderr, "[fslic dbg] full_assign %dx%d blocks=%d avg ticks: load+gather %.0f  prune+rank %.0f  argmin %.0f  store %.0f  update %.0f | nraw %.1f n %.1f | first-start..last-end %llu ticks\n",
+                W, H, nb, ph[0] / nb, ph[1] / nb, ph[2] / nb, ph[3] / nb, ph[4] / nb, nr / nb, nn / nb, tmax - tmin);
+        f.dbg = nullptr;
+    }
     // cluster state + overflow flag back to the host
     HIPCHK(hipMemcpyAsync(s.h_cl, f.cl_yx, sizeof(uint32_t) * 4 * (size_t)K, hipMemcpyDeviceToHost, s.st));
     HIPCHK(hipMemcpyAsync(s.h_misc + 2, s.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s.st));

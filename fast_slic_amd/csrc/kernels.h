@@ -51,6 +51,7 @@ struct FrameDev {
     ClusterRec* cell_items[2]; // ncell * kCellCap
     uint32_t* ovf_cnt[2];      // 1
     ClusterRec* ovf_items[2];  // K
+    unsigned long long* dbg;   // optional per-block phase stamps of k_assign (FSLIC_DEBUG_TIMING=1), else nullptr
     uint32_t* err_flag;        // != 0: a block overflowed its LDS candidate list -> host reruns generic
     // LDS spatial table of the tiled kernel (lut_words == 0: fixed-point mode, no table)
     const uint32_t* lut;       // lut_words entries: patch value << 16, or kHuge for out-of-window indices

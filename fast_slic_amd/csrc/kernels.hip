@@ -232,6 +232,12 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
     const int yw_lo = rem + vrow_w0 * stride;
     const bool okx = x < W;
 
+#define FSLIC_STAMP(slot_)                                                                              \
+    do {                                                                                                 \
+        if (f.dbg && tid == 0)                                                                           \
+            f.dbg[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot_)] = __builtin_readcyclecounter(); \
+    } while (0)
+    FSLIC_STAMP(0);
     if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
     const uint32_t novf = *f.ovf_cnt[buf];        // issued early, consumed after the cell gather
     if (LUT) {
@@ -286,6 +292,7 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
         }
     }
     __syncthreads();
+    FSLIC_STAMP(1);
     int nraw = (int)rfl(s_cnt[0]);
     if (nraw > kMaxRaw) { nraw = kMaxRaw; if (tid == 0) *f.err_flag = 1u; }
 
@@ -338,6 +345,7 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
     }
     __syncthreads();
 
+    FSLIC_STAMP(2);
     // 4. the argmin
     uint32_t best[R];
 #pragma unroll
@@ -379,6 +387,7 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
         }
     }
 
+    FSLIC_STAMP(3);
     // 5. write labels (+ fused centroid sums)
     uint32_t slot[R];
 #pragma unroll
@@ -403,6 +412,7 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
             }
         }
     }
+    FSLIC_STAMP(4);
     if (FUSE) {
         bool uni = slot[0] != 0xFFFFFFFFu;
 #pragma unroll
@@ -445,6 +455,12 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
             }
         }
     }
+    FSLIC_STAMP(5);
+    if (f.dbg && tid == 0) {
+        f.dbg[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] = (unsigned long long)nraw;
+        f.dbg[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = (unsigned long long)n;
+    }
+#undef FSLIC_STAMP
 }
 
 void launch_assign(const FrameDev& f, int rem, int stride, int buf, bool fuse_update, hipStream_t st) {
@@ -539,34 +555,44 @@ void launch_assign_generic(const FrameDev& f, int rem, int stride, int buf, bool
 //                  above) its leader, src/cca.cpp:240-254, resolved by chasing toward smaller leaders
 //   k_cca_relabel  out[p] = final[root(p)]
 // =============================================================================================
+// LDS accessors.  They are relaxed workgroup-scope atomics rather than `volatile` accesses on purpose:
+// volatile blocks the address-space inference and the accesses become FLAT instructions, which reach the LDS
+// through the vector-memory path at global-memory latency (measured: 1.2 ms instead of tens of us for the
+// tile kernel); atomics still lower to ds_read_b32 / ds_write_b32 and are re-read on every loop trip.
+static __device__ __forceinline__ uint32_t lds_ld(uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+static __device__ __forceinline__ void lds_st(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 // find with path halving.  The halving store races with concurrent atomicMin hooks, which is safe:
 // it only ever replaces a parent by one of its ancestors (cf. ECL-CC style concurrent union-find).
-static __device__ __forceinline__ uint32_t lds_find(volatile uint32_t* par, uint32_t x) {
+static __device__ __forceinline__ uint32_t lds_find(uint32_t* par, uint32_t x) {
     for (;;) {
-        const uint32_t p = par[x];
+        const uint32_t p = lds_ld(par + x);
         if (p == x) return x;
-        const uint32_t gp = par[p];
+        const uint32_t gp = lds_ld(par + p);
         if (gp == p) return p;
-        par[x] = gp;
+        lds_st(par + x, gp);
         x = gp;
     }
 }
-static __device__ __forceinline__ void lds_union(volatile uint32_t* par, uint32_t a, uint32_t b) {
+static __device__ __forceinline__ void lds_union(uint32_t* par, uint32_t a, uint32_t b) {
     for (;;) {
         a = lds_find(par, a);
         b = lds_find(par, b);
         if (a == b) return;
         if (a < b) { const uint32_t t = a; a = b; b = t; }
-        const uint32_t old = atomicMin(const_cast<uint32_t*>(par) + a, b);
+        const uint32_t old = atomicMin(par + a, b);
         if (old == a) return;
         a = old;
     }
 }
 
 // read-only find (no halving stores), unrolled for the flatten pass
-static __device__ __forceinline__ uint32_t lds_find_ro(const volatile uint32_t* par, uint32_t x) {
-    uint32_t p = par[x];
-    while (p != x) { x = p; p = par[x]; }
+static __device__ __forceinline__ uint32_t lds_find_ro(uint32_t* par, uint32_t x) {
+    uint32_t p = lds_ld(par + x);
+    while (p != x) { x = p; p = lds_ld(par + x); }
     return x;
 }
 
