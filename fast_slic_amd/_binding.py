@@ -57,11 +57,35 @@ def build_library(force=False):
     return _LIB_PATH
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.  If this library pulled in the system runtime first
+    and torch were imported afterwards, the process would hold two HIP runtimes and torch would report
+    "No HIP GPUs are available".  When torch is installed (not necessarily imported) bind to ITS runtime, so
+    device pointers from torch tensors and this engine share one runtime whatever the import order."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library():
     global _lib
     with _lib_lock:
         if _lib is not None:
             return _lib
+        _preload_torch_hip_runtime()
         if not os.path.exists(_LIB_PATH):
             raise ImportError(
                 "fast_slic_amd: %s is missing; build it with `python -c 'import __graft_entry__ as g; g.build()'` "

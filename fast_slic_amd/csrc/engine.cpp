@@ -144,6 +144,8 @@ struct Slot {
     int32_t* d_keep_leader = nullptr;
     uint16_t* d_keep_label = nullptr;
     uint32_t* d_err = nullptr;
+    int32_t* d_dense_leader = nullptr;
+    uint32_t* d_dense_area = nullptr;
     // pinned host
     uint32_t* h_cl = nullptr;        // [0,K) yx in; out: 4K words (yx, lab, n, moved)
     uint32_t* h_misc = nullptr;      // [0] roots, [1] candidates, [2] err flag
@@ -167,6 +169,8 @@ struct Slot {
     float total_ms = 0, fa_ms = 0, lab_ms = 0, loop_ms = 0, cca_ms = 0;
     int last_path = 0;
     bool have_pre = false;
+    bool host_topk = false;
+    int hKeep = 0;
 };
 
 }  // namespace
@@ -211,6 +215,7 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S) {
         HIPCHK(hipHostMalloc((void**)&s.h_keep_leader, sizeof(int32_t) * (size_t)K));
         HIPCHK(hipHostMalloc((void**)&s.h_keep_label, sizeof(uint16_t) * (size_t)K));
         s.hK = K;
+        s.hKeep = K;
     }
     if (!s.h_misc) HIPCHK(hipHostMalloc((void**)&s.h_misc, 64));
     if (!s.h_lut) HIPCHK(hipHostMalloc((void**)&s.h_lut, kLutMaxWords * 4));
@@ -234,8 +239,12 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S) {
     const size_t o_ov0 = take((size_t)K * sizeof(ClusterRec)), o_ov1 = take((size_t)K * sizeof(ClusterRec));
     const size_t o_patch = take(P * P * 2);
     const size_t o_lut = take(kLutMaxWords * 4);
-    const size_t o_parent = take(N * 4), o_area = take(N * 4), o_final = take(N * 2), o_roots = take(N * 4);
-    const size_t o_candl = take(N * 4), o_canda = take(N * 4);
+    const size_t ntiles = (size_t)((W + kCcaTile - 1) / kCcaTile) * ((H + kCcaTile - 1) / kCcaTile);
+    const size_t TT = (size_t)kCcaTile * kCcaTile;
+    const size_t o_parent = take(N * 4), o_area = take(N * 4), o_final = take(N * 2), o_roots = take(ntiles * TT * 4);
+    const size_t o_candl = take(ntiles * TT * 4), o_canda = take(ntiles * TT * 4);
+    const size_t o_densel = take(ntiles * TT * 4), o_densea = take(ntiles * TT * 4);
+    const size_t o_tcnt = take(ntiles * 4), o_tccnt = take(ntiles * 4);
     const size_t o_keepl = take((size_t)K * 4), o_keepb = take((size_t)K * 2);
     const size_t o_rgb = take(N * 3), o_out = take(N * 2);
     const size_t total = off;
@@ -270,6 +279,8 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S) {
     c.final_lab = (uint16_t*)(b + o_final); c.roots = (int32_t*)(b + o_roots);
     c.counters = misc + 4;
     c.cand_leader = (int32_t*)(b + o_candl); c.cand_area = (uint32_t*)(b + o_canda);
+    c.tile_cnt = (uint32_t*)(b + o_tcnt); c.tile_ccnt = (uint32_t*)(b + o_tccnt);
+    s.d_dense_leader = (int32_t*)(b + o_densel); s.d_dense_area = (uint32_t*)(b + o_densea);
     s.d_keep_leader = (int32_t*)(b + o_keepl); s.d_keep_label = (uint16_t*)(b + o_keepb);
     s.d_rgb_stage = (uint8_t*)(b + o_rgb); s.d_out_stage = (uint16_t*)(b + o_out);
     s.keyH = H; s.keyW = W; s.keyK = K;
@@ -329,31 +340,48 @@ int ensure_cand_capacity(Slot& s, size_t M) {
     return FSLIC_OK;
 }
 
-// Connectivity pass on the slot's stream: phase 1 (device), host top-K, phase 2 (device).
-int cca_enqueue_phase1(Slot& s, const uint16_t* d_in, uint16_t* d_out, int K, int min_threshold) {
+// Connectivity pass, fully asynchronous on the slot's stream: tile CCL, seams, compress, collect, device
+// top-K + ranking, chain, relabel.  The select status (0 = done on device, 1 = host top-K needed) is copied
+// to h_misc[3]; cca_finish() redoes the tail with std::partial_sort when it is 1.
+int cca_enqueue(Slot& s, const uint16_t* d_in, uint16_t* d_out, int K, int min_threshold) {
     CcaDev& c = s.c;
     c.in = d_in; c.out = d_out; c.K = K; c.min_threshold = min_threshold;
     launch_cca_phase1(c, s.st);
-    HIPCHK(hipMemcpyAsync(s.h_misc, c.counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.st));
+    launch_cca_select(c, s.st);
+    launch_cca_phase2(c, s.st);
+    HIPCHK(hipMemcpyAsync(s.h_misc + 4, c.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.st));
     return FSLIC_OK;
 }
-int cca_host_and_phase2(Slot& s) {
+// After the stream has been synchronised.
+int cca_finish(Slot& s) {
     CcaDev& c = s.c;
+    if (s.h_misc[4 + 3] == 0) return FSLIC_OK;
+    // host top-K: dense candidate list -> std::partial_sort -> kept labels -> chain + relabel again
+    launch_cca_densify(c, s.d_dense_leader, s.d_dense_area, s.st);
+    HIPCHK(hipMemcpyAsync(s.h_misc + 4, c.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.st));
     HIPCHK(hipStreamSynchronize(s.st));
-    const uint32_t M = s.h_misc[1];
+    const uint32_t M = s.h_misc[4 + 1];
     uint32_t n_keep = 0;
     if (M > 0) {
         int rc = ensure_cand_capacity(s, M);
         if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(s.h_cand_leader, c.cand_leader, sizeof(int32_t) * M, hipMemcpyDeviceToHost, s.st));
-        HIPCHK(hipMemcpyAsync(s.h_cand_area, c.cand_area, sizeof(uint32_t) * M, hipMemcpyDeviceToHost, s.st));
+        HIPCHK(hipMemcpyAsync(s.h_cand_leader, s.d_dense_leader, sizeof(int32_t) * M, hipMemcpyDeviceToHost, s.st));
+        HIPCHK(hipMemcpyAsync(s.h_cand_area, s.d_dense_area, sizeof(uint32_t) * M, hipMemcpyDeviceToHost, s.st));
         HIPCHK(hipStreamSynchronize(s.st));
+        if ((size_t)std::min<uint32_t>(M, (uint32_t)c.K) > (size_t)s.hKeep) {
+            if (s.h_keep_leader) { hipHostFree(s.h_keep_leader); hipHostFree(s.h_keep_label); }
+            s.hKeep = (int)std::min<uint32_t>(M, (uint32_t)c.K);
+            HIPCHK(hipHostMalloc((void**)&s.h_keep_leader, sizeof(int32_t) * (size_t)s.hKeep));
+            HIPCHK(hipHostMalloc((void**)&s.h_keep_label, sizeof(uint16_t) * (size_t)s.hKeep));
+        }
         select_kept(s, M, c.K, n_keep);
         HIPCHK(hipMemcpyAsync(s.d_keep_leader, s.h_keep_leader, sizeof(int32_t) * n_keep, hipMemcpyHostToDevice, s.st));
         HIPCHK(hipMemcpyAsync(s.d_keep_label, s.h_keep_label, sizeof(uint16_t) * n_keep, hipMemcpyHostToDevice, s.st));
-        launch_cca_set_kept(c, s.d_keep_leader, s.d_keep_label, (int)n_keep, s.st);
     }
+    launch_cca_set_kept(c, s.d_keep_leader, s.d_keep_label, (int)n_keep, s.st);
     launch_cca_phase2(c, s.st);
+    HIPCHK(hipStreamSynchronize(s.st));
+    s.host_topk = true;
     return FSLIC_OK;
 }
 
@@ -476,25 +504,26 @@ int frame_enqueue_phase1(fslic_engine* e, Slot& s, const fslic_params* p, int H,
     HIPCHK(hipMemcpyAsync(s.h_misc + 2, s.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s.st));
     // enforce_connectivity, src/context.cpp:14-20
     const int thres = (int)round((double)(S * S) * (double)p->min_size_factor);
-    rc = cca_enqueue_phase1(s, f.labels, d_out, K, thres);
+    rc = cca_enqueue(s, f.labels, d_out, K, thres);
     if (rc) return rc;
+    HIPCHK(hipEventRecord(s.ev[4], s.st));
     s.have_pre = true;
+    s.host_topk = false;
     s.last_path = s.generic ? 1 : 0;
     return FSLIC_OK;
 }
 
-int frame_phase2(Slot& s) {
-    int rc = cca_host_and_phase2(s);
-    if (rc) return rc;
-    HIPCHK(hipEventRecord(s.ev[4], s.st));
-    return FSLIC_OK;
-}
+int frame_phase2(Slot&) { return FSLIC_OK; }   // kept for the batch driver's structure: everything is enqueued in phase 1
 
 // returns 1 when the tiled kernel overflowed an LDS candidate list and the frame must be redone
 int frame_finish(Slot& s, bool& redo) {
     HIPCHK(hipStreamSynchronize(s.st));
     redo = (!s.generic && s.h_misc[2] != 0);
     if (redo) return FSLIC_OK;
+    {
+        int rc = cca_finish(s);
+        if (rc) return rc;
+    }
     hipEventElapsedTime(&s.total_ms, s.ev[0], s.ev[4]);
     hipEventElapsedTime(&s.lab_ms, s.ev[0], s.ev[1]);
     hipEventElapsedTime(&s.loop_ms, s.ev[1], s.ev[2]);
@@ -781,9 +810,10 @@ int fslic_hip_enforce_connectivity(fslic_engine* e, uint16_t* labels, int H, int
     const size_t N = (size_t)H * W;
     HIPCHK(hipMemsetAsync(s.zero_block, 0, s.zero_bytes, s.st));
     HIPCHK(hipMemcpyAsync(s.d_out_stage, labels, N * 2, hipMemcpyHostToDevice, s.st));
-    rc = cca_enqueue_phase1(s, s.d_out_stage, s.d_out_stage, K, min_threshold);
+    rc = cca_enqueue(s, s.d_out_stage, s.d_out_stage, K, min_threshold);
     if (rc) return rc;
-    rc = cca_host_and_phase2(s);
+    HIPCHK(hipStreamSynchronize(s.st));
+    rc = cca_finish(s);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(labels, s.d_out_stage, N * 2, hipMemcpyDeviceToHost, s.st));
     HIPCHK(hipStreamSynchronize(s.st));

@@ -68,10 +68,12 @@ struct CcaDev {
     int32_t* parent;      // N
     uint32_t* area;       // N (sparse: valid at tile-local roots)
     uint16_t* final_lab;  // N (sparse: valid at global roots)
-    int32_t* roots;       // N  list of tile-local roots
-    uint32_t* counters;   // [0] = #roots, [1] = #candidates (area >= threshold)
-    int32_t* cand_leader; // N
-    uint32_t* cand_area;  // N
+    int32_t* roots;       // ntiles * 4096: tile t's tile-local roots at [t*4096, t*4096 + tile_cnt[t])
+    uint32_t* tile_cnt;   // ntiles
+    uint32_t* tile_ccnt;  // ntiles: candidates (global roots with area >= threshold) of tile t
+    uint32_t* counters;   // [1] dense candidate count (host path), [2] M, [3] select status (0 done, 1 host)
+    int32_t* cand_leader; // ntiles * 4096, per-tile slices
+    uint32_t* cand_area;  // ntiles * 4096
 };
 
 struct LabTables {
@@ -93,6 +95,8 @@ void launch_assign(const FrameDev& f, int rem, int stride, int buf, bool fuse_up
 void launch_assign_generic(const FrameDev& f, int rem, int stride, int buf, bool fuse_update, hipStream_t st);
 // connectivity
 void launch_cca_phase1(const CcaDev& c, hipStream_t st);   // local CCL, border merge, compress, collect
+void launch_cca_select(const CcaDev& c, hipStream_t st);   // device top-K + ranking (counters[3] = status)
+void launch_cca_densify(const CcaDev& c, int32_t* d_leader, uint32_t* d_area, hipStream_t st);   // host path
 void launch_cca_set_kept(const CcaDev& c, const int32_t* d_leaders, const uint16_t* d_labels, int n, hipStream_t st);
 void launch_cca_phase2(const CcaDev& c, hipStream_t st);   // chain resolution + relabel
 

@@ -256,9 +256,17 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
     }
     __syncthreads();
 
-    // 2. gather the clusters whose window can touch this block from the coarse cells.  A slot is live
-    //    when its generation stamp equals this pass's, so one round trip fetches count and payload.
-    {
+    // 2+3. candidate list, built by wavefront 0 alone while the other three wait at the barrier (a waiting
+    //      wavefront issues nothing, and with ~8 resident blocks per CU the prologue's issue slots are what
+    //      the argmin phase of the other blocks needs).
+    //   gather : every slot of every coarse cell the block's pixels can see; a slot is live when its
+    //            generation stamp equals this pass's, so one round trip fetches count and payload;
+    //            ballot compaction, no atomics
+    //   prune  : a cluster with the same integer (y, x, L, a, b) as an earlier-ordered one has the same distance
+    //            everywhere and loses every tie, so it can never win a pixel: dropped (exact)
+    //   rank   : survivors ordered by (phase, k): list index order == visit order of the reference scatter
+    int nraw = 0, n = 0;
+    if (wave == 0) {
         const int vlast = min(vrow_b0 + kWavesPerBlock * R - 1, Hv - 1);
         const int yb_lo = rem + vrow_b0 * stride, yb_hi = rem + vlast * stride;
         const int xb_hi = min(x0 + kTileW - 1, W - 1);
@@ -268,61 +276,81 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
         const int cya = max(wy_lo, 0) >> sh, cyb = min(wy_hi, f.H - 1) >> sh;
         const int ncxr = cxb - cxa + 1, ncyr = cyb - cya + 1;
         const int total = ncxr * ncyr * kCellCap;
+        const uint32_t inv = (uint32_t)(4294967296.0f / (float)ncxr) + 1u;   // exact quotient for the small operands here
         const ClusterRec* __restrict__ citems = f.cell_items[buf];
-        for (int i = tid; i < total; i += 256) {
-            const int slot = i & (kCellCap - 1);
-            const int c = i / kCellCap;
-            const int cyi = c / ncxr;
-            const int cell = (cya + cyi) * f.ncx + cxa + (c - cyi * ncxr);
-            const ClusterRec rec = citems[(size_t)cell * kCellCap + slot];
-            const int cy = (int)(rec.yx >> 16), cx = (int)(rec.yx & 0xFFFF);
-            if (rec.pad == f.gen && cy >= wy_lo && cy <= wy_hi && cx >= wx_lo && cx <= wx_hi) {
-                const uint32_t pos = atomicAdd(&s_cnt[0], 1u);
-                if (pos < (uint32_t)kMaxRaw) { s_raw_yx[pos] = rec.yx; s_raw_lab[pos] = rec.lab; s_raw_tag[pos] = rec.tag; }
+        const unsigned long long lowmask = (1ull << lane) - 1ull;
+        for (int c0 = 0; c0 < total; c0 += 256) {
+            ClusterRec rec[4];
+            bool val[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = c0 + u * 64 + lane;
+                val[u] = e < total;
+                const uint32_t ce = (uint32_t)e >> 3;
+                uint32_t cyi = __umulhi(ce, inv);
+                if (cyi * (uint32_t)ncxr > ce) cyi--;            // guard the float reciprocal
+                const uint32_t cxi = ce - cyi * (uint32_t)ncxr;
+                const size_t cell = (size_t)(cya + (int)cyi) * f.ncx + cxa + (int)cxi;
+                if (val[u]) rec[u] = citems[cell * kCellCap + (e & 7)];
+                else { rec[u].yx = 0; rec[u].lab = 0; rec[u].tag = 0; rec[u].pad = 0; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int cy = (int)(rec[u].yx >> 16), cx = (int)(rec[u].yx & 0xFFFF);
+                const bool keep = val[u] && rec[u].pad == f.gen && cy >= wy_lo && cy <= wy_hi && cx >= wx_lo && cx <= wx_hi;
+                const unsigned long long m = __ballot(keep);
+                const int pos = nraw + __popcll(m & lowmask);
+                if (keep && pos < kMaxRaw) { s_raw_yx[pos] = rec[u].yx; s_raw_lab[pos] = rec[u].lab; s_raw_tag[pos] = rec[u].tag; }
+                nraw += __popcll(m);
             }
         }
         const ClusterRec* __restrict__ oitems = f.ovf_items[buf];
-        for (uint32_t i = tid; i < novf; i += 256) {
-            const ClusterRec rec = oitems[i];
+        for (uint32_t i0 = 0; i0 < novf; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            ClusterRec rec;
+            rec.yx = 0; rec.lab = 0; rec.tag = 0; rec.pad = 0;
+            if (i < novf) rec = oitems[i];
             const int cy = (int)(rec.yx >> 16), cx = (int)(rec.yx & 0xFFFF);
-            if (cy >= wy_lo && cy <= wy_hi && cx >= wx_lo && cx <= wx_hi) {
-                const uint32_t pos = atomicAdd(&s_cnt[0], 1u);
-                if (pos < (uint32_t)kMaxRaw) { s_raw_yx[pos] = rec.yx; s_raw_lab[pos] = rec.lab; s_raw_tag[pos] = rec.tag; }
-            }
+            const bool keep = i < novf && cy >= wy_lo && cy <= wy_hi && cx >= wx_lo && cx <= wx_hi;
+            const unsigned long long m = __ballot(keep);
+            const int pos = nraw + __popcll(m & lowmask);
+            if (keep && pos < kMaxRaw) { s_raw_yx[pos] = rec.yx; s_raw_lab[pos] = rec.lab; s_raw_tag[pos] = rec.tag; }
+            nraw += __popcll(m);
         }
+        if (nraw <= 64) {
+            // one record per lane; pair tests by readlane broadcast, no further LDS traffic
+            const bool act = lane < nraw;
+            const uint32_t yx_j = act ? s_raw_yx[lane] : 0u;
+            const uint32_t lab_j = act ? s_raw_lab[lane] : 0u;
+            const uint32_t tag_j = act ? s_raw_tag[lane] : 0xFFFFFFFFu;
+            bool dup = false;
+            for (int i = 0; i < nraw; ++i) {
+                const uint32_t ty = __builtin_amdgcn_readlane(yx_j, i);
+                const uint32_t tl = __builtin_amdgcn_readlane(lab_j, i);
+                const uint32_t tt = __builtin_amdgcn_readlane(tag_j, i);
+                dup = dup || (act && (tt < tag_j) && (ty == yx_j) && (tl == lab_j));
+            }
+            // rank of lane j's record among the survivors = number of surviving records with a smaller tag
+            int rank = 0;
+            for (int i = 0; i < nraw; ++i) {
+                const uint32_t tt = __builtin_amdgcn_readlane(tag_j, i);
+                const bool di = __builtin_amdgcn_readlane((uint32_t)dup, i) != 0u;
+                rank += (int)(!di && tt < tag_j);
+            }
+            if (act && !dup) s_list[rank] = make_uint4(yx_j, lab_j, tag_j & 0xFFFFu, 0u);
+            n = nraw - __popcll(__ballot(dup));
+        }
+        if (lane == 0) { s_cnt[0] = (uint32_t)nraw; s_cnt[1] = (uint32_t)n; }
     }
     __syncthreads();
     FSLIC_STAMP(1);
-    int nraw = (int)rfl(s_cnt[0]);
-    if (nraw > kMaxRaw) { nraw = kMaxRaw; if (tid == 0) *f.err_flag = 1u; }
-
-    // 3. exact prune + rank.  A cluster with the same integer (y, x, L, a, b) as an earlier-ordered one has
-    //    the same distance everywhere and loses every tie, so it can never win a pixel: drop it.  The
-    //    survivors are ranked by (phase, k): list index order == visit order of the reference scatter.
-    int n;
-    if (nraw <= 64) {
-        // one record per lane; every wavefront does the pair tests with readlane broadcasts, no LDS traffic
-        const bool act = lane < nraw;
-        const uint32_t yx_j = act ? s_raw_yx[lane] : 0u;
-        const uint32_t lab_j = act ? s_raw_lab[lane] : 0u;
-        const uint32_t tag_j = act ? s_raw_tag[lane] : 0xFFFFFFFFu;
-        bool dup = false;
-        for (int i = 0; i < nraw; ++i) {
-            const uint32_t ty = __builtin_amdgcn_readlane(yx_j, i);
-            const uint32_t tl = __builtin_amdgcn_readlane(lab_j, i);
-            const uint32_t tt = __builtin_amdgcn_readlane(tag_j, i);
-            dup = dup || (act && (tt < tag_j) && (ty == yx_j) && (tl == lab_j));
-        }
-        const unsigned long long dupmask = __ballot(dup);
-        for (int i = wave; i < nraw; i += kWavesPerBlock) {
-            if ((dupmask >> i) & 1ull) continue;
-            const uint32_t tt = __builtin_amdgcn_readlane(tag_j, i);
-            const int rank = __popcll(__ballot(act && !dup && tag_j < tt));
-            if (lane == 0)
-                s_list[rank] = make_uint4(__builtin_amdgcn_readlane(yx_j, i), __builtin_amdgcn_readlane(lab_j, i), tt & 0xFFFFu, 0u);
-        }
-        n = nraw - __popcll(dupmask);
-    } else {
+    nraw = (int)rfl(s_cnt[0]);
+    n = (int)rfl(s_cnt[1]);
+    if (nraw > 64) {
+        // rare: a pile-up of clusters (e.g. the leftover seeds of initialize_clusters on the image centre);
+        // all four wavefronts share the O(nraw^2) pair tests through LDS
+        if (nraw > kMaxRaw) { nraw = kMaxRaw; if (tid == 0) *f.err_flag = 1u; }
+        if (tid == 0) s_cnt[1] = 0;
         for (int i = tid; i < nraw; i += 256) {
             const uint32_t yx = s_raw_yx[i], lb = s_raw_lab[i], tg = s_raw_tag[i];
             uint32_t dup = 0;
@@ -343,7 +371,6 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
         n = (int)rfl(s_cnt[1]);
         if (n > kMaxList) { n = kMaxList; if (tid == 0) *f.err_flag = 1u; }
     }
-    __syncthreads();
 
     FSLIC_STAMP(2);
     // 4. the argmin
@@ -351,6 +378,8 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
 #pragma unroll
     for (int r = 0; r < R; ++r) best[r] = 0xFFFFFFFFu;
     const uint32_t M = f.M, Coff = f.C;
+    uint32_t hi16;   // 0xffff0000 in a VGPR so that (w & hi16) | c is one v_and_or_b32 with c in an SGPR
+    asm volatile("v_mov_b32 %0, 0xffff0000" : "=v"(hi16));
     const int yw_hi = yw_lo + (R - 1) * stride;
     uint2 nxt = *reinterpret_cast<const uint2*>(&s_list[0]);
 #pragma unroll 1
@@ -381,7 +410,7 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
                 const uint32_t uy = (uint32_t)(dy < 0 ? -dy : dy);
                 const uint32_t B = uy <= (uint32_t)S ? uy * M : kHuge;   // SALU
                 const uint32_t w = __builtin_amdgcn_sad_hi_u8(pix[r], clab, A + B);
-                const uint32_t key = (w & 0xFFFF0000u) | (uint32_t)c;
+                const uint32_t key = (w & hi16) | (uint32_t)c;
                 best[r] = min(best[r], key);
             }
         }
@@ -687,7 +716,14 @@ __global__ __launch_bounds__(256) void k_cca_local(CcaDev c) {
         }
     }
     __syncthreads();
-    // ---- D ----
+    // ---- D ---- tile-local roots -> this tile's slice of the root list.  No global atomic: a single
+    // returning atomic word saturates near 88 ops/us on this chip, which at one append per wavefront-row
+    // (130k at 4K) cost 1.2 ms in the first version of this kernel.
+    __shared__ uint32_t s_nroots;
+    if (threadIdx.x == 0) s_nroots = 0;
+    __syncthreads();
+    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+    int32_t* const my_roots = c.roots + (size_t)tile * (T * T);
 #pragma unroll 4
     for (int i = 0; i < RW; ++i) {
         const int ly = ly0 + i;
@@ -699,15 +735,17 @@ __global__ __launch_bounds__(256) void k_cca_local(CcaDev c) {
         if (m) {
             const int leader = __ffsll((long long)m) - 1;
             uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(&c.counters[0], (uint32_t)__popcll(m));
+            if (lane == leader) base = atomicAdd(&s_nroots, (uint32_t)__popcll(m));
             base = __shfl(base, leader);
             if (isroot) {
                 const int32_t g = (int32_t)((size_t)y * c.W + x);
                 c.area[g] = s_area[p];
-                c.roots[base + __popcll(m & ((1ull << lane) - 1ull))] = g;
+                my_roots[base + __popcll(m & ((1ull << lane) - 1ull))] = g;
             }
         }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) c.tile_cnt[tile] = s_nroots;
 }
 
 static __device__ __forceinline__ int32_t g_load(int32_t* p) {
@@ -759,11 +797,14 @@ __global__ __launch_bounds__(256) void k_cca_border(CcaDev c, int nh, int nv) {
     }
 }
 
+// One block per tile for the passes over tile-local roots.
 __global__ __launch_bounds__(256) void k_cca_compress(CcaDev c) {
-    const uint32_t n = c.counters[0];
-    const uint32_t gstride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gstride) {
-        const int32_t r = c.roots[i];
+    constexpr int TT = kCcaTile * kCcaTile;
+    const int tile = blockIdx.x;
+    const uint32_t n = c.tile_cnt[tile];
+    const int32_t* __restrict__ my_roots = c.roots + (size_t)tile * TT;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const int32_t r = my_roots[i];
         const int32_t g = g_find(c.parent, r);
         if (g != r) {
             c.parent[r] = g;
@@ -772,20 +813,164 @@ __global__ __launch_bounds__(256) void k_cca_compress(CcaDev c) {
     }
 }
 
+// Global roots: reset their final label; those with area >= threshold (src/cca.cpp:213-217) become
+// candidates in this tile's candidate slice (no global atomic).
 __global__ __launch_bounds__(256) void k_cca_collect(CcaDev c) {
-    const uint32_t n = c.counters[0];
-    const uint32_t gstride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gstride) {
-        const int32_t r = c.roots[i];
+    constexpr int TT = kCcaTile * kCcaTile;
+    __shared__ uint32_t s_n;
+    const int tile = blockIdx.x;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const uint32_t n = c.tile_cnt[tile];
+    const int32_t* __restrict__ my_roots = c.roots + (size_t)tile * TT;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const int32_t r = my_roots[i];
         if (c.parent[r] != r) continue;
         c.final_lab[r] = 0xFFFFu;
         const uint32_t a = c.area[r];
-        if ((int64_t)a >= (int64_t)c.min_threshold) {     // src/cca.cpp:213-217
-            const uint32_t pos = atomicAdd(&c.counters[1], 1u);
-            c.cand_leader[pos] = r;
-            c.cand_area[pos] = a;
+        if ((int64_t)a >= (int64_t)c.min_threshold) {
+            const uint32_t pos = atomicAdd(&s_n, 1u);
+            c.cand_leader[(size_t)tile * TT + pos] = r;
+            c.cand_area[(size_t)tile * TT + pos] = a;
         }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) c.tile_ccnt[tile] = s_n;
+}
+
+// Dense candidate list for the host top-K path (rare: area tie at the cut, or more kept components than the
+// device path sorts).  counters[1] = M.
+__global__ __launch_bounds__(256) void k_cca_densify(CcaDev c, int32_t* __restrict__ out_leader, uint32_t* __restrict__ out_area) {
+    constexpr int TT = kCcaTile * kCcaTile;
+    __shared__ uint32_t s_base;
+    const int tile = blockIdx.x;
+    const uint32_t n = c.tile_ccnt[tile];
+    if (n == 0) return;
+    if (threadIdx.x == 0) s_base = atomicAdd(&c.counters[1], n);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        out_leader[s_base + i] = c.cand_leader[(size_t)tile * TT + i];
+        out_area[s_base + i] = c.cand_area[(size_t)tile * TT + i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device top-K + ranking (src/cca.cpp:205-237) in ONE block, for the unambiguous case:
+//   M <= K            : every candidate is kept
+//   M >  K            : the K largest areas are kept; the K-th largest area a* is found by an 8-bit radix
+//                       select.  If only part of the components with area == a* fit, which ones
+//                       std::partial_sort keeps depends on libstdc++'s heap order -> status = 1 and the host
+//                       redoes the step with std::partial_sort itself.
+// Kept leaders are sorted (bitonic, LDS) and final_lab[leader] = rank, i.e. labels 0,1,2.. in raster order
+// of each component's first pixel (src/cca.cpp:229-237).
+// status word: 0 = done here, 1 = host path required.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSelMax = 8192;
+__global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int ntiles) {
+    constexpr int TT = kCcaTile * kCcaTile;
+    __shared__ uint32_t s_key[kSelMax];
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_red[1024];
+    __shared__ uint32_t s_v[4];     // [0] M, [1] prefix (a*), [2] kk, [3] n_keep
+    const int tid = threadIdx.x;
+    const int K = c.K;
+    // M = total candidates
+    uint32_t mine = 0;
+    for (int t = tid; t < ntiles; t += 1024) mine += c.tile_ccnt[t];
+    s_red[tid] = mine;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (tid < off) s_red[tid] += s_red[tid + off];
+        __syncthreads();
+    }
+    const uint32_t M = s_red[0];
+    __syncthreads();
+    if (tid == 0) { c.counters[2] = M; s_v[3] = 0; }
+    uint32_t astar = 0;           // keep iff area >= astar
+    if (M > (uint32_t)K) {
+        // radix select of the K-th largest area, most significant byte first
+        uint32_t prefix = 0, kk = (uint32_t)K;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            if (tid < 256) s_hist[tid] = 0;
+            __syncthreads();
+            for (int t = tid; t < ntiles; t += 1024) {
+                const uint32_t n = c.tile_ccnt[t];
+                for (uint32_t j = 0; j < n; ++j) {
+                    const uint32_t a = c.cand_area[(size_t)t * TT + j];
+                    if (shift == 24 || (a >> (shift + 8)) == prefix) atomicAdd(&s_hist[(a >> shift) & 255u], 1u);
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t cum = 0;
+                int b = 255;
+                for (; b > 0; --b) {
+                    if (cum + s_hist[b] >= kk) break;
+                    cum += s_hist[b];
+                }
+                s_v[1] = (prefix << 8) | (uint32_t)b;
+                s_v[2] = kk - cum;
+            }
+            __syncthreads();
+            prefix = s_v[1];
+            kk = s_v[2];
+            __syncthreads();
+        }
+        astar = prefix;
+        // kk = how many of the components with area == a* are needed; all of them -> unambiguous
+        if (tid < 256) s_hist[tid] = 0;
+        __syncthreads();
+        for (int t = tid; t < ntiles; t += 1024) {
+            const uint32_t n = c.tile_ccnt[t];
+            for (uint32_t j = 0; j < n; ++j)
+                if (c.cand_area[(size_t)t * TT + j] == astar) atomicAdd(&s_hist[0], 1u);
+        }
+        __syncthreads();
+        if (s_hist[0] != kk) {
+            if (tid == 0) c.counters[3] = 1u;
+            return;
+        }
+    }
+    const uint32_t n_keep_expected = M > (uint32_t)K ? (uint32_t)K : M;
+    if (n_keep_expected > (uint32_t)kSelMax) {
+        if (tid == 0) c.counters[3] = 1u;
+        return;
+    }
+    // kept leaders -> LDS
+    for (int t = tid; t < ntiles; t += 1024) {
+        const uint32_t n = c.tile_ccnt[t];
+        for (uint32_t j = 0; j < n; ++j) {
+            if (c.cand_area[(size_t)t * TT + j] >= astar) {
+                const uint32_t pos = atomicAdd(&s_v[3], 1u);
+                if (pos < (uint32_t)kSelMax) s_key[pos] = (uint32_t)c.cand_leader[(size_t)t * TT + j];
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t n_keep = s_v[3];
+    if (n_keep != n_keep_expected) {     // cannot happen; be safe and let the host decide
+        if (tid == 0) c.counters[3] = 1u;
+        return;
+    }
+    uint32_t P2 = 1;
+    while (P2 < n_keep) P2 <<= 1;
+    for (uint32_t i = n_keep + tid; i < P2; i += 1024) s_key[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t k = 2; k <= P2; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < P2; i += 1024) {
+                const uint32_t ixj = i ^ j;
+                if (ixj > i) {
+                    const uint32_t a = s_key[i], b = s_key[ixj];
+                    const bool up = ((i & k) == 0);
+                    if ((a > b) == up) { s_key[i] = b; s_key[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = tid; i < n_keep; i += 1024) c.final_lab[s_key[i]] = (uint16_t)i;
+    if (tid == 0) c.counters[3] = 0u;
 }
 
 void launch_cca_phase1(const CcaDev& c, hipStream_t st) {
@@ -795,39 +980,68 @@ void launch_cca_phase1(const CcaDev& c, hipStream_t st) {
     const int nh = (ty - 1) * c.W, nv = (tx - 1) * c.H;
     if (nh + nv > 0)
         hipLaunchKernelGGL(k_cca_border, dim3((nh + nv + 255) / 256), dim3(256), 0, st, c, nh, nv);
-    hipLaunchKernelGGL(k_cca_compress, dim3(1024), dim3(256), 0, st, c);
-    hipLaunchKernelGGL(k_cca_collect, dim3(1024), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_cca_compress, dim3(tx * ty), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_cca_collect, dim3(tx * ty), dim3(256), 0, st, c);
 }
 
+void launch_cca_select(const CcaDev& c, hipStream_t st) {
+    constexpr int T = kCcaTile;
+    const int ntiles = ((c.W + T - 1) / T) * ((c.H + T - 1) / T);
+    hipLaunchKernelGGL(k_cca_select, dim3(1), dim3(1024), 0, st, c, ntiles);
+}
+
+void launch_cca_densify(const CcaDev& c, int32_t* d_leader, uint32_t* d_area, hipStream_t st) {
+    constexpr int T = kCcaTile;
+    const int ntiles = ((c.W + T - 1) / T) * ((c.H + T - 1) / T);
+    hipLaunchKernelGGL(k_cca_densify, dim3(ntiles), dim3(256), 0, st, c, d_leader, d_area);
+}
+
+// Host path only: forget what the device select / chain wrote, then set the host's choice.
+__global__ __launch_bounds__(256) void k_cca_reset_final(CcaDev c) {
+    constexpr int TT = kCcaTile * kCcaTile;
+    const int tile = blockIdx.x;
+    const uint32_t n = c.tile_cnt[tile];
+    const int32_t* __restrict__ my_roots = c.roots + (size_t)tile * TT;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const int32_t r = my_roots[i];
+        if (c.parent[r] == r) c.final_lab[r] = 0xFFFFu;
+    }
+}
 __global__ void k_cca_set_kept(CcaDev c, const int32_t* __restrict__ leaders, const uint16_t* __restrict__ labels, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) c.final_lab[leaders[i]] = labels[i];
 }
 void launch_cca_set_kept(const CcaDev& c, const int32_t* d_leaders, const uint16_t* d_labels, int n, hipStream_t st) {
+    constexpr int T = kCcaTile;
+    const int ntiles = ((c.W + T - 1) / T) * ((c.H + T - 1) / T);
+    hipLaunchKernelGGL(k_cca_reset_final, dim3(ntiles), dim3(256), 0, st, c);
     if (n <= 0) return;
     hipLaunchKernelGGL(k_cca_set_kept, dim3((n + 255) / 256), dim3(256), 0, st, c, d_leaders, d_labels, n);
 }
 
+// Every component that was not kept takes the final label of the component left of (or, in column 0,
+// above) its leader (src/cca.cpp:240-254).  Leaders strictly decrease along the chase, so it terminates.
 __global__ __launch_bounds__(256) void k_cca_chain(CcaDev c) {
-    const uint32_t n = c.counters[0];
-    const uint32_t gstride = gridDim.x * blockDim.x;
+    constexpr int TT = kCcaTile * kCcaTile;
+    const int tile = blockIdx.x;
+    const uint32_t n = c.tile_cnt[tile];
+    const int32_t* __restrict__ my_roots = c.roots + (size_t)tile * TT;
     const int W = c.W;
-    volatile uint16_t* fin = c.final_lab;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gstride) {
-        const int32_t r = c.roots[i];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const int32_t r = my_roots[i];
         if (c.parent[r] != r) continue;
-        if (fin[r] != 0xFFFFu) continue;          // kept component
+        if (__hip_atomic_load(c.final_lab + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0xFFFFu) continue;   // kept
         int32_t cur = r;
         uint32_t f;
         for (;;) {
             if (cur == 0) { f = 0; break; }        // src/cca.cpp:238
             const int32_t t = (cur % W > 0) ? cur - 1 : cur - W;   // src/cca.cpp:243-248
             const int32_t g = c.parent[c.parent[t]];
-            f = fin[g];
+            f = __hip_atomic_load(c.final_lab + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (f != 0xFFFFu) break;
             cur = g;
         }
-        fin[r] = (uint16_t)f;
+        __hip_atomic_store(c.final_lab + r, (uint16_t)f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -848,7 +1062,9 @@ __global__ __launch_bounds__(256) void k_cca_relabel(CcaDev c) {
 }
 
 void launch_cca_phase2(const CcaDev& c, hipStream_t st) {
-    hipLaunchKernelGGL(k_cca_chain, dim3(1024), dim3(256), 0, st, c);
+    constexpr int T = kCcaTile;
+    const int ntiles = ((c.W + T - 1) / T) * ((c.H + T - 1) / T);
+    hipLaunchKernelGGL(k_cca_chain, dim3(ntiles), dim3(256), 0, st, c);
     int blocks = (c.N / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
