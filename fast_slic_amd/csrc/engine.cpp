@@ -472,6 +472,7 @@ int frame_enqueue_phase1(fslic_engine* e, Slot& s, const fslic_params* p, int H,
     }
     if (getenv("FSLIC_DEBUG_TIMING")) {
         if (!s.d_dbg) HIPCHK(hipMalloc((void**)&s.d_dbg, sizeof(unsigned long long) * 8 * 65536));
+        HIPCHK(hipMemsetAsync(s.d_dbg, 0, sizeof(unsigned long long) * 8 * 65536, s.st));
         f.dbg = s.d_dbg;
     } else f.dbg = nullptr;
     HIPCHK(hipEventRecord(s.ev[2], s.st));
@@ -481,22 +482,22 @@ int frame_enqueue_phase1(fslic_engine* e, Slot& s, const fslic_params* p, int H,
     HIPCHK(hipEventRecord(s.ev[3], s.st));
     if (f.dbg) {   // bring-up aid: average per-phase cycles of the full-assign launch, printed to stderr
         HIPCHK(hipStreamSynchronize(s.st));
-        const int R2 = 16, R1 = 8;
-        const int tiles_x = (W + kTileW - 1) / kTileW;
-        int ty = (H + 4 * R1 - 1) / (4 * R1);
-        if (tiles_x * ty > 1536) ty = (H + 4 * R2 - 1) / (4 * R2);
-        const int nb = std::min(tiles_x * ty, 65536);
-        std::vector<unsigned long long> h((size_t)nb * 8);
+        const int nw = 65536;
+        std::vector<unsigned long long> h((size_t)nw * 8);
         HIPCHK(hipMemcpy(h.data(), s.d_dbg, h.size() * 8, hipMemcpyDeviceToHost));
         double ph[5] = {0, 0, 0, 0, 0}, nr = 0, nn = 0;
         unsigned long long tmin = ~0ull, tmax = 0;
-        for (int b = 0; b < nb; b++) {
+        int cnt = 0;
+        for (int b = 0; b < nw; b++) {
+            if (h[(size_t)b * 8] == 0 || h[(size_t)b * 8 + 5] == 0) continue;
+            cnt++;
             for (int q = 0; q < 5; q++) ph[q] += (double)(h[(size_t)b * 8 + q + 1] - h[(size_t)b * 8 + q]);
             nr += (double)h[(size_t)b * 8 + 6]; nn += (double)h[(size_t)b * 8 + 7];
             tmin = std::min(tmin, h[(size_t)b * 8]); tmax = std::max(tmax, h[(size_t)b * 8 + 5]);
         }
-        fprintf(stderr, "[fslic dbg] full_assign %dx%d blocks=%d avg ticks: load+gather %.0f  prune+rank %.0f  argmin %.0f  store %.0f  update %.0f | nraw %.1f n %.1f | first-start..last-end %llu ticks\n",
-                W, H, nb, ph[0] / nb, ph[1] / nb, ph[2] / nb, ph[3] / nb, ph[4] / nb, nr / nb, nn / nb, tmax - tmin);
+        if (cnt == 0) cnt = 1;
+        fprintf(stderr, "[fslic dbg] full_assign %dx%d waves=%d avg ticks: loads+gather %.0f  prune+rank %.0f  argmin %.0f  store %.0f  update %.0f | nraw %.1f n %.1f | span %llu ticks\n",
+                W, H, cnt, ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt, ph[4] / cnt, nr / cnt, nn / cnt, tmax - tmin);
         f.dbg = nullptr;
     }
     // cluster state + overflow flag back to the host

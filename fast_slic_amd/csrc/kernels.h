@@ -11,9 +11,7 @@ constexpr int kTileW = 64;          // assign tile width  = one wavefront of col
 constexpr int kWavesPerBlock = 4;   // assign block = 4 wavefronts stacked vertically
 constexpr int kRowsPerWave = 8;     // visited rows per wavefront
 constexpr int kCellCap = 8;         // cluster records per coarse cell before spilling to overflow
-constexpr int kMaxRaw = 1024;       // gathered candidate records per block (LDS)
-constexpr int kMaxList = 256;       // sorted + de-duplicated candidates per block (LDS)
-constexpr int kAccSlots = 32;       // candidates with LDS-privatised centroid sums
+constexpr int kAccSlots = 16;       // candidates per wavefront with LDS-privatised centroid sums
 constexpr int kAccCopies = 8;       // privatised copies per (slot, quantity)
 constexpr uint32_t kHuge = 0x40000000u;   // out-of-window marker added to the distance key
 constexpr int kCcaTile = 64;        // connectivity tile: 64 x 64 pixels, one block of 256 threads

@@ -8,6 +8,7 @@
 //
 // All arithmetic on this path is integer, so the results are bit-identical to the reference.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace fslic {
 
@@ -179,20 +180,27 @@ void launch_bin_clusters(const FrameDev& f, int mode, int buf, hipStream_t st) {
 }
 
 // =============================================================================================
-// Assign kernel (the roofline kernel).  One block = 64 columns x (4 wavefronts x R visited rows).
-// Lane = column, so |x - cx| and the x window test are per-lane-per-candidate, while |y - cy| and
-// the y window test are wave-uniform per row and live in SGPRs.  Per pixel-candidate the VALU does
+// Assign kernel (the roofline kernel).  One WAVEFRONT = one tile of 64 columns x R visited rows; the four
+// wavefronts of a block are independent (no barrier, no shared list), so they drift apart in time and the
+// loads of one overlap the argmin of another.
+// Lane = column, so |x - cx| and the x window test are per-lane-per-candidate, while |y - cy| and the y window
+// test are wave-uniform per row and live in SGPRs.  Per pixel-candidate the VALU does
 //     a   = A + B                      (spatial term, 16 fractional bits, window folded in as kHuge)
 //     w   = v_sad_hi_u8(pix, clab, a)  ((|dL|+|da|+|db|) << 16) + a
-//     key = (w & 0xffff0000) | idx     idx = rank of the candidate in (phase, k) order
+//     key = v_and_or(w, 0xffff0000, idx)   idx = rank of the candidate in (phase, k) order
 //     best = min(best, key)
-// so `best` ends up as the lexicographic minimum of (distance, phase, k).  Pixels that no window
-// covers are not written: the previous label persists (src/context.cpp:138-145 clears the
-// assignment plane once per call, not per iteration).
+// so `best` ends up as the lexicographic minimum of (distance, phase, k).  Pixels that no window covers are
+// not written: the previous label persists (src/context.cpp:138-145 clears the assignment plane once per
+// call, not per iteration).
+// Candidate list per wavefront: every slot of every coarse cell the tile's pixels can see (a slot is live
+// when its generation stamp equals this pass's: one round trip fetches count and payload) plus the spill
+// list; ballot compaction into 64 LDS slots; exact prune of clusters with identical (y,x,L,a,b) to an
+// earlier-ordered one (same distance everywhere, loses every tie); rank by (phase,k) with readlane
+// broadcasts.  More than 64 live candidates (a pile-up of seeds on one pixel): the records are streamed
+// again and compared unsorted with a two-register (distance, phase<<16|k) key; no capacity limit.
 // Algorithmic traffic: 4 B read + 2 B written per visited pixel; min-distances never leave VGPRs.
-// With FUSE the centroid sums of update() (src/context.cpp:301-354) for the same rows are
-// accumulated in LDS (privatised copies) and flushed with one global atomic per (candidate,
-// quantity) and block.
+// With FUSE the centroid sums of update() (src/context.cpp:301-354) for the same rows are accumulated in a
+// wave-private LDS region (privatised copies) and flushed with one global atomic per (candidate, quantity).
 // =============================================================================================
 static __device__ __forceinline__ void global_accumulate(uint32_t* sums, uint32_t k, uint32_t y, uint32_t x, uint32_t pix) {
     uint32_t* s = sums + 6 * (size_t)k;
@@ -204,225 +212,238 @@ static __device__ __forceinline__ void global_accumulate(uint32_t* sums, uint32_
     atomicAdd(s + 5, (pix >> 16) & 255u);
 }
 
-// LUT == false: spatial term = (d*M + C) >> 16 formed in VALU (exact multiplier found by the host).
-// LUT == true : spatial term read from an LDS table indexed by ux' + uy'*lut_row (Manhattan patches the
-//               fixed point cannot express because of the float rounding in set_spatial_patch, and the
-//               hypotf patch of manhattan_spatial_dist=False); entries are pre-shifted by 16, out-of-window
-//               indices hold kHuge.
+struct TileWindow { int wy_lo, wy_hi, wx_lo, wx_hi; };
+static __device__ __forceinline__ bool in_window(const ClusterRec& r, const TileWindow& w) {
+    const int cy = (int)(r.yx >> 16), cx = (int)(r.yx & 0xFFFF);
+    return cy >= w.wy_lo && cy <= w.wy_hi && cx >= w.wx_lo && cx <= w.wx_hi;
+}
+
 template <int R, bool FUSE, bool LUT>
 __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride, int Hv, int buf) {
     extern __shared__ uint32_t s_lut[];
-    __shared__ uint32_t s_raw[3 * kMaxRaw];
-    __shared__ uint4 s_list[kMaxList];
-    __shared__ uint8_t s_dup[kMaxRaw];
-    __shared__ uint32_t s_cnt[2];
-    __shared__ uint32_t s_acc[FUSE ? kAccSlots * 6 * kAccCopies : 1];
-    uint32_t* const s_raw_yx = s_raw;
-    uint32_t* const s_raw_lab = s_raw + kMaxRaw;
-    uint32_t* const s_raw_tag = s_raw + 2 * kMaxRaw;
+    __shared__ uint32_t s_rawbuf[kWavesPerBlock][3 * 64];
+    __shared__ uint4 s_listbuf[kWavesPerBlock][64];
+    __shared__ uint32_t s_accbuf[FUSE ? kWavesPerBlock * kAccSlots * 6 * kAccCopies : 1];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = (int)rfl((uint32_t)(tid >> 6));
+    uint32_t* const s_raw = s_rawbuf[wave];
+    uint4* const s_list = s_listbuf[wave];
+    uint32_t* const s_acc = s_accbuf + (FUSE ? wave * (kAccSlots * 6 * kAccCopies) : 0);
     const int W = f.W, S = f.S;
     const int x0 = blockIdx.x * kTileW;
     const int x = x0 + lane;
-    const int vrow_b0 = blockIdx.y * (kWavesPerBlock * R);
-    const int vrow_w0 = vrow_b0 + wave * R;
-    const int yw_lo = rem + vrow_w0 * stride;
+    const int vrow_w0 = (blockIdx.y * kWavesPerBlock + wave) * R;
     const bool okx = x < W;
-
 #define FSLIC_STAMP(slot_)                                                                              \
     do {                                                                                                 \
-        if (f.dbg && tid == 0)                                                                           \
-            f.dbg[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot_)] = __builtin_readcyclecounter(); \
+        if (f.dbg && lane == 0)                                                                          \
+            f.dbg[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kWavesPerBlock + wave) * 8 + (slot_)] = __builtin_readcyclecounter(); \
     } while (0)
-    FSLIC_STAMP(0);
-    if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
-    const uint32_t novf = *f.ovf_cnt[buf];        // issued early, consumed after the cell gather
     if (LUT) {
         for (int i = tid; i < f.lut_words; i += 256) s_lut[i] = f.lut[i];
+        __syncthreads();                     // the only barrier of the kernel
     }
-    if (FUSE) {
-        for (int i = tid; i < kAccSlots * 6 * kAccCopies; i += 256) s_acc[i] = 0u;
-    }
+    if (vrow_w0 >= Hv) return;               // wave-uniform
+    FSLIC_STAMP(0);
+    const int yw_lo = rem + vrow_w0 * stride;
+    const int nrows = min(R, Hv - vrow_w0);
+    const uint32_t novf = *f.ovf_cnt[buf];   // issued early, consumed after the cell gather
 
-    // 1. issue the pixel loads first; they do not depend on the candidate list
+    // 1. pixel loads first; they do not depend on the candidate list
     uint32_t pix[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const bool ok = okx && (vrow_w0 + r) < Hv;
+        const bool ok = okx && r < nrows;
         pix[r] = ok ? f.lab[(size_t)(yw_lo + r * stride) * W + x] : 0u;
     }
-    __syncthreads();
+    if (FUSE) {
+#pragma unroll
+        for (int i = 0; i < kAccSlots * 6 * kAccCopies / 64; ++i) s_acc[i * 64 + lane] = 0u;
+    }
 
-    // 2+3. candidate list, built by wavefront 0 alone while the other three wait at the barrier (a waiting
-    //      wavefront issues nothing, and with ~8 resident blocks per CU the prologue's issue slots are what
-    //      the argmin phase of the other blocks needs).
-    //   gather : every slot of every coarse cell the block's pixels can see; a slot is live when its
-    //            generation stamp equals this pass's, so one round trip fetches count and payload;
-    //            ballot compaction, no atomics
-    //   prune  : a cluster with the same integer (y, x, L, a, b) as an earlier-ordered one has the same distance
-    //            everywhere and loses every tie, so it can never win a pixel: dropped (exact)
-    //   rank   : survivors ordered by (phase, k): list index order == visit order of the reference scatter
-    int nraw = 0, n = 0;
-    if (wave == 0) {
-        const int vlast = min(vrow_b0 + kWavesPerBlock * R - 1, Hv - 1);
-        const int yb_lo = rem + vrow_b0 * stride, yb_hi = rem + vlast * stride;
-        const int xb_hi = min(x0 + kTileW - 1, W - 1);
-        const int wy_lo = yb_lo - S, wy_hi = yb_hi + S, wx_lo = x0 - S, wx_hi = xb_hi + S;
-        const int sh = f.cs_shift;
-        const int cxa = max(wx_lo, 0) >> sh, cxb = min(wx_hi, W - 1) >> sh;
-        const int cya = max(wy_lo, 0) >> sh, cyb = min(wy_hi, f.H - 1) >> sh;
-        const int ncxr = cxb - cxa + 1, ncyr = cyb - cya + 1;
-        const int total = ncxr * ncyr * kCellCap;
-        const uint32_t inv = (uint32_t)(4294967296.0f / (float)ncxr) + 1u;   // exact quotient for the small operands here
-        const ClusterRec* __restrict__ citems = f.cell_items[buf];
-        const unsigned long long lowmask = (1ull << lane) - 1ull;
-        for (int c0 = 0; c0 < total; c0 += 256) {
-            ClusterRec rec[4];
-            bool val[4];
+    // 2. gather
+    TileWindow win;
+    win.wy_lo = yw_lo - S; win.wy_hi = yw_lo + (nrows - 1) * stride + S;
+    win.wx_lo = x0 - S;    win.wx_hi = min(x0 + kTileW - 1, W - 1) + S;
+    const int sh = f.cs_shift;
+    const int cxa = max(win.wx_lo, 0) >> sh, cxb = min(win.wx_hi, W - 1) >> sh;
+    const int cya = max(win.wy_lo, 0) >> sh, cyb = min(win.wy_hi, f.H - 1) >> sh;
+    const int ncxr = cxb - cxa + 1, ncyr = cyb - cya + 1;
+    const int total = ncxr * ncyr * kCellCap;
+    const uint32_t inv = (uint32_t)(4294967296.0f / (float)ncxr) + 1u;   // exact quotient for the small operands here
+    const ClusterRec* __restrict__ citems = f.cell_items[buf];
+    const ClusterRec* __restrict__ oitems = f.ovf_items[buf];
+    const unsigned long long lowmask = (1ull << lane) - 1ull;
+    auto cell_slot = [&](int e) -> size_t {
+        const uint32_t ce = (uint32_t)e >> 3;
+        uint32_t cyi = __umulhi(ce, inv);
+        if (cyi * (uint32_t)ncxr > ce) cyi--;                // guard the float reciprocal
+        const uint32_t cxi = ce - cyi * (uint32_t)ncxr;
+        return ((size_t)(cya + (int)cyi) * f.ncx + cxa + (int)cxi) * kCellCap + (e & 7);
+    };
+    int nraw = 0;
+    for (int c0 = 0; c0 < total; c0 += 256) {
+        ClusterRec rec[4];
+        bool live[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = c0 + u * 64 + lane;
-                val[u] = e < total;
-                const uint32_t ce = (uint32_t)e >> 3;
-                uint32_t cyi = __umulhi(ce, inv);
-                if (cyi * (uint32_t)ncxr > ce) cyi--;            // guard the float reciprocal
-                const uint32_t cxi = ce - cyi * (uint32_t)ncxr;
-                const size_t cell = (size_t)(cya + (int)cyi) * f.ncx + cxa + (int)cxi;
-                if (val[u]) rec[u] = citems[cell * kCellCap + (e & 7)];
-                else { rec[u].yx = 0; rec[u].lab = 0; rec[u].tag = 0; rec[u].pad = 0; }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int cy = (int)(rec[u].yx >> 16), cx = (int)(rec[u].yx & 0xFFFF);
-                const bool keep = val[u] && rec[u].pad == f.gen && cy >= wy_lo && cy <= wy_hi && cx >= wx_lo && cx <= wx_hi;
-                const unsigned long long m = __ballot(keep);
-                const int pos = nraw + __popcll(m & lowmask);
-                if (keep && pos < kMaxRaw) { s_raw_yx[pos] = rec[u].yx; s_raw_lab[pos] = rec[u].lab; s_raw_tag[pos] = rec[u].tag; }
-                nraw += __popcll(m);
-            }
+        for (int u = 0; u < 4; ++u) {
+            const int e = c0 + u * 64 + lane;
+            live[u] = e < total;
+            if (live[u]) rec[u] = citems[cell_slot(e)];
+            else { rec[u].yx = 0; rec[u].lab = 0; rec[u].tag = 0; rec[u].pad = 0; }
         }
-        const ClusterRec* __restrict__ oitems = f.ovf_items[buf];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool keep = live[u] && rec[u].pad == f.gen && in_window(rec[u], win);
+            const unsigned long long m = __ballot(keep);
+            const int pos = nraw + __popcll(m & lowmask);
+            if (keep && pos < 64) { s_raw[pos] = rec[u].yx; s_raw[64 + pos] = rec[u].lab; s_raw[128 + pos] = rec[u].tag; }
+            nraw += __popcll(m);
+        }
+    }
+    for (uint32_t i0 = 0; i0 < novf; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        ClusterRec rec;
+        rec.yx = 0; rec.lab = 0; rec.tag = 0; rec.pad = 0;
+        if (i < novf) rec = oitems[i];
+        const bool keep = i < novf && in_window(rec, win);
+        const unsigned long long m = __ballot(keep);
+        const int pos = nraw + __popcll(m & lowmask);
+        if (keep && pos < 64) { s_raw[pos] = rec.yx; s_raw[64 + pos] = rec.lab; s_raw[128 + pos] = rec.tag; }
+        nraw += __popcll(m);
+    }
+    __builtin_amdgcn_wave_barrier();   // staging writes above, cross-lane reads below: keep program order
+    FSLIC_STAMP(1);
+
+    const uint32_t M = f.M, Coff = f.C;
+    uint32_t hi16;   // 0xffff0000 in a VGPR so that (w & hi16) | c is one v_and_or_b32 with c in an SGPR
+    asm volatile("v_mov_b32 %0, 0xffff0000" : "=v"(hi16));
+    // spatial + colour term of one candidate for row r, window folded in: < kHuge iff the pixel is covered
+    auto spatial_A = [&](int cx) -> uint32_t {
+        const int dx = x - cx;
+        const uint32_t ux = (uint32_t)(dx < 0 ? -dx : dx);
+        if (LUT) return ux <= (uint32_t)S ? ux : (uint32_t)f.lut_oow;
+        return ux <= (uint32_t)S ? __umul24(ux, M) + Coff : kHuge;
+    };
+    auto dist_w = [&](int r, int cy, uint32_t clab, uint32_t A) -> uint32_t {
+        const int dy = yw_lo + r * stride - cy;
+        const uint32_t uy = (uint32_t)(dy < 0 ? -dy : dy);                   // SALU
+        if (LUT) {
+            const uint32_t B = (uy <= (uint32_t)S ? uy : (uint32_t)f.lut_oow) * (uint32_t)f.lut_row;
+            return __builtin_amdgcn_sad_hi_u8(pix[r], clab, s_lut[A + B]);
+        }
+        const uint32_t B = uy <= (uint32_t)S ? uy * M : kHuge;
+        return __builtin_amdgcn_sad_hi_u8(pix[r], clab, A + B);
+    };
+    const int yw_hi = yw_lo + (R - 1) * stride;
+
+    if (nraw > 64) {
+        // ---- unsorted streaming path (no capacity limit): lexicographic (distance, phase<<16|k) in two registers
+        uint32_t bw[R], bt[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { bw[r] = 0xFFFFFFFFu; bt[r] = 0xFFFFFFFFu; }
+        auto stream = [&](const ClusterRec& rec, bool keep) {
+            unsigned long long m = __ballot(keep);
+            while (m) {
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const uint32_t cyx = __builtin_amdgcn_readlane(rec.yx, src);
+                const uint32_t clab = __builtin_amdgcn_readlane(rec.lab, src);
+                const uint32_t tag = __builtin_amdgcn_readlane(rec.tag, src);
+                const int cy = (int)(cyx >> 16), cx = (int)(cyx & 0xFFFFu);
+                if (cy + S < yw_lo || cy - S > yw_hi) continue;
+                const uint32_t A = spatial_A(cx);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t w = dist_w(r, cy, clab, A) & hi16;
+                    const bool better = (w < bw[r]) || (w == bw[r] && tag < bt[r]);
+                    bw[r] = better ? w : bw[r];
+                    bt[r] = better ? tag : bt[r];
+                }
+            }
+        };
+        for (int c0 = 0; c0 < total; c0 += 64) {
+            const int e = c0 + lane;
+            ClusterRec rec;
+            rec.yx = 0; rec.lab = 0; rec.tag = 0; rec.pad = 0;
+            if (e < total) rec = citems[cell_slot(e)];
+            stream(rec, e < total && rec.pad == f.gen && in_window(rec, win));
+        }
         for (uint32_t i0 = 0; i0 < novf; i0 += 64) {
             const uint32_t i = i0 + lane;
             ClusterRec rec;
             rec.yx = 0; rec.lab = 0; rec.tag = 0; rec.pad = 0;
             if (i < novf) rec = oitems[i];
-            const int cy = (int)(rec.yx >> 16), cx = (int)(rec.yx & 0xFFFF);
-            const bool keep = i < novf && cy >= wy_lo && cy <= wy_hi && cx >= wx_lo && cx <= wx_hi;
-            const unsigned long long m = __ballot(keep);
-            const int pos = nraw + __popcll(m & lowmask);
-            if (keep && pos < kMaxRaw) { s_raw_yx[pos] = rec.yx; s_raw_lab[pos] = rec.lab; s_raw_tag[pos] = rec.tag; }
-            nraw += __popcll(m);
+            stream(rec, i < novf && in_window(rec, win));
         }
-        if (nraw <= 64) {
-            // one record per lane; pair tests by readlane broadcast, no further LDS traffic
-            const bool act = lane < nraw;
-            const uint32_t yx_j = act ? s_raw_yx[lane] : 0u;
-            const uint32_t lab_j = act ? s_raw_lab[lane] : 0u;
-            const uint32_t tag_j = act ? s_raw_tag[lane] : 0xFFFFFFFFu;
-            bool dup = false;
-            for (int i = 0; i < nraw; ++i) {
-                const uint32_t ty = __builtin_amdgcn_readlane(yx_j, i);
-                const uint32_t tl = __builtin_amdgcn_readlane(lab_j, i);
-                const uint32_t tt = __builtin_amdgcn_readlane(tag_j, i);
-                dup = dup || (act && (tt < tag_j) && (ty == yx_j) && (tl == lab_j));
-            }
-            // rank of lane j's record among the survivors = number of surviving records with a smaller tag
-            int rank = 0;
-            for (int i = 0; i < nraw; ++i) {
-                const uint32_t tt = __builtin_amdgcn_readlane(tag_j, i);
-                const bool di = __builtin_amdgcn_readlane((uint32_t)dup, i) != 0u;
-                rank += (int)(!di && tt < tag_j);
-            }
-            if (act && !dup) s_list[rank] = make_uint4(yx_j, lab_j, tag_j & 0xFFFFu, 0u);
-            n = nraw - __popcll(__ballot(dup));
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (!(okx && r < nrows)) continue;
+            const int y = yw_lo + r * stride;
+            const size_t p = (size_t)y * W + x;
+            uint32_t lbl;
+            if (bw[r] < kHuge) { lbl = bt[r] & 0xFFFFu; f.labels[p] = (uint16_t)lbl; }
+            else lbl = f.labels[p];
+            if (FUSE && lbl != 0xFFFFu) global_accumulate(f.sums, lbl, (uint32_t)y, (uint32_t)x, pix[r]);
         }
-        if (lane == 0) { s_cnt[0] = (uint32_t)nraw; s_cnt[1] = (uint32_t)n; }
-    }
-    __syncthreads();
-    FSLIC_STAMP(1);
-    nraw = (int)rfl(s_cnt[0]);
-    n = (int)rfl(s_cnt[1]);
-    if (nraw > 64) {
-        // rare: a pile-up of clusters (e.g. the leftover seeds of initialize_clusters on the image centre);
-        // all four wavefronts share the O(nraw^2) pair tests through LDS
-        if (nraw > kMaxRaw) { nraw = kMaxRaw; if (tid == 0) *f.err_flag = 1u; }
-        if (tid == 0) s_cnt[1] = 0;
-        for (int i = tid; i < nraw; i += 256) {
-            const uint32_t yx = s_raw_yx[i], lb = s_raw_lab[i], tg = s_raw_tag[i];
-            uint32_t dup = 0;
-            for (int j = 0; j < nraw; ++j)
-                dup |= (uint32_t)(s_raw_tag[j] < tg && s_raw_yx[j] == yx && s_raw_lab[j] == lb);
-            s_dup[i] = (uint8_t)dup;
-        }
-        __syncthreads();
-        for (int i = tid; i < nraw; i += 256) {
-            if (s_dup[i]) continue;
-            const uint32_t tg = s_raw_tag[i];
-            int rank = 0;
-            for (int j = 0; j < nraw; ++j) rank += (int)(s_raw_tag[j] < tg && !s_dup[j]);
-            if (rank < kMaxList) s_list[rank] = make_uint4(s_raw_yx[i], s_raw_lab[i], tg & 0xFFFFu, 0u);
-            atomicAdd(&s_cnt[1], 1u);
-        }
-        __syncthreads();
-        n = (int)rfl(s_cnt[1]);
-        if (n > kMaxList) { n = kMaxList; if (tid == 0) *f.err_flag = 1u; }
+        return;
     }
 
+    // 3. exact prune + rank (one record per lane, pair tests by readlane broadcast)
+    int n;
+    {
+        const bool act = lane < nraw;
+        const uint32_t yx_j = act ? s_raw[lane] : 0u;
+        const uint32_t lab_j = act ? s_raw[64 + lane] : 0u;
+        const uint32_t tag_j = act ? s_raw[128 + lane] : 0xFFFFFFFFu;
+        bool dup = false;
+        for (int i = 0; i < nraw; ++i) {
+            const uint32_t ty = __builtin_amdgcn_readlane(yx_j, i);
+            const uint32_t tl = __builtin_amdgcn_readlane(lab_j, i);
+            const uint32_t tt = __builtin_amdgcn_readlane(tag_j, i);
+            dup = dup || (act && (tt < tag_j) && (ty == yx_j) && (tl == lab_j));
+        }
+        const unsigned long long dupmask = __ballot(dup);
+        int rank = 0;
+        for (int i = 0; i < nraw; ++i) {
+            const uint32_t tt = __builtin_amdgcn_readlane(tag_j, i);
+            rank += (int)((((dupmask >> i) & 1ull) == 0ull) && tt < tag_j);
+        }
+        if (act && !dup) s_list[rank] = make_uint4(yx_j, lab_j, tag_j & 0xFFFFu, 0u);
+        n = nraw - __popcll(dupmask);
+    }
+    __builtin_amdgcn_wave_barrier();
     FSLIC_STAMP(2);
-    // 4. the argmin
+
+    // 4. the argmin over the sorted list
     uint32_t best[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) best[r] = 0xFFFFFFFFu;
-    const uint32_t M = f.M, Coff = f.C;
-    uint32_t hi16;   // 0xffff0000 in a VGPR so that (w & hi16) | c is one v_and_or_b32 with c in an SGPR
-    asm volatile("v_mov_b32 %0, 0xffff0000" : "=v"(hi16));
-    const int yw_hi = yw_lo + (R - 1) * stride;
     uint2 nxt = *reinterpret_cast<const uint2*>(&s_list[0]);
 #pragma unroll 1
     for (int c = 0; c < n; ++c) {
         const uint2 rec = nxt;
-        nxt = *reinterpret_cast<const uint2*>(&s_list[min(c + 1, kMaxList - 1)]);   // prefetch: hides the LDS latency
+        nxt = *reinterpret_cast<const uint2*>(&s_list[min(c + 1, 63)]);   // prefetch: hides the LDS latency
         const uint32_t cyx = rfl(rec.x);
         const uint32_t clab = rfl(rec.y);
         const int cy = (int)(cyx >> 16), cx = (int)(cyx & 0xFFFFu);
-        if (cy + S < yw_lo || cy - S > yw_hi) continue;   // wave-uniform cull
-        const int dx = x - cx;
-        const uint32_t ux = (uint32_t)(dx < 0 ? -dx : dx);
-        if (LUT) {
-            const uint32_t A = ux <= (uint32_t)S ? ux : (uint32_t)f.lut_oow;
+        const uint32_t A = spatial_A(cx);
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int dy = yw_lo + r * stride - cy;
-                const uint32_t uy = (uint32_t)(dy < 0 ? -dy : dy);
-                const uint32_t B = (uy <= (uint32_t)S ? uy : (uint32_t)f.lut_oow) * (uint32_t)f.lut_row;   // SALU
-                const uint32_t w = __builtin_amdgcn_sad_hi_u8(pix[r], clab, s_lut[A + B]);
-                best[r] = min(best[r], w | (uint32_t)c);
-            }
-        } else {
-            const uint32_t A = ux <= (uint32_t)S ? __umul24(ux, M) + Coff : kHuge;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int dy = yw_lo + r * stride - cy;
-                const uint32_t uy = (uint32_t)(dy < 0 ? -dy : dy);
-                const uint32_t B = uy <= (uint32_t)S ? uy * M : kHuge;   // SALU
-                const uint32_t w = __builtin_amdgcn_sad_hi_u8(pix[r], clab, A + B);
-                const uint32_t key = (w & hi16) | (uint32_t)c;
-                best[r] = min(best[r], key);
-            }
+        for (int r = 0; r < R; ++r) {
+            const uint32_t w = dist_w(r, cy, clab, A);
+            best[r] = min(best[r], LUT ? (w | (uint32_t)c) : ((w & hi16) | (uint32_t)c));
         }
     }
-
     FSLIC_STAMP(3);
+
     // 5. write labels (+ fused centroid sums)
     uint32_t slot[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int y = yw_lo + r * stride;
-        const bool ok = okx && (vrow_w0 + r) < Hv;
+        const bool ok = okx && r < nrows;
         const bool found = best[r] < kHuge;
         const uint32_t idx = found ? (best[r] & 0xFFFFu) : 0u;
         const uint32_t k = s_list[idx].z;
@@ -472,9 +493,10 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
                 }
             }
         }
-        __syncthreads();
+        // flush (wave-private region: the LDS executes one wavefront's operations in order, no barrier needed)
+        __builtin_amdgcn_wave_barrier();
         const int nacc = min(n, kAccSlots) * 6;
-        for (int i = tid; i < nacc; i += 256) {
+        for (int i = lane; i < nacc; i += 64) {
             uint32_t v = 0;
 #pragma unroll
             for (int c = 0; c < kAccCopies; ++c) v += s_acc[i * kAccCopies + c];
@@ -485,29 +507,26 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
         }
     }
     FSLIC_STAMP(5);
-    if (f.dbg && tid == 0) {
-        f.dbg[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] = (unsigned long long)nraw;
-        f.dbg[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = (unsigned long long)n;
+    if (f.dbg && lane == 0) {
+        const size_t o = ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kWavesPerBlock + wave) * 8;
+        f.dbg[o + 6] = (unsigned long long)nraw;
+        f.dbg[o + 7] = (unsigned long long)n;
     }
 #undef FSLIC_STAMP
 }
 
-void launch_assign(const FrameDev& f, int rem, int stride, int buf, bool fuse_update, hipStream_t st) {
-    const int Hv = (f.H - rem + stride - 1) / stride;
-    if (Hv <= 0) return;
-    constexpr int R = kRowsPerWave;
+static int assign_rows_per_wave(const FrameDev& f, int Hv, bool fuse_update) {
+    const char* e = getenv("FSLIC_ASSIGN_R");
+    if (e && (atoi(e) == 8 || atoi(e) == 16)) return atoi(e);
     const int tiles_x = (f.W + kTileW - 1) / kTileW;
-    dim3 grid(tiles_x, (Hv + kWavesPerBlock * R - 1) / (kWavesPerBlock * R));
+    const int blocks8 = tiles_x * ((Hv + kWavesPerBlock * 8 - 1) / (kWavesPerBlock * 8));
+    return (!fuse_update && blocks8 > 3072) ? 16 : 8;
+}
+
+template <int R>
+static void launch_assign_r(const FrameDev& f, int rem, int stride, int Hv, int buf, bool fuse_update, hipStream_t st) {
+    dim3 grid((f.W + kTileW - 1) / kTileW, (Hv + kWavesPerBlock * R - 1) / (kWavesPerBlock * R));
     const size_t lds = (size_t)f.lut_words * sizeof(uint32_t);
-    // Every block pays a fixed candidate-list prologue; when the 8-row grid would need more than one wave of
-    // resident blocks (256 CUs x ~6), the un-fused pass uses 16 rows per wavefront to stay at one wave.
-    if (!fuse_update && (int)(grid.x * grid.y) > 1536) {
-        constexpr int R2 = 2 * kRowsPerWave;
-        dim3 grid2(tiles_x, (Hv + kWavesPerBlock * R2 - 1) / (kWavesPerBlock * R2));
-        if (f.lut_words > 0) hipLaunchKernelGGL((k_assign<R2, false, true>), grid2, dim3(256), lds, st, f, rem, stride, Hv, buf);
-        else hipLaunchKernelGGL((k_assign<R2, false, false>), grid2, dim3(256), 0, st, f, rem, stride, Hv, buf);
-        return;
-    }
     if (f.lut_words > 0) {
         if (fuse_update) hipLaunchKernelGGL((k_assign<R, true, true>), grid, dim3(256), lds, st, f, rem, stride, Hv, buf);
         else hipLaunchKernelGGL((k_assign<R, false, true>), grid, dim3(256), lds, st, f, rem, stride, Hv, buf);
@@ -515,6 +534,13 @@ void launch_assign(const FrameDev& f, int rem, int stride, int buf, bool fuse_up
         if (fuse_update) hipLaunchKernelGGL((k_assign<R, true, false>), grid, dim3(256), 0, st, f, rem, stride, Hv, buf);
         else hipLaunchKernelGGL((k_assign<R, false, false>), grid, dim3(256), 0, st, f, rem, stride, Hv, buf);
     }
+}
+
+void launch_assign(const FrameDev& f, int rem, int stride, int buf, bool fuse_update, hipStream_t st) {
+    const int Hv = (f.H - rem + stride - 1) / stride;
+    if (Hv <= 0) return;
+    if (assign_rows_per_wave(f, Hv, fuse_update) == 16) launch_assign_r<16>(f, rem, stride, Hv, buf, fuse_update, st);
+    else launch_assign_r<8>(f, rem, stride, Hv, buf, fuse_update, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -654,6 +680,9 @@ __global__ __launch_bounds__(256) void k_cca_local(CcaDev c) {
         lbl[i] = (okx && y < c.H) ? (uint32_t)c.in[(size_t)y * c.W + x] : 0x10000u;
     }
     // ---- A ----
+    // Per row: every pixel whose upper neighbour has the same label folds the (possibly stale) root carried in
+    // its VGPR into its run's node with a non-returning ds_min; one dependent ds_read then yields the run's
+    // root.  Only where a run joins two so-far distinct components (U shapes) is a real union needed.
     uint32_t up_root = 0;
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
@@ -670,11 +699,10 @@ __global__ __launch_bounds__(256) void k_cca_local(CcaDev c) {
         s_par[p] = node;
         uint32_t cur_root = node;
         if (i > 0) {
-            const uint32_t u = lbl[i - 1];
-            const uint32_t upl = __shfl_up(u, 1);
-            const bool first = ok && (u == l) && ((lane == 0) || (left != l) || (upl != l));
-            if (first) lds_union(s_par, node, up_root);
-            if (ok) cur_root = lds_find(s_par, node);
+            const bool up_same = ok && (lbl[i - 1] == l);
+            if (up_same) __hip_atomic_fetch_min(s_par + node, up_root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (ok) cur_root = lds_ld(s_par + node);
+            if (up_same && up_root != cur_root) lds_union(s_par, up_root, cur_root);
         }
         up_root = cur_root;
     }
@@ -865,40 +893,56 @@ __global__ __launch_bounds__(256) void k_cca_densify(CcaDev c, int32_t* __restri
 // of each component's first pixel (src/cca.cpp:229-237).
 // status word: 0 = done here, 1 = host path required.
 // ---------------------------------------------------------------------------------------------
-constexpr int kSelMax = 8192;
+constexpr int kSelCap = 12288;    // candidates the device path holds in LDS (3 x 48 KB)
 __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int ntiles) {
     constexpr int TT = kCcaTile * kCcaTile;
-    __shared__ uint32_t s_key[kSelMax];
+    extern __shared__ uint32_t s_dyn[];
+    uint32_t* const s_area = s_dyn;
+    uint32_t* const s_lead = s_dyn + kSelCap;
+    uint32_t* const s_key = s_dyn + 2 * kSelCap;
     __shared__ uint32_t s_hist[256];
-    __shared__ uint32_t s_red[1024];
-    __shared__ uint32_t s_v[4];     // [0] M, [1] prefix (a*), [2] kk, [3] n_keep
+    __shared__ uint32_t s_scan[1024];
+    __shared__ uint32_t s_v[4];     // [1] prefix (a*), [2] kk, [3] n_keep
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
     const int K = c.K;
-    // M = total candidates
+    // 1. candidates of all tiles -> LDS (offsets by a block-wide exclusive scan of per-thread counts)
     uint32_t mine = 0;
     for (int t = tid; t < ntiles; t += 1024) mine += c.tile_ccnt[t];
-    s_red[tid] = mine;
+    s_scan[tid] = mine;
     __syncthreads();
-    for (int off = 512; off > 0; off >>= 1) {
-        if (tid < off) s_red[tid] += s_red[tid + off];
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
+        __syncthreads();
+        s_scan[tid] += v;
         __syncthreads();
     }
-    const uint32_t M = s_red[0];
-    __syncthreads();
+    const uint32_t M = s_scan[1023];
+    uint32_t off0 = s_scan[tid] - mine;
     if (tid == 0) { c.counters[2] = M; s_v[3] = 0; }
+    if (M > (uint32_t)kSelCap) {
+        if (tid == 0) c.counters[3] = 1u;
+        return;
+    }
+    for (int t = tid; t < ntiles; t += 1024) {
+        const uint32_t n = c.tile_ccnt[t];
+        for (uint32_t j = 0; j < n; ++j) {
+            s_area[off0 + j] = c.cand_area[(size_t)t * TT + j];
+            s_lead[off0 + j] = (uint32_t)c.cand_leader[(size_t)t * TT + j];
+        }
+        off0 += n;
+    }
+    __syncthreads();
+    // 2. K-th largest area by an 8-bit radix select over LDS
     uint32_t astar = 0;           // keep iff area >= astar
     if (M > (uint32_t)K) {
-        // radix select of the K-th largest area, most significant byte first
         uint32_t prefix = 0, kk = (uint32_t)K;
         for (int shift = 24; shift >= 0; shift -= 8) {
             if (tid < 256) s_hist[tid] = 0;
             __syncthreads();
-            for (int t = tid; t < ntiles; t += 1024) {
-                const uint32_t n = c.tile_ccnt[t];
-                for (uint32_t j = 0; j < n; ++j) {
-                    const uint32_t a = c.cand_area[(size_t)t * TT + j];
-                    if (shift == 24 || (a >> (shift + 8)) == prefix) atomicAdd(&s_hist[(a >> shift) & 255u], 1u);
-                }
+            for (uint32_t i = tid; i < M; i += 1024) {
+                const uint32_t a = s_area[i];
+                if (shift == 24 || (a >> (shift + 8)) == prefix) atomicAdd(&s_hist[(a >> shift) & 255u], 1u);
             }
             __syncthreads();
             if (tid == 0) {
@@ -917,41 +961,33 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int ntiles) {
             __syncthreads();
         }
         astar = prefix;
-        // kk = how many of the components with area == a* are needed; all of them -> unambiguous
-        if (tid < 256) s_hist[tid] = 0;
+        // kk of the components with area == a* are needed; unless that is all of them the choice is libstdc++'s
+        if (tid == 0) s_hist[0] = 0;
         __syncthreads();
-        for (int t = tid; t < ntiles; t += 1024) {
-            const uint32_t n = c.tile_ccnt[t];
-            for (uint32_t j = 0; j < n; ++j)
-                if (c.cand_area[(size_t)t * TT + j] == astar) atomicAdd(&s_hist[0], 1u);
-        }
+        uint32_t eq = 0;
+        for (uint32_t i = tid; i < M; i += 1024) eq += (uint32_t)(s_area[i] == astar);
+        if (eq) atomicAdd(&s_hist[0], eq);
         __syncthreads();
         if (s_hist[0] != kk) {
             if (tid == 0) c.counters[3] = 1u;
             return;
         }
     }
-    const uint32_t n_keep_expected = M > (uint32_t)K ? (uint32_t)K : M;
-    if (n_keep_expected > (uint32_t)kSelMax) {
-        if (tid == 0) c.counters[3] = 1u;
-        return;
-    }
-    // kept leaders -> LDS
-    for (int t = tid; t < ntiles; t += 1024) {
-        const uint32_t n = c.tile_ccnt[t];
-        for (uint32_t j = 0; j < n; ++j) {
-            if (c.cand_area[(size_t)t * TT + j] >= astar) {
-                const uint32_t pos = atomicAdd(&s_v[3], 1u);
-                if (pos < (uint32_t)kSelMax) s_key[pos] = (uint32_t)c.cand_leader[(size_t)t * TT + j];
-            }
+    // 3. kept leaders -> s_key (ballot compaction), bitonic sort, labels = rank
+    for (uint32_t i0 = 0; i0 < M; i0 += 1024) {
+        const uint32_t i = i0 + tid;
+        const bool keep = i < M && s_area[i] >= astar;
+        const unsigned long long m = __ballot(keep);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&s_v[3], (uint32_t)__popcll(m));
+            base = __shfl(base, leader);
+            if (keep) s_key[base + __popcll(m & ((1ull << lane) - 1ull))] = s_lead[i];
         }
     }
     __syncthreads();
     const uint32_t n_keep = s_v[3];
-    if (n_keep != n_keep_expected) {     // cannot happen; be safe and let the host decide
-        if (tid == 0) c.counters[3] = 1u;
-        return;
-    }
     uint32_t P2 = 1;
     while (P2 < n_keep) P2 <<= 1;
     for (uint32_t i = n_keep + tid; i < P2; i += 1024) s_key[i] = 0xFFFFFFFFu;
@@ -987,7 +1023,9 @@ void launch_cca_phase1(const CcaDev& c, hipStream_t st) {
 void launch_cca_select(const CcaDev& c, hipStream_t st) {
     constexpr int T = kCcaTile;
     const int ntiles = ((c.W + T - 1) / T) * ((c.H + T - 1) / T);
-    hipLaunchKernelGGL(k_cca_select, dim3(1), dim3(1024), 0, st, c, ntiles);
+    const size_t lds = 3 * (size_t)kSelCap * sizeof(uint32_t);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cca_select), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_cca_select, dim3(1), dim3(1024), lds, st, c, ntiles);
 }
 
 void launch_cca_densify(const CcaDev& c, int32_t* d_leader, uint32_t* d_area, hipStream_t st) {
