@@ -124,6 +124,7 @@ bool find_multiplier(int S, float coef, const std::vector<uint16_t>& patch, uint
     return false;
 }
 
+constexpr size_t kTabMaxBytes = 40960;   // LDS budget of the packed kernel's spatial table
 constexpr size_t kLutMaxWords = 12288;   // 48 KB of LDS for the spatial table at most
 
 struct Slot {
@@ -141,6 +142,8 @@ struct Slot {
     uint16_t* d_patch = nullptr;
     uint32_t* d_lut = nullptr;
     uint32_t* h_lut = nullptr;
+    uint16_t* d_tab = nullptr;
+    uint16_t* h_tab = nullptr;
     int32_t* d_keep_leader = nullptr;
     uint16_t* d_keep_label = nullptr;
     uint32_t* d_err = nullptr;
@@ -170,6 +173,10 @@ struct Slot {
     int last_path = 0;
     bool have_pre = false;
     bool host_topk = false;
+    // cached spatial configuration (configure_spatial)
+    bool sp_valid = false, sp_tiled_ok = false, sp_manhattan = true, sp_patch_uploaded = false;
+    int sp_S = 0, sp_shift = 0, sp_stride = 0;
+    float sp_compactness = 0.0f;
     int hKeep = 0;
 };
 
@@ -191,6 +198,7 @@ void free_slot(Slot& s) {
     if (s.h_cl) hipHostFree(s.h_cl);
     if (s.h_misc) hipHostFree(s.h_misc);
     if (s.h_lut) hipHostFree(s.h_lut);
+    if (s.h_tab) hipHostFree(s.h_tab);
     if (s.h_keep_leader) hipHostFree(s.h_keep_leader);
     if (s.h_keep_label) hipHostFree(s.h_keep_label);
     if (s.h_patch) hipHostFree(s.h_patch);
@@ -219,6 +227,7 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S) {
     }
     if (!s.h_misc) HIPCHK(hipHostMalloc((void**)&s.h_misc, 64));
     if (!s.h_lut) HIPCHK(hipHostMalloc((void**)&s.h_lut, kLutMaxWords * 4));
+    if (!s.h_tab) HIPCHK(hipHostMalloc((void**)&s.h_tab, kTabMaxBytes));
     if (s.h_patch_cap < P * P) {
         if (s.h_patch) hipHostFree(s.h_patch);
         HIPCHK(hipHostMalloc((void**)&s.h_patch, sizeof(uint16_t) * P * P));
@@ -231,7 +240,7 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S) {
     const size_t o_lab = take(N * 4), o_labels = take(N * 2);
     const size_t o_cl = take((size_t)K * 4 * 5);                     // yx, lab, n, moved, tag (contiguous)
     const size_t o_zero = off;
-    const size_t o_sums = take((size_t)K * 6 * 4);
+    const size_t o_sums = take((size_t)K * 6 * 4), o_sums1 = take((size_t)K * 6 * 4);
     const size_t o_cc0 = take(ncell * 4), o_cc1 = take(ncell * 4);
     const size_t o_misc = take(256);                                 // ovf_cnt[2], err, cca counters
     const size_t zero_bytes = off - o_zero;
@@ -239,6 +248,7 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S) {
     const size_t o_ov0 = take((size_t)K * sizeof(ClusterRec)), o_ov1 = take((size_t)K * sizeof(ClusterRec));
     const size_t o_patch = take(P * P * 2);
     const size_t o_lut = take(kLutMaxWords * 4);
+    const size_t o_tab = take(kTabMaxBytes);
     const size_t ntiles = (size_t)((W + kCcaTile - 1) / kCcaTile) * ((H + kCcaTile - 1) / kCcaTile);
     const size_t TT = (size_t)kCcaTile * kCcaTile;
     const size_t o_parent = take(N * 4), o_area = take(N * 4), o_final = take(N * 2), o_roots = take(ntiles * TT * 4);
@@ -262,7 +272,7 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S) {
     f.labels = (uint16_t*)(b + o_labels);
     uint32_t* cl = (uint32_t*)(b + o_cl);
     f.cl_yx = cl; f.cl_lab = cl + K; f.cl_n = cl + 2 * (size_t)K; f.cl_moved = cl + 3 * (size_t)K; f.cl_tag = cl + 4 * (size_t)K;
-    f.sums = (uint32_t*)(b + o_sums);
+    f.sums[0] = (uint32_t*)(b + o_sums); f.sums[1] = (uint32_t*)(b + o_sums1);
     f.cell_cnt[0] = (uint32_t*)(b + o_cc0); f.cell_cnt[1] = (uint32_t*)(b + o_cc1);
     uint32_t* misc = (uint32_t*)(b + o_misc);
     f.ovf_cnt[0] = misc + 0; f.ovf_cnt[1] = misc + 1; f.err_flag = misc + 2;
@@ -271,6 +281,7 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S) {
     s.d_patch = (uint16_t*)(b + o_patch);
     f.patch2d = s.d_patch;
     s.d_lut = (uint32_t*)(b + o_lut);
+    s.d_tab = (uint16_t*)(b + o_tab);
     s.d_err = misc + 2;
     s.zero_block = b + o_zero; s.zero_bytes = zero_bytes;
     CcaDev& c = s.c;
@@ -284,6 +295,7 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S) {
     s.d_keep_leader = (int32_t*)(b + o_keepl); s.d_keep_label = (uint16_t*)(b + o_keepb);
     s.d_rgb_stage = (uint8_t*)(b + o_rgb); s.d_out_stage = (uint16_t*)(b + o_out);
     s.keyH = H; s.keyW = W; s.keyK = K;
+    s.sp_valid = false;    // device copies of the spatial tables live in the arena that was just re-carved
     (void)e;
     // Bin slots are validated by a generation stamp (ClusterRec::pad == FrameDev::gen, gen >= 1 and strictly
     // increasing per slot), so a freshly carved region must not contain bytes that could pass for a stamp.
@@ -385,6 +397,87 @@ int cca_finish(Slot& s) {
     return FSLIC_OK;
 }
 
+// Spatial-distance configuration of a frame: the reference's patch (src/context.cpp:22-40) and the three device
+// encodings of it.  Cached per slot: a video stream calls iterate() with the same (S, compactness, options)
+// for every frame, so the tables are built and uploaded once.
+//   packed kernel : column-major u16 table tab[ux'][dy + dyoff] of (patch << 6), 0xffff outside the window
+//   32-bit kernel : exact fixed-point multiplier (M, C), or an LDS table when none exists / non-Manhattan
+//   generic kernel: the patch itself
+int configure_spatial(Slot& s, int S, const fslic_params* p) {
+    const int color_shift = p->convert_to_lab ? 1 : 0;   // src/cielab.h:284,352 ; src/context.cpp:126
+    const bool manhattan = p->manhattan_spatial_dist != 0;
+    const int stride_it = p->subsample_stride;
+    if (s.sp_valid && s.sp_S == S && s.sp_compactness == p->compactness && s.sp_shift == color_shift &&
+        s.sp_manhattan == manhattan && s.sp_stride == stride_it)
+        return FSLIC_OK;
+    FrameDev& f = s.f;
+    std::vector<uint16_t> patch;
+    build_patch(S, p->compactness, color_shift, manhattan, patch);
+    std::memcpy(s.h_patch, patch.data(), patch.size() * sizeof(uint16_t));
+    s.sp_patch_uploaded = false;
+    uint32_t M = 0, Coff = 0, max_sp = 0;
+    float coef = 1.0f / ((float)S / p->compactness);
+    coef *= (1 << color_shift);
+    const bool have_mc = manhattan && find_multiplier(S, coef, patch, M, Coff, max_sp);
+    for (uint16_t v : patch) max_sp = std::max<uint32_t>(max_sp, v);
+    bool tiled_ok = (max_sp + 765u < 16384u) && S >= 8;
+    f.lut_words = 0; f.lut_row = 0; f.lut_oow = 0; f.lut = s.d_lut;
+    const size_t Pp = (size_t)(2 * S + 1);
+    if (tiled_ok && !have_mc) {
+        // LDS table mode.  Manhattan: 1-D in d = ux + uy (out-of-window -> 2S+1, so any index > 2S is huge).
+        // Otherwise 2-D in (uy, ux) with one extra out-of-window row and column.
+        if (manhattan) {
+            const int oow = 2 * S + 1, words = 4 * S + 3;
+            if ((size_t)words <= kLutMaxWords) {
+                for (int d = 0; d < words; d++) {
+                    if (d <= 2 * S) { const int di = std::min(d, S), dj = d - di; s.h_lut[d] = (uint32_t)patch[(size_t)(S - di) * Pp + (S + dj)] << 16; }
+                    else s.h_lut[d] = kHuge;
+                }
+                f.lut_words = words; f.lut_row = 1; f.lut_oow = oow;
+            }
+        } else {
+            const int row = S + 2, words = row * row;
+            if ((size_t)words <= kLutMaxWords) {
+                for (int uy = 0; uy < row; uy++)
+                    for (int ux = 0; ux < row; ux++)
+                        s.h_lut[uy * row + ux] = (uy > S || ux > S) ? kHuge : ((uint32_t)patch[(size_t)(S + uy) * Pp + (S + ux)] << 16);
+                f.lut_words = words; f.lut_row = row; f.lut_oow = S + 1;
+            }
+        }
+    }
+    if (!have_mc && f.lut_words == 0) tiled_ok = false;        // the 32-bit kernel has neither multiplier nor table
+    f.tab = s.d_tab; f.tab_words = 0; f.tab_nrpad = 0; f.tab_dyoff = 0;
+    if (S >= 8 && max_sp + 765u < 1024u) {
+        const int pad = std::max(7 * std::min(stride_it, 3), 15);   // (R-1)*stride of the kernels launch_assign picks
+        const int dyoff = S + pad, NR = 2 * dyoff + 1;
+        int nrpad = NR;
+        while ((nrpad & 3) != 2) nrpad++;                        // odd dword pitch: conflict-free columns
+        const size_t bytes = ((size_t)(S + 2) * nrpad * 2 + 15) / 16 * 16;
+        if (bytes <= kTabMaxBytes) {
+            for (int ux = 0; ux <= S + 1; ux++)
+                for (int dyi = 0; dyi < nrpad; dyi++) {
+                    const int dy = dyi - dyoff;
+                    uint16_t v = 0xFFFFu;
+                    if (dyi < NR && dy >= -S && dy <= S && ux <= S) v = (uint16_t)(patch[(size_t)(S + dy) * Pp + (S + ux)] << 6);
+                    s.h_tab[(size_t)ux * nrpad + dyi] = v;
+                }
+            for (size_t i = (size_t)(S + 2) * nrpad; i < bytes / 2; i++) s.h_tab[i] = 0xFFFFu;
+            f.tab_words = (int)(bytes / 4); f.tab_nrpad = nrpad; f.tab_dyoff = dyoff;
+            tiled_ok = true;
+        }
+    }
+    f.M = M;
+    f.C = Coff;
+    if (f.tab_words > 0)
+        HIPCHK(hipMemcpyAsync(s.d_tab, s.h_tab, (size_t)f.tab_words * 4, hipMemcpyHostToDevice, s.st));
+    if (f.lut_words > 0)
+        HIPCHK(hipMemcpyAsync(s.d_lut, s.h_lut, (size_t)f.lut_words * 4, hipMemcpyHostToDevice, s.st));
+    s.sp_tiled_ok = tiled_ok;
+    s.sp_valid = true; s.sp_S = S; s.sp_compactness = p->compactness; s.sp_shift = color_shift;
+    s.sp_manhattan = manhattan; s.sp_stride = stride_it;
+    return FSLIC_OK;
+}
+
 // Everything of iterate() up to and including the device half of the connectivity pass.
 int frame_enqueue_phase1(fslic_engine* e, Slot& s, const fslic_params* p, int H, int W, int K,
                          const uint8_t* d_rgb, fslic_cluster* clusters, uint16_t* d_out, bool generic) {
@@ -401,51 +494,12 @@ int frame_enqueue_phase1(fslic_engine* e, Slot& s, const fslic_params* p, int H,
     FrameDev& f = s.f;
     f.rgb = d_rgb;
 
-    const int color_shift = p->convert_to_lab ? 1 : 0;   // src/cielab.h:284,352 ; src/context.cpp:126
-    const bool manhattan = p->manhattan_spatial_dist != 0;
-    std::vector<uint16_t> patch;
-    build_patch(S, p->compactness, color_shift, manhattan, patch);
-    uint32_t M = 0, Coff = 0, max_sp = 0;
-    float coef = 1.0f / ((float)S / p->compactness);
-    coef *= (1 << color_shift);
-    const bool have_mc = manhattan && find_multiplier(S, coef, patch, M, Coff, max_sp);
-    for (uint16_t v : patch) max_sp = std::max<uint32_t>(max_sp, v);
-    bool tiled_ok = (max_sp + 765u < 16384u) && S >= 8;
-    f.lut_words = 0; f.lut_row = 0; f.lut_oow = 0; f.lut = s.d_lut;
-    if (tiled_ok && !have_mc) {
-        // LDS table mode.  Manhattan: 1-D in d = ux + uy (out-of-window -> 2S+1, so any index > 2S is huge).
-        // Otherwise 2-D in (uy, ux) with one extra out-of-window row and column.
-        const size_t Pp = (size_t)(2 * S + 1);
-        if (manhattan) {
-            const int oow = 2 * S + 1, words = 4 * S + 3;
-            if ((size_t)words > kLutMaxWords) tiled_ok = false;
-            else {
-                for (int d = 0; d < words; d++) {
-                    if (d <= 2 * S) { const int di = std::min(d, S), dj = d - di; s.h_lut[d] = (uint32_t)patch[(size_t)(S - di) * Pp + (S + dj)] << 16; }
-                    else s.h_lut[d] = kHuge;
-                }
-                f.lut_words = words; f.lut_row = 1; f.lut_oow = oow;
-            }
-        } else {
-            const int row = S + 2, words = row * row;
-            if ((size_t)words > kLutMaxWords) tiled_ok = false;
-            else {
-                for (int uy = 0; uy < row; uy++)
-                    for (int ux = 0; ux < row; ux++)
-                        s.h_lut[uy * row + ux] = (uy > S || ux > S) ? kHuge : ((uint32_t)patch[(size_t)(S + uy) * Pp + (S + ux)] << 16);
-                f.lut_words = words; f.lut_row = row; f.lut_oow = S + 1;
-            }
-        }
-    }
-    if (generic || p->force_generic) tiled_ok = false;
-    s.generic = !tiled_ok;
-    f.M = M;
-    f.C = Coff;
-    if (tiled_ok && f.lut_words > 0)
-        HIPCHK(hipMemcpyAsync(s.d_lut, s.h_lut, (size_t)f.lut_words * 4, hipMemcpyHostToDevice, s.st));
-    if (s.generic) {
-        std::memcpy(s.h_patch, patch.data(), patch.size() * sizeof(uint16_t));
-        HIPCHK(hipMemcpyAsync(s.d_patch, s.h_patch, patch.size() * sizeof(uint16_t), hipMemcpyHostToDevice, s.st));
+    rc = configure_spatial(s, S, p);
+    if (rc) return rc;
+    s.generic = generic || p->force_generic || !s.sp_tiled_ok;
+    if (s.generic && !s.sp_patch_uploaded) {
+        HIPCHK(hipMemcpyAsync(s.d_patch, s.h_patch, (size_t)(2 * S + 1) * (2 * S + 1) * sizeof(uint16_t), hipMemcpyHostToDevice, s.st));
+        s.sp_patch_uploaded = true;
     }
     // cluster centres: integer part of the clamped position (src/context.cpp:129-131,208-211,262)
     for (int k = 0; k < K; k++) {
@@ -460,14 +514,14 @@ int frame_enqueue_phase1(fslic_engine* e, Slot& s, const fslic_params* p, int H,
     launch_rgb_to_lab(d_rgb, f.lab, f.N, p->convert_to_lab, e->tables, f.labels, s.st);   // + labels <- 0xFFFF
     HIPCHK(hipEventRecord(s.ev[1], s.st));
     f.gen = ++s.gen_counter;
-    launch_bin_clusters(f, 0, 0, s.st);
+    launch_bin_clusters(f, 0, 0, 0, s.st);
     const int stride = p->subsample_stride;
     int rem = 0;
     for (int it = 0; it < p->max_iter; it++) {                  // src/context.cpp:158-175
-        if (s.generic) launch_assign_generic(f, rem, stride, it & 1, true, s.st);
-        else launch_assign(f, rem, stride, it & 1, true, s.st);
+        if (s.generic) launch_assign_generic(f, rem, stride, it & 1, it & 1, true, s.st);
+        else launch_assign(f, rem, stride, it & 1, it & 1, true, s.st);
         f.gen = ++s.gen_counter;
-        launch_bin_clusters(f, 1, (it + 1) & 1, s.st);
+        launch_bin_clusters(f, 1, (it + 1) & 1, it & 1, s.st);
         rem = (rem + 1) % stride;
     }
     if (getenv("FSLIC_DEBUG_TIMING")) {
@@ -477,8 +531,8 @@ int frame_enqueue_phase1(fslic_engine* e, Slot& s, const fslic_params* p, int H,
     } else f.dbg = nullptr;
     HIPCHK(hipEventRecord(s.ev[2], s.st));
     // full_assign: stride 1, rem 0, no update afterwards (src/context.cpp:246-256)
-    if (s.generic) launch_assign_generic(f, 0, 1, p->max_iter & 1, false, s.st);
-    else launch_assign(f, 0, 1, p->max_iter & 1, false, s.st);
+    if (s.generic) launch_assign_generic(f, 0, 1, p->max_iter & 1, 0, false, s.st);
+    else launch_assign(f, 0, 1, p->max_iter & 1, 0, false, s.st);
     HIPCHK(hipEventRecord(s.ev[3], s.st));
     if (f.dbg) {   // bring-up aid: average per-phase cycles of the full-assign launch, printed to stderr
         HIPCHK(hipStreamSynchronize(s.st));

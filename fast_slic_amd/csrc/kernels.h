@@ -43,7 +43,7 @@ struct FrameDev {
     uint32_t* cl_tag;    // K  phase << 16 | k of the current centres
     uint32_t* cl_n;      // K  num_members of the last update
     uint32_t* cl_moved;  // K  1 once an update with n > 0 has moved the cluster
-    uint32_t* sums;      // K*6: count, sum y, sum x, sum L, sum a, sum b (zero between iterations)
+    uint32_t* sums[2];   // K*6 each: count, sum y, sum x, sum L, sum a, sum b; pass `it` accumulates into [it&1]
     // coarse bins, double buffered by iteration parity
     uint32_t* cell_cnt[2];     // ncell
     ClusterRec* cell_items[2]; // ncell * kCellCap
@@ -54,6 +54,9 @@ struct FrameDev {
     // LDS spatial table of the tiled kernel (lut_words == 0: fixed-point mode, no table)
     const uint32_t* lut;       // lut_words entries: patch value << 16, or kHuge for out-of-window indices
     int lut_words, lut_row, lut_oow;   // index = ux' + uy' * lut_row, ux'/uy' = |d| if <= S else lut_oow
+    // packed 16-bit kernel: column-major spatial table tab[ux'][dy + tab_dyoff], (patch << 6) or 0xffff
+    const uint16_t* tab;       // tab_words * 2 entries (tab_words == 0: packed kernel not applicable)
+    int tab_words, tab_nrpad, tab_dyoff;
     // generic-path tables
     const uint16_t* patch2d;   // (2S+1)^2, src/context.cpp:22-40
 };
@@ -86,11 +89,11 @@ void launch_rgb_to_lab(const uint8_t* rgb, uint32_t* lab, int N, int convert, co
 void launch_fill_u16(uint16_t* p, int n, uint16_t v, hipStream_t st);
 // mode 0: resample colours at the current centres (src/context.cpp:128-135) and bin;
 // mode 1: integer centroid update from `sums` (src/context.cpp:356-373), zero sums, and bin.
-void launch_bin_clusters(const FrameDev& f, int mode, int buf, hipStream_t st);
+void launch_bin_clusters(const FrameDev& f, int mode, int buf, int sbuf, hipStream_t st);
 // One assign pass over rows == rem (mod stride); fuse_update also accumulates the centroid sums
 // of src/context.cpp:301-354 for the same rows.
-void launch_assign(const FrameDev& f, int rem, int stride, int buf, bool fuse_update, hipStream_t st);
-void launch_assign_generic(const FrameDev& f, int rem, int stride, int buf, bool fuse_update, hipStream_t st);
+void launch_assign(const FrameDev& f, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st);
+void launch_assign_generic(const FrameDev& f, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st);
 // connectivity
 void launch_cca_phase1(const CcaDev& c, hipStream_t st);   // local CCL, border merge, compress, collect
 void launch_cca_select(const CcaDev& c, hipStream_t st);   // device top-K + ranking (counters[3] = status)

@@ -126,7 +126,7 @@ void launch_fill_u16(uint16_t* p, int n, uint16_t v, hipStream_t st) {
 // next iteration, so no per-iteration memset launch is needed.
 // =============================================================================================
 template <int MODE>
-__global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, int buf) {
+__global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, int buf, int sbuf) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < f.ncell) f.cell_cnt[buf ^ 1][k] = 0;
     if (k == 0) *f.ovf_cnt[buf ^ 1] = 0;
@@ -134,12 +134,21 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, int buf) {
     uint32_t yx = f.cl_yx[k];
     int y = (int)(yx >> 16), x = (int)(yx & 0xFFFF);
     uint32_t lab;
+    // A cluster whose integer state (y, x, L, a, b) equals that of cluster k-1 has the same distance to every
+    // pixel and the same phase, and k-1 is visited first: it can never win a pixel.  Such runs come from
+    // initialize_clusters piling its leftover seeds on the image centre (src/context.cpp:80-86; 225 of 6000
+    // at 4K) and stay identical for ever because they never receive members.  They are kept out of the bins
+    // (exact), which keeps every candidate list short.  Detected only where it is race-free: both clusters
+    // unchanged by this pass (mode 1), or equal uploaded centres (mode 0).
+    bool shadowed = false;
     if (MODE == 0) {
         lab = f.lab[(size_t)y * f.W + x] & 0x00FFFFFFu;
         f.cl_lab[k] = lab;
+        shadowed = k > 0 && f.cl_yx[k - 1] == yx;
     } else {
         lab = f.cl_lab[k];
-        uint32_t* s = f.sums + 6 * (size_t)k;
+        const uint32_t* s = f.sums[sbuf] + 6 * (size_t)k;
+        uint32_t* z = f.sums[sbuf ^ 1] + 6 * (size_t)k;     // the next pass accumulates here
         const int32_t n = (int32_t)s[0];
         f.cl_n[k] = (uint32_t)n;
         if (n != 0) {
@@ -154,14 +163,17 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, int buf) {
             f.cl_yx[k] = yx;
             f.cl_lab[k] = lab;
             f.cl_moved[k] = 1;
+        } else if (k > 0 && f.sums[sbuf][6 * (size_t)(k - 1)] == 0u) {
+            shadowed = f.cl_yx[k - 1] == yx && f.cl_lab[k - 1] == lab;
         }
-        s[0] = 0; s[1] = 0; s[2] = 0; s[3] = 0; s[4] = 0; s[5] = 0;
+        z[0] = 0; z[1] = 0; z[2] = 0; z[3] = 0; z[4] = 0; z[5] = 0;
     }
     // visit order of the reference scatter: phase = 2*((cy/T)&1) + ((cx/T)&1), then k
     const uint32_t phase = (uint32_t)(2 * ((y / f.T) & 1) + ((x / f.T) & 1));
     ClusterRec rec;
     rec.yx = yx; rec.lab = lab; rec.tag = (phase << 16) | (uint32_t)k; rec.pad = f.gen;
     f.cl_tag[k] = rec.tag;
+    if (shadowed) return;
     const int cell = (y >> f.cs_shift) * f.ncx + (x >> f.cs_shift);
     const uint32_t slot = atomicAdd(&f.cell_cnt[buf][cell], 1u);
     if (slot < (uint32_t)kCellCap) {
@@ -172,11 +184,11 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, int buf) {
     }
 }
 
-void launch_bin_clusters(const FrameDev& f, int mode, int buf, hipStream_t st) {
+void launch_bin_clusters(const FrameDev& f, int mode, int buf, int sbuf, hipStream_t st) {
     const int n = f.K > f.ncell ? f.K : f.ncell;
     const int blocks = (n + 255) / 256;
-    if (mode == 0) hipLaunchKernelGGL(k_bin_clusters<0>, dim3(blocks), dim3(256), 0, st, f, buf);
-    else hipLaunchKernelGGL(k_bin_clusters<1>, dim3(blocks), dim3(256), 0, st, f, buf);
+    if (mode == 0) hipLaunchKernelGGL(k_bin_clusters<0>, dim3(blocks), dim3(256), 0, st, f, buf, sbuf);
+    else hipLaunchKernelGGL(k_bin_clusters<1>, dim3(blocks), dim3(256), 0, st, f, buf, sbuf);
 }
 
 // =============================================================================================
@@ -219,7 +231,7 @@ static __device__ __forceinline__ bool in_window(const ClusterRec& r, const Tile
 }
 
 template <int R, bool FUSE, bool LUT>
-__global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride, int Hv, int buf) {
+__global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride, int Hv, int buf, int sbuf) {
     extern __shared__ uint32_t s_lut[];
     __shared__ uint32_t s_rawbuf[kWavesPerBlock][3 * 64];
     __shared__ uint4 s_listbuf[kWavesPerBlock][64];
@@ -386,7 +398,7 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
             uint32_t lbl;
             if (bw[r] < kHuge) { lbl = bt[r] & 0xFFFFu; f.labels[p] = (uint16_t)lbl; }
             else lbl = f.labels[p];
-            if (FUSE && lbl != 0xFFFFu) global_accumulate(f.sums, lbl, (uint32_t)y, (uint32_t)x, pix[r]);
+            if (FUSE && lbl != 0xFFFFu) global_accumulate(f.sums[sbuf], lbl, (uint32_t)y, (uint32_t)x, pix[r]);
         }
         return;
     }
@@ -454,11 +466,11 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
                 f.labels[p] = (uint16_t)k;
                 if (FUSE) {
                     if (idx < (uint32_t)kAccSlots) slot[r] = idx;
-                    else global_accumulate(f.sums, k, (uint32_t)y, (uint32_t)x, pix[r]);
+                    else global_accumulate(f.sums[sbuf], k, (uint32_t)y, (uint32_t)x, pix[r]);
                 }
             } else if (FUSE) {
                 const uint32_t old = f.labels[p];     // stale label still takes part in update()
-                if (old != 0xFFFFu) global_accumulate(f.sums, old, (uint32_t)y, (uint32_t)x, pix[r]);
+                if (old != 0xFFFFu) global_accumulate(f.sums[sbuf], old, (uint32_t)y, (uint32_t)x, pix[r]);
             }
         }
     }
@@ -502,7 +514,7 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
             for (int c = 0; c < kAccCopies; ++c) v += s_acc[i * kAccCopies + c];
             if (v) {
                 const int sl = i / 6;
-                atomicAdd(f.sums + 6 * (size_t)s_list[sl].z + (i - sl * 6), v);
+                atomicAdd(f.sums[sbuf] + 6 * (size_t)s_list[sl].z + (i - sl * 6), v);
             }
         }
     }
@@ -515,6 +527,302 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
 #undef FSLIC_STAMP
 }
 
+// =============================================================================================
+// Packed 16-bit assign kernel (the default): two rows per VALU instruction.
+// The key of a pixel-candidate is 16 bits, (distance << 6) | idx, idx = rank of the candidate in (phase, k)
+// order within the wavefront's list (<= 64 entries), distance < 1024.  The spatial term comes from an LDS
+// copy of the reference's patch (src/context.cpp:22-40), stored column-major as tab[ux'][dy + DYOFF],
+// pre-shifted by 6, with 0xffff wherever |dy| > S or ux' = S+1 (window test folded in, saturating add keeps
+// it at 0xffff).  Column-major makes the address of row r  a0 + r*STRIDE  with a0 per lane and candidate, so
+// rows are DS *immediate offsets*: no per-row VALU or SALU work at all.  Per pair of rows:
+//     s   = v_sad_u8 (pix[r],   clab, 0)
+//     s   = v_sad_hi_u8(pix[r+1], clab, s)           two colour distances packed
+//     t   = v_lshl_add_u32(s, 6, idx|idx<<16)
+//     key = v_pk_add_u16(t, tab pair) clamp
+//     best= v_pk_min_u16(best, key)
+// i.e. 2.5 VALU + 1 LDS read per pixel-candidate (the 32-bit kernel above: 4 VALU + 5 SALU).
+// Exactness: the table IS the patch, so no fixed-point condition; ordering of (distance, idx) is unchanged.
+// The candidate list of a wavefront is filtered from a block-level list gathered once by wavefront 0.
+// =============================================================================================
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+template <int R, bool FUSE, int STRIDE>
+__global__ __launch_bounds__(256) void k_assign16(FrameDev f, int rem, int Hv, int buf, int sbuf) {
+    extern __shared__ uint32_t s_dyn[];                  // spatial table (u16), f.tab_words dwords
+    const uint16_t* const s_tab = reinterpret_cast<const uint16_t*>(s_dyn);
+    __shared__ uint32_t s_braw[3 * 64];
+    __shared__ uint32_t s_bn;
+    __shared__ uint32_t s_rawbuf[kWavesPerBlock][3 * 64];
+    __shared__ uint4 s_listbuf[kWavesPerBlock][64];
+    __shared__ uint32_t s_accbuf[FUSE ? kWavesPerBlock * kAccSlots * 6 * kAccCopies : 1];
+    static_assert(R % 2 == 0, "rows are processed in pairs");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = (int)rfl((uint32_t)(tid >> 6));
+    uint32_t* const s_raw = s_rawbuf[wave];
+    uint4* const s_list = s_listbuf[wave];
+    uint32_t* const s_acc = s_accbuf + (FUSE ? wave * (kAccSlots * 6 * kAccCopies) : 0);
+    const int W = f.W, S = f.S;
+    const int x0 = blockIdx.x * kTileW;
+    const int x = x0 + lane;
+    const int vrow_b0 = blockIdx.y * (kWavesPerBlock * R);
+    const int vrow_w0 = vrow_b0 + wave * R;
+    const bool okx = x < W;
+    const bool wave_live = vrow_w0 < Hv;
+    const int yw_lo = rem + vrow_w0 * STRIDE;
+    const int nrows = wave_live ? min(R, Hv - vrow_w0) : 0;
+#define FSLIC_STAMP(slot_)                                                                              \
+    do {                                                                                                 \
+        if (f.dbg && lane == 0)                                                                          \
+            f.dbg[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kWavesPerBlock + wave) * 8 + (slot_)] = __builtin_readcyclecounter(); \
+    } while (0)
+    FSLIC_STAMP(0);
+    const uint32_t novf = *f.ovf_cnt[buf];
+
+    // 1. pixel loads first; nothing below depends on them until the argmin
+    uint32_t pix[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const bool ok = okx && r < nrows;
+        pix[r] = ok ? f.lab[(size_t)(yw_lo + r * STRIDE) * W + x] : 0u;
+    }
+    if (FUSE) {
+#pragma unroll
+        for (int i = 0; i < kAccSlots * 6 * kAccCopies / 64; ++i) s_acc[i * 64 + lane] = 0u;
+    }
+
+    // 2. gather into 64 LDS slots: returns the number of live records inside `win` (may exceed 64)
+    const int sh = f.cs_shift;
+    const ClusterRec* __restrict__ citems = f.cell_items[buf];
+    const ClusterRec* __restrict__ oitems = f.ovf_items[buf];
+    const unsigned long long lowmask = (1ull << lane) - 1ull;
+    auto gather = [&](const TileWindow& win, uint32_t* dst) -> int {
+        const int cxa = max(win.wx_lo, 0) >> sh, cxb = min(win.wx_hi, W - 1) >> sh;
+        const int cya = max(win.wy_lo, 0) >> sh, cyb = min(win.wy_hi, f.H - 1) >> sh;
+        const int ncxr = cxb - cxa + 1, ncyr = cyb - cya + 1;
+        const int total = ncxr * ncyr * kCellCap;
+        const uint32_t inv = (uint32_t)(4294967296.0f / (float)ncxr) + 1u;
+        int cnt = 0;
+        for (int c0 = 0; c0 < total; c0 += 256) {
+            ClusterRec rec[4];
+            bool live[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = c0 + u * 64 + lane;
+                live[u] = e < total;
+                const uint32_t ce = (uint32_t)e >> 3;
+                uint32_t cyi = __umulhi(ce, inv);
+                if (cyi * (uint32_t)ncxr > ce) cyi--;
+                const uint32_t cxi = ce - cyi * (uint32_t)ncxr;
+                const size_t slot = ((size_t)(cya + (int)cyi) * f.ncx + cxa + (int)cxi) * kCellCap + (e & 7);
+                if (live[u]) rec[u] = citems[slot];
+                else { rec[u].yx = 0; rec[u].lab = 0; rec[u].tag = 0; rec[u].pad = 0; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool keep = live[u] && rec[u].pad == f.gen && in_window(rec[u], win);
+                const unsigned long long m = __ballot(keep);
+                const int pos = cnt + __popcll(m & lowmask);
+                if (keep && pos < 64) { dst[pos] = rec[u].yx; dst[64 + pos] = rec[u].lab; dst[128 + pos] = rec[u].tag; }
+                cnt += __popcll(m);
+            }
+        }
+        for (uint32_t i0 = 0; i0 < novf; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            ClusterRec rec;
+            rec.yx = 0; rec.lab = 0; rec.tag = 0; rec.pad = 0;
+            if (i < novf) rec = oitems[i];
+            const bool keep = i < novf && in_window(rec, win);
+            const unsigned long long m = __ballot(keep);
+            const int pos = cnt + __popcll(m & lowmask);
+            if (keep && pos < 64) { dst[pos] = rec.yx; dst[64 + pos] = rec.lab; dst[128 + pos] = rec.tag; }
+            cnt += __popcll(m);
+        }
+        return cnt;
+    };
+    if (wave == 0) {
+        TileWindow bw;
+        const int vlast = min(vrow_b0 + kWavesPerBlock * R - 1, Hv - 1);
+        bw.wy_lo = rem + vrow_b0 * STRIDE - S; bw.wy_hi = rem + vlast * STRIDE + S;
+        bw.wx_lo = x0 - S;                     bw.wx_hi = min(x0 + kTileW - 1, W - 1) + S;
+        const int bn = gather(bw, s_braw);
+        if (lane == 0) s_bn = (uint32_t)bn;
+    }
+    // spatial table -> LDS (all wavefronts)
+    {
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(f.tab);
+        uint4* dst = reinterpret_cast<uint4*>(s_dyn);
+        for (int i = tid; i < (f.tab_words >> 2); i += 256) dst[i] = src[i];
+    }
+    __syncthreads();                          // the only barrier
+    if (!wave_live) return;
+    FSLIC_STAMP(1);
+
+    // 3. this wavefront's candidates: block list filtered to the wavefront's rows (own gather if it overflowed)
+    TileWindow win;
+    win.wy_lo = yw_lo - S; win.wy_hi = yw_lo + (nrows - 1) * STRIDE + S;
+    win.wx_lo = x0 - S;    win.wx_hi = min(x0 + kTileW - 1, W - 1) + S;
+    int nraw;
+    const int bn = (int)rfl(s_bn);
+    if (bn <= 64) {
+        ClusterRec rec;
+        rec.yx = lane < bn ? s_braw[lane] : 0u;
+        rec.lab = lane < bn ? s_braw[64 + lane] : 0u;
+        rec.tag = lane < bn ? s_braw[128 + lane] : 0u;
+        rec.pad = 0;
+        const bool keep = lane < bn && in_window(rec, win);
+        const unsigned long long m = __ballot(keep);
+        const int pos = __popcll(m & lowmask);
+        if (keep) { s_raw[pos] = rec.yx; s_raw[64 + pos] = rec.lab; s_raw[128 + pos] = rec.tag; }
+        nraw = __popcll(m);
+    } else {
+        nraw = gather(win, s_raw);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (nraw > 64) {                          // more live candidates than idx bits: the host redoes the frame generically
+        if (lane == 0) *f.err_flag = 1u;
+        return;
+    }
+    int n;
+    {
+        const bool act = lane < nraw;
+        const uint32_t yx_j = act ? s_raw[lane] : 0u;
+        const uint32_t lab_j = act ? s_raw[64 + lane] : 0u;
+        const uint32_t tag_j = act ? s_raw[128 + lane] : 0xFFFFFFFFu;
+        bool dup = false;
+        for (int i = 0; i < nraw; ++i) {
+            const uint32_t ty = __builtin_amdgcn_readlane(yx_j, i);
+            const uint32_t tl = __builtin_amdgcn_readlane(lab_j, i);
+            const uint32_t tt = __builtin_amdgcn_readlane(tag_j, i);
+            dup = dup || (act && (tt < tag_j) && (ty == yx_j) && (tl == lab_j));
+        }
+        const unsigned long long dupmask = __ballot(dup);
+        int rank = 0;
+        for (int i = 0; i < nraw; ++i) {
+            const uint32_t tt = __builtin_amdgcn_readlane(tag_j, i);
+            rank += (int)((((dupmask >> i) & 1ull) == 0ull) && tt < tag_j);
+        }
+        if (act && !dup) s_list[rank] = make_uint4(yx_j, lab_j, tag_j & 0xFFFFu, 0u);
+        n = nraw - __popcll(dupmask);
+    }
+    __builtin_amdgcn_wave_barrier();
+    FSLIC_STAMP(2);
+
+    // 4. the argmin, two rows per instruction
+    us2 best[R / 2];
+#pragma unroll
+    for (int q = 0; q < R / 2; ++q) best[q] = (us2){0xFFFF, 0xFFFF};
+    const uint32_t nrpad = (uint32_t)f.tab_nrpad;
+    const int dyoff = f.tab_dyoff;
+    uint2 nxt = *reinterpret_cast<const uint2*>(&s_list[0]);
+#pragma unroll 1
+    for (int c = 0; c < n; ++c) {
+        const uint2 rec = nxt;
+        nxt = *reinterpret_cast<const uint2*>(&s_list[min(c + 1, 63)]);
+        const uint32_t cyx = rfl(rec.x);
+        const uint32_t clab = rfl(rec.y);
+        const int cy = (int)(cyx >> 16), cx = (int)(cyx & 0xFFFFu);
+        const uint32_t ux = __builtin_amdgcn_sad_u16((uint32_t)x, (uint32_t)cx, 0u);      // |x - cx|
+        const uint32_t uxc = min(ux, (uint32_t)(S + 1));
+        const uint32_t a0 = __umul24(uxc, nrpad) + (uint32_t)(yw_lo - cy + dyoff);        // element index of row 0
+        const uint32_t idx01 = (uint32_t)c | ((uint32_t)c << 16);
+#pragma unroll
+        for (int q = 0; q < R / 2; ++q) {
+            const us2 sp = (us2){s_tab[a0 + (2 * q) * STRIDE], s_tab[a0 + (2 * q + 1) * STRIDE]};
+            const uint32_t s0 = __builtin_amdgcn_sad_u8(pix[2 * q], clab, 0u);
+            const uint32_t s01 = __builtin_amdgcn_sad_hi_u8(pix[2 * q + 1], clab, s0);
+            const uint32_t t = (s01 << 6) + idx01;
+            const us2 key = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, t), sp);
+            best[q] = __builtin_elementwise_min(best[q], key);
+        }
+    }
+    FSLIC_STAMP(3);
+
+    // 5. write labels (+ fused centroid sums)
+    uint32_t slot[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int y = yw_lo + r * STRIDE;
+        const bool ok = okx && r < nrows;
+        const uint32_t key = (r & 1) ? (uint32_t)best[r / 2].y : (uint32_t)best[r / 2].x;
+        const bool found = key != 0xFFFFu;
+        const uint32_t idx = found ? (key & 63u) : 0u;
+        const uint32_t k = s_list[idx].z;
+        slot[r] = 0xFFFFFFFFu;
+        if (ok) {
+            const size_t p = (size_t)y * W + x;
+            if (found) {
+                f.labels[p] = (uint16_t)k;
+                if (FUSE) {
+                    if (idx < (uint32_t)kAccSlots) slot[r] = idx;
+                    else global_accumulate(f.sums[sbuf], k, (uint32_t)y, (uint32_t)x, pix[r]);
+                }
+            } else if (FUSE) {
+                const uint32_t old = f.labels[p];     // stale label still takes part in update()
+                if (old != 0xFFFFu) global_accumulate(f.sums[sbuf], old, (uint32_t)y, (uint32_t)x, pix[r]);
+            }
+        }
+    }
+    FSLIC_STAMP(4);
+    if (FUSE) {
+        bool uni = slot[0] != 0xFFFFFFFFu;
+#pragma unroll
+        for (int r = 1; r < R; ++r) uni = uni && (slot[r] == slot[0]);
+        const uint32_t copy = (uint32_t)lane & (kAccCopies - 1);
+        if (uni) {
+            uint32_t sL = 0, sa = 0, sb = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { sL += pix[r] & 255u; sa += (pix[r] >> 8) & 255u; sb += (pix[r] >> 16) & 255u; }
+            uint32_t* a = s_acc + (slot[0] * 6) * kAccCopies + copy;
+            atomicAdd(a + 0 * kAccCopies, (uint32_t)R);
+            atomicAdd(a + 1 * kAccCopies, (uint32_t)(R * yw_lo + STRIDE * (R * (R - 1) / 2)));
+            atomicAdd(a + 2 * kAccCopies, (uint32_t)(R * x));
+            atomicAdd(a + 3 * kAccCopies, sL);
+            atomicAdd(a + 4 * kAccCopies, sa);
+            atomicAdd(a + 5 * kAccCopies, sb);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (slot[r] != 0xFFFFFFFFu) {
+                    uint32_t* a = s_acc + (slot[r] * 6) * kAccCopies + copy;
+                    atomicAdd(a + 0 * kAccCopies, 1u);
+                    atomicAdd(a + 1 * kAccCopies, (uint32_t)(yw_lo + r * STRIDE));
+                    atomicAdd(a + 2 * kAccCopies, (uint32_t)x);
+                    atomicAdd(a + 3 * kAccCopies, pix[r] & 255u);
+                    atomicAdd(a + 4 * kAccCopies, (pix[r] >> 8) & 255u);
+                    atomicAdd(a + 5 * kAccCopies, (pix[r] >> 16) & 255u);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int nacc = min(n, kAccSlots) * 6;
+        for (int i = lane; i < nacc; i += 64) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int c = 0; c < kAccCopies; ++c) v += s_acc[i * kAccCopies + c];
+            if (v) {
+                const int sl = i / 6;
+                atomicAdd(f.sums[sbuf] + 6 * (size_t)s_list[sl].z + (i - sl * 6), v);
+            }
+        }
+    }
+    FSLIC_STAMP(5);
+    if (f.dbg && lane == 0) {
+        const size_t o = ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kWavesPerBlock + wave) * 8;
+        f.dbg[o + 6] = (unsigned long long)nraw;
+        f.dbg[o + 7] = (unsigned long long)n;
+    }
+#undef FSLIC_STAMP
+}
+
+template <int R, bool FUSE, int STRIDE>
+static void launch_assign16_t(const FrameDev& f, int rem, int Hv, int buf, int sbuf, hipStream_t st) {
+    dim3 grid((f.W + kTileW - 1) / kTileW, (Hv + kWavesPerBlock * R - 1) / (kWavesPerBlock * R));
+    const size_t lds = (size_t)f.tab_words * sizeof(uint32_t);
+    hipLaunchKernelGGL((k_assign16<R, FUSE, STRIDE>), grid, dim3(256), lds, st, f, rem, Hv, buf, sbuf);
+}
+
 static int assign_rows_per_wave(const FrameDev& f, int Hv, bool fuse_update) {
     const char* e = getenv("FSLIC_ASSIGN_R");
     if (e && (atoi(e) == 8 || atoi(e) == 16)) return atoi(e);
@@ -524,23 +832,34 @@ static int assign_rows_per_wave(const FrameDev& f, int Hv, bool fuse_update) {
 }
 
 template <int R>
-static void launch_assign_r(const FrameDev& f, int rem, int stride, int Hv, int buf, bool fuse_update, hipStream_t st) {
+static void launch_assign_r(const FrameDev& f, int rem, int stride, int Hv, int buf, int sbuf, bool fuse_update, hipStream_t st) {
     dim3 grid((f.W + kTileW - 1) / kTileW, (Hv + kWavesPerBlock * R - 1) / (kWavesPerBlock * R));
     const size_t lds = (size_t)f.lut_words * sizeof(uint32_t);
     if (f.lut_words > 0) {
-        if (fuse_update) hipLaunchKernelGGL((k_assign<R, true, true>), grid, dim3(256), lds, st, f, rem, stride, Hv, buf);
-        else hipLaunchKernelGGL((k_assign<R, false, true>), grid, dim3(256), lds, st, f, rem, stride, Hv, buf);
+        if (fuse_update) hipLaunchKernelGGL((k_assign<R, true, true>), grid, dim3(256), lds, st, f, rem, stride, Hv, buf, sbuf);
+        else hipLaunchKernelGGL((k_assign<R, false, true>), grid, dim3(256), lds, st, f, rem, stride, Hv, buf, sbuf);
     } else {
-        if (fuse_update) hipLaunchKernelGGL((k_assign<R, true, false>), grid, dim3(256), 0, st, f, rem, stride, Hv, buf);
-        else hipLaunchKernelGGL((k_assign<R, false, false>), grid, dim3(256), 0, st, f, rem, stride, Hv, buf);
+        if (fuse_update) hipLaunchKernelGGL((k_assign<R, true, false>), grid, dim3(256), 0, st, f, rem, stride, Hv, buf, sbuf);
+        else hipLaunchKernelGGL((k_assign<R, false, false>), grid, dim3(256), 0, st, f, rem, stride, Hv, buf, sbuf);
     }
 }
 
-void launch_assign(const FrameDev& f, int rem, int stride, int buf, bool fuse_update, hipStream_t st) {
+void launch_assign(const FrameDev& f, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st) {
     const int Hv = (f.H - rem + stride - 1) / stride;
     if (Hv <= 0) return;
-    if (assign_rows_per_wave(f, Hv, fuse_update) == 16) launch_assign_r<16>(f, rem, stride, Hv, buf, fuse_update, st);
-    else launch_assign_r<8>(f, rem, stride, Hv, buf, fuse_update, st);
+    if (f.tab_words > 0 && stride >= 1 && stride <= 3) {       // packed 16-bit kernel
+        const int R = assign_rows_per_wave(f, Hv, fuse_update);
+        if (!fuse_update) {
+            if (stride == 1 && R == 16) { launch_assign16_t<16, false, 1>(f, rem, Hv, buf, sbuf, st); return; }
+            if (stride == 1) { launch_assign16_t<8, false, 1>(f, rem, Hv, buf, sbuf, st); return; }
+        } else {
+            if (stride == 1) { launch_assign16_t<8, true, 1>(f, rem, Hv, buf, sbuf, st); return; }
+            if (stride == 2) { launch_assign16_t<8, true, 2>(f, rem, Hv, buf, sbuf, st); return; }
+            if (stride == 3) { launch_assign16_t<8, true, 3>(f, rem, Hv, buf, sbuf, st); return; }
+        }
+    }
+    if (assign_rows_per_wave(f, Hv, fuse_update) == 16) launch_assign_r<16>(f, rem, stride, Hv, buf, sbuf, fuse_update, st);
+    else launch_assign_r<8>(f, rem, stride, Hv, buf, sbuf, fuse_update, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -561,7 +880,7 @@ static __device__ __forceinline__ void generic_test(const ClusterRec& rec, int y
 }
 
 template <bool FUSE>
-__global__ __launch_bounds__(256) void k_assign_generic(FrameDev f, int rem, int stride, int Hv, int buf) {
+__global__ __launch_bounds__(256) void k_assign_generic(FrameDev f, int rem, int stride, int Hv, int buf, int sbuf) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)Hv * f.W) return;
     const int v = (int)(i / f.W), x = (int)(i - (size_t)v * f.W);
@@ -584,16 +903,16 @@ __global__ __launch_bounds__(256) void k_assign_generic(FrameDev f, int rem, int
     uint32_t lbl;
     if (best != ~0ull) { lbl = (uint32_t)(best & 0xFFFFull); f.labels[p] = (uint16_t)lbl; }
     else lbl = f.labels[p];
-    if (FUSE && lbl != 0xFFFFu) global_accumulate(f.sums, lbl, (uint32_t)y, (uint32_t)x, pix);
+    if (FUSE && lbl != 0xFFFFu) global_accumulate(f.sums[sbuf], lbl, (uint32_t)y, (uint32_t)x, pix);
 }
 
-void launch_assign_generic(const FrameDev& f, int rem, int stride, int buf, bool fuse_update, hipStream_t st) {
+void launch_assign_generic(const FrameDev& f, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st) {
     const int Hv = (f.H - rem + stride - 1) / stride;
     if (Hv <= 0) return;
     const size_t n = (size_t)Hv * f.W;
     const int blocks = (int)((n + 255) / 256);
-    if (fuse_update) hipLaunchKernelGGL(k_assign_generic<true>, dim3(blocks), dim3(256), 0, st, f, rem, stride, Hv, buf);
-    else hipLaunchKernelGGL(k_assign_generic<false>, dim3(blocks), dim3(256), 0, st, f, rem, stride, Hv, buf);
+    if (fuse_update) hipLaunchKernelGGL(k_assign_generic<true>, dim3(blocks), dim3(256), 0, st, f, rem, stride, Hv, buf, sbuf);
+    else hipLaunchKernelGGL(k_assign_generic<false>, dim3(blocks), dim3(256), 0, st, f, rem, stride, Hv, buf, sbuf);
 }
 
 // =============================================================================================
