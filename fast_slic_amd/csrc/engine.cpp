@@ -249,8 +249,8 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S) {
     const size_t o_patch = take(P * P * 2);
     const size_t o_lut = take(kLutMaxWords * 4);
     const size_t o_tab = take(kTabMaxBytes);
-    const size_t ntiles = (size_t)((W + kCcaTile - 1) / kCcaTile) * ((H + kCcaTile - 1) / kCcaTile);
-    const size_t TT = (size_t)kCcaTile * kCcaTile;
+    const size_t ntiles = (size_t)((W + kCcaTile - 1) / kCcaTile) * ((H + kCcaTileH - 1) / kCcaTileH);
+    const size_t TT = (size_t)kCcaTilePx;
     const size_t o_parent = take(N * 4), o_area = take(N * 4), o_final = take(N * 2), o_roots = take(ntiles * TT * 4);
     const size_t o_candl = take(ntiles * TT * 4), o_canda = take(ntiles * TT * 4);
     const size_t o_densel = take(ntiles * TT * 4), o_densea = take(ntiles * TT * 4);

@@ -14,7 +14,9 @@ constexpr int kCellCap = 8;         // cluster records per coarse cell before sp
 constexpr int kAccSlots = 16;       // candidates per wavefront with LDS-privatised centroid sums
 constexpr int kAccCopies = 8;       // privatised copies per (slot, quantity)
 constexpr uint32_t kHuge = 0x40000000u;   // out-of-window marker added to the distance key
-constexpr int kCcaTile = 64;        // connectivity tile: 64 x 64 pixels, one block of 256 threads
+constexpr int kCcaTile = 64;        // connectivity tile width  (one wavefront of columns)
+constexpr int kCcaTileH = 32;       // connectivity tile height (4 wavefronts x 8 rows), one block of 256 threads
+constexpr int kCcaTilePx = kCcaTile * kCcaTileH;
 
 // One cluster as the kernels see it (16 B, one ds_read_b128 / global_load_dwordx4).
 //   yx  = y << 16 | x          (integer centre, src/context.cpp:262 casts to int16)
@@ -69,12 +71,12 @@ struct CcaDev {
     int32_t* parent;      // N
     uint32_t* area;       // N (sparse: valid at tile-local roots)
     uint16_t* final_lab;  // N (sparse: valid at global roots)
-    int32_t* roots;       // ntiles * 4096: tile t's tile-local roots at [t*4096, t*4096 + tile_cnt[t])
+    int32_t* roots;       // ntiles * kCcaTilePx: tile t's tile-local roots at [t*kCcaTilePx, +tile_cnt[t])
     uint32_t* tile_cnt;   // ntiles
     uint32_t* tile_ccnt;  // ntiles: candidates (global roots with area >= threshold) of tile t
     uint32_t* counters;   // [1] dense candidate count (host path), [2] M, [3] select status (0 done, 1 host)
-    int32_t* cand_leader; // ntiles * 4096, per-tile slices
-    uint32_t* cand_area;  // ntiles * 4096
+    int32_t* cand_leader; // ntiles * kCcaTilePx, per-tile slices
+    uint32_t* cand_area;  // ntiles * kCcaTilePx
 };
 
 struct LabTables {

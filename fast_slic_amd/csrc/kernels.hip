@@ -582,10 +582,13 @@ __global__ __launch_bounds__(256) void k_assign16(FrameDev f, int rem, int Hv, i
 
     // 1. pixel loads first; nothing below depends on them until the argmin
     uint32_t pix[R];
+    {
+        const uint32_t* rowp = f.lab + (size_t)yw_lo * W;          // wave-uniform base, lane offset x
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const bool ok = okx && r < nrows;
-        pix[r] = ok ? f.lab[(size_t)(yw_lo + r * STRIDE) * W + x] : 0u;
+        for (int r = 0; r < R; ++r) {
+            pix[r] = (okx && r < nrows) ? rowp[(uint32_t)x] : 0u;
+            rowp += (size_t)STRIDE * W;
+        }
     }
     if (FUSE) {
 #pragma unroll
@@ -600,32 +603,29 @@ __global__ __launch_bounds__(256) void k_assign16(FrameDev f, int rem, int Hv, i
     auto gather = [&](const TileWindow& win, uint32_t* dst) -> int {
         const int cxa = max(win.wx_lo, 0) >> sh, cxb = min(win.wx_hi, W - 1) >> sh;
         const int cya = max(win.wy_lo, 0) >> sh, cyb = min(win.wy_hi, f.H - 1) >> sh;
-        const int ncxr = cxb - cxa + 1, ncyr = cyb - cya + 1;
-        const int total = ncxr * ncyr * kCellCap;
-        const uint32_t inv = (uint32_t)(4294967296.0f / (float)ncxr) + 1u;
+        const int ncxr = cxb - cxa + 1;
         int cnt = 0;
-        for (int c0 = 0; c0 < total; c0 += 256) {
-            ClusterRec rec[4];
-            bool live[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = c0 + u * 64 + lane;
-                live[u] = e < total;
-                const uint32_t ce = (uint32_t)e >> 3;
-                uint32_t cyi = __umulhi(ce, inv);
-                if (cyi * (uint32_t)ncxr > ce) cyi--;
-                const uint32_t cxi = ce - cyi * (uint32_t)ncxr;
-                const size_t slot = ((size_t)(cya + (int)cyi) * f.ncx + cxa + (int)cxi) * kCellCap + (e & 7);
-                if (live[u]) rec[u] = citems[slot];
-                else { rec[u].yx = 0; rec[u].lab = 0; rec[u].tag = 0; rec[u].pad = 0; }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool keep = live[u] && rec[u].pad == f.gen && in_window(rec[u], win);
-                const unsigned long long m = __ballot(keep);
-                const int pos = cnt + __popcll(m & lowmask);
-                if (keep && pos < 64) { dst[pos] = rec[u].yx; dst[64 + pos] = rec[u].lab; dst[128 + pos] = rec[u].tag; }
-                cnt += __popcll(m);
+        auto visit = [&](const ClusterRec& rec, bool keep) {
+            const unsigned long long m = __ballot(keep);
+            const int pos = cnt + __popcll(m & lowmask);
+            if (keep && pos < 64) { dst[pos] = rec.yx; dst[64 + pos] = rec.lab; dst[128 + pos] = rec.tag; }
+            cnt += __popcll(m);
+        };
+        // lane -> (cell column, slot); a cell row of up to 8 cells is one 16-byte load per lane
+        for (int cx0 = 0; cx0 < ncxr; cx0 += 8) {
+            const int cxi = cx0 + (lane >> 3);
+            const bool colok = cxi < ncxr;
+            const ClusterRec* base = citems + ((size_t)cya * f.ncx + cxa + cxi) * kCellCap + (lane & 7);
+            for (int cyi = cya; cyi <= cyb; cyi += 2) {
+                ClusterRec r0, r1;
+                r0.yx = 0; r0.lab = 0; r0.tag = 0; r0.pad = 0;
+                r1 = r0;
+                const bool ok1 = colok && (cyi + 1) <= cyb;
+                if (colok) r0 = base[0];
+                if (ok1) r1 = base[(size_t)f.ncx * kCellCap];
+                base += 2 * (size_t)f.ncx * kCellCap;
+                visit(r0, colok && r0.pad == f.gen && in_window(r0, win));
+                visit(r1, ok1 && r1.pad == f.gen && in_window(r1, win));
             }
         }
         for (uint32_t i0 = 0; i0 < novf; i0 += 64) {
@@ -633,11 +633,7 @@ __global__ __launch_bounds__(256) void k_assign16(FrameDev f, int rem, int Hv, i
             ClusterRec rec;
             rec.yx = 0; rec.lab = 0; rec.tag = 0; rec.pad = 0;
             if (i < novf) rec = oitems[i];
-            const bool keep = i < novf && in_window(rec, win);
-            const unsigned long long m = __ballot(keep);
-            const int pos = cnt + __popcll(m & lowmask);
-            if (keep && pos < 64) { dst[pos] = rec.yx; dst[64 + pos] = rec.lab; dst[128 + pos] = rec.tag; }
-            cnt += __popcll(m);
+            visit(rec, i < novf && in_window(rec, win));
         }
         return cnt;
     };
@@ -684,27 +680,16 @@ __global__ __launch_bounds__(256) void k_assign16(FrameDev f, int rem, int Hv, i
         if (lane == 0) *f.err_flag = 1u;
         return;
     }
-    int n;
+    // rank by (phase, k): list index order == visit order of the reference scatter.  Clusters with identical
+    // state are kept out of the bins by k_bin_clusters; one that slips through only costs a list slot (it has
+    // the same distance as its earlier twin and loses the tie on idx).
+    const int n = nraw;
     {
         const bool act = lane < nraw;
-        const uint32_t yx_j = act ? s_raw[lane] : 0u;
-        const uint32_t lab_j = act ? s_raw[64 + lane] : 0u;
         const uint32_t tag_j = act ? s_raw[128 + lane] : 0xFFFFFFFFu;
-        bool dup = false;
-        for (int i = 0; i < nraw; ++i) {
-            const uint32_t ty = __builtin_amdgcn_readlane(yx_j, i);
-            const uint32_t tl = __builtin_amdgcn_readlane(lab_j, i);
-            const uint32_t tt = __builtin_amdgcn_readlane(tag_j, i);
-            dup = dup || (act && (tt < tag_j) && (ty == yx_j) && (tl == lab_j));
-        }
-        const unsigned long long dupmask = __ballot(dup);
         int rank = 0;
-        for (int i = 0; i < nraw; ++i) {
-            const uint32_t tt = __builtin_amdgcn_readlane(tag_j, i);
-            rank += (int)((((dupmask >> i) & 1ull) == 0ull) && tt < tag_j);
-        }
-        if (act && !dup) s_list[rank] = make_uint4(yx_j, lab_j, tag_j & 0xFFFFu, 0u);
-        n = nraw - __popcll(dupmask);
+        for (int i = 0; i < nraw; ++i) rank += (int)(__builtin_amdgcn_readlane(tag_j, i) < tag_j);
+        if (act) s_list[rank] = make_uint4(s_raw[lane], s_raw[64 + lane], tag_j & 0xFFFFu, 0u);
     }
     __builtin_amdgcn_wave_barrier();
     FSLIC_STAMP(2);
@@ -739,29 +724,36 @@ __global__ __launch_bounds__(256) void k_assign16(FrameDev f, int rem, int Hv, i
     }
     FSLIC_STAMP(3);
 
-    // 5. write labels (+ fused centroid sums)
+    // 5. write labels (+ fused centroid sums).  All idx -> k lookups are issued before the first store so their
+    //    LDS latency overlaps; rows are addressed as wave-uniform row pointer + unsigned lane offset (saddr form).
     uint32_t slot[R];
+    {
+        uint32_t kk[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int y = yw_lo + r * STRIDE;
-        const bool ok = okx && r < nrows;
-        const uint32_t key = (r & 1) ? (uint32_t)best[r / 2].y : (uint32_t)best[r / 2].x;
-        const bool found = key != 0xFFFFu;
-        const uint32_t idx = found ? (key & 63u) : 0u;
-        const uint32_t k = s_list[idx].z;
-        slot[r] = 0xFFFFFFFFu;
-        if (ok) {
-            const size_t p = (size_t)y * W + x;
-            if (found) {
-                f.labels[p] = (uint16_t)k;
-                if (FUSE) {
+        for (int r = 0; r < R; ++r) {
+            const uint32_t key = (r & 1) ? (uint32_t)best[r / 2].y : (uint32_t)best[r / 2].x;
+            kk[r] = s_list[key & 63u].z;                            // idx 63 when not found: read, never used
+        }
+        uint16_t* rowp = f.labels + (size_t)yw_lo * W;
+        const uint32_t xo = (uint32_t)x;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool ok = okx && r < nrows;
+            const uint32_t key = (r & 1) ? (uint32_t)best[r / 2].y : (uint32_t)best[r / 2].x;
+            const bool found = key != 0xFFFFu;
+            slot[r] = 0xFFFFFFFFu;
+            if (ok && found) rowp[xo] = (uint16_t)kk[r];
+            if (FUSE && ok) {
+                const uint32_t idx = key & 63u;
+                if (found) {
                     if (idx < (uint32_t)kAccSlots) slot[r] = idx;
-                    else global_accumulate(f.sums[sbuf], k, (uint32_t)y, (uint32_t)x, pix[r]);
+                    else global_accumulate(f.sums[sbuf], kk[r], (uint32_t)(yw_lo + r * STRIDE), xo, pix[r]);
+                } else {
+                    const uint32_t old = rowp[xo];     // stale label still takes part in update()
+                    if (old != 0xFFFFu) global_accumulate(f.sums[sbuf], old, (uint32_t)(yw_lo + r * STRIDE), xo, pix[r]);
                 }
-            } else if (FUSE) {
-                const uint32_t old = f.labels[p];     // stale label still takes part in update()
-                if (old != 0xFFFFu) global_accumulate(f.sums[sbuf], old, (uint32_t)y, (uint32_t)x, pix[r]);
             }
+            rowp += (size_t)STRIDE * W;
         }
     }
     FSLIC_STAMP(4);
@@ -980,13 +972,14 @@ static __device__ __forceinline__ uint32_t lds_find_ro(uint32_t* par, uint32_t x
 //  D  tile-local roots appended to the root list (one global atomic per wavefront row)
 __global__ __launch_bounds__(256) void k_cca_local(CcaDev c) {
     constexpr int T = kCcaTile;
-    constexpr int RW = T / 4;
-    __shared__ uint16_t s_lbl[T * T];
-    __shared__ uint32_t s_par[T * T];
-    __shared__ uint32_t s_area[T * T];
+    constexpr int TH = kCcaTileH;
+    constexpr int RW = TH / 4;
+    __shared__ uint16_t s_lbl[T * TH];
+    __shared__ uint32_t s_par[T * TH];
+    __shared__ uint32_t s_area[T * TH];
     const int lane = LANE();
     const int wave = (int)rfl((uint32_t)(threadIdx.x >> 6));
-    const int tx0 = blockIdx.x * T, ty0 = blockIdx.y * T;
+    const int tx0 = blockIdx.x * T, ty0 = blockIdx.y * TH;
     const int x = tx0 + lane;
     const bool okx = x < c.W;
     const int ly0 = wave * RW;
@@ -1070,7 +1063,7 @@ __global__ __launch_bounds__(256) void k_cca_local(CcaDev c) {
     if (threadIdx.x == 0) s_nroots = 0;
     __syncthreads();
     const int tile = blockIdx.y * gridDim.x + blockIdx.x;
-    int32_t* const my_roots = c.roots + (size_t)tile * (T * T);
+    int32_t* const my_roots = c.roots + (size_t)tile * (T * TH);
 #pragma unroll 4
     for (int i = 0; i < RW; ++i) {
         const int ly = ly0 + i;
@@ -1122,11 +1115,12 @@ static __device__ __forceinline__ void g_union(int32_t* parent, int32_t a, int32
 
 __global__ __launch_bounds__(256) void k_cca_border(CcaDev c, int nh, int nv) {
     constexpr int T = kCcaTile;
+    constexpr int TH = kCcaTileH;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int W = c.W, H = c.H;
     if (i < nh) {            // pixel on the first row of a tile row, merge with the pixel above
         const int by = i / W + 1, x = i - (by - 1) * W;
-        const int p = by * T * W + x;
+        const int p = by * TH * W + x;
         const uint16_t lbl = c.in[p];
         if (c.in[p - W] == lbl) {
             const bool first = (x % T == 0) || c.in[p - 1] != lbl || c.in[p - W - 1] != lbl;
@@ -1138,7 +1132,7 @@ __global__ __launch_bounds__(256) void k_cca_border(CcaDev c, int nh, int nv) {
         const int p = y * W + bx * T;
         const uint16_t lbl = c.in[p];
         if (c.in[p - 1] == lbl) {
-            const bool first = (y % T == 0) || c.in[p - W] != lbl || c.in[p - W - 1] != lbl;
+            const bool first = (y % TH == 0) || c.in[p - W] != lbl || c.in[p - W - 1] != lbl;
             if (first) g_union(c.parent, p, p - 1);
         }
     }
@@ -1146,7 +1140,7 @@ __global__ __launch_bounds__(256) void k_cca_border(CcaDev c, int nh, int nv) {
 
 // One block per tile for the passes over tile-local roots.
 __global__ __launch_bounds__(256) void k_cca_compress(CcaDev c) {
-    constexpr int TT = kCcaTile * kCcaTile;
+    constexpr int TT = kCcaTilePx;
     const int tile = blockIdx.x;
     const uint32_t n = c.tile_cnt[tile];
     const int32_t* __restrict__ my_roots = c.roots + (size_t)tile * TT;
@@ -1163,7 +1157,7 @@ __global__ __launch_bounds__(256) void k_cca_compress(CcaDev c) {
 // Global roots: reset their final label; those with area >= threshold (src/cca.cpp:213-217) become
 // candidates in this tile's candidate slice (no global atomic).
 __global__ __launch_bounds__(256) void k_cca_collect(CcaDev c) {
-    constexpr int TT = kCcaTile * kCcaTile;
+    constexpr int TT = kCcaTilePx;
     __shared__ uint32_t s_n;
     const int tile = blockIdx.x;
     if (threadIdx.x == 0) s_n = 0;
@@ -1188,7 +1182,7 @@ __global__ __launch_bounds__(256) void k_cca_collect(CcaDev c) {
 // Dense candidate list for the host top-K path (rare: area tie at the cut, or more kept components than the
 // device path sorts).  counters[1] = M.
 __global__ __launch_bounds__(256) void k_cca_densify(CcaDev c, int32_t* __restrict__ out_leader, uint32_t* __restrict__ out_area) {
-    constexpr int TT = kCcaTile * kCcaTile;
+    constexpr int TT = kCcaTilePx;
     __shared__ uint32_t s_base;
     const int tile = blockIdx.x;
     const uint32_t n = c.tile_ccnt[tile];
@@ -1214,7 +1208,7 @@ __global__ __launch_bounds__(256) void k_cca_densify(CcaDev c, int32_t* __restri
 // ---------------------------------------------------------------------------------------------
 constexpr int kSelCap = 12288;    // candidates the device path holds in LDS (3 x 48 KB)
 __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int ntiles) {
-    constexpr int TT = kCcaTile * kCcaTile;
+    constexpr int TT = kCcaTilePx;
     extern __shared__ uint32_t s_dyn[];
     uint32_t* const s_area = s_dyn;
     uint32_t* const s_lead = s_dyn + kSelCap;
@@ -1264,15 +1258,24 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int ntiles) {
                 if (shift == 24 || (a >> (shift + 8)) == prefix) atomicAdd(&s_hist[(a >> shift) & 255u], 1u);
             }
             __syncthreads();
-            if (tid == 0) {
-                uint32_t cum = 0;
-                int b = 255;
-                for (; b > 0; --b) {
-                    if (cum + s_hist[b] >= kk) break;
-                    cum += s_hist[b];
+            // bin search: largest b with sum(hist[b..255]) >= kk, by an inclusive scan over the reversed histogram
+            {
+                uint32_t v = tid < 256 ? s_hist[255 - tid] : 0u;
+                if (tid < 256) s_scan[tid] = v;
+                __syncthreads();
+                for (int off = 1; off < 256; off <<= 1) {
+                    const uint32_t u = (tid < 256 && tid >= off) ? s_scan[tid - off] : 0u;
+                    __syncthreads();
+                    if (tid < 256) s_scan[tid] += u;
+                    __syncthreads();
                 }
-                s_v[1] = (prefix << 8) | (uint32_t)b;
-                s_v[2] = kk - cum;
+                if (tid < 256) {
+                    const uint32_t incl = s_scan[tid], excl = incl - v;
+                    if (incl >= kk && excl < kk) {
+                        s_v[1] = (prefix << 8) | (uint32_t)(255 - tid);
+                        s_v[2] = kk - excl;
+                    }
+                }
             }
             __syncthreads();
             prefix = s_v[1];
@@ -1330,7 +1333,7 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int ntiles) {
 
 void launch_cca_phase1(const CcaDev& c, hipStream_t st) {
     constexpr int T = kCcaTile;
-    const int tx = (c.W + T - 1) / T, ty = (c.H + T - 1) / T;
+    const int tx = (c.W + T - 1) / T, ty = (c.H + kCcaTileH - 1) / kCcaTileH;
     hipLaunchKernelGGL(k_cca_local, dim3(tx, ty), dim3(256), 0, st, c);
     const int nh = (ty - 1) * c.W, nv = (tx - 1) * c.H;
     if (nh + nv > 0)
@@ -1341,7 +1344,7 @@ void launch_cca_phase1(const CcaDev& c, hipStream_t st) {
 
 void launch_cca_select(const CcaDev& c, hipStream_t st) {
     constexpr int T = kCcaTile;
-    const int ntiles = ((c.W + T - 1) / T) * ((c.H + T - 1) / T);
+    const int ntiles = ((c.W + T - 1) / T) * ((c.H + kCcaTileH - 1) / kCcaTileH);
     const size_t lds = 3 * (size_t)kSelCap * sizeof(uint32_t);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cca_select), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_cca_select, dim3(1), dim3(1024), lds, st, c, ntiles);
@@ -1349,13 +1352,13 @@ void launch_cca_select(const CcaDev& c, hipStream_t st) {
 
 void launch_cca_densify(const CcaDev& c, int32_t* d_leader, uint32_t* d_area, hipStream_t st) {
     constexpr int T = kCcaTile;
-    const int ntiles = ((c.W + T - 1) / T) * ((c.H + T - 1) / T);
+    const int ntiles = ((c.W + T - 1) / T) * ((c.H + kCcaTileH - 1) / kCcaTileH);
     hipLaunchKernelGGL(k_cca_densify, dim3(ntiles), dim3(256), 0, st, c, d_leader, d_area);
 }
 
 // Host path only: forget what the device select / chain wrote, then set the host's choice.
 __global__ __launch_bounds__(256) void k_cca_reset_final(CcaDev c) {
-    constexpr int TT = kCcaTile * kCcaTile;
+    constexpr int TT = kCcaTilePx;
     const int tile = blockIdx.x;
     const uint32_t n = c.tile_cnt[tile];
     const int32_t* __restrict__ my_roots = c.roots + (size_t)tile * TT;
@@ -1370,7 +1373,7 @@ __global__ void k_cca_set_kept(CcaDev c, const int32_t* __restrict__ leaders, co
 }
 void launch_cca_set_kept(const CcaDev& c, const int32_t* d_leaders, const uint16_t* d_labels, int n, hipStream_t st) {
     constexpr int T = kCcaTile;
-    const int ntiles = ((c.W + T - 1) / T) * ((c.H + T - 1) / T);
+    const int ntiles = ((c.W + T - 1) / T) * ((c.H + kCcaTileH - 1) / kCcaTileH);
     hipLaunchKernelGGL(k_cca_reset_final, dim3(ntiles), dim3(256), 0, st, c);
     if (n <= 0) return;
     hipLaunchKernelGGL(k_cca_set_kept, dim3((n + 255) / 256), dim3(256), 0, st, c, d_leaders, d_labels, n);
@@ -1379,7 +1382,7 @@ void launch_cca_set_kept(const CcaDev& c, const int32_t* d_leaders, const uint16
 // Every component that was not kept takes the final label of the component left of (or, in column 0,
 // above) its leader (src/cca.cpp:240-254).  Leaders strictly decrease along the chase, so it terminates.
 __global__ __launch_bounds__(256) void k_cca_chain(CcaDev c) {
-    constexpr int TT = kCcaTile * kCcaTile;
+    constexpr int TT = kCcaTilePx;
     const int tile = blockIdx.x;
     const uint32_t n = c.tile_cnt[tile];
     const int32_t* __restrict__ my_roots = c.roots + (size_t)tile * TT;
@@ -1420,7 +1423,7 @@ __global__ __launch_bounds__(256) void k_cca_relabel(CcaDev c) {
 
 void launch_cca_phase2(const CcaDev& c, hipStream_t st) {
     constexpr int T = kCcaTile;
-    const int ntiles = ((c.W + T - 1) / T) * ((c.H + T - 1) / T);
+    const int ntiles = ((c.W + T - 1) / T) * ((c.H + kCcaTileH - 1) / kCcaTileH);
     hipLaunchKernelGGL(k_cca_chain, dim3(ntiles), dim3(256), 0, st, c);
     int blocks = (c.N / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
