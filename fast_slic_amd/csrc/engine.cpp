@@ -212,7 +212,7 @@ void free_slot(Slot& s) {
 // (Re)allocate the slot's buffers for an H x W frame with K clusters and carve the device arena.
 int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S) {
     const size_t N = (size_t)H * W;
-    const int sh = [&] { int v = 2; while ((1 << (v + 1)) <= S) v++; return v; }();
+    const int sh = [&] { int v = 2; while ((1 << v) < S) v++; return v; }();   // bin side = 2^ceil(log2 S): ~(side/S)^2 <= 4 clusters per bin
     const int ncx = (W + (1 << sh) - 1) >> sh, ncy = (H + (1 << sh) - 1) >> sh;
     const size_t ncell = (size_t)ncx * ncy;
     const size_t P = (size_t)(2 * S + 1);
@@ -397,6 +397,26 @@ int cca_finish(Slot& s) {
     return FSLIC_OK;
 }
 
+// bring-up aid: average per-phase cycle stamps of one assign launch (FSLIC_DEBUG_TIMING=1|2), to stderr
+int print_phase_stamps(Slot& s, const char* what) {
+    HIPCHK(hipStreamSynchronize(s.st));
+    const int nw = 65536;
+    std::vector<unsigned long long> h((size_t)nw * 8);
+    HIPCHK(hipMemcpy(h.data(), s.d_dbg, h.size() * 8, hipMemcpyDeviceToHost));
+    double ph[5] = {0, 0, 0, 0, 0}, nr = 0, nn = 0;
+    int cnt = 0;
+    for (int b = 0; b < nw; b++) {
+        if (h[(size_t)b * 8] == 0 || h[(size_t)b * 8 + 5] == 0) continue;
+        cnt++;
+        for (int q = 0; q < 5; q++) ph[q] += (double)(h[(size_t)b * 8 + q + 1] - h[(size_t)b * 8 + q]);
+        nr += (double)h[(size_t)b * 8 + 6]; nn += (double)h[(size_t)b * 8 + 7];
+    }
+    if (cnt == 0) cnt = 1;
+    fprintf(stderr, "[fslic dbg] %s %dx%d waves=%d avg ticks: loads+gather+barrier %.0f  filter+rank %.0f  argmin %.0f  store %.0f  update %.0f | nraw %.1f n %.1f\n",
+            what, s.W, s.H, cnt, ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt, ph[4] / cnt, nr / cnt, nn / cnt);
+    return FSLIC_OK;
+}
+
 // Spatial-distance configuration of a frame: the reference's patch (src/context.cpp:22-40) and the three device
 // encodings of it.  Cached per slot: a video stream calls iterate() with the same (S, compactness, options)
 // for every frame, so the tables are built and uploaded once.
@@ -517,41 +537,37 @@ int frame_enqueue_phase1(fslic_engine* e, Slot& s, const fslic_params* p, int H,
     launch_bin_clusters(f, 0, 0, 0, s.st);
     const int stride = p->subsample_stride;
     int rem = 0;
+    f.dbg = nullptr;
     for (int it = 0; it < p->max_iter; it++) {                  // src/context.cpp:158-175
+        if (it == p->max_iter - 1 && getenv("FSLIC_DEBUG_TIMING") && atoi(getenv("FSLIC_DEBUG_TIMING")) == 2) {
+            if (!s.d_dbg) HIPCHK(hipMalloc((void**)&s.d_dbg, sizeof(unsigned long long) * 8 * 65536));
+            HIPCHK(hipMemsetAsync(s.d_dbg, 0, sizeof(unsigned long long) * 8 * 65536, s.st));
+            f.dbg = s.d_dbg;
+        }
         if (s.generic) launch_assign_generic(f, rem, stride, it & 1, it & 1, true, s.st);
         else launch_assign(f, rem, stride, it & 1, it & 1, true, s.st);
+        if (f.dbg && atoi(getenv("FSLIC_DEBUG_TIMING")) == 2) {
+            int rc2 = print_phase_stamps(s, "last fused assign");
+            if (rc2) return rc2;
+            f.dbg = nullptr;
+        }
         f.gen = ++s.gen_counter;
         launch_bin_clusters(f, 1, (it + 1) & 1, it & 1, s.st);
         rem = (rem + 1) % stride;
     }
-    if (getenv("FSLIC_DEBUG_TIMING")) {
+    if (getenv("FSLIC_DEBUG_TIMING") && atoi(getenv("FSLIC_DEBUG_TIMING")) == 1) {
         if (!s.d_dbg) HIPCHK(hipMalloc((void**)&s.d_dbg, sizeof(unsigned long long) * 8 * 65536));
         HIPCHK(hipMemsetAsync(s.d_dbg, 0, sizeof(unsigned long long) * 8 * 65536, s.st));
         f.dbg = s.d_dbg;
-    } else f.dbg = nullptr;
+    }
     HIPCHK(hipEventRecord(s.ev[2], s.st));
     // full_assign: stride 1, rem 0, no update afterwards (src/context.cpp:246-256)
     if (s.generic) launch_assign_generic(f, 0, 1, p->max_iter & 1, 0, false, s.st);
     else launch_assign(f, 0, 1, p->max_iter & 1, 0, false, s.st);
     HIPCHK(hipEventRecord(s.ev[3], s.st));
-    if (f.dbg) {   // bring-up aid: average per-phase cycles of the full-assign launch, printed to stderr
-        HIPCHK(hipStreamSynchronize(s.st));
-        const int nw = 65536;
-        std::vector<unsigned long long> h((size_t)nw * 8);
-        HIPCHK(hipMemcpy(h.data(), s.d_dbg, h.size() * 8, hipMemcpyDeviceToHost));
-        double ph[5] = {0, 0, 0, 0, 0}, nr = 0, nn = 0;
-        unsigned long long tmin = ~0ull, tmax = 0;
-        int cnt = 0;
-        for (int b = 0; b < nw; b++) {
-            if (h[(size_t)b * 8] == 0 || h[(size_t)b * 8 + 5] == 0) continue;
-            cnt++;
-            for (int q = 0; q < 5; q++) ph[q] += (double)(h[(size_t)b * 8 + q + 1] - h[(size_t)b * 8 + q]);
-            nr += (double)h[(size_t)b * 8 + 6]; nn += (double)h[(size_t)b * 8 + 7];
-            tmin = std::min(tmin, h[(size_t)b * 8]); tmax = std::max(tmax, h[(size_t)b * 8 + 5]);
-        }
-        if (cnt == 0) cnt = 1;
-        fprintf(stderr, "[fslic dbg] full_assign %dx%d waves=%d avg ticks: loads+gather %.0f  prune+rank %.0f  argmin %.0f  store %.0f  update %.0f | nraw %.1f n %.1f | span %llu ticks\n",
-                W, H, cnt, ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt, ph[4] / cnt, nr / cnt, nn / cnt, tmax - tmin);
+    if (f.dbg) {
+        int rc2 = print_phase_stamps(s, "full_assign");
+        if (rc2) return rc2;
         f.dbg = nullptr;
     }
     // cluster state + overflow flag back to the host

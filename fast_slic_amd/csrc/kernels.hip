@@ -611,21 +611,24 @@ __global__ __launch_bounds__(256) void k_assign16(FrameDev f, int rem, int Hv, i
             if (keep && pos < 64) { dst[pos] = rec.yx; dst[64 + pos] = rec.lab; dst[128 + pos] = rec.tag; }
             cnt += __popcll(m);
         };
-        // lane -> (cell column, slot); a cell row of up to 8 cells is one 16-byte load per lane
+        // lane -> (cell column, slot); a cell row of up to 8 cells is one 16-byte load per lane.  Up to six cell
+        // rows are fetched before the first one is examined, so the whole gather is one memory round trip.
         for (int cx0 = 0; cx0 < ncxr; cx0 += 8) {
             const int cxi = cx0 + (lane >> 3);
             const bool colok = cxi < ncxr;
             const ClusterRec* base = citems + ((size_t)cya * f.ncx + cxa + cxi) * kCellCap + (lane & 7);
-            for (int cyi = cya; cyi <= cyb; cyi += 2) {
-                ClusterRec r0, r1;
-                r0.yx = 0; r0.lab = 0; r0.tag = 0; r0.pad = 0;
-                r1 = r0;
-                const bool ok1 = colok && (cyi + 1) <= cyb;
-                if (colok) r0 = base[0];
-                if (ok1) r1 = base[(size_t)f.ncx * kCellCap];
-                base += 2 * (size_t)f.ncx * kCellCap;
-                visit(r0, colok && r0.pad == f.gen && in_window(r0, win));
-                visit(r1, ok1 && r1.pad == f.gen && in_window(r1, win));
+            for (int cy0 = cya; cy0 <= cyb; cy0 += 6) {
+                ClusterRec rr[6];
+                bool okr[6];
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    okr[u] = colok && (cy0 + u) <= cyb;
+                    rr[u].yx = 0; rr[u].lab = 0; rr[u].tag = 0; rr[u].pad = 0;
+                    if (okr[u]) rr[u] = base[(size_t)u * f.ncx * kCellCap];
+                }
+                base += 6 * (size_t)f.ncx * kCellCap;
+#pragma unroll
+                for (int u = 0; u < 6; ++u) visit(rr[u], okr[u] && rr[u].pad == f.gen && in_window(rr[u], win));
             }
         }
         for (uint32_t i0 = 0; i0 < novf; i0 += 64) {

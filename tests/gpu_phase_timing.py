@@ -1,6 +1,6 @@
 """Bring-up aid: per-phase cycle stamps of the full-assign launch (FSLIC_DEBUG_TIMING=1)."""
 import os, sys
-os.environ["FSLIC_DEBUG_TIMING"] = "1"
+os.environ.setdefault("FSLIC_DEBUG_TIMING", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
