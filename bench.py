@@ -93,23 +93,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="720p", choices=sorted(WORKLOADS))
     ap.add_argument("--frames-per-gpu", type=int, default=0)
-    ap.add_argument("--slots", type=int, default=8)
+    ap.add_argument("--slots", type=int, default=2, help="streams per GPU; the frames of a step are cut into one group per slot")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-4k", action="store_true")
     args = ap.parse_args()
 
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from fast_slic_amd import batch
+    rank, local_rank, world = batch.env_rank_world()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+    dist = batch.init_process_group("nccl", rank, world)     # "nccl" is RCCL on ROCm; barrier + timing reduction only
 
     from fast_slic_amd import Engine, make_params, CLUSTER_DTYPE
     from fast_slic_amd import _binding as B
@@ -118,11 +113,11 @@ def main():
     wl = WORKLOADS[args.workload]
     H, W, K = wl["H"], wl["W"], wl["K"]
     fpg = args.frames_per_gpu or (8 if args.workload == "720p" else 2)
-    eng = Engine(local_rank, max(1, min(args.slots, fpg)))
+    eng = Engine(local_rank, max(1, min(args.slots, fpg)))   # groups of fpg/slots frames, one launch sequence each
     params = make_params(10, 10.0, 0.25, 3)
 
     # this rank's shard of the synthetic frame stream: frames are independent, rank r owns seeds r*fpg .. r*fpg+fpg-1
-    seeds = [rank * fpg + i for i in range(fpg)]
+    seeds = batch.weak_shard(fpg, rank)
     frames = [variant("A", H, W, seed=s) for s in seeds]
     d_rgb = [torch.from_numpy(f).cuda() for f in frames]
     d_lab = [torch.empty((H, W), dtype=torch.int16, device="cuda") for _ in frames]
@@ -148,26 +143,27 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    fa_ms, tot_ms = [], []
+    fa_ms, tot_ms, grp = [], [], []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         for s in range(eng.n_slots):
-            t, f = eng.last_device_times(s)
-            tot_ms.append(t)
-            fa_ms.append(f)
+            g = eng.last_group_frames(s)
+            if g > 0:
+                t, f = eng.last_device_times(s)     # HIP events on the slot's own stream, per group launch
+                tot_ms.append(t / g)
+                fa_ms.append(f)
+                grp.append(g)
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = batch.max_over_ranks(elapsed, dist, "cuda")
 
     if rank == 0:
         total_px = float(H) * W * fpg * world * args.steps
         fa_avg_ms = float(np.mean(fa_ms))
-        achieved = ASSIGN_BYTES_PER_PX * H * W / (fa_avg_ms * 1e-3) / 1e9
+        frames_per_launch = float(np.mean(grp))
+        achieved = ASSIGN_BYTES_PER_PX * H * W * frames_per_launch / (fa_avg_ms * 1e-3) / 1e9
         out = {
             "metric": "megapixels/sec @10 iters (1280x720 & 4K, K=1600); % HBM roofline",
             "value": round(total_px / elapsed / 1e6, 2),
@@ -180,10 +176,11 @@ def main():
                        "slots_per_gpu": eng.n_slots, "inputs": "device-resident uint8 RGB, device int16 labels",
                        "parallelism": "frames sharded across GPUs, no collective"},
             "device_ms_per_frame": round(float(np.mean(tot_ms)), 4),
-            "roofline": {"kernel": "k_assign<8,false> (full_assign launch, %dx%d)" % (W, H), "bound": "hbm",
-                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": "full_assign launch (k_assign16<R,false,1>), %dx%d x %g frames per launch" % (W, H, frames_per_launch),
+                         "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "bytes_per_launch": ASSIGN_BYTES_PER_PX * H * W, "avg_launch_ms": round(fa_avg_ms, 5)},
+                         "bytes_per_launch": ASSIGN_BYTES_PER_PX * H * W * frames_per_launch,
+                         "avg_launch_ms": round(fa_avg_ms, 5)},
         }
         if not args.no_4k and args.workload == "720p":
             # the north-star kernel: full-assign at 3840x2160, K=1600, same engine, after the timed region

@@ -40,7 +40,7 @@ EXPORTS = [
     "fslic_hip_device_count", "fslic_hip_create", "fslic_hip_destroy", "fslic_hip_initialize_clusters",
     "fslic_hip_iterate", "fslic_hip_iterate_device", "fslic_hip_iterate_batch", "fslic_hip_rgb_to_lab",
     "fslic_hip_enforce_connectivity", "fslic_hip_last_prelabels", "fslic_hip_last_timing_report",
-    "fslic_hip_last_device_times", "fslic_hip_last_path", "fslic_hip_last_error", "fslic_hip_version",
+    "fslic_hip_last_device_times", "fslic_hip_last_group_frames", "fslic_hip_last_path", "fslic_hip_last_error", "fslic_hip_version",
 ]
 
 _lib = None
@@ -106,6 +106,7 @@ def load_library():
         lib.fslic_hip_last_timing_report.argtypes = [vp]
         lib.fslic_hip_last_timing_report.restype = C.c_char_p
         lib.fslic_hip_last_device_times.argtypes = [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        lib.fslic_hip_last_group_frames.argtypes = [vp, i32]
         lib.fslic_hip_last_path.argtypes = [vp, i32]
         lib.fslic_hip_last_error.restype = C.c_char_p
         lib.fslic_hip_version.restype = C.c_char_p
@@ -201,6 +202,9 @@ class Engine(object):
         t, f = C.c_float(), C.c_float()
         _check(load_library().fslic_hip_last_device_times(self._h, int(slot), C.byref(t), C.byref(f)))
         return t.value, f.value
+
+    def last_group_frames(self, slot=0):
+        return load_library().fslic_hip_last_group_frames(self._h, int(slot))
 
     def last_path(self, slot=0):
         return load_library().fslic_hip_last_path(self._h, int(slot))

@@ -130,28 +130,36 @@ constexpr size_t kLutMaxWords = 12288;   // 48 KB of LDS for the spatial table a
 struct Slot {
     hipStream_t st = nullptr;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    // device
+    // device: one arena = [shared spatial tables][frame 0][frame 1]...; f / c hold frame 0's pointers
     char* arena = nullptr;
     size_t arena_cap = 0;
+    int cap_frames = 0;              // frames the arena is carved for
+    size_t frame_bytes = 0;
     FrameDev f{};
     CcaDev c{};
+    // per-frame regions, given as frame 0's pointers (frame i: + i * frame_bytes)
     char* zero_block = nullptr;
     size_t zero_bytes = 0;
+    uint32_t* d_misc = nullptr;      // 64 B: ovf_cnt[2], err flag, pad, cca counters[4]
     uint8_t* d_rgb_stage = nullptr;
     uint16_t* d_out_stage = nullptr;
+    int32_t* d_keep_leader = nullptr;
+    uint16_t* d_keep_label = nullptr;
+    int32_t* d_dense_leader = nullptr;
+    uint32_t* d_dense_area = nullptr;
+    // per-frame caller pointers of the current group: [0, kMaxGroup) inputs, [kMaxGroup, 2*kMaxGroup) outputs
+    void** d_ptrs = nullptr;         // device copy (allocated with the slot)
+    void** h_ptrs = nullptr;         // pinned staging
+    // shared tables
     uint16_t* d_patch = nullptr;
     uint32_t* d_lut = nullptr;
     uint32_t* h_lut = nullptr;
     uint16_t* d_tab = nullptr;
     uint16_t* h_tab = nullptr;
-    int32_t* d_keep_leader = nullptr;
-    uint16_t* d_keep_label = nullptr;
-    uint32_t* d_err = nullptr;
-    int32_t* d_dense_leader = nullptr;
-    uint32_t* d_dense_area = nullptr;
     // pinned host
-    uint32_t* h_cl = nullptr;        // [0,K) yx in; out: 4K words (yx, lab, n, moved)
-    uint32_t* h_misc = nullptr;      // [0] roots, [1] candidates, [2] err flag
+    uint32_t* h_cl = nullptr;        // per frame 4K words: in [0,K) yx; out (yx, lab, n, moved)
+    size_t h_cl_words = 0;
+    uint32_t* h_misc = nullptr;      // per frame 16 words (copy of d_misc)
     int32_t* h_keep_leader = nullptr;
     uint16_t* h_keep_label = nullptr;
     uint16_t* h_patch = nullptr;
@@ -159,31 +167,34 @@ struct Slot {
     int32_t* h_cand_leader = nullptr;
     uint32_t* h_cand_area = nullptr;
     size_t h_cand_cap = 0;
-    int hK = 0;
+    int hKeep = 0;
     uint32_t gen_counter = 0;
     unsigned long long* d_dbg = nullptr;
     int keyH = 0, keyW = 0, keyK = 0;
     // per-call state
     int H = 0, W = 0, K = 0, S = 0;
+    int nframes = 0;
     bool generic = false;
     fslic_params p{};
-    fslic_cluster* clusters = nullptr;
-    uint16_t* d_out = nullptr;
+    fslic_cluster* clusters[kMaxGroup] = {};
+    const uint8_t* d_rgb[kMaxGroup] = {};
+    uint16_t* d_out[kMaxGroup] = {};
     float total_ms = 0, fa_ms = 0, lab_ms = 0, loop_ms = 0, cca_ms = 0;
     int last_path = 0;
     bool have_pre = false;
-    bool host_topk = false;
     // cached spatial configuration (configure_spatial)
     bool sp_valid = false, sp_tiled_ok = false, sp_manhattan = true, sp_patch_uploaded = false;
     int sp_S = 0, sp_shift = 0, sp_stride = 0;
     float sp_compactness = 0.0f;
-    int hKeep = 0;
+
+    template <class T> T* at(T* p, int frame) const { return reinterpret_cast<T*>(reinterpret_cast<char*>(p) + (size_t)frame * frame_bytes); }
 };
 
 }  // namespace
 
 struct fslic_engine {
     int device = 0;
+    int group_size = 8;              // frames per launch group of iterate_batch (FSLIC_GROUP)
     std::vector<Slot> slots;
     uint16_t* d_gamma = nullptr;
     uint16_t* d_labtbl = nullptr;
@@ -195,6 +206,9 @@ namespace {
 
 void free_slot(Slot& s) {
     if (s.arena) hipFree(s.arena);
+    if (s.d_dbg) hipFree(s.d_dbg);
+    if (s.d_ptrs) hipFree(s.d_ptrs);
+    if (s.h_ptrs) hipHostFree(s.h_ptrs);
     if (s.h_cl) hipHostFree(s.h_cl);
     if (s.h_misc) hipHostFree(s.h_misc);
     if (s.h_lut) hipHostFree(s.h_lut);
@@ -209,34 +223,46 @@ void free_slot(Slot& s) {
     s = Slot();
 }
 
-// (Re)allocate the slot's buffers for an H x W frame with K clusters and carve the device arena.
-int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S) {
+// (Re)allocate the slot's buffers for groups of up to G frames of H x W with K clusters and carve the arena.
+int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     const size_t N = (size_t)H * W;
     const int sh = [&] { int v = 2; while ((1 << v) < S) v++; return v; }();   // bin side = 2^ceil(log2 S): ~(side/S)^2 <= 4 clusters per bin
     const int ncx = (W + (1 << sh) - 1) >> sh, ncy = (H + (1 << sh) - 1) >> sh;
     const size_t ncell = (size_t)ncx * ncy;
     const size_t P = (size_t)(2 * S + 1);
+    if (G < s.cap_frames && s.keyH == H && s.keyW == W && s.keyK == K) G = s.cap_frames;
 
-    if (s.hK < K) {
-        if (s.h_cl) { hipHostFree(s.h_cl); hipHostFree(s.h_keep_leader); hipHostFree(s.h_keep_label); }
-        HIPCHK(hipHostMalloc((void**)&s.h_cl, sizeof(uint32_t) * 4 * (size_t)K));
+    if (s.h_cl_words < (size_t)G * 4 * K) {
+        if (s.h_cl) hipHostFree(s.h_cl);
+        s.h_cl = nullptr; s.h_cl_words = 0;
+        HIPCHK(hipHostMalloc((void**)&s.h_cl, sizeof(uint32_t) * 4 * (size_t)K * G));
+        s.h_cl_words = (size_t)G * 4 * K;
+    }
+    if (s.hKeep < K) {
+        if (s.h_keep_leader) { hipHostFree(s.h_keep_leader); hipHostFree(s.h_keep_label); }
+        s.h_keep_leader = nullptr; s.h_keep_label = nullptr; s.hKeep = 0;
         HIPCHK(hipHostMalloc((void**)&s.h_keep_leader, sizeof(int32_t) * (size_t)K));
         HIPCHK(hipHostMalloc((void**)&s.h_keep_label, sizeof(uint16_t) * (size_t)K));
-        s.hK = K;
         s.hKeep = K;
     }
-    if (!s.h_misc) HIPCHK(hipHostMalloc((void**)&s.h_misc, 64));
+    if (!s.h_misc) HIPCHK(hipHostMalloc((void**)&s.h_misc, 64 * kMaxGroup));
     if (!s.h_lut) HIPCHK(hipHostMalloc((void**)&s.h_lut, kLutMaxWords * 4));
     if (!s.h_tab) HIPCHK(hipHostMalloc((void**)&s.h_tab, kTabMaxBytes));
     if (s.h_patch_cap < P * P) {
         if (s.h_patch) hipHostFree(s.h_patch);
+        s.h_patch = nullptr; s.h_patch_cap = 0;
         HIPCHK(hipHostMalloc((void**)&s.h_patch, sizeof(uint16_t) * P * P));
         s.h_patch_cap = P * P;
     }
 
-    // ---- carve ----
+    // ---- carve: shared tables, then one frame's sub-arena ----
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_patch = take(P * P * 2);
+    const size_t o_lut = take(kLutMaxWords * 4);
+    const size_t o_tab = take(kTabMaxBytes);
+    const size_t shared_bytes = off;
+    off = 0;
     const size_t o_lab = take(N * 4), o_labels = take(N * 2);
     const size_t o_cl = take((size_t)K * 4 * 5);                     // yx, lab, n, moved, tag (contiguous)
     const size_t o_zero = off;
@@ -246,9 +272,6 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S) {
     const size_t zero_bytes = off - o_zero;
     const size_t o_ci0 = take(ncell * kCellCap * sizeof(ClusterRec)), o_ci1 = take(ncell * kCellCap * sizeof(ClusterRec));
     const size_t o_ov0 = take((size_t)K * sizeof(ClusterRec)), o_ov1 = take((size_t)K * sizeof(ClusterRec));
-    const size_t o_patch = take(P * P * 2);
-    const size_t o_lut = take(kLutMaxWords * 4);
-    const size_t o_tab = take(kTabMaxBytes);
     const size_t ntiles = (size_t)((W + kCcaTile - 1) / kCcaTile) * ((H + kCcaTileH - 1) / kCcaTileH);
     const size_t TT = (size_t)kCcaTilePx;
     const size_t o_parent = take(N * 4), o_area = take(N * 4), o_final = take(N * 2), o_roots = take(ntiles * TT * 4);
@@ -257,15 +280,19 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S) {
     const size_t o_tcnt = take(ntiles * 4), o_tccnt = take(ntiles * 4);
     const size_t o_keepl = take((size_t)K * 4), o_keepb = take((size_t)K * 2);
     const size_t o_rgb = take(N * 3), o_out = take(N * 2);
-    const size_t total = off;
+    const size_t frame_bytes = off;
+    const size_t total = shared_bytes + frame_bytes * (size_t)G;
 
     if (s.arena_cap < total) {
         if (s.arena) { hipFree(s.arena); s.arena = nullptr; s.arena_cap = 0; }
         HIPCHK(hipMalloc((void**)&s.arena, total));
         s.arena_cap = total;
     }
-    char* b = s.arena;
+    s.cap_frames = G;
+    s.frame_bytes = frame_bytes;
+    char* b = s.arena + shared_bytes;          // frame 0
     FrameDev& f = s.f;
+    f.frame_bytes = frame_bytes;
     f.H = H; f.W = W; f.N = (int)N; f.K = K; f.S = S; f.T = 2 * S + 32;
     f.cs_shift = sh; f.ncx = ncx; f.ncy = ncy; f.ncell = (int)ncell;
     f.lab = (uint32_t*)(b + o_lab);
@@ -275,16 +302,18 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S) {
     f.sums[0] = (uint32_t*)(b + o_sums); f.sums[1] = (uint32_t*)(b + o_sums1);
     f.cell_cnt[0] = (uint32_t*)(b + o_cc0); f.cell_cnt[1] = (uint32_t*)(b + o_cc1);
     uint32_t* misc = (uint32_t*)(b + o_misc);
+    s.d_misc = misc;
     f.ovf_cnt[0] = misc + 0; f.ovf_cnt[1] = misc + 1; f.err_flag = misc + 2;
     f.cell_items[0] = (ClusterRec*)(b + o_ci0); f.cell_items[1] = (ClusterRec*)(b + o_ci1);
     f.ovf_items[0] = (ClusterRec*)(b + o_ov0); f.ovf_items[1] = (ClusterRec*)(b + o_ov1);
-    s.d_patch = (uint16_t*)(b + o_patch);
+    f.dbg = nullptr;
+    s.d_patch = (uint16_t*)(s.arena + o_patch);
     f.patch2d = s.d_patch;
-    s.d_lut = (uint32_t*)(b + o_lut);
-    s.d_tab = (uint16_t*)(b + o_tab);
-    s.d_err = misc + 2;
+    s.d_lut = (uint32_t*)(s.arena + o_lut);
+    s.d_tab = (uint16_t*)(s.arena + o_tab);
     s.zero_block = b + o_zero; s.zero_bytes = zero_bytes;
     CcaDev& c = s.c;
+    c.frame_bytes = frame_bytes;
     c.H = H; c.W = W; c.N = (int)N; c.K = K;
     c.parent = (int32_t*)(b + o_parent); c.area = (uint32_t*)(b + o_area);
     c.final_lab = (uint16_t*)(b + o_final); c.roots = (int32_t*)(b + o_roots);
@@ -299,8 +328,14 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S) {
     (void)e;
     // Bin slots are validated by a generation stamp (ClusterRec::pad == FrameDev::gen, gen >= 1 and strictly
     // increasing per slot), so a freshly carved region must not contain bytes that could pass for a stamp.
-    HIPCHK(hipMemsetAsync(b + o_ci0, 0, (o_ov0 - o_ci0), s.st));
+    HIPCHK(hipMemset2DAsync(b + o_ci0, frame_bytes, 0, (o_ov0 - o_ci0), (size_t)G, s.st));
     return FSLIC_OK;
+}
+
+int ensure_prepared(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
+    if (s.keyH == H && s.keyW == W && s.keyK == K && s.cap_frames >= G) return FSLIC_OK;
+    HIPCHK(hipStreamSynchronize(s.st));
+    return prepare(e, s, H, W, K, S, G);
 }
 
 int validate(const fslic_params* p, int H, int W, int K, int& S) {
@@ -352,48 +387,74 @@ int ensure_cand_capacity(Slot& s, size_t M) {
     return FSLIC_OK;
 }
 
-// Connectivity pass, fully asynchronous on the slot's stream: tile CCL, seams, compress, collect, device
-// top-K + ranking, chain, relabel.  The select status (0 = done on device, 1 = host top-K needed) is copied
-// to h_misc[3]; cca_finish() redoes the tail with std::partial_sort when it is 1.
-int cca_enqueue(Slot& s, const uint16_t* d_in, uint16_t* d_out, int K, int min_threshold) {
-    CcaDev& c = s.c;
-    c.in = d_in; c.out = d_out; c.K = K; c.min_threshold = min_threshold;
-    launch_cca_phase1(c, s.st);
-    launch_cca_select(c, s.st);
-    launch_cca_phase2(c, s.st);
-    HIPCHK(hipMemcpyAsync(s.h_misc + 4, c.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.st));
+// CcaDev of frames [i0, i0+n) of the slot: pointers advanced to frame i0, outputs = the given per-frame buffers.
+// The per-frame output pointers must already be in s.d_ptrs[kMaxGroup + i] (upload_ptrs).
+CcaDev cca_view(const Slot& s, int i0, const uint16_t* d_in0, size_t in_stride, int K, int min_threshold) {
+    CcaDev c = s.c;
+    c.in = d_in0; c.in_stride = in_stride; c.K = K; c.min_threshold = min_threshold;
+    c.outs = nullptr;
+    c.out = nullptr;
+    // host-side advance to frame i0 (CcaDev::select dereferences the device array, so spell it out here)
+    FrameDev::adv(c.in, (size_t)i0 * in_stride);
+    const size_t d = (size_t)i0 * c.frame_bytes;
+    FrameDev::adv(c.parent, d); FrameDev::adv(c.area, d); FrameDev::adv(c.final_lab, d); FrameDev::adv(c.roots, d);
+    FrameDev::adv(c.tile_cnt, d); FrameDev::adv(c.tile_ccnt, d); FrameDev::adv(c.counters, d);
+    FrameDev::adv(c.cand_leader, d); FrameDev::adv(c.cand_area, d);
+    c.outs = reinterpret_cast<uint16_t* const*>(s.d_ptrs + kMaxGroup + i0);
+    return c;
+}
+
+// Caller's per-frame buffers of the group -> device pointer arrays.
+int upload_ptrs(Slot& s, int n, const uint8_t* const* d_rgb, uint16_t* const* d_out) {
+    for (int i = 0; i < kMaxGroup; i++) {
+        s.h_ptrs[i] = (i < n && d_rgb) ? const_cast<uint8_t*>(d_rgb[i]) : nullptr;
+        s.h_ptrs[kMaxGroup + i] = (i < n && d_out) ? d_out[i] : nullptr;
+    }
+    HIPCHK(hipMemcpyAsync(s.d_ptrs, s.h_ptrs, sizeof(void*) * 2 * kMaxGroup, hipMemcpyHostToDevice, s.st));
     return FSLIC_OK;
 }
-// After the stream has been synchronised.
-int cca_finish(Slot& s) {
-    CcaDev& c = s.c;
-    if (s.h_misc[4 + 3] == 0) return FSLIC_OK;
-    // host top-K: dense candidate list -> std::partial_sort -> kept labels -> chain + relabel again
-    launch_cca_densify(c, s.d_dense_leader, s.d_dense_area, s.st);
-    HIPCHK(hipMemcpyAsync(s.h_misc + 4, c.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.st));
+
+// Connectivity pass, fully asynchronous on the slot's stream: tile CCL, seams, compress, collect, device
+// top-K + ranking, chain, relabel.  The select status (0 = done on device, 1 = host top-K needed) ends up in the
+// frame's misc words; cca_finish_frame() redoes the tail with std::partial_sort when it is 1.
+void cca_enqueue(Slot& s, const CcaDev& c, int n) {
+    launch_cca_phase1(c, n, s.st);
+    launch_cca_select(c, n, s.st);
+    launch_cca_phase2(c, n, s.st);
+}
+// After the stream has been synchronised and h_misc refreshed: host top-K for frame i when the device asked for it.
+int cca_finish_frame(Slot& s, const CcaDev& c1, int i) {     // c1: view of frame i alone
+    uint32_t* hm = s.h_misc + 16 * (size_t)i;
+    if (hm[4 + 3] == 0) return FSLIC_OK;
+    int32_t* d_dense_leader = s.at(s.d_dense_leader, i);
+    uint32_t* d_dense_area = s.at(s.d_dense_area, i);
+    int32_t* d_keep_leader = s.at(s.d_keep_leader, i);
+    uint16_t* d_keep_label = s.at(s.d_keep_label, i);
+    launch_cca_densify(c1, d_dense_leader, d_dense_area, s.st);
+    HIPCHK(hipMemcpyAsync(hm + 4, c1.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.st));
     HIPCHK(hipStreamSynchronize(s.st));
-    const uint32_t M = s.h_misc[4 + 1];
+    const uint32_t M = hm[4 + 1];
     uint32_t n_keep = 0;
     if (M > 0) {
         int rc = ensure_cand_capacity(s, M);
         if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(s.h_cand_leader, s.d_dense_leader, sizeof(int32_t) * M, hipMemcpyDeviceToHost, s.st));
-        HIPCHK(hipMemcpyAsync(s.h_cand_area, s.d_dense_area, sizeof(uint32_t) * M, hipMemcpyDeviceToHost, s.st));
+        HIPCHK(hipMemcpyAsync(s.h_cand_leader, d_dense_leader, sizeof(int32_t) * M, hipMemcpyDeviceToHost, s.st));
+        HIPCHK(hipMemcpyAsync(s.h_cand_area, d_dense_area, sizeof(uint32_t) * M, hipMemcpyDeviceToHost, s.st));
         HIPCHK(hipStreamSynchronize(s.st));
-        if ((size_t)std::min<uint32_t>(M, (uint32_t)c.K) > (size_t)s.hKeep) {
+        if ((size_t)std::min<uint32_t>(M, (uint32_t)c1.K) > (size_t)s.hKeep) {
             if (s.h_keep_leader) { hipHostFree(s.h_keep_leader); hipHostFree(s.h_keep_label); }
-            s.hKeep = (int)std::min<uint32_t>(M, (uint32_t)c.K);
+            s.h_keep_leader = nullptr; s.h_keep_label = nullptr;
+            s.hKeep = (int)std::min<uint32_t>(M, (uint32_t)c1.K);
             HIPCHK(hipHostMalloc((void**)&s.h_keep_leader, sizeof(int32_t) * (size_t)s.hKeep));
             HIPCHK(hipHostMalloc((void**)&s.h_keep_label, sizeof(uint16_t) * (size_t)s.hKeep));
         }
-        select_kept(s, M, c.K, n_keep);
-        HIPCHK(hipMemcpyAsync(s.d_keep_leader, s.h_keep_leader, sizeof(int32_t) * n_keep, hipMemcpyHostToDevice, s.st));
-        HIPCHK(hipMemcpyAsync(s.d_keep_label, s.h_keep_label, sizeof(uint16_t) * n_keep, hipMemcpyHostToDevice, s.st));
+        select_kept(s, M, c1.K, n_keep);
+        HIPCHK(hipMemcpyAsync(d_keep_leader, s.h_keep_leader, sizeof(int32_t) * n_keep, hipMemcpyHostToDevice, s.st));
+        HIPCHK(hipMemcpyAsync(d_keep_label, s.h_keep_label, sizeof(uint16_t) * n_keep, hipMemcpyHostToDevice, s.st));
     }
-    launch_cca_set_kept(c, s.d_keep_leader, s.d_keep_label, (int)n_keep, s.st);
-    launch_cca_phase2(c, s.st);
-    HIPCHK(hipStreamSynchronize(s.st));
-    s.host_topk = true;
+    launch_cca_set_kept(c1, d_keep_leader, d_keep_label, (int)n_keep, s.st);
+    launch_cca_phase2(c1, 1, s.st);
+    HIPCHK(hipStreamSynchronize(s.st));     // the pinned keep arrays are reused by the next frame
     return FSLIC_OK;
 }
 
@@ -416,7 +477,6 @@ int print_phase_stamps(Slot& s, const char* what) {
             what, s.W, s.H, cnt, ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt, ph[4] / cnt, nr / cnt, nn / cnt);
     return FSLIC_OK;
 }
-
 // Spatial-distance configuration of a frame: the reference's patch (src/context.cpp:22-40) and the three device
 // encodings of it.  Cached per slot: a video stream calls iterate() with the same (S, compactness, options)
 // for every frame, so the tables are built and uploaded once.
@@ -498,148 +558,161 @@ int configure_spatial(Slot& s, int S, const fslic_params* p) {
     return FSLIC_OK;
 }
 
-// Everything of iterate() up to and including the device half of the connectivity pass.
-int frame_enqueue_phase1(fslic_engine* e, Slot& s, const fslic_params* p, int H, int W, int K,
-                         const uint8_t* d_rgb, fslic_cluster* clusters, uint16_t* d_out, bool generic) {
-    int S = 0;
-    int rc = validate(p, H, W, K, S);
-    if (rc) return rc;
-    if (!clusters || !d_rgb || !d_out) return fail(FSLIC_E_INVALID, "NULL pointer argument");
-    if (s.keyH != H || s.keyW != W || s.keyK != K) {
-        HIPCHK(hipStreamSynchronize(s.st));
-        rc = prepare(e, s, H, W, K, S);
-        if (rc) return rc;
-    }
-    s.H = H; s.W = W; s.K = K; s.S = S; s.p = *p; s.clusters = clusters; s.d_out = d_out;
-    FrameDev& f = s.f;
-    f.rgb = d_rgb;
 
-    rc = configure_spatial(s, S, p);
-    if (rc) return rc;
-    s.generic = generic || p->force_generic || !s.sp_tiled_ok;
-    if (s.generic && !s.sp_patch_uploaded) {
+// Everything of iterate() for frames [i0, i0+n) of the slot's current group, enqueued asynchronously on the
+// slot's stream: cluster upload, LAB, the assign/update loop, full assign, connectivity, result download.
+int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool timed) {
+    const fslic_params* p = &s.p;
+    const int H = s.H, W = s.W, K = s.K, S = s.S;
+    FrameDev f = s.f;
+    f.rgbs = nullptr;
+    f.select(i0);                                  // host-side: pointers of frame i0
+    f.rgbs = reinterpret_cast<const uint8_t* const*>(s.d_ptrs + i0);
+    const size_t fb = s.frame_bytes;
+
+    if (generic && !s.sp_patch_uploaded) {
         HIPCHK(hipMemcpyAsync(s.d_patch, s.h_patch, (size_t)(2 * S + 1) * (2 * S + 1) * sizeof(uint16_t), hipMemcpyHostToDevice, s.st));
         s.sp_patch_uploaded = true;
     }
     // cluster centres: integer part of the clamped position (src/context.cpp:129-131,208-211,262)
-    for (int k = 0; k < K; k++) {
-        const int y = clampi((int)clusters[k].y, 0, H - 1), x = clampi((int)clusters[k].x, 0, W - 1);
-        s.h_cl[k] = ((uint32_t)y << 16) | (uint32_t)x;
+    for (int z = 0; z < n; z++) {
+        const fslic_cluster* cl = s.clusters[i0 + z];
+        uint32_t* h = s.h_cl + (size_t)(i0 + z) * 4 * K;
+        for (int k = 0; k < K; k++) {
+            const int y = clampi((int)cl[k].y, 0, H - 1), x = clampi((int)cl[k].x, 0, W - 1);
+            h[k] = ((uint32_t)y << 16) | (uint32_t)x;
+        }
     }
-    HIPCHK(hipMemcpyAsync(f.cl_yx, s.h_cl, sizeof(uint32_t) * (size_t)K, hipMemcpyHostToDevice, s.st));
-    HIPCHK(hipMemsetAsync(s.zero_block, 0, s.zero_bytes, s.st));
-    HIPCHK(hipMemsetAsync(f.cl_n, 0, sizeof(uint32_t) * 2 * (size_t)K, s.st));   // cl_n, cl_moved
+    HIPCHK(hipMemcpy2DAsync(f.cl_yx, fb, s.h_cl + (size_t)i0 * 4 * K, sizeof(uint32_t) * 4 * (size_t)K,
+                            sizeof(uint32_t) * (size_t)K, (size_t)n, hipMemcpyHostToDevice, s.st));
+    HIPCHK(hipMemset2DAsync(s.at(s.zero_block, i0), fb, 0, s.zero_bytes, (size_t)n, s.st));
+    HIPCHK(hipMemset2DAsync(f.cl_n, fb, 0, sizeof(uint32_t) * 2 * (size_t)K, (size_t)n, s.st));   // cl_n, cl_moved
 
-    HIPCHK(hipEventRecord(s.ev[0], s.st));
-    launch_rgb_to_lab(d_rgb, f.lab, f.N, p->convert_to_lab, e->tables, f.labels, s.st);   // + labels <- 0xFFFF
-    HIPCHK(hipEventRecord(s.ev[1], s.st));
+    if (timed) HIPCHK(hipEventRecord(s.ev[0], s.st));
+    launch_rgb_to_lab(f, n, p->convert_to_lab, e->tables, true, s.st);   // + labels <- 0xFFFF (src/context.cpp:138-145)
+    if (timed) HIPCHK(hipEventRecord(s.ev[1], s.st));
     f.gen = ++s.gen_counter;
-    launch_bin_clusters(f, 0, 0, 0, s.st);
+    launch_bin_clusters(f, n, 0, 0, 0, s.st);
     const int stride = p->subsample_stride;
     int rem = 0;
     f.dbg = nullptr;
+    const int dbg_mode = getenv("FSLIC_DEBUG_TIMING") ? atoi(getenv("FSLIC_DEBUG_TIMING")) : 0;
     for (int it = 0; it < p->max_iter; it++) {                  // src/context.cpp:158-175
-        if (it == p->max_iter - 1 && getenv("FSLIC_DEBUG_TIMING") && atoi(getenv("FSLIC_DEBUG_TIMING")) == 2) {
+        if (it == p->max_iter - 1 && dbg_mode == 2) {
             if (!s.d_dbg) HIPCHK(hipMalloc((void**)&s.d_dbg, sizeof(unsigned long long) * 8 * 65536));
             HIPCHK(hipMemsetAsync(s.d_dbg, 0, sizeof(unsigned long long) * 8 * 65536, s.st));
             f.dbg = s.d_dbg;
         }
-        if (s.generic) launch_assign_generic(f, rem, stride, it & 1, it & 1, true, s.st);
-        else launch_assign(f, rem, stride, it & 1, it & 1, true, s.st);
-        if (f.dbg && atoi(getenv("FSLIC_DEBUG_TIMING")) == 2) {
+        if (generic) launch_assign_generic(f, n, rem, stride, it & 1, it & 1, true, s.st);
+        else launch_assign(f, n, rem, stride, it & 1, it & 1, true, s.st);
+        if (f.dbg && dbg_mode == 2) {
             int rc2 = print_phase_stamps(s, "last fused assign");
             if (rc2) return rc2;
             f.dbg = nullptr;
         }
         f.gen = ++s.gen_counter;
-        launch_bin_clusters(f, 1, (it + 1) & 1, it & 1, s.st);
+        launch_bin_clusters(f, n, 1, (it + 1) & 1, it & 1, s.st);
         rem = (rem + 1) % stride;
     }
-    if (getenv("FSLIC_DEBUG_TIMING") && atoi(getenv("FSLIC_DEBUG_TIMING")) == 1) {
+    if (dbg_mode == 1) {
         if (!s.d_dbg) HIPCHK(hipMalloc((void**)&s.d_dbg, sizeof(unsigned long long) * 8 * 65536));
         HIPCHK(hipMemsetAsync(s.d_dbg, 0, sizeof(unsigned long long) * 8 * 65536, s.st));
         f.dbg = s.d_dbg;
     }
-    HIPCHK(hipEventRecord(s.ev[2], s.st));
+    if (timed) HIPCHK(hipEventRecord(s.ev[2], s.st));
     // full_assign: stride 1, rem 0, no update afterwards (src/context.cpp:246-256)
-    if (s.generic) launch_assign_generic(f, 0, 1, p->max_iter & 1, 0, false, s.st);
-    else launch_assign(f, 0, 1, p->max_iter & 1, 0, false, s.st);
-    HIPCHK(hipEventRecord(s.ev[3], s.st));
+    if (generic) launch_assign_generic(f, n, 0, 1, p->max_iter & 1, 0, false, s.st);
+    else launch_assign(f, n, 0, 1, p->max_iter & 1, 0, false, s.st);
+    if (timed) HIPCHK(hipEventRecord(s.ev[3], s.st));
     if (f.dbg) {
         int rc2 = print_phase_stamps(s, "full_assign");
         if (rc2) return rc2;
         f.dbg = nullptr;
     }
-    // cluster state + overflow flag back to the host
-    HIPCHK(hipMemcpyAsync(s.h_cl, f.cl_yx, sizeof(uint32_t) * 4 * (size_t)K, hipMemcpyDeviceToHost, s.st));
-    HIPCHK(hipMemcpyAsync(s.h_misc + 2, s.d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s.st));
     // enforce_connectivity, src/context.cpp:14-20
     const int thres = (int)round((double)(S * S) * (double)p->min_size_factor);
-    rc = cca_enqueue(s, f.labels, d_out, K, thres);
+    const CcaDev c = cca_view(s, i0, s.f.labels, fb, K, thres);
+    cca_enqueue(s, c, n);
+    if (timed) HIPCHK(hipEventRecord(s.ev[4], s.st));
+    // cluster state, overflow flag and connectivity status back to the host
+    HIPCHK(hipMemcpy2DAsync(s.h_cl + (size_t)i0 * 4 * K, sizeof(uint32_t) * 4 * (size_t)K, f.cl_yx, fb,
+                            sizeof(uint32_t) * 4 * (size_t)K, (size_t)n, hipMemcpyDeviceToHost, s.st));
+    HIPCHK(hipMemcpy2DAsync(s.h_misc + 16 * (size_t)i0, 64, s.at(s.d_misc, i0), fb, 64, (size_t)n, hipMemcpyDeviceToHost, s.st));
+    return FSLIC_OK;
+}
+
+// Start a group of n frames (identical geometry) on the slot.  d_rgb / d_out are device pointers.
+int group_begin(fslic_engine* e, Slot& s, const fslic_params* p, int H, int W, int K, int n,
+                const uint8_t* const* d_rgb, fslic_cluster* const* clusters, uint16_t* const* d_out) {
+    int S = 0;
+    int rc = validate(p, H, W, K, S);
     if (rc) return rc;
-    HIPCHK(hipEventRecord(s.ev[4], s.st));
+    if (n < 1 || n > kMaxGroup) return fail(FSLIC_E_INTERNAL, "bad group size");
+    for (int i = 0; i < n; i++)
+        if (!clusters[i] || !d_rgb[i] || !d_out[i]) return fail(FSLIC_E_INVALID, "NULL pointer argument");
+    rc = ensure_prepared(e, s, H, W, K, S, n);
+    if (rc) return rc;
+    s.H = H; s.W = W; s.K = K; s.S = S; s.p = *p; s.nframes = n;
+    for (int i = 0; i < n; i++) { s.clusters[i] = clusters[i]; s.d_rgb[i] = d_rgb[i]; s.d_out[i] = d_out[i]; }
+    rc = configure_spatial(s, S, p);
+    if (rc) return rc;
+    rc = upload_ptrs(s, n, d_rgb, d_out);
+    if (rc) return rc;
+    s.generic = p->force_generic || !s.sp_tiled_ok;
+    rc = enqueue_frames(e, s, 0, n, s.generic, true);
+    if (rc) return rc;
     s.have_pre = true;
-    s.host_topk = false;
     s.last_path = s.generic ? 1 : 0;
     return FSLIC_OK;
 }
 
-int frame_phase2(Slot&) { return FSLIC_OK; }   // kept for the batch driver's structure: everything is enqueued in phase 1
-
-// returns 1 when the tiled kernel overflowed an LDS candidate list and the frame must be redone
-int frame_finish(Slot& s, bool& redo) {
+// Wait for the group, serve the rare host-side steps frame by frame (candidate-list overflow -> generic redo,
+// area tie at the top-K cut -> std::partial_sort on the host), then write the cluster state back.
+int group_finish(fslic_engine* e, Slot& s) {
     HIPCHK(hipStreamSynchronize(s.st));
-    redo = (!s.generic && s.h_misc[2] != 0);
-    if (redo) return FSLIC_OK;
-    {
-        int rc = cca_finish(s);
-        if (rc) return rc;
-    }
+    const int n = s.nframes, K = s.K, H = s.H, W = s.W;
     hipEventElapsedTime(&s.total_ms, s.ev[0], s.ev[4]);
     hipEventElapsedTime(&s.lab_ms, s.ev[0], s.ev[1]);
     hipEventElapsedTime(&s.loop_ms, s.ev[1], s.ev[2]);
     hipEventElapsedTime(&s.fa_ms, s.ev[2], s.ev[3]);
     hipEventElapsedTime(&s.cca_ms, s.ev[3], s.ev[4]);
-    // write the cluster state back the way the reference leaves it
-    const int K = s.K, H = s.H, W = s.W;
-    const uint32_t* yx = s.h_cl;
-    const uint32_t* lab = s.h_cl + K;
-    const uint32_t* n = s.h_cl + 2 * (size_t)K;
-    const uint32_t* moved = s.h_cl + 3 * (size_t)K;
-    fslic_cluster* cl = s.clusters;
-    for (int k = 0; k < K; k++) {
-        cl[k].r = (float)(lab[k] & 255u);                 // src/context.cpp:132-134 / :370-372
-        cl[k].g = (float)((lab[k] >> 8) & 255u);
-        cl[k].b = (float)((lab[k] >> 16) & 255u);
-        if (moved[k]) {                                    // src/context.cpp:368-369
-            cl[k].y = (float)(yx[k] >> 16);
-            cl[k].x = (float)(yx[k] & 0xFFFFu);
-        } else {                                           // assign() safeguard, src/context.cpp:208-211
-            cl[k].x = clampf(cl[k].x, 0.0f, (float)(W - 1));
-            cl[k].y = clampf(cl[k].y, 0.0f, (float)(H - 1));
+    const int thres = (int)round((double)(s.S * s.S) * (double)s.p.min_size_factor);
+    for (int i = 0; i < n; i++) {
+        if (!s.generic && s.h_misc[16 * (size_t)i + 2] != 0) {     // the tiled kernel overflowed an LDS candidate list
+            int rc = enqueue_frames(e, s, i, 1, true, false);
+            if (rc) return rc;
+            HIPCHK(hipStreamSynchronize(s.st));
+            if (s.h_misc[16 * (size_t)i + 2] != 0) return fail(FSLIC_E_INTERNAL, "generic path reported a candidate overflow");
+            s.last_path = 1;
         }
-        if (s.p.max_iter > 0) cl[k].num_members = n[k];   // src/context.cpp:362
-        cl[k].is_updatable = 2;                            // src/preemptive.h:59-67
-        cl[k].is_active = 1;                               // src/preemptive.h:69-74
+        const CcaDev c1 = cca_view(s, i, s.f.labels, s.frame_bytes, K, thres);
+        int rc = cca_finish_frame(s, c1, i);
+        if (rc) return rc;
+    }
+    // write the cluster state back the way the reference leaves it
+    for (int i = 0; i < n; i++) {
+        const uint32_t* yx = s.h_cl + (size_t)i * 4 * K;
+        const uint32_t* lab = yx + K;
+        const uint32_t* nm = yx + 2 * (size_t)K;
+        const uint32_t* moved = yx + 3 * (size_t)K;
+        fslic_cluster* cl = s.clusters[i];
+        for (int k = 0; k < K; k++) {
+            cl[k].r = (float)(lab[k] & 255u);                 // src/context.cpp:132-134 / :370-372
+            cl[k].g = (float)((lab[k] >> 8) & 255u);
+            cl[k].b = (float)((lab[k] >> 16) & 255u);
+            if (moved[k]) {                                    // src/context.cpp:368-369
+                cl[k].y = (float)(yx[k] >> 16);
+                cl[k].x = (float)(yx[k] & 0xFFFFu);
+            } else {                                           // assign() safeguard, src/context.cpp:208-211
+                cl[k].x = clampf(cl[k].x, 0.0f, (float)(W - 1));
+                cl[k].y = clampf(cl[k].y, 0.0f, (float)(H - 1));
+            }
+            if (s.p.max_iter > 0) cl[k].num_members = nm[k];  // src/context.cpp:362
+            cl[k].is_updatable = 2;                            // src/preemptive.h:59-67
+            cl[k].is_active = 1;                               // src/preemptive.h:69-74
+        }
     }
     return FSLIC_OK;
-}
-
-int run_frame(fslic_engine* e, Slot& s, const fslic_params* p, int H, int W, int K, const uint8_t* d_rgb,
-              fslic_cluster* clusters, uint16_t* d_out) {
-    bool generic = false;
-    for (int attempt = 0; attempt < 2; attempt++) {
-        int rc = frame_enqueue_phase1(e, s, p, H, W, K, d_rgb, clusters, d_out, generic);
-        if (rc) return rc;
-        rc = frame_phase2(s);
-        if (rc) return rc;
-        bool redo = false;
-        rc = frame_finish(s, redo);
-        if (rc) return rc;
-        if (!redo) return FSLIC_OK;
-        generic = true;
-    }
-    return fail(FSLIC_E_INTERNAL, "generic path reported a candidate overflow");
 }
 
 void make_timing_report(fslic_engine* e, const Slot& s) {
@@ -680,11 +753,14 @@ int fslic_hip_create(int device, int n_slots, fslic_engine** out) {
     std::call_once(g_tables_once, build_host_tables);
     fslic_engine* e = new fslic_engine();
     e->device = device;
+    if (const char* g = getenv("FSLIC_GROUP")) e->group_size = std::min(std::max(atoi(g), 1), (int)kMaxGroup);
     e->slots.resize(n_slots);
     for (auto& s : e->slots) {
         if (hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) { fslic_hip_destroy(e); return fail(FSLIC_E_HIP, "hipStreamCreate failed"); }
         for (auto& ev : s.ev)
             if (hipEventCreate(&ev) != hipSuccess) { fslic_hip_destroy(e); return fail(FSLIC_E_HIP, "hipEventCreate failed"); }
+        if (hipMalloc((void**)&s.d_ptrs, sizeof(void*) * 2 * kMaxGroup) != hipSuccess ||
+            hipHostMalloc((void**)&s.h_ptrs, sizeof(void*) * 2 * kMaxGroup) != hipSuccess) { fslic_hip_destroy(e); return fail(FSLIC_E_HIP, "pointer table allocation failed"); }
     }
     if (hipMalloc((void**)&e->d_gamma, sizeof g_tables.gamma) != hipSuccess ||
         hipMalloc((void**)&e->d_labtbl, sizeof g_tables.lab) != hipSuccess) { fslic_hip_destroy(e); return fail(FSLIC_E_HIP, "hipMalloc(tables) failed"); }
@@ -757,7 +833,9 @@ int fslic_hip_iterate_device(fslic_engine* e, int slot, const fslic_params* p, i
     if (slot < 0 || slot >= (int)e->slots.size()) return fail(FSLIC_E_INVALID, "slot out of range");
     HIPCHK(hipSetDevice(e->device));
     Slot& s = e->slots[slot];
-    int rc = run_frame(e, s, p, H, W, K, d_rgb, clusters, d_labels);
+    int rc = group_begin(e, s, p, H, W, K, 1, &d_rgb, &clusters, &d_labels);
+    if (rc) return rc;
+    rc = group_finish(e, s);
     if (rc == FSLIC_OK && slot == 0) make_timing_report(e, s);
     return rc;
 }
@@ -766,24 +844,12 @@ int fslic_hip_iterate(fslic_engine* e, const fslic_params* p, int H, int W, int 
                       fslic_cluster* clusters, uint16_t* labels) {
     if (!e) return fail(FSLIC_E_INVALID, "engine is NULL");
     if (!rgb || !labels || !clusters) return fail(FSLIC_E_INVALID, "NULL pointer argument");
-    HIPCHK(hipSetDevice(e->device));
-    Slot& s = e->slots[0];
-    int S = 0;
-    int rc = validate(p, H, W, K, S);
-    if (rc) return rc;
-    if (s.keyH != H || s.keyW != W || s.keyK != K) {
-        HIPCHK(hipStreamSynchronize(s.st));
-        rc = prepare(e, s, H, W, K, S);
-        if (rc) return rc;
-    }
-    const size_t N = (size_t)H * W;
-    HIPCHK(hipMemcpyAsync(s.d_rgb_stage, rgb, N * 3, hipMemcpyHostToDevice, s.st));
-    rc = run_frame(e, s, p, H, W, K, s.d_rgb_stage, clusters, s.d_out_stage);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(labels, s.d_out_stage, N * 2, hipMemcpyDeviceToHost, s.st));
-    HIPCHK(hipStreamSynchronize(s.st));
-    make_timing_report(e, s);
-    return FSLIC_OK;
+    const uint8_t* rgbs[1] = {rgb};
+    fslic_cluster* cls[1] = {clusters};
+    uint16_t* labs[1] = {labels};
+    int rc = fslic_hip_iterate_batch(e, p, H, W, K, 1, rgbs, cls, labs, 0);
+    if (rc == FSLIC_OK) make_timing_report(e, e->slots[0]);
+    return rc;
 }
 
 int fslic_hip_iterate_batch(fslic_engine* e, const fslic_params* p, int H, int W, int K, int n_frames,
@@ -797,49 +863,60 @@ int fslic_hip_iterate_batch(fslic_engine* e, const fslic_params* p, int H, int W
     int S = 0;
     int rc = validate(p, H, W, K, S);
     if (rc) return rc;
-    for (int base = 0; base < n_frames; base += ns) {
-        const int cnt = std::min(ns, n_frames - base);
-        // enqueue the device half of every frame of the group, then serve the host top-K step of each
-        // while the other slots' kernels keep the GPU busy
-        for (int i = 0; i < cnt; i++) {
-            Slot& s = e->slots[i];
-            const uint8_t* d_rgb = rgb[base + i];
-            uint16_t* d_out = labels[base + i];
-            if (!device_ptrs) {
-                if (s.keyH != H || s.keyW != W || s.keyK != K) {
-                    HIPCHK(hipStreamSynchronize(s.st));
-                    rc = prepare(e, s, H, W, K, S);
-                    if (rc) return rc;
-                }
-                HIPCHK(hipMemcpyAsync(s.d_rgb_stage, rgb[base + i], N * 3, hipMemcpyHostToDevice, s.st));
-                d_rgb = s.d_rgb_stage;
-                d_out = s.d_out_stage;
-            }
-            rc = frame_enqueue_phase1(e, s, p, H, W, K, d_rgb, clusters[base + i], d_out, false);
-            if (rc) return rc;
+    for (int i = 0; i < n_frames; i++)
+        if (!rgb[i] || !clusters[i] || !labels[i]) return fail(FSLIC_E_INVALID, "NULL pointer argument");
+    // Frames are cut into groups of up to group_size; every launch of a group covers all of its frames (frame =
+    // last grid dimension).  Groups rotate over the slots (one stream each), so the host-side tail of one group
+    // (cluster write-back, rare host top-K) overlaps the kernels of the next.
+    int G = std::min(std::max(e->group_size, 1), (int)kMaxGroup);
+    if (n_frames < G * ns) G = std::max(1, (n_frames + ns - 1) / ns);       // spread a small batch over the slots
+    struct Pending { int slot, first, n; };
+    std::vector<Pending> inflight;
+    auto finish_one = [&](const Pending& pd) -> int {
+        Slot& s = e->slots[pd.slot];
+        int r = group_finish(e, s);
+        if (r) return r;
+        if (!device_ptrs) {
+            for (int i = 0; i < pd.n; i++)
+                HIPCHK(hipMemcpyAsync(labels[pd.first + i], s.at(s.d_out_stage, i), N * 2, hipMemcpyDeviceToHost, s.st));
+            HIPCHK(hipStreamSynchronize(s.st));
         }
-        for (int i = 0; i < cnt; i++) {
-            rc = frame_phase2(e->slots[i]);
-            if (rc) return rc;
-        }
-        for (int i = 0; i < cnt; i++) {
-            Slot& s = e->slots[i];
-            bool redo = false;
-            rc = frame_finish(s, redo);
-            if (rc) return rc;
-            if (redo) {
-                rc = frame_enqueue_phase1(e, s, p, H, W, K, s.f.rgb, clusters[base + i], s.d_out, true);
+        return FSLIC_OK;
+    };
+    int next_slot = 0;
+    for (int first = 0; first < n_frames; first += G) {
+        const int n = std::min(G, n_frames - first);
+        const int si = next_slot;
+        next_slot = (next_slot + 1) % ns;
+        // the slot may still own an unfinished group
+        for (size_t q = 0; q < inflight.size(); q++)
+            if (inflight[q].slot == si) {
+                rc = finish_one(inflight[q]);
                 if (rc) return rc;
-                rc = frame_phase2(s);
-                if (rc) return rc;
-                rc = frame_finish(s, redo);
-                if (rc) return rc;
+                inflight.erase(inflight.begin() + q);
+                break;
             }
-            if (!device_ptrs) {
-                HIPCHK(hipMemcpyAsync(labels[base + i], s.d_out_stage, N * 2, hipMemcpyDeviceToHost, s.st));
-                HIPCHK(hipStreamSynchronize(s.st));
+        Slot& s = e->slots[si];
+        const uint8_t* d_rgb[kMaxGroup];
+        uint16_t* d_out[kMaxGroup];
+        if (!device_ptrs) {
+            rc = ensure_prepared(e, s, H, W, K, S, n);
+            if (rc) return rc;
+            for (int i = 0; i < n; i++) {
+                HIPCHK(hipMemcpyAsync(s.at(s.d_rgb_stage, i), rgb[first + i], N * 3, hipMemcpyHostToDevice, s.st));
+                d_rgb[i] = s.at(s.d_rgb_stage, i);
+                d_out[i] = s.at(s.d_out_stage, i);
             }
+        } else {
+            for (int i = 0; i < n; i++) { d_rgb[i] = rgb[first + i]; d_out[i] = labels[first + i]; }
         }
+        rc = group_begin(e, s, p, H, W, K, n, d_rgb, clusters + first, d_out);
+        if (rc) return rc;
+        inflight.push_back({si, first, n});
+    }
+    for (const Pending& pd : inflight) {
+        rc = finish_one(pd);
+        if (rc) return rc;
     }
     return FSLIC_OK;
 }
@@ -855,7 +932,13 @@ int fslic_hip_rgb_to_lab(fslic_engine* e, int H, int W, const uint8_t* rgb, int 
     if (hipMalloc((void**)&d_lab, N * 4) != hipSuccess) { hipFree(d_rgb); return fail(FSLIC_E_HIP, "hipMalloc failed"); }
     hipStream_t st = e->slots[0].st;
     hipMemcpyAsync(d_rgb, rgb, N * 3, hipMemcpyHostToDevice, st);
-    launch_rgb_to_lab(d_rgb, d_lab, (int)N, convert, e->tables, nullptr, st);
+    FrameDev f{};
+    f.N = (int)N; f.H = H; f.W = W;
+    f.lab = d_lab;
+    const uint8_t* in1[1] = {d_rgb};
+    if (upload_ptrs(e->slots[0], 1, in1, nullptr) != FSLIC_OK) { hipFree(d_rgb); hipFree(d_lab); return FSLIC_E_HIP; }
+    f.rgbs = reinterpret_cast<const uint8_t* const*>(e->slots[0].d_ptrs);
+    launch_rgb_to_lab(f, 1, convert, e->tables, false, st);
     hipMemcpyAsync(lab4, d_lab, N * 4, hipMemcpyDeviceToHost, st);
     hipError_t err = hipStreamSynchronize(st);
     hipFree(d_rgb);
@@ -875,16 +958,21 @@ int fslic_hip_enforce_connectivity(fslic_engine* e, uint16_t* labels, int H, int
     int S = (int)sqrt((double)H * W / Kb);
     if (S < 1) S = 1;
     HIPCHK(hipStreamSynchronize(s.st));
-    int rc = prepare(e, s, H, W, Kb, S);
+    int rc = prepare(e, s, H, W, Kb, S, 1);
     if (rc) return rc;
     s.keyH = s.keyW = s.keyK = 0;   // the carve above is not a frame configuration
+    s.have_pre = false;
     const size_t N = (size_t)H * W;
     HIPCHK(hipMemsetAsync(s.zero_block, 0, s.zero_bytes, s.st));
     HIPCHK(hipMemcpyAsync(s.d_out_stage, labels, N * 2, hipMemcpyHostToDevice, s.st));
-    rc = cca_enqueue(s, s.d_out_stage, s.d_out_stage, K, min_threshold);
+    uint16_t* outs[1] = {s.d_out_stage};
+    rc = upload_ptrs(s, 1, nullptr, outs);
     if (rc) return rc;
+    const CcaDev c = cca_view(s, 0, s.d_out_stage, 0, K, min_threshold);
+    cca_enqueue(s, c, 1);
+    HIPCHK(hipMemcpyAsync(s.h_misc, s.d_misc, 64, hipMemcpyDeviceToHost, s.st));
     HIPCHK(hipStreamSynchronize(s.st));
-    rc = cca_finish(s);
+    rc = cca_finish_frame(s, c, 0);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(labels, s.d_out_stage, N * 2, hipMemcpyDeviceToHost, s.st));
     HIPCHK(hipStreamSynchronize(s.st));
@@ -908,6 +996,11 @@ int fslic_hip_last_device_times(fslic_engine* e, int slot, float* total_ms, floa
     if (total_ms) *total_ms = e->slots[slot].total_ms;
     if (full_assign_ms) *full_assign_ms = e->slots[slot].fa_ms;
     return FSLIC_OK;
+}
+
+int fslic_hip_last_group_frames(fslic_engine* e, int slot) {
+    if (!e || slot < 0 || slot >= (int)e->slots.size()) return -1;
+    return e->slots[slot].nframes;
 }
 
 int fslic_hip_last_path(fslic_engine* e, int slot) {

@@ -17,6 +17,7 @@ constexpr uint32_t kHuge = 0x40000000u;   // out-of-window marker added to the d
 constexpr int kCcaTile = 64;        // connectivity tile width  (one wavefront of columns)
 constexpr int kCcaTileH = 32;       // connectivity tile height (4 wavefronts x 8 rows), one block of 256 threads
 constexpr int kCcaTilePx = kCcaTile * kCcaTileH;
+constexpr int kMaxGroup = 16;       // frames of one group share every launch (frame index = last grid dimension)
 
 // One cluster as the kernels see it (16 B, one ds_read_b128 / global_load_dwordx4).
 //   yx  = y << 16 | x          (integer centre, src/context.cpp:262 casts to int16)
@@ -26,8 +27,13 @@ struct ClusterRec {
     uint32_t yx, lab, tag, pad;
 };
 
-// Per-frame device state that every kernel of the frame shares.
+// Device state of a GROUP of frames with identical geometry (H, W, K, S).  Every per-frame buffer lives in
+// a per-frame sub-arena of identical layout; the pointers below are those of the group's first frame and
+// select(z) advances them to frame z (z = the launch's last grid dimension).  Input frames and output label
+// maps are the caller's buffers and come as per-frame pointers.
 struct FrameDev {
+    size_t frame_bytes;  // distance between the sub-arenas of consecutive frames
+    const uint8_t* const* rgbs;       // DEVICE array: the group's input frames (N*3 bytes each), caller's buffers
     // geometry
     int H, W, N, K, S;
     int T;               // 2S + 32, phase cell side (src/context.cpp:213)
@@ -36,7 +42,7 @@ struct FrameDev {
     uint32_t gen;        // generation stamp of the bin pass that filled cell_items[buf] (ClusterRec::pad)
     uint32_t M, C;       // spatial fixed point: patch[d] == (d * M + C) >> 16 for d in [0, 2S]
     // image planes
-    const uint8_t* rgb;  // N*3
+    const uint8_t* rgb;  // N*3 (set by select)
     uint32_t* lab;       // N, L|a<<8|b<<16
     uint16_t* labels;    // N, pre-connectivity assignment (persists across iterations)
     // cluster state (SoA)
@@ -61,13 +67,34 @@ struct FrameDev {
     int tab_words, tab_nrpad, tab_dyoff;
     // generic-path tables
     const uint16_t* patch2d;   // (2S+1)^2, src/context.cpp:22-40
+
+    template <class T> static __host__ __device__ __forceinline__ void adv(T*& p, size_t d) {
+        p = reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + d);
+    }
+    // advance every per-frame pointer to frame z of the group (tables lut / tab / patch2d are shared)
+    __host__ __device__ __forceinline__ void select(int z) {
+        // NB: no run-time index into a member array here; that would force this by-value kernel argument into
+        // scratch memory.  The caller's per-frame pointers therefore live in a small device array.
+        rgb = rgbs ? rgbs[z] : nullptr;
+        const size_t d = (size_t)z * frame_bytes;
+        adv(lab, d); adv(labels, d);
+        adv(cl_yx, d); adv(cl_lab, d); adv(cl_tag, d); adv(cl_n, d); adv(cl_moved, d);
+        adv(sums[0], d); adv(sums[1], d);
+        adv(cell_cnt[0], d); adv(cell_cnt[1], d); adv(cell_items[0], d); adv(cell_items[1], d);
+        adv(ovf_cnt[0], d); adv(ovf_cnt[1], d); adv(ovf_items[0], d); adv(ovf_items[1], d);
+        adv(err_flag, d);
+        if (z != 0) dbg = nullptr;   // phase stamps (bring-up aid) cover the group's first frame only
+    }
 };
 
 struct CcaDev {
+    size_t frame_bytes;
+    uint16_t* const* outs;       // DEVICE array: per-frame output label maps (caller's buffers; may alias `in`)
+    size_t in_stride;            // bytes between the input label maps of consecutive frames
     int H, W, N, K;
     int min_threshold;
     const uint16_t* in;   // N labels
-    uint16_t* out;        // N labels (may alias in)
+    uint16_t* out;        // N labels (set by select)
     int32_t* parent;      // N
     uint32_t* area;       // N (sparse: valid at tile-local roots)
     uint16_t* final_lab;  // N (sparse: valid at global roots)
@@ -77,6 +104,15 @@ struct CcaDev {
     uint32_t* counters;   // [1] dense candidate count (host path), [2] M, [3] select status (0 done, 1 host)
     int32_t* cand_leader; // ntiles * kCcaTilePx, per-tile slices
     uint32_t* cand_area;  // ntiles * kCcaTilePx
+
+    __host__ __device__ __forceinline__ void select(int z) {
+        out = outs[z];
+        FrameDev::adv(in, (size_t)z * in_stride);
+        const size_t d = (size_t)z * frame_bytes;
+        FrameDev::adv(parent, d); FrameDev::adv(area, d); FrameDev::adv(final_lab, d); FrameDev::adv(roots, d);
+        FrameDev::adv(tile_cnt, d); FrameDev::adv(tile_ccnt, d); FrameDev::adv(counters, d);
+        FrameDev::adv(cand_leader, d); FrameDev::adv(cand_area, d);
+    }
 };
 
 struct LabTables {
@@ -87,20 +123,20 @@ struct LabTables {
 
 // ---- launches (all asynchronous on `st`) ----------------------------------------------------
 // labels_init != nullptr: also fill the N-entry label plane with 0xFFFF (src/context.cpp:138-145)
-void launch_rgb_to_lab(const uint8_t* rgb, uint32_t* lab, int N, int convert, const LabTables& t, uint16_t* labels_init, hipStream_t st);
-void launch_fill_u16(uint16_t* p, int n, uint16_t v, hipStream_t st);
+void launch_rgb_to_lab(const FrameDev& f, int nframes, int convert, const LabTables& t, bool init_labels, hipStream_t st);
 // mode 0: resample colours at the current centres (src/context.cpp:128-135) and bin;
 // mode 1: integer centroid update from `sums` (src/context.cpp:356-373), zero sums, and bin.
-void launch_bin_clusters(const FrameDev& f, int mode, int buf, int sbuf, hipStream_t st);
+void launch_bin_clusters(const FrameDev& f, int nframes, int mode, int buf, int sbuf, hipStream_t st);
 // One assign pass over rows == rem (mod stride); fuse_update also accumulates the centroid sums
 // of src/context.cpp:301-354 for the same rows.
-void launch_assign(const FrameDev& f, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st);
-void launch_assign_generic(const FrameDev& f, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st);
+void launch_assign(const FrameDev& f, int nframes, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st);
+void launch_assign_generic(const FrameDev& f, int nframes, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st);
 // connectivity
-void launch_cca_phase1(const CcaDev& c, hipStream_t st);   // local CCL, border merge, compress, collect
-void launch_cca_select(const CcaDev& c, hipStream_t st);   // device top-K + ranking (counters[3] = status)
-void launch_cca_densify(const CcaDev& c, int32_t* d_leader, uint32_t* d_area, hipStream_t st);   // host path
+void launch_cca_phase1(const CcaDev& c, int nframes, hipStream_t st);   // local CCL, border merge, compress, collect
+void launch_cca_select(const CcaDev& c, int nframes, hipStream_t st);   // device top-K + ranking (counters[3] = status)
+void launch_cca_phase2(const CcaDev& c, int nframes, hipStream_t st);   // chain resolution + relabel
+// host top-K path, one frame at a time (the CcaDev passed in is already select()ed to that frame)
+void launch_cca_densify(const CcaDev& c, int32_t* d_leader, uint32_t* d_area, hipStream_t st);
 void launch_cca_set_kept(const CcaDev& c, const int32_t* d_leaders, const uint16_t* d_labels, int n, hipStream_t st);
-void launch_cca_phase2(const CcaDev& c, hipStream_t st);   // chain resolution + relabel
 
 }  // namespace fslic

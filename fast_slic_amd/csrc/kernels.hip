@@ -14,6 +14,19 @@ namespace fslic {
 
 #define LANE() (threadIdx.x & 63)
 
+// Kernels index the double-buffered members with the constants 0 (this pass) and 1 (the other parity): a
+// run-time index into the by-value FrameDev argument would push the whole struct into scratch memory once
+// select() has modified it.  The launchers rotate the arrays accordingly.
+static FrameDev rotated(const FrameDev& f, int buf, int sbuf) {
+    FrameDev g = f;
+    g.cell_cnt[0] = f.cell_cnt[buf]; g.cell_cnt[1] = f.cell_cnt[buf ^ 1];
+    g.cell_items[0] = f.cell_items[buf]; g.cell_items[1] = f.cell_items[buf ^ 1];
+    g.ovf_cnt[0] = f.ovf_cnt[buf]; g.ovf_cnt[1] = f.ovf_cnt[buf ^ 1];
+    g.ovf_items[0] = f.ovf_items[buf]; g.ovf_items[1] = f.ovf_items[buf ^ 1];
+    g.sums[0] = f.sums[sbuf]; g.sums[1] = f.sums[sbuf ^ 1];
+    return g;
+}
+
 static __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // =============================================================================================
@@ -43,12 +56,16 @@ static __device__ __forceinline__ uint32_t lab_px(uint32_t R, uint32_t G, uint32
 }
 
 template <bool CONVERT>
-__global__ __launch_bounds__(1024) void k_rgb_to_lab(const uint8_t* __restrict__ rgb, uint32_t* __restrict__ lab,
-                                                     int N, const uint16_t* __restrict__ g_gamma,
-                                                     const uint16_t* __restrict__ g_labtbl, LabConst kc, int aligned4,
-                                                     uint16_t* __restrict__ labels_init) {
+__global__ __launch_bounds__(1024) void k_rgb_to_lab(FrameDev f, const uint16_t* __restrict__ g_gamma,
+                                                     const uint16_t* __restrict__ g_labtbl, LabConst kc, int init_labels) {
     __shared__ uint16_t s_gamma[256];
     __shared__ uint16_t s_lab[8194];
+    f.select(blockIdx.y);
+    const uint8_t* __restrict__ rgb = f.rgb;
+    uint32_t* __restrict__ lab = f.lab;
+    uint16_t* __restrict__ labels_init = init_labels ? f.labels : nullptr;
+    const int N = f.N;
+    const int aligned4 = ((reinterpret_cast<uintptr_t>(rgb) & 3) == 0) ? 1 : 0;
     if (CONVERT) {
         for (int i = threadIdx.x; i < 128; i += blockDim.x)
             reinterpret_cast<uint32_t*>(s_gamma)[i] = reinterpret_cast<const uint32_t*>(g_gamma)[i];
@@ -89,31 +106,17 @@ __global__ __launch_bounds__(1024) void k_rgb_to_lab(const uint8_t* __restrict__
     }
 }
 
-void launch_rgb_to_lab(const uint8_t* rgb, uint32_t* lab, int N, int convert, const LabTables& t, uint16_t* labels_init, hipStream_t st) {
+void launch_rgb_to_lab(const FrameDev& f, int nframes, int convert, const LabTables& t, bool init_labels, hipStream_t st) {
     LabConst kc;
     for (int i = 0; i < 9; i++) kc.cb[i] = t.cb[i];
-    const int aligned4 = ((reinterpret_cast<uintptr_t>(rgb) & 3) == 0) ? 1 : 0;
-    int blocks = (N / 4 + 1023) / 1024;
-    if (blocks > 256) blocks = 256;   // one resident block per CU, grid-stride: tables are staged once per block
+    int blocks = (f.N / 4 + 1023) / 1024;
+    const int cap = (512 + nframes - 1) / nframes;   // about two resident blocks per CU over the whole group, grid-stride
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     if (convert)
-        hipLaunchKernelGGL(k_rgb_to_lab<true>, dim3(blocks), dim3(1024), 0, st, rgb, lab, N, t.gamma, t.labtbl, kc, aligned4, labels_init);
+        hipLaunchKernelGGL(k_rgb_to_lab<true>, dim3(blocks, nframes), dim3(1024), 0, st, f, t.gamma, t.labtbl, kc, init_labels ? 1 : 0);
     else
-        hipLaunchKernelGGL(k_rgb_to_lab<false>, dim3(blocks), dim3(1024), 0, st, rgb, lab, N, t.gamma, t.labtbl, kc, aligned4, labels_init);
-}
-
-__global__ void k_fill_u16(uint32_t* p, int nwords, uint32_t v, uint16_t* tailp, int tail) {
-    const int gstride = gridDim.x * blockDim.x;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += gstride) p[i] = v;
-    if (tail && blockIdx.x == 0 && threadIdx.x == 0) *tailp = (uint16_t)v;
-}
-void launch_fill_u16(uint16_t* p, int n, uint16_t v, hipStream_t st) {
-    const int nwords = n >> 1;
-    int blocks = (nwords + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_fill_u16, dim3(blocks), dim3(256), 0, st, reinterpret_cast<uint32_t*>(p), nwords,
-                       (uint32_t)v | ((uint32_t)v << 16), p + (n - 1), n & 1);
+        hipLaunchKernelGGL(k_rgb_to_lab<false>, dim3(blocks, nframes), dim3(1024), 0, st, f, t.gamma, t.labtbl, kc, init_labels ? 1 : 0);
 }
 
 // =============================================================================================
@@ -127,9 +130,10 @@ void launch_fill_u16(uint16_t* p, int n, uint16_t v, hipStream_t st) {
 // =============================================================================================
 template <int MODE>
 __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, int buf, int sbuf) {
+    f.select(blockIdx.y);
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < f.ncell) f.cell_cnt[buf ^ 1][k] = 0;
-    if (k == 0) *f.ovf_cnt[buf ^ 1] = 0;
+    if (k < f.ncell) f.cell_cnt[1][k] = 0;
+    if (k == 0) *f.ovf_cnt[1] = 0;
     if (k >= f.K) return;
     uint32_t yx = f.cl_yx[k];
     int y = (int)(yx >> 16), x = (int)(yx & 0xFFFF);
@@ -147,8 +151,8 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, int buf, int s
         shadowed = k > 0 && f.cl_yx[k - 1] == yx;
     } else {
         lab = f.cl_lab[k];
-        const uint32_t* s = f.sums[sbuf] + 6 * (size_t)k;
-        uint32_t* z = f.sums[sbuf ^ 1] + 6 * (size_t)k;     // the next pass accumulates here
+        const uint32_t* s = f.sums[0] + 6 * (size_t)k;
+        uint32_t* z = f.sums[1] + 6 * (size_t)k;     // the next pass accumulates here
         const int32_t n = (int32_t)s[0];
         f.cl_n[k] = (uint32_t)n;
         if (n != 0) {
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, int buf, int s
             f.cl_yx[k] = yx;
             f.cl_lab[k] = lab;
             f.cl_moved[k] = 1;
-        } else if (k > 0 && f.sums[sbuf][6 * (size_t)(k - 1)] == 0u) {
+        } else if (k > 0 && f.sums[0][6 * (size_t)(k - 1)] == 0u) {
             shadowed = f.cl_yx[k - 1] == yx && f.cl_lab[k - 1] == lab;
         }
         z[0] = 0; z[1] = 0; z[2] = 0; z[3] = 0; z[4] = 0; z[5] = 0;
@@ -175,20 +179,21 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, int buf, int s
     f.cl_tag[k] = rec.tag;
     if (shadowed) return;
     const int cell = (y >> f.cs_shift) * f.ncx + (x >> f.cs_shift);
-    const uint32_t slot = atomicAdd(&f.cell_cnt[buf][cell], 1u);
+    const uint32_t slot = atomicAdd(&f.cell_cnt[0][cell], 1u);
     if (slot < (uint32_t)kCellCap) {
-        f.cell_items[buf][(size_t)cell * kCellCap + slot] = rec;
+        f.cell_items[0][(size_t)cell * kCellCap + slot] = rec;
     } else {
-        const uint32_t o = atomicAdd(f.ovf_cnt[buf], 1u);
-        f.ovf_items[buf][o] = rec;
+        const uint32_t o = atomicAdd(f.ovf_cnt[0], 1u);
+        f.ovf_items[0][o] = rec;
     }
 }
 
-void launch_bin_clusters(const FrameDev& f, int mode, int buf, int sbuf, hipStream_t st) {
+void launch_bin_clusters(const FrameDev& f_, int nframes, int mode, int buf, int sbuf, hipStream_t st) {
+    const FrameDev f = rotated(f_, buf, sbuf);
     const int n = f.K > f.ncell ? f.K : f.ncell;
     const int blocks = (n + 255) / 256;
-    if (mode == 0) hipLaunchKernelGGL(k_bin_clusters<0>, dim3(blocks), dim3(256), 0, st, f, buf, sbuf);
-    else hipLaunchKernelGGL(k_bin_clusters<1>, dim3(blocks), dim3(256), 0, st, f, buf, sbuf);
+    if (mode == 0) hipLaunchKernelGGL(k_bin_clusters<0>, dim3(blocks, nframes), dim3(256), 0, st, f, buf, sbuf);
+    else hipLaunchKernelGGL(k_bin_clusters<1>, dim3(blocks, nframes), dim3(256), 0, st, f, buf, sbuf);
 }
 
 // =============================================================================================
@@ -237,6 +242,7 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
     __shared__ uint4 s_listbuf[kWavesPerBlock][64];
     __shared__ uint32_t s_accbuf[FUSE ? kWavesPerBlock * kAccSlots * 6 * kAccCopies : 1];
 
+    f.select(blockIdx.z);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = (int)rfl((uint32_t)(tid >> 6));
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
     FSLIC_STAMP(0);
     const int yw_lo = rem + vrow_w0 * stride;
     const int nrows = min(R, Hv - vrow_w0);
-    const uint32_t novf = *f.ovf_cnt[buf];   // issued early, consumed after the cell gather
+    const uint32_t novf = *f.ovf_cnt[0];   // issued early, consumed after the cell gather
 
     // 1. pixel loads first; they do not depend on the candidate list
     uint32_t pix[R];
@@ -285,8 +291,8 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
     const int ncxr = cxb - cxa + 1, ncyr = cyb - cya + 1;
     const int total = ncxr * ncyr * kCellCap;
     const uint32_t inv = (uint32_t)(4294967296.0f / (float)ncxr) + 1u;   // exact quotient for the small operands here
-    const ClusterRec* __restrict__ citems = f.cell_items[buf];
-    const ClusterRec* __restrict__ oitems = f.ovf_items[buf];
+    const ClusterRec* __restrict__ citems = f.cell_items[0];
+    const ClusterRec* __restrict__ oitems = f.ovf_items[0];
     const unsigned long long lowmask = (1ull << lane) - 1ull;
     auto cell_slot = [&](int e) -> size_t {
         const uint32_t ce = (uint32_t)e >> 3;
@@ -398,7 +404,7 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
             uint32_t lbl;
             if (bw[r] < kHuge) { lbl = bt[r] & 0xFFFFu; f.labels[p] = (uint16_t)lbl; }
             else lbl = f.labels[p];
-            if (FUSE && lbl != 0xFFFFu) global_accumulate(f.sums[sbuf], lbl, (uint32_t)y, (uint32_t)x, pix[r]);
+            if (FUSE && lbl != 0xFFFFu) global_accumulate(f.sums[0], lbl, (uint32_t)y, (uint32_t)x, pix[r]);
         }
         return;
     }
@@ -466,11 +472,11 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
                 f.labels[p] = (uint16_t)k;
                 if (FUSE) {
                     if (idx < (uint32_t)kAccSlots) slot[r] = idx;
-                    else global_accumulate(f.sums[sbuf], k, (uint32_t)y, (uint32_t)x, pix[r]);
+                    else global_accumulate(f.sums[0], k, (uint32_t)y, (uint32_t)x, pix[r]);
                 }
             } else if (FUSE) {
                 const uint32_t old = f.labels[p];     // stale label still takes part in update()
-                if (old != 0xFFFFu) global_accumulate(f.sums[sbuf], old, (uint32_t)y, (uint32_t)x, pix[r]);
+                if (old != 0xFFFFu) global_accumulate(f.sums[0], old, (uint32_t)y, (uint32_t)x, pix[r]);
             }
         }
     }
@@ -514,7 +520,7 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
             for (int c = 0; c < kAccCopies; ++c) v += s_acc[i * kAccCopies + c];
             if (v) {
                 const int sl = i / 6;
-                atomicAdd(f.sums[sbuf] + 6 * (size_t)s_list[sl].z + (i - sl * 6), v);
+                atomicAdd(f.sums[0] + 6 * (size_t)s_list[sl].z + (i - sl * 6), v);
             }
         }
     }
@@ -557,6 +563,7 @@ __global__ __launch_bounds__(256) void k_assign16(FrameDev f, int rem, int Hv, i
     __shared__ uint32_t s_accbuf[FUSE ? kWavesPerBlock * kAccSlots * 6 * kAccCopies : 1];
     static_assert(R % 2 == 0, "rows are processed in pairs");
 
+    f.select(blockIdx.z);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = (int)rfl((uint32_t)(tid >> 6));
@@ -578,7 +585,7 @@ __global__ __launch_bounds__(256) void k_assign16(FrameDev f, int rem, int Hv, i
             f.dbg[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kWavesPerBlock + wave) * 8 + (slot_)] = __builtin_readcyclecounter(); \
     } while (0)
     FSLIC_STAMP(0);
-    const uint32_t novf = *f.ovf_cnt[buf];
+    const uint32_t novf = *f.ovf_cnt[0];
 
     // 1. pixel loads first; nothing below depends on them until the argmin
     uint32_t pix[R];
@@ -597,8 +604,8 @@ __global__ __launch_bounds__(256) void k_assign16(FrameDev f, int rem, int Hv, i
 
     // 2. gather into 64 LDS slots: returns the number of live records inside `win` (may exceed 64)
     const int sh = f.cs_shift;
-    const ClusterRec* __restrict__ citems = f.cell_items[buf];
-    const ClusterRec* __restrict__ oitems = f.ovf_items[buf];
+    const ClusterRec* __restrict__ citems = f.cell_items[0];
+    const ClusterRec* __restrict__ oitems = f.ovf_items[0];
     const unsigned long long lowmask = (1ull << lane) - 1ull;
     auto gather = [&](const TileWindow& win, uint32_t* dst) -> int {
         const int cxa = max(win.wx_lo, 0) >> sh, cxb = min(win.wx_hi, W - 1) >> sh;
@@ -750,10 +757,10 @@ __global__ __launch_bounds__(256) void k_assign16(FrameDev f, int rem, int Hv, i
                 const uint32_t idx = key & 63u;
                 if (found) {
                     if (idx < (uint32_t)kAccSlots) slot[r] = idx;
-                    else global_accumulate(f.sums[sbuf], kk[r], (uint32_t)(yw_lo + r * STRIDE), xo, pix[r]);
+                    else global_accumulate(f.sums[0], kk[r], (uint32_t)(yw_lo + r * STRIDE), xo, pix[r]);
                 } else {
                     const uint32_t old = rowp[xo];     // stale label still takes part in update()
-                    if (old != 0xFFFFu) global_accumulate(f.sums[sbuf], old, (uint32_t)(yw_lo + r * STRIDE), xo, pix[r]);
+                    if (old != 0xFFFFu) global_accumulate(f.sums[0], old, (uint32_t)(yw_lo + r * STRIDE), xo, pix[r]);
                 }
             }
             rowp += (size_t)STRIDE * W;
@@ -798,7 +805,7 @@ __global__ __launch_bounds__(256) void k_assign16(FrameDev f, int rem, int Hv, i
             for (int c = 0; c < kAccCopies; ++c) v += s_acc[i * kAccCopies + c];
             if (v) {
                 const int sl = i / 6;
-                atomicAdd(f.sums[sbuf] + 6 * (size_t)s_list[sl].z + (i - sl * 6), v);
+                atomicAdd(f.sums[0] + 6 * (size_t)s_list[sl].z + (i - sl * 6), v);
             }
         }
     }
@@ -812,23 +819,23 @@ __global__ __launch_bounds__(256) void k_assign16(FrameDev f, int rem, int Hv, i
 }
 
 template <int R, bool FUSE, int STRIDE>
-static void launch_assign16_t(const FrameDev& f, int rem, int Hv, int buf, int sbuf, hipStream_t st) {
-    dim3 grid((f.W + kTileW - 1) / kTileW, (Hv + kWavesPerBlock * R - 1) / (kWavesPerBlock * R));
+static void launch_assign16_t(const FrameDev& f, int nframes, int rem, int Hv, int buf, int sbuf, hipStream_t st) {
+    dim3 grid((f.W + kTileW - 1) / kTileW, (Hv + kWavesPerBlock * R - 1) / (kWavesPerBlock * R), nframes);
     const size_t lds = (size_t)f.tab_words * sizeof(uint32_t);
     hipLaunchKernelGGL((k_assign16<R, FUSE, STRIDE>), grid, dim3(256), lds, st, f, rem, Hv, buf, sbuf);
 }
 
-static int assign_rows_per_wave(const FrameDev& f, int Hv, bool fuse_update) {
+static int assign_rows_per_wave(const FrameDev& f, int nframes, int Hv, bool fuse_update) {
     const char* e = getenv("FSLIC_ASSIGN_R");
     if (e && (atoi(e) == 8 || atoi(e) == 16)) return atoi(e);
     const int tiles_x = (f.W + kTileW - 1) / kTileW;
-    const int blocks8 = tiles_x * ((Hv + kWavesPerBlock * 8 - 1) / (kWavesPerBlock * 8));
+    const int blocks8 = nframes * tiles_x * ((Hv + kWavesPerBlock * 8 - 1) / (kWavesPerBlock * 8));
     return (!fuse_update && blocks8 > 3072) ? 16 : 8;
 }
 
 template <int R>
-static void launch_assign_r(const FrameDev& f, int rem, int stride, int Hv, int buf, int sbuf, bool fuse_update, hipStream_t st) {
-    dim3 grid((f.W + kTileW - 1) / kTileW, (Hv + kWavesPerBlock * R - 1) / (kWavesPerBlock * R));
+static void launch_assign_r(const FrameDev& f, int nframes, int rem, int stride, int Hv, int buf, int sbuf, bool fuse_update, hipStream_t st) {
+    dim3 grid((f.W + kTileW - 1) / kTileW, (Hv + kWavesPerBlock * R - 1) / (kWavesPerBlock * R), nframes);
     const size_t lds = (size_t)f.lut_words * sizeof(uint32_t);
     if (f.lut_words > 0) {
         if (fuse_update) hipLaunchKernelGGL((k_assign<R, true, true>), grid, dim3(256), lds, st, f, rem, stride, Hv, buf, sbuf);
@@ -839,22 +846,23 @@ static void launch_assign_r(const FrameDev& f, int rem, int stride, int Hv, int 
     }
 }
 
-void launch_assign(const FrameDev& f, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st) {
+void launch_assign(const FrameDev& f_, int nframes, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st) {
+    const FrameDev f = rotated(f_, buf, sbuf);
     const int Hv = (f.H - rem + stride - 1) / stride;
     if (Hv <= 0) return;
     if (f.tab_words > 0 && stride >= 1 && stride <= 3) {       // packed 16-bit kernel
-        const int R = assign_rows_per_wave(f, Hv, fuse_update);
+        const int R = assign_rows_per_wave(f, nframes, Hv, fuse_update);
         if (!fuse_update) {
-            if (stride == 1 && R == 16) { launch_assign16_t<16, false, 1>(f, rem, Hv, buf, sbuf, st); return; }
-            if (stride == 1) { launch_assign16_t<8, false, 1>(f, rem, Hv, buf, sbuf, st); return; }
+            if (stride == 1 && R == 16) { launch_assign16_t<16, false, 1>(f, nframes, rem, Hv, buf, sbuf, st); return; }
+            if (stride == 1) { launch_assign16_t<8, false, 1>(f, nframes, rem, Hv, buf, sbuf, st); return; }
         } else {
-            if (stride == 1) { launch_assign16_t<8, true, 1>(f, rem, Hv, buf, sbuf, st); return; }
-            if (stride == 2) { launch_assign16_t<8, true, 2>(f, rem, Hv, buf, sbuf, st); return; }
-            if (stride == 3) { launch_assign16_t<8, true, 3>(f, rem, Hv, buf, sbuf, st); return; }
+            if (stride == 1) { launch_assign16_t<8, true, 1>(f, nframes, rem, Hv, buf, sbuf, st); return; }
+            if (stride == 2) { launch_assign16_t<8, true, 2>(f, nframes, rem, Hv, buf, sbuf, st); return; }
+            if (stride == 3) { launch_assign16_t<8, true, 3>(f, nframes, rem, Hv, buf, sbuf, st); return; }
         }
     }
-    if (assign_rows_per_wave(f, Hv, fuse_update) == 16) launch_assign_r<16>(f, rem, stride, Hv, buf, sbuf, fuse_update, st);
-    else launch_assign_r<8>(f, rem, stride, Hv, buf, sbuf, fuse_update, st);
+    if (assign_rows_per_wave(f, nframes, Hv, fuse_update) == 16) launch_assign_r<16>(f, nframes, rem, stride, Hv, buf, sbuf, fuse_update, st);
+    else launch_assign_r<8>(f, nframes, rem, stride, Hv, buf, sbuf, fuse_update, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -876,6 +884,7 @@ static __device__ __forceinline__ void generic_test(const ClusterRec& rec, int y
 
 template <bool FUSE>
 __global__ __launch_bounds__(256) void k_assign_generic(FrameDev f, int rem, int stride, int Hv, int buf, int sbuf) {
+    f.select(blockIdx.y);
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)Hv * f.W) return;
     const int v = (int)(i / f.W), x = (int)(i - (size_t)v * f.W);
@@ -889,25 +898,26 @@ __global__ __launch_bounds__(256) void k_assign_generic(FrameDev f, int rem, int
     for (int cyi = cya; cyi <= cyb; ++cyi)
         for (int cxi = cxa; cxi <= cxb; ++cxi) {
             const int cell = cyi * f.ncx + cxi;
-            const uint32_t cnt = min(f.cell_cnt[buf][cell], (uint32_t)kCellCap);
+            const uint32_t cnt = min(f.cell_cnt[0][cell], (uint32_t)kCellCap);
             for (uint32_t s = 0; s < cnt; ++s)
-                generic_test(f.cell_items[buf][(size_t)cell * kCellCap + s], y, x, S, P, pix, f.patch2d, best);
+                generic_test(f.cell_items[0][(size_t)cell * kCellCap + s], y, x, S, P, pix, f.patch2d, best);
         }
-    const uint32_t novf = *f.ovf_cnt[buf];
-    for (uint32_t s = 0; s < novf; ++s) generic_test(f.ovf_items[buf][s], y, x, S, P, pix, f.patch2d, best);
+    const uint32_t novf = *f.ovf_cnt[0];
+    for (uint32_t s = 0; s < novf; ++s) generic_test(f.ovf_items[0][s], y, x, S, P, pix, f.patch2d, best);
     uint32_t lbl;
     if (best != ~0ull) { lbl = (uint32_t)(best & 0xFFFFull); f.labels[p] = (uint16_t)lbl; }
     else lbl = f.labels[p];
-    if (FUSE && lbl != 0xFFFFu) global_accumulate(f.sums[sbuf], lbl, (uint32_t)y, (uint32_t)x, pix);
+    if (FUSE && lbl != 0xFFFFu) global_accumulate(f.sums[0], lbl, (uint32_t)y, (uint32_t)x, pix);
 }
 
-void launch_assign_generic(const FrameDev& f, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st) {
+void launch_assign_generic(const FrameDev& f_, int nframes, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st) {
+    const FrameDev f = rotated(f_, buf, sbuf);
     const int Hv = (f.H - rem + stride - 1) / stride;
     if (Hv <= 0) return;
     const size_t n = (size_t)Hv * f.W;
     const int blocks = (int)((n + 255) / 256);
-    if (fuse_update) hipLaunchKernelGGL(k_assign_generic<true>, dim3(blocks), dim3(256), 0, st, f, rem, stride, Hv, buf, sbuf);
-    else hipLaunchKernelGGL(k_assign_generic<false>, dim3(blocks), dim3(256), 0, st, f, rem, stride, Hv, buf, sbuf);
+    if (fuse_update) hipLaunchKernelGGL(k_assign_generic<true>, dim3(blocks, nframes), dim3(256), 0, st, f, rem, stride, Hv, buf, sbuf);
+    else hipLaunchKernelGGL(k_assign_generic<false>, dim3(blocks, nframes), dim3(256), 0, st, f, rem, stride, Hv, buf, sbuf);
 }
 
 // =============================================================================================
@@ -974,6 +984,7 @@ static __device__ __forceinline__ uint32_t lds_find_ro(uint32_t* par, uint32_t x
 //     to the root's area
 //  D  tile-local roots appended to the root list (one global atomic per wavefront row)
 __global__ __launch_bounds__(256) void k_cca_local(CcaDev c) {
+    c.select(blockIdx.z);
     constexpr int T = kCcaTile;
     constexpr int TH = kCcaTileH;
     constexpr int RW = TH / 4;
@@ -1117,6 +1128,7 @@ static __device__ __forceinline__ void g_union(int32_t* parent, int32_t a, int32
 }
 
 __global__ __launch_bounds__(256) void k_cca_border(CcaDev c, int nh, int nv) {
+    c.select(blockIdx.y);
     constexpr int T = kCcaTile;
     constexpr int TH = kCcaTileH;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1143,6 +1155,7 @@ __global__ __launch_bounds__(256) void k_cca_border(CcaDev c, int nh, int nv) {
 
 // One block per tile for the passes over tile-local roots.
 __global__ __launch_bounds__(256) void k_cca_compress(CcaDev c) {
+    c.select(blockIdx.y);
     constexpr int TT = kCcaTilePx;
     const int tile = blockIdx.x;
     const uint32_t n = c.tile_cnt[tile];
@@ -1160,6 +1173,7 @@ __global__ __launch_bounds__(256) void k_cca_compress(CcaDev c) {
 // Global roots: reset their final label; those with area >= threshold (src/cca.cpp:213-217) become
 // candidates in this tile's candidate slice (no global atomic).
 __global__ __launch_bounds__(256) void k_cca_collect(CcaDev c) {
+    c.select(blockIdx.y);
     constexpr int TT = kCcaTilePx;
     __shared__ uint32_t s_n;
     const int tile = blockIdx.x;
@@ -1211,6 +1225,7 @@ __global__ __launch_bounds__(256) void k_cca_densify(CcaDev c, int32_t* __restri
 // ---------------------------------------------------------------------------------------------
 constexpr int kSelCap = 12288;    // candidates the device path holds in LDS (3 x 48 KB)
 __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int ntiles) {
+    c.select(blockIdx.x);
     constexpr int TT = kCcaTilePx;
     extern __shared__ uint32_t s_dyn[];
     uint32_t* const s_area = s_dyn;
@@ -1334,23 +1349,23 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int ntiles) {
     if (tid == 0) c.counters[3] = 0u;
 }
 
-void launch_cca_phase1(const CcaDev& c, hipStream_t st) {
+void launch_cca_phase1(const CcaDev& c, int nframes, hipStream_t st) {
     constexpr int T = kCcaTile;
     const int tx = (c.W + T - 1) / T, ty = (c.H + kCcaTileH - 1) / kCcaTileH;
-    hipLaunchKernelGGL(k_cca_local, dim3(tx, ty), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_cca_local, dim3(tx, ty, nframes), dim3(256), 0, st, c);
     const int nh = (ty - 1) * c.W, nv = (tx - 1) * c.H;
     if (nh + nv > 0)
-        hipLaunchKernelGGL(k_cca_border, dim3((nh + nv + 255) / 256), dim3(256), 0, st, c, nh, nv);
-    hipLaunchKernelGGL(k_cca_compress, dim3(tx * ty), dim3(256), 0, st, c);
-    hipLaunchKernelGGL(k_cca_collect, dim3(tx * ty), dim3(256), 0, st, c);
+        hipLaunchKernelGGL(k_cca_border, dim3((nh + nv + 255) / 256, nframes), dim3(256), 0, st, c, nh, nv);
+    hipLaunchKernelGGL(k_cca_compress, dim3(tx * ty, nframes), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_cca_collect, dim3(tx * ty, nframes), dim3(256), 0, st, c);
 }
 
-void launch_cca_select(const CcaDev& c, hipStream_t st) {
+void launch_cca_select(const CcaDev& c, int nframes, hipStream_t st) {
     constexpr int T = kCcaTile;
     const int ntiles = ((c.W + T - 1) / T) * ((c.H + kCcaTileH - 1) / kCcaTileH);
     const size_t lds = 3 * (size_t)kSelCap * sizeof(uint32_t);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cca_select), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_cca_select, dim3(1), dim3(1024), lds, st, c, ntiles);
+    hipLaunchKernelGGL(k_cca_select, dim3(nframes), dim3(1024), lds, st, c, ntiles);
 }
 
 void launch_cca_densify(const CcaDev& c, int32_t* d_leader, uint32_t* d_area, hipStream_t st) {
@@ -1385,6 +1400,7 @@ void launch_cca_set_kept(const CcaDev& c, const int32_t* d_leaders, const uint16
 // Every component that was not kept takes the final label of the component left of (or, in column 0,
 // above) its leader (src/cca.cpp:240-254).  Leaders strictly decrease along the chase, so it terminates.
 __global__ __launch_bounds__(256) void k_cca_chain(CcaDev c) {
+    c.select(blockIdx.y);
     constexpr int TT = kCcaTilePx;
     const int tile = blockIdx.x;
     const uint32_t n = c.tile_cnt[tile];
@@ -1409,6 +1425,7 @@ __global__ __launch_bounds__(256) void k_cca_chain(CcaDev c) {
 }
 
 __global__ __launch_bounds__(256) void k_cca_relabel(CcaDev c) {
+    c.select(blockIdx.y);
     const int gstride = gridDim.x * blockDim.x;
     const int nquad = c.N >> 2;
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += gstride) {
@@ -1424,14 +1441,15 @@ __global__ __launch_bounds__(256) void k_cca_relabel(CcaDev c) {
         c.out[p] = c.final_lab[c.parent[c.parent[p]]];
 }
 
-void launch_cca_phase2(const CcaDev& c, hipStream_t st) {
+void launch_cca_phase2(const CcaDev& c, int nframes, hipStream_t st) {
     constexpr int T = kCcaTile;
     const int ntiles = ((c.W + T - 1) / T) * ((c.H + kCcaTileH - 1) / kCcaTileH);
-    hipLaunchKernelGGL(k_cca_chain, dim3(ntiles), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_cca_chain, dim3(ntiles, nframes), dim3(256), 0, st, c);
     int blocks = (c.N / 4 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    const int cap = (4096 + nframes - 1) / nframes;
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_cca_relabel, dim3(blocks), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_cca_relabel, dim3(blocks, nframes), dim3(256), 0, st, c);
 }
 
 }  // namespace fslic

@@ -93,7 +93,9 @@ int fslic_hip_iterate(fslic_engine* e, const fslic_params* p, int H, int W, int 
 int fslic_hip_iterate_device(fslic_engine* e, int slot, const fslic_params* p, int H, int W, int K,
                              const uint8_t* d_rgb, fslic_cluster* clusters, uint16_t* d_labels);
 
-/* Independent frames, round-robin over the engine's slots (NEW surface; BASELINE.json config 4).
+/* Independent frames of identical geometry (NEW surface; BASELINE.json config 4).  The frames are cut into
+ * groups of up to 8 (FSLIC_GROUP, at most 16); every kernel launch of a group covers all of its frames (frame =
+ * last grid dimension), groups rotate over the engine's slots (one stream each).
  * rgb[i] / labels[i] are host pointers when device_ptrs == 0 and device pointers otherwise;
  * clusters[i] are host pointers, each K clusters. */
 int fslic_hip_iterate_batch(fslic_engine* e, const fslic_params* p, int H, int W, int K, int n_frames,
@@ -119,9 +121,12 @@ int fslic_hip_last_prelabels(fslic_engine* e, int slot, uint16_t* prelabels);
  * call on slot 0.  Pointer valid until the next call on the engine. */
 const char* fslic_hip_last_timing_report(fslic_engine* e);
 
-/* Device time (ms, HIP events on the slot's stream) of the last iterate*() on `slot`:
- * whole pipeline, and the full-assign kernel alone (the roofline kernel).  */
+/* Device time (ms, HIP events on the slot's stream) of the last frame GROUP on `slot`: whole pipeline, and
+ * the full-assign launch alone (the roofline kernel; it covers every frame of the group).  */
 int fslic_hip_last_device_times(fslic_engine* e, int slot, float* total_ms, float* full_assign_ms);
+
+/* Number of frames in the last group on `slot` (1 for iterate / iterate_device). */
+int fslic_hip_last_group_frames(fslic_engine* e, int slot);
 
 /* Which kernel family served the last call on `slot`: 0 = tiled (LDS candidate lists), 1 = generic. */
 int fslic_hip_last_path(fslic_engine* e, int slot);

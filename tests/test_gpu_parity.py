@@ -249,3 +249,30 @@ def test_device_resident_and_batch_entry_points(engine):
     engine.iterate_batch([f.ctypes.data for f in frames], cls, [o.ctypes.data for o in outs], H, W, p, device_ptrs=False)
     for i in range(n):
         assert np.array_equal(outs[i], exp[i][0]), i
+
+
+def test_group_of_eight_frames_in_one_launch_sequence():
+    # one slot => all 8 frames share every kernel launch (frame = last grid dimension); mixed content so that
+    # per-frame state (clusters, bins, connectivity counters, host top-K fallback) must not leak between frames
+    import torch
+    from fast_slic_amd import Engine
+    H, W, K = 200, 264, 120
+    kinds = ["A", "B", "C", "D", "A", "A", "B", "C"]
+    frames = [variant(k, H, W, seed=i) for i, k in enumerate(kinds)]
+    p = make_params(10, 10.0, 0.25, 3)
+    exp = [orc.slic_iterate(f, orc.initialize_clusters(f, K)) for f in frames]
+    e = Engine(0, 1)
+    try:
+        d_rgb = [torch.from_numpy(f).cuda() for f in frames]
+        d_lab = [torch.empty((H, W), dtype=torch.int16, device="cuda") for _ in frames]
+        torch.cuda.synchronize()
+        for rep in range(2):     # second pass reuses the carved arena and the generation stamps
+            cls = [orc.initialize_clusters(f, K) for f in frames]
+            e.iterate_batch([t.data_ptr() for t in d_rgb], cls, [t.data_ptr() for t in d_lab], H, W, p, device_ptrs=True)
+            assert e.last_group_frames(0) == 8
+            for i in range(8):
+                got = d_lab[i].cpu().numpy().view(np.uint16)
+                assert np.array_equal(got, exp[i][0]), describe_mismatch("rep %d frame %d" % (rep, i), got, exp[i][0])
+                assert cls[i].tobytes() == exp[i][1].tobytes(), (rep, i)
+    finally:
+        e.close()
