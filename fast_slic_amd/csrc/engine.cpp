@@ -8,6 +8,7 @@
 #include "../../include/fslic_hip.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -124,6 +125,7 @@ bool find_multiplier(int S, float coef, const std::vector<uint16_t>& patch, uint
     return false;
 }
 
+constexpr int kDenseCap = 8192;          // leader-sorted candidates the select kernel hands over on a tie (== its LDS sort capacity)
 constexpr size_t kTabMaxBytes = 40960;   // LDS budget of the packed kernel's spatial table
 constexpr size_t kLutMaxWords = 12288;   // 48 KB of LDS for the spatial table at most
 
@@ -160,8 +162,12 @@ struct Slot {
     uint32_t* h_cl = nullptr;        // per frame 4K words: in [0,K) yx; out (yx, lab, n, moved)
     size_t h_cl_words = 0;
     uint32_t* h_misc = nullptr;      // per frame 16 words (copy of d_misc)
-    int32_t* h_keep_leader = nullptr;
+    int32_t* h_keep_leader = nullptr;   // per frame hKeep entries
     uint16_t* h_keep_label = nullptr;
+    int hKeepFrames = 0;
+    int32_t* h_dense_leader = nullptr;  // per frame kDenseCap entries: leader-sorted candidates of a tie frame
+    uint32_t* h_dense_area = nullptr;
+    int hDenseFrames = 0;
     uint16_t* h_patch = nullptr;
     size_t h_patch_cap = 0;
     int32_t* h_cand_leader = nullptr;
@@ -215,6 +221,8 @@ void free_slot(Slot& s) {
     if (s.h_tab) hipHostFree(s.h_tab);
     if (s.h_keep_leader) hipHostFree(s.h_keep_leader);
     if (s.h_keep_label) hipHostFree(s.h_keep_label);
+    if (s.h_dense_leader) hipHostFree(s.h_dense_leader);
+    if (s.h_dense_area) hipHostFree(s.h_dense_area);
     if (s.h_patch) hipHostFree(s.h_patch);
     if (s.h_cand_leader) hipHostFree(s.h_cand_leader);
     if (s.h_cand_area) hipHostFree(s.h_cand_area);
@@ -238,12 +246,20 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
         HIPCHK(hipHostMalloc((void**)&s.h_cl, sizeof(uint32_t) * 4 * (size_t)K * G));
         s.h_cl_words = (size_t)G * 4 * K;
     }
-    if (s.hKeep < K) {
+    if (s.hKeep < K || s.hKeepFrames < G) {
         if (s.h_keep_leader) { hipHostFree(s.h_keep_leader); hipHostFree(s.h_keep_label); }
-        s.h_keep_leader = nullptr; s.h_keep_label = nullptr; s.hKeep = 0;
-        HIPCHK(hipHostMalloc((void**)&s.h_keep_leader, sizeof(int32_t) * (size_t)K));
-        HIPCHK(hipHostMalloc((void**)&s.h_keep_label, sizeof(uint16_t) * (size_t)K));
-        s.hKeep = K;
+        s.h_keep_leader = nullptr; s.h_keep_label = nullptr; s.hKeep = 0; s.hKeepFrames = 0;
+        const int kk = std::max(K, s.hKeep), gg = std::max(G, s.hKeepFrames);
+        HIPCHK(hipHostMalloc((void**)&s.h_keep_leader, sizeof(int32_t) * (size_t)kk * gg));
+        HIPCHK(hipHostMalloc((void**)&s.h_keep_label, sizeof(uint16_t) * (size_t)kk * gg));
+        s.hKeep = kk; s.hKeepFrames = gg;
+    }
+    if (s.hDenseFrames < G) {
+        if (s.h_dense_leader) { hipHostFree(s.h_dense_leader); hipHostFree(s.h_dense_area); }
+        s.h_dense_leader = nullptr; s.h_dense_area = nullptr; s.hDenseFrames = 0;
+        HIPCHK(hipHostMalloc((void**)&s.h_dense_leader, sizeof(int32_t) * (size_t)kDenseCap * G));
+        HIPCHK(hipHostMalloc((void**)&s.h_dense_area, sizeof(uint32_t) * (size_t)kDenseCap * G));
+        s.hDenseFrames = G;
     }
     if (!s.h_misc) HIPCHK(hipHostMalloc((void**)&s.h_misc, 64 * kMaxGroup));
     if (!s.h_lut) HIPCHK(hipHostMalloc((void**)&s.h_lut, kLutMaxWords * 4));
@@ -264,7 +280,11 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     const size_t shared_bytes = off;
     off = 0;
     const size_t o_lab = take(N * 4), o_labels = take(N * 2);
-    const size_t o_cl = take((size_t)K * 4 * 5);                     // yx, lab, n, moved, tag (contiguous)
+    const size_t o_cl = take((size_t)K * 4 * 6);                     // yx, lab, n, moved, tag, shadow (contiguous)
+    // partial centroid sums of the block kernel: one entry per (cluster, assign block its window can overlap);
+    // blocks are 64 px wide and at least 32 visited rows (stride >= 1) tall
+    const int nbx = 2 * S / 64 + 2, nby = 2 * S / 32 + 2;
+    const size_t o_cpart = take((size_t)K * nbx * nby * 6 * 4);
     const size_t o_zero = off;
     const size_t o_sums = take((size_t)K * 6 * 4), o_sums1 = take((size_t)K * 6 * 4);
     const size_t o_cc0 = take(ncell * 4), o_cc1 = take(ncell * 4);
@@ -299,6 +319,8 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     f.labels = (uint16_t*)(b + o_labels);
     uint32_t* cl = (uint32_t*)(b + o_cl);
     f.cl_yx = cl; f.cl_lab = cl + K; f.cl_n = cl + 2 * (size_t)K; f.cl_moved = cl + 3 * (size_t)K; f.cl_tag = cl + 4 * (size_t)K;
+    f.cl_shadow = cl + 5 * (size_t)K;
+    f.cpart = (uint32_t*)(b + o_cpart); f.cpart_ns = nbx * nby; f.nbx = nbx;
     f.sums[0] = (uint32_t*)(b + o_sums); f.sums[1] = (uint32_t*)(b + o_sums1);
     f.cell_cnt[0] = (uint32_t*)(b + o_cc0); f.cell_cnt[1] = (uint32_t*)(b + o_cc1);
     uint32_t* misc = (uint32_t*)(b + o_misc);
@@ -354,27 +376,27 @@ int validate(const fslic_params* p, int H, int W, int K, int& S) {
 }
 
 // ---- the top-K / ranking step of ConnectivityEnforcer::execute (src/cca.cpp:205-237) on the host ----
-// Input: candidates (components with area >= threshold) in arbitrary order.  Output: kept leaders in
-// ascending order; label = position.  libstdc++'s std::partial_sort decides ties at the cut exactly as it
-// does for the reference (same library, same input order: ascending component number == ascending leader).
-int select_kept(Slot& s, uint32_t M, int K, uint32_t& n_keep) {
+// Input: candidates (components with area >= threshold) in ASCENDING LEADER order, which is ascending component
+// number, the order the reference hands to std::partial_sort.  libstdc++'s std::partial_sort decides ties at
+// the cut exactly as it does for the reference (same library, same input order).  Output: kept leaders in
+// ascending order; label = position (src/cca.cpp:229-237).
+void select_kept_sorted(const int32_t* leader, const uint32_t* area, uint32_t M, int K,
+                        int32_t* keep_leader, uint16_t* keep_label, uint32_t& n_keep) {
+    if ((size_t)K >= (size_t)M) {
+        for (uint32_t i = 0; i < M; i++) { keep_leader[i] = leader[i]; keep_label[i] = (uint16_t)i; }
+        n_keep = M;
+        return;
+    }
     std::vector<uint32_t> order(M);
     std::iota(order.begin(), order.end(), 0u);
-    const int32_t* leader = s.h_cand_leader;
-    const uint32_t* area = s.h_cand_area;
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return leader[a] < leader[b]; });
-    if ((size_t)K < order.size()) {
-        std::partial_sort(order.begin(), order.begin() + K, order.end(),
-                          [&](uint32_t a, uint32_t b) { return area[a] > area[b]; });
-        order.resize(K);
-        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return leader[a] < leader[b]; });
-    }
-    n_keep = (uint32_t)order.size();
-    for (uint32_t i = 0; i < n_keep; i++) {
-        s.h_keep_leader[i] = leader[order[i]];
-        s.h_keep_label[i] = (uint16_t)i;
-    }
-    return FSLIC_OK;
+    std::partial_sort(order.begin(), order.begin() + K, order.end(),
+                      [&](uint32_t a, uint32_t b) { return area[a] > area[b]; });
+    std::vector<uint8_t> kept(M, 0);
+    for (int i = 0; i < K; i++) kept[order[i]] = 1;
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < M; i++)
+        if (kept[i]) { keep_leader[n] = leader[i]; keep_label[n] = (uint16_t)n; n++; }
+    n_keep = n;
 }
 
 int ensure_cand_capacity(Slot& s, size_t M) {
@@ -387,7 +409,6 @@ int ensure_cand_capacity(Slot& s, size_t M) {
     return FSLIC_OK;
 }
 
-// CcaDev of frames [i0, i0+n) of the slot: pointers advanced to frame i0, outputs = the given per-frame buffers.
 // The per-frame output pointers must already be in s.d_ptrs[kMaxGroup + i] (upload_ptrs).
 CcaDev cca_view(const Slot& s, int i0, const uint16_t* d_in0, size_t in_stride, int K, int min_threshold) {
     CcaDev c = s.c;
@@ -415,46 +436,89 @@ int upload_ptrs(Slot& s, int n, const uint8_t* const* d_rgb, uint16_t* const* d_
 }
 
 // Connectivity pass, fully asynchronous on the slot's stream: tile CCL, seams, compress, collect, device
-// top-K + ranking, chain, relabel.  The select status (0 = done on device, 1 = host top-K needed) ends up in the
-// frame's misc words; cca_finish_frame() redoes the tail with std::partial_sort when it is 1.
-void cca_enqueue(Slot& s, const CcaDev& c, int n) {
+// top-K + ranking, chain, relabel, for frames [i0, i0+n) (c = cca_view(s, i0, ...)).  The select status of every
+// frame ends up in its misc words; cca_finish_group() serves the frames whose status is not 0.
+void cca_enqueue(Slot& s, const CcaDev& c, int i0, int n) {
     launch_cca_phase1(c, n, s.st);
-    launch_cca_select(c, n, s.st);
+    launch_cca_select(c, n, s.at(s.d_dense_leader, i0), s.at(s.d_dense_area, i0), kDenseCap, s.st);
     launch_cca_phase2(c, n, s.st);
 }
-// After the stream has been synchronised and h_misc refreshed: host top-K for frame i when the device asked for it.
-int cca_finish_frame(Slot& s, const CcaDev& c1, int i) {     // c1: view of frame i alone
-    uint32_t* hm = s.h_misc + 16 * (size_t)i;
-    if (hm[4 + 3] == 0) return FSLIC_OK;
-    int32_t* d_dense_leader = s.at(s.d_dense_leader, i);
-    uint32_t* d_dense_area = s.at(s.d_dense_area, i);
-    int32_t* d_keep_leader = s.at(s.d_keep_leader, i);
-    uint16_t* d_keep_label = s.at(s.d_keep_label, i);
-    launch_cca_densify(c1, d_dense_leader, d_dense_area, s.st);
-    HIPCHK(hipMemcpyAsync(hm + 4, c1.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.st));
-    HIPCHK(hipStreamSynchronize(s.st));
-    const uint32_t M = hm[4 + 1];
-    uint32_t n_keep = 0;
-    if (M > 0) {
-        int rc = ensure_cand_capacity(s, M);
-        if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(s.h_cand_leader, d_dense_leader, sizeof(int32_t) * M, hipMemcpyDeviceToHost, s.st));
-        HIPCHK(hipMemcpyAsync(s.h_cand_area, d_dense_area, sizeof(uint32_t) * M, hipMemcpyDeviceToHost, s.st));
-        HIPCHK(hipStreamSynchronize(s.st));
-        if ((size_t)std::min<uint32_t>(M, (uint32_t)c1.K) > (size_t)s.hKeep) {
-            if (s.h_keep_leader) { hipHostFree(s.h_keep_leader); hipHostFree(s.h_keep_label); }
-            s.h_keep_leader = nullptr; s.h_keep_label = nullptr;
-            s.hKeep = (int)std::min<uint32_t>(M, (uint32_t)c1.K);
-            HIPCHK(hipHostMalloc((void**)&s.h_keep_leader, sizeof(int32_t) * (size_t)s.hKeep));
-            HIPCHK(hipHostMalloc((void**)&s.h_keep_label, sizeof(uint16_t) * (size_t)s.hKeep));
-        }
-        select_kept(s, M, c1.K, n_keep);
-        HIPCHK(hipMemcpyAsync(d_keep_leader, s.h_keep_leader, sizeof(int32_t) * n_keep, hipMemcpyHostToDevice, s.st));
-        HIPCHK(hipMemcpyAsync(d_keep_label, s.h_keep_label, sizeof(uint16_t) * n_keep, hipMemcpyHostToDevice, s.st));
+
+// After the stream has been synchronised and h_misc refreshed.  Status 1 (area tie at the top-K cut): the device
+// left the candidates sorted by leader; fetch them, run std::partial_sort, upload the kept set, redo chain +
+// relabel.  All such frames of the group share two stream synchronisations.  Status 2 (more candidates than
+// the device sorts): gather + sort on the host, frame by frame.
+int cca_finish_group(Slot& s, int first, int n, const uint16_t* d_in0, size_t in_stride, int K, int thres) {
+    int n_tie = 0, n_slow = 0;
+    for (int i = first; i < first + n; i++) {
+        const uint32_t st = s.h_misc[16 * (size_t)i + 4 + 3];
+        n_tie += st == 1; n_slow += st == 2;
     }
-    launch_cca_set_kept(c1, d_keep_leader, d_keep_label, (int)n_keep, s.st);
-    launch_cca_phase2(c1, 1, s.st);
-    HIPCHK(hipStreamSynchronize(s.st));     // the pinned keep arrays are reused by the next frame
+    if (n_tie == 0 && n_slow == 0) return FSLIC_OK;
+    if (n_tie) {
+        for (int i = first; i < first + n; i++) {
+            const uint32_t* hm = s.h_misc + 16 * (size_t)i;
+            if (hm[4 + 3] != 1) continue;
+            const uint32_t M = hm[4 + 1];
+            HIPCHK(hipMemcpyAsync(s.h_dense_leader + (size_t)i * kDenseCap, s.at(s.d_dense_leader, i), sizeof(int32_t) * M, hipMemcpyDeviceToHost, s.st));
+            HIPCHK(hipMemcpyAsync(s.h_dense_area + (size_t)i * kDenseCap, s.at(s.d_dense_area, i), sizeof(uint32_t) * M, hipMemcpyDeviceToHost, s.st));
+        }
+        HIPCHK(hipStreamSynchronize(s.st));
+        for (int i = first; i < first + n; i++) {
+            const uint32_t* hm = s.h_misc + 16 * (size_t)i;
+            if (hm[4 + 3] != 1) continue;
+            const uint32_t M = hm[4 + 1];
+            int32_t* kl = s.h_keep_leader + (size_t)i * s.hKeep;
+            uint16_t* kb = s.h_keep_label + (size_t)i * s.hKeep;
+            uint32_t n_keep = 0;
+            select_kept_sorted(s.h_dense_leader + (size_t)i * kDenseCap, s.h_dense_area + (size_t)i * kDenseCap, M, K, kl, kb, n_keep);
+            int32_t* d_kl = s.at(s.d_keep_leader, i);
+            uint16_t* d_kb = s.at(s.d_keep_label, i);
+            if (n_keep) {
+                HIPCHK(hipMemcpyAsync(d_kl, kl, sizeof(int32_t) * n_keep, hipMemcpyHostToDevice, s.st));
+                HIPCHK(hipMemcpyAsync(d_kb, kb, sizeof(uint16_t) * n_keep, hipMemcpyHostToDevice, s.st));
+            }
+            const CcaDev c1 = cca_view(s, i, d_in0, in_stride, K, thres);
+            launch_cca_set_kept(c1, d_kl, d_kb, (int)n_keep, s.st);
+            launch_cca_phase2(c1, 1, s.st);
+        }
+    }
+    for (int i = first; i < first + n && n_slow; i++) {
+        uint32_t* hm = s.h_misc + 16 * (size_t)i;
+        if (hm[4 + 3] != 2) continue;
+        const CcaDev c1 = cca_view(s, i, d_in0, in_stride, K, thres);
+        int32_t* d_dl = s.at(s.d_dense_leader, i);
+        uint32_t* d_da = s.at(s.d_dense_area, i);
+        launch_cca_densify(c1, d_dl, d_da, s.st);
+        HIPCHK(hipMemcpyAsync(hm + 4, c1.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.st));
+        HIPCHK(hipStreamSynchronize(s.st));
+        const uint32_t M = hm[4 + 1];
+        int rc = ensure_cand_capacity(s, std::max<size_t>(M, 1) * 2);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(s.h_cand_leader, d_dl, sizeof(int32_t) * M, hipMemcpyDeviceToHost, s.st));
+        HIPCHK(hipMemcpyAsync(s.h_cand_area, d_da, sizeof(uint32_t) * M, hipMemcpyDeviceToHost, s.st));
+        HIPCHK(hipStreamSynchronize(s.st));
+        // ascending-leader order first (the device gathered tile by tile)
+        std::vector<uint32_t> order(M);
+        std::iota(order.begin(), order.end(), 0u);
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return s.h_cand_leader[a] < s.h_cand_leader[b]; });
+        int32_t* sl = s.h_cand_leader + M;       // second half of the (2M-entry) host buffers
+        uint32_t* sa = s.h_cand_area + M;
+        for (uint32_t q = 0; q < M; q++) { sl[q] = s.h_cand_leader[order[q]]; sa[q] = s.h_cand_area[order[q]]; }
+        std::vector<int32_t> kl(std::min<size_t>(M, (size_t)K) + 1);
+        std::vector<uint16_t> kb(kl.size());
+        uint32_t n_keep = 0;
+        select_kept_sorted(sl, sa, M, K, kl.data(), kb.data(), n_keep);
+        int32_t* d_kl = s.at(s.d_keep_leader, i);
+        uint16_t* d_kb = s.at(s.d_keep_label, i);
+        if (n_keep) {
+            HIPCHK(hipMemcpy(d_kl, kl.data(), sizeof(int32_t) * n_keep, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(d_kb, kb.data(), sizeof(uint16_t) * n_keep, hipMemcpyHostToDevice));
+        }
+        launch_cca_set_kept(c1, d_kl, d_kb, (int)n_keep, s.st);
+        launch_cca_phase2(c1, 1, s.st);
+    }
+    HIPCHK(hipStreamSynchronize(s.st));
     return FSLIC_OK;
 }
 
@@ -568,6 +632,7 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     f.rgbs = nullptr;
     f.select(i0);                                  // host-side: pointers of frame i0
     f.rgbs = reinterpret_cast<const uint8_t* const*>(s.d_ptrs + i0);
+    f.exp_flags = getenv("FSLIC_EXP") ? atoi(getenv("FSLIC_EXP")) : 0;
     const size_t fb = s.frame_bytes;
 
     if (generic && !s.sp_patch_uploaded) {
@@ -592,7 +657,8 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     launch_rgb_to_lab(f, n, p->convert_to_lab, e->tables, true, s.st);   // + labels <- 0xFFFF (src/context.cpp:138-145)
     if (timed) HIPCHK(hipEventRecord(s.ev[1], s.st));
     f.gen = ++s.gen_counter;
-    launch_bin_clusters(f, n, 0, 0, 0, s.st);
+    PassGeom pg{};
+    launch_bin_clusters(f, n, 0, 0, 0, pg, s.st);
     const int stride = p->subsample_stride;
     int rem = 0;
     f.dbg = nullptr;
@@ -603,15 +669,16 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
             HIPCHK(hipMemsetAsync(s.d_dbg, 0, sizeof(unsigned long long) * 8 * 65536, s.st));
             f.dbg = s.d_dbg;
         }
+        pg = PassGeom{};
         if (generic) launch_assign_generic(f, n, rem, stride, it & 1, it & 1, true, s.st);
-        else launch_assign(f, n, rem, stride, it & 1, it & 1, true, s.st);
+        else pg = launch_assign(f, n, rem, stride, it & 1, it & 1, true, s.st);
         if (f.dbg && dbg_mode == 2) {
             int rc2 = print_phase_stamps(s, "last fused assign");
             if (rc2) return rc2;
             f.dbg = nullptr;
         }
         f.gen = ++s.gen_counter;
-        launch_bin_clusters(f, n, 1, (it + 1) & 1, it & 1, s.st);
+        launch_bin_clusters(f, n, 1, (it + 1) & 1, it & 1, pg, s.st);
         rem = (rem + 1) % stride;
     }
     if (dbg_mode == 1) {
@@ -622,7 +689,7 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     if (timed) HIPCHK(hipEventRecord(s.ev[2], s.st));
     // full_assign: stride 1, rem 0, no update afterwards (src/context.cpp:246-256)
     if (generic) launch_assign_generic(f, n, 0, 1, p->max_iter & 1, 0, false, s.st);
-    else launch_assign(f, n, 0, 1, p->max_iter & 1, 0, false, s.st);
+    else (void)launch_assign(f, n, 0, 1, p->max_iter & 1, 0, false, s.st);
     if (timed) HIPCHK(hipEventRecord(s.ev[3], s.st));
     if (f.dbg) {
         int rc2 = print_phase_stamps(s, "full_assign");
@@ -632,7 +699,7 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     // enforce_connectivity, src/context.cpp:14-20
     const int thres = (int)round((double)(S * S) * (double)p->min_size_factor);
     const CcaDev c = cca_view(s, i0, s.f.labels, fb, K, thres);
-    cca_enqueue(s, c, n);
+    cca_enqueue(s, c, i0, n);
     if (timed) HIPCHK(hipEventRecord(s.ev[4], s.st));
     // cluster state, overflow flag and connectivity status back to the host
     HIPCHK(hipMemcpy2DAsync(s.h_cl + (size_t)i0 * 4 * K, sizeof(uint32_t) * 4 * (size_t)K, f.cl_yx, fb,
@@ -642,8 +709,14 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
 }
 
 // Start a group of n frames (identical geometry) on the slot.  d_rgb / d_out are device pointers.
+double now_us() {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+const bool g_host_timing = getenv("FSLIC_HOST_TIMING") != nullptr;
+
 int group_begin(fslic_engine* e, Slot& s, const fslic_params* p, int H, int W, int K, int n,
                 const uint8_t* const* d_rgb, fslic_cluster* const* clusters, uint16_t* const* d_out) {
+    const double t_begin = now_us();
     int S = 0;
     int rc = validate(p, H, W, K, S);
     if (rc) return rc;
@@ -663,13 +736,16 @@ int group_begin(fslic_engine* e, Slot& s, const fslic_params* p, int H, int W, i
     if (rc) return rc;
     s.have_pre = true;
     s.last_path = s.generic ? 1 : 0;
+    if (g_host_timing) fprintf(stderr, "[fslic host] group_begin n=%d: %.1f us\n", n, now_us() - t_begin);
     return FSLIC_OK;
 }
 
 // Wait for the group, serve the rare host-side steps frame by frame (candidate-list overflow -> generic redo,
 // area tie at the top-K cut -> std::partial_sort on the host), then write the cluster state back.
 int group_finish(fslic_engine* e, Slot& s) {
+    const double t_begin = now_us();
     HIPCHK(hipStreamSynchronize(s.st));
+    const double t_sync = now_us();
     const int n = s.nframes, K = s.K, H = s.H, W = s.W;
     hipEventElapsedTime(&s.total_ms, s.ev[0], s.ev[4]);
     hipEventElapsedTime(&s.lab_ms, s.ev[0], s.ev[1]);
@@ -677,7 +753,10 @@ int group_finish(fslic_engine* e, Slot& s) {
     hipEventElapsedTime(&s.fa_ms, s.ev[2], s.ev[3]);
     hipEventElapsedTime(&s.cca_ms, s.ev[3], s.ev[4]);
     const int thres = (int)round((double)(s.S * s.S) * (double)s.p.min_size_factor);
+    const double t_ev = now_us();
+    int n_host_topk = 0;
     for (int i = 0; i < n; i++) {
+        n_host_topk += s.h_misc[16 * (size_t)i + 4 + 3] != 0;
         if (!s.generic && s.h_misc[16 * (size_t)i + 2] != 0) {     // the tiled kernel overflowed an LDS candidate list
             int rc = enqueue_frames(e, s, i, 1, true, false);
             if (rc) return rc;
@@ -685,10 +764,12 @@ int group_finish(fslic_engine* e, Slot& s) {
             if (s.h_misc[16 * (size_t)i + 2] != 0) return fail(FSLIC_E_INTERNAL, "generic path reported a candidate overflow");
             s.last_path = 1;
         }
-        const CcaDev c1 = cca_view(s, i, s.f.labels, s.frame_bytes, K, thres);
-        int rc = cca_finish_frame(s, c1, i);
+    }
+    {
+        int rc = cca_finish_group(s, 0, n, s.f.labels, s.frame_bytes, K, thres);
         if (rc) return rc;
     }
+    const double t_cca = now_us();
     // write the cluster state back the way the reference leaves it
     for (int i = 0; i < n; i++) {
         const uint32_t* yx = s.h_cl + (size_t)i * 4 * K;
@@ -712,6 +793,9 @@ int group_finish(fslic_engine* e, Slot& s) {
             cl[k].is_active = 1;                               // src/preemptive.h:69-74
         }
     }
+    if (g_host_timing)
+        fprintf(stderr, "[fslic host] group_finish n=%d: sync wait %.1f us, events %.1f us, host top-K (%d frames) %.1f us, write-back %.1f us (device %.1f us)\n",
+                n, t_sync - t_begin, t_ev - t_sync, n_host_topk, t_cca - t_ev, now_us() - t_cca, s.total_ms * 1e3);
     return FSLIC_OK;
 }
 
@@ -969,10 +1053,10 @@ int fslic_hip_enforce_connectivity(fslic_engine* e, uint16_t* labels, int H, int
     rc = upload_ptrs(s, 1, nullptr, outs);
     if (rc) return rc;
     const CcaDev c = cca_view(s, 0, s.d_out_stage, 0, K, min_threshold);
-    cca_enqueue(s, c, 1);
+    cca_enqueue(s, c, 0, 1);
     HIPCHK(hipMemcpyAsync(s.h_misc, s.d_misc, 64, hipMemcpyDeviceToHost, s.st));
     HIPCHK(hipStreamSynchronize(s.st));
-    rc = cca_finish_frame(s, c, 0);
+    rc = cca_finish_group(s, 0, 1, s.d_out_stage, 0, K, min_threshold);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(labels, s.d_out_stage, N * 2, hipMemcpyDeviceToHost, s.st));
     HIPCHK(hipStreamSynchronize(s.st));

@@ -13,6 +13,7 @@ constexpr int kRowsPerWave = 8;     // visited rows per wavefront
 constexpr int kCellCap = 8;         // cluster records per coarse cell before spilling to overflow
 constexpr int kAccSlots = 16;       // candidates per wavefront with LDS-privatised centroid sums
 constexpr int kAccCopies = 8;       // privatised copies per (slot, quantity)
+constexpr int kBlkCopies = 4;       // block-level kernel: privatised copies per (candidate, quantity)
 constexpr uint32_t kHuge = 0x40000000u;   // out-of-window marker added to the distance key
 constexpr int kCcaTile = 64;        // connectivity tile width  (one wavefront of columns)
 constexpr int kCcaTileH = 32;       // connectivity tile height (4 wavefronts x 8 rows), one block of 256 threads
@@ -39,6 +40,7 @@ struct FrameDev {
     int T;               // 2S + 32, phase cell side (src/context.cpp:213)
     int cs_shift;        // coarse bin side = 1 << cs_shift
     int ncx, ncy, ncell;
+    int exp_flags;       // timing experiments only (FSLIC_EXP): 1 = skip the global flush, 2 = skip the whole fused update
     uint32_t gen;        // generation stamp of the bin pass that filled cell_items[buf] (ClusterRec::pad)
     uint32_t M, C;       // spatial fixed point: patch[d] == (d * M + C) >> 16 for d in [0, 2S]
     // image planes
@@ -51,7 +53,13 @@ struct FrameDev {
     uint32_t* cl_tag;    // K  phase << 16 | k of the current centres
     uint32_t* cl_n;      // K  num_members of the last update
     uint32_t* cl_moved;  // K  1 once an update with n > 0 has moved the cluster
+    uint32_t* cl_shadow; // K  1 while the cluster is kept out of the bins (identical to an earlier-ordered one)
     uint32_t* sums[2];   // K*6 each: count, sum y, sum x, sum L, sum a, sum b; pass `it` accumulates into [it&1]
+                         // (global atomics: generic / 32-bit kernels, and stale-label pixels of the block kernel)
+    uint32_t* cpart;     // K * cpart_ns * 6: per-(cluster, overlapping assign block) partial sums of the block
+                         // kernel, written with plain stores (one writer per entry), gathered by the cluster pass
+    int cpart_ns;        // entries per cluster (allocation), >= NBX * NBY of every pass geometry
+    int nbx;             // assign blocks (64 px wide) a cluster window can overlap horizontally: 2S/64 + 2
     // coarse bins, double buffered by iteration parity
     uint32_t* cell_cnt[2];     // ncell
     ClusterRec* cell_items[2]; // ncell * kCellCap
@@ -78,13 +86,20 @@ struct FrameDev {
         rgb = rgbs ? rgbs[z] : nullptr;
         const size_t d = (size_t)z * frame_bytes;
         adv(lab, d); adv(labels, d);
-        adv(cl_yx, d); adv(cl_lab, d); adv(cl_tag, d); adv(cl_n, d); adv(cl_moved, d);
-        adv(sums[0], d); adv(sums[1], d);
+        adv(cl_yx, d); adv(cl_lab, d); adv(cl_tag, d); adv(cl_n, d); adv(cl_moved, d); adv(cl_shadow, d);
+        adv(sums[0], d); adv(sums[1], d); adv(cpart, d);
         adv(cell_cnt[0], d); adv(cell_cnt[1], d); adv(cell_items[0], d); adv(cell_items[1], d);
         adv(ovf_cnt[0], d); adv(ovf_cnt[1], d); adv(ovf_items[0], d); adv(ovf_items[1], d);
         adv(err_flag, d);
         if (z != 0) dbg = nullptr;   // phase stamps (bring-up aid) cover the group's first frame only
     }
+};
+
+// Geometry of the assign pass whose partial sums a cluster pass gathers (mode 1).
+struct PassGeom {
+    int rem, stride, Hv;   // visited rows y = rem + stride * v, v in [0, Hv)
+    int BH;                // visited rows per assign block
+    int use_slots;         // 1: the block kernel wrote FrameDev::cpart; 0: everything is in FrameDev::sums
 };
 
 struct CcaDev {
@@ -126,14 +141,16 @@ struct LabTables {
 void launch_rgb_to_lab(const FrameDev& f, int nframes, int convert, const LabTables& t, bool init_labels, hipStream_t st);
 // mode 0: resample colours at the current centres (src/context.cpp:128-135) and bin;
 // mode 1: integer centroid update from `sums` (src/context.cpp:356-373), zero sums, and bin.
-void launch_bin_clusters(const FrameDev& f, int nframes, int mode, int buf, int sbuf, hipStream_t st);
+void launch_bin_clusters(const FrameDev& f, int nframes, int mode, int buf, int sbuf, const PassGeom& pg, hipStream_t st);
 // One assign pass over rows == rem (mod stride); fuse_update also accumulates the centroid sums
-// of src/context.cpp:301-354 for the same rows.
-void launch_assign(const FrameDev& f, int nframes, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st);
+// of src/context.cpp:301-354 for the same rows.  Returns the geometry the following cluster pass needs.
+PassGeom launch_assign(const FrameDev& f, int nframes, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st);
 void launch_assign_generic(const FrameDev& f, int nframes, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st);
 // connectivity
 void launch_cca_phase1(const CcaDev& c, int nframes, hipStream_t st);   // local CCL, border merge, compress, collect
-void launch_cca_select(const CcaDev& c, int nframes, hipStream_t st);   // device top-K + ranking (counters[3] = status)
+// device top-K + ranking; counters[3] = status (see k_cca_select).  dense_* are frame 0's buffers (frame stride =
+// c.frame_bytes) of dense_cap entries each: leader-sorted candidates for the host when the status is 1
+void launch_cca_select(const CcaDev& c, int nframes, int32_t* dense_leader, uint32_t* dense_area, int dense_cap, hipStream_t st);
 void launch_cca_phase2(const CcaDev& c, int nframes, hipStream_t st);   // chain resolution + relabel
 // host top-K path, one frame at a time (the CcaDev passed in is already select()ed to that frame)
 void launch_cca_densify(const CcaDev& c, int32_t* d_leader, uint32_t* d_area, hipStream_t st);

@@ -128,14 +128,51 @@ void launch_rgb_to_lab(const FrameDev& f, int nframes, int convert, const LabTab
 // its centre (spill list when a cell is full).  The other parity's counters are cleared for the
 // next iteration, so no per-iteration memset launch is needed.
 // =============================================================================================
+// Which assign blocks (64 px x BH visited rows) can hold pixels of a cluster centred at (cy, cx): the blocks its
+// (2S+1)^2 window overlaps, in block columns [bx0, bx1] and block rows [by0, by1] (any == false: no visited row).
+// The block kernel and the cluster pass evaluate this identically, which is what pairs writer and reader of
+// FrameDev::cpart.
+struct SlotGeom { int bx0, bx1, by0, by1; bool any; };
+static __device__ __forceinline__ SlotGeom slot_geom(int cy, int cx, int S, int H, int W, int rem, int stride, int BH, int Hv) {
+    SlotGeom g;
+    g.bx0 = max(cx - S, 0) >> 6;
+    g.bx1 = min(cx + S, W - 1) >> 6;
+    const int t = max(cy - S, 0) - rem;
+    const int v0 = t <= 0 ? 0 : (t + stride - 1) / stride;
+    const int u = min(cy + S, H - 1) - rem;
+    const int v1 = u < 0 ? -1 : min(u / stride, Hv - 1);
+    g.any = v0 <= v1;
+    g.by0 = v0 / BH;
+    g.by1 = g.any ? v1 / BH : -1;
+    return g;
+}
+
+// Sums of cluster k over the pass: the block kernel's partial sums (one entry per overlapping block) plus whatever
+// went through global atomics.  out[0..5] = count, sum y, sum x, sum L, sum a, sum b.
+static __device__ __forceinline__ void gather_sums(const FrameDev& f, const PassGeom& pg, int k, uint32_t yx, uint32_t* out) {
+    const uint32_t* s = f.sums[0] + 6 * (size_t)k;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) out[q] = s[q];
+    if (!pg.use_slots) return;
+    const SlotGeom g = slot_geom((int)(yx >> 16), (int)(yx & 0xFFFFu), f.S, f.H, f.W, pg.rem, pg.stride, pg.BH, pg.Hv);
+    if (!g.any) return;
+    const uint32_t* cp = f.cpart + (size_t)k * f.cpart_ns * 6;
+    for (int by = g.by0; by <= g.by1; ++by)
+        for (int bx = g.bx0; bx <= g.bx1; ++bx) {
+            const uint32_t* e = cp + ((by - g.by0) * f.nbx + (bx - g.bx0)) * 6;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) out[q] += e[q];
+        }
+}
+
 template <int MODE>
-__global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, int buf, int sbuf) {
+__global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg) {
     f.select(blockIdx.y);
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < f.ncell) f.cell_cnt[1][k] = 0;
     if (k == 0) *f.ovf_cnt[1] = 0;
-    if (k >= f.K) return;
-    uint32_t yx = f.cl_yx[k];
+    const bool live = k < f.K;
+    uint32_t yx = live ? f.cl_yx[k] : 0u;
     int y = (int)(yx >> 16), x = (int)(yx & 0xFFFF);
     uint32_t lab;
     // A cluster whose integer state (y, x, L, a, b) equals that of cluster k-1 has the same distance to every
@@ -146,13 +183,25 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, int buf, int s
     // unchanged by this pass (mode 1), or equal uploaded centres (mode 0).
     bool shadowed = false;
     if (MODE == 0) {
+        if (!live) return;
         lab = f.lab[(size_t)y * f.W + x] & 0x00FFFFFFu;
         f.cl_lab[k] = lab;
         shadowed = k > 0 && f.cl_yx[k - 1] == yx;
+        f.cl_shadow[k] = shadowed ? 1u : 0u;
     } else {
+        // a shadowed cluster is in no candidate list: it received nothing and its cpart entries are stale
+        uint32_t s[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+        if (live && !(pg.use_slots && f.cl_shadow[k])) gather_sums(f, pg, k, yx, s);
+        // member count of cluster k-1 (needed below): the neighbouring lane's, recomputed at wavefront starts
+        uint32_t n_prev = __shfl_up(s[0], 1);
+        if ((threadIdx.x & 63) == 0 && live && k > 0) {
+            uint32_t sp[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+            if (!(pg.use_slots && f.cl_shadow[k - 1])) gather_sums(f, pg, k - 1, f.cl_yx[k - 1], sp);
+            n_prev = sp[0];
+        }
+        if (!live) return;
         lab = f.cl_lab[k];
-        const uint32_t* s = f.sums[0] + 6 * (size_t)k;
-        uint32_t* z = f.sums[1] + 6 * (size_t)k;     // the next pass accumulates here
+        uint32_t* z0 = f.sums[1] + 6 * (size_t)k;    // the next pass accumulates here (sums[0] is still being read by neighbours)
         const int32_t n = (int32_t)s[0];
         f.cl_n[k] = (uint32_t)n;
         if (n != 0) {
@@ -167,10 +216,11 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, int buf, int s
             f.cl_yx[k] = yx;
             f.cl_lab[k] = lab;
             f.cl_moved[k] = 1;
-        } else if (k > 0 && f.sums[0][6 * (size_t)(k - 1)] == 0u) {
+        } else if (k > 0 && n_prev == 0u) {
             shadowed = f.cl_yx[k - 1] == yx && f.cl_lab[k - 1] == lab;
         }
-        z[0] = 0; z[1] = 0; z[2] = 0; z[3] = 0; z[4] = 0; z[5] = 0;
+        f.cl_shadow[k] = shadowed ? 1u : 0u;
+        z0[0] = 0; z0[1] = 0; z0[2] = 0; z0[3] = 0; z0[4] = 0; z0[5] = 0;
     }
     // visit order of the reference scatter: phase = 2*((cy/T)&1) + ((cx/T)&1), then k
     const uint32_t phase = (uint32_t)(2 * ((y / f.T) & 1) + ((x / f.T) & 1));
@@ -188,12 +238,12 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, int buf, int s
     }
 }
 
-void launch_bin_clusters(const FrameDev& f_, int nframes, int mode, int buf, int sbuf, hipStream_t st) {
+void launch_bin_clusters(const FrameDev& f_, int nframes, int mode, int buf, int sbuf, const PassGeom& pg, hipStream_t st) {
     const FrameDev f = rotated(f_, buf, sbuf);
     const int n = f.K > f.ncell ? f.K : f.ncell;
     const int blocks = (n + 255) / 256;
-    if (mode == 0) hipLaunchKernelGGL(k_bin_clusters<0>, dim3(blocks, nframes), dim3(256), 0, st, f, buf, sbuf);
-    else hipLaunchKernelGGL(k_bin_clusters<1>, dim3(blocks, nframes), dim3(256), 0, st, f, buf, sbuf);
+    if (mode == 0) hipLaunchKernelGGL(k_bin_clusters<0>, dim3(blocks, nframes), dim3(256), 0, st, f, pg);
+    else hipLaunchKernelGGL(k_bin_clusters<1>, dim3(blocks, nframes), dim3(256), 0, st, f, pg);
 }
 
 // =============================================================================================
@@ -767,7 +817,7 @@ __global__ __launch_bounds__(256) void k_assign16(FrameDev f, int rem, int Hv, i
         }
     }
     FSLIC_STAMP(4);
-    if (FUSE) {
+    if (FUSE && !(f.exp_flags & 2)) {
         bool uni = slot[0] != 0xFFFFFFFFu;
 #pragma unroll
         for (int r = 1; r < R; ++r) uni = uni && (slot[r] == slot[0]);
@@ -798,7 +848,7 @@ __global__ __launch_bounds__(256) void k_assign16(FrameDev f, int rem, int Hv, i
             }
         }
         __builtin_amdgcn_wave_barrier();
-        const int nacc = min(n, kAccSlots) * 6;
+        const int nacc = (f.exp_flags & 1) ? 0 : min(n, kAccSlots) * 6;
         for (int i = lane; i < nacc; i += 64) {
             uint32_t v = 0;
 #pragma unroll
@@ -816,6 +866,299 @@ __global__ __launch_bounds__(256) void k_assign16(FrameDev f, int rem, int Hv, i
         f.dbg[o + 7] = (unsigned long long)n;
     }
 #undef FSLIC_STAMP
+}
+
+// =============================================================================================
+// Block-level packed assign kernel (the default, and the roofline kernel).
+// One block = 64 columns x (4 wavefronts x R) visited rows.  Same 16-bit key arithmetic as k_assign16 above
+// ((distance << 6) | idx, two rows per VALU instruction, spatial term from the column-major LDS copy of the
+// reference's patch), but the prologue is paid once per BLOCK and costs one memory round trip:
+//   wavefront 0   fetches every bin slot the block's pixels can see (all loads in flight at once), compacts the
+//                 live records by ballot, ranks them by (phase, k) with readlane broadcasts and writes the sorted
+//                 block list to LDS: idx = position in that list = visit order of the reference's scatter
+//   wavefronts 1-3 stage the spatial table (and clear the centroid accumulators) meanwhile
+//   one barrier
+//   every wavefront takes the list into registers (lane j = candidate j), ballots the candidates whose window
+//   reaches its own rows and walks that bit mask: cluster fields arrive by v_readlane, no LDS latency per candidate.
+// Fused update (src/context.cpp:301-354): block-level LDS accumulators (privatised copies, LDS atomics), then ONE
+// plain store per (candidate, quantity) into FrameDev::cpart at the entry reserved for (cluster, this block).
+// No global atomic on the common path: device-scope atomics cost 21 of the 39 us of the per-wavefront-flush
+// version of this pass (8 x 720p frames).  Pixels that no window covers keep their label and reach the sums through
+// global atomics (rare).
+// Algorithmic traffic: 4 B read + 2 B written per visited pixel.
+// =============================================================================================
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+
+template <int R, bool FUSE, int STRIDE>
+__global__ __launch_bounds__(256) void k_assign_blk(FrameDev f, int rem, int Hv) {
+    extern __shared__ uint32_t s_dyn[];                  // spatial table (u16), f.tab_words dwords
+    const uint16_t* const s_tab = reinterpret_cast<const uint16_t*>(s_dyn);
+    __shared__ uint32_t s_braw[3 * 64];
+    __shared__ uint4 s_list[64];                         // {yx, lab, k, cpart entry | kNoSlot}
+    __shared__ uint32_t s_bn;
+    __shared__ uint32_t s_acc[FUSE ? 64 * 6 * kBlkCopies : 1];
+    static_assert(R % 2 == 0, "rows are processed in pairs");
+    constexpr int BH = kWavesPerBlock * R;
+
+    f.select(blockIdx.z);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = (int)rfl((uint32_t)(tid >> 6));
+    const int W = f.W, S = f.S;
+    const int x0 = blockIdx.x * kTileW;
+    const int x = x0 + lane;
+    const int vrow_b0 = blockIdx.y * BH;
+    const int vrow_w0 = vrow_b0 + wave * R;
+    const bool okx = x < W;
+    const int nrows = max(0, min(R, Hv - vrow_w0));      // 0: this wavefront has no rows (bottom edge)
+    const int yw_lo = rem + vrow_w0 * STRIDE;
+#define FSLIC_STAMP(slot_)                                                                              \
+    do {                                                                                                 \
+        if (f.dbg && lane == 0)                                                                          \
+            f.dbg[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kWavesPerBlock + wave) * 8 + (slot_)] = __builtin_readcyclecounter(); \
+    } while (0)
+    FSLIC_STAMP(0);
+
+    // 1. pixel loads first; nothing below depends on them until the argmin
+    uint32_t pix[R];
+    {
+        const uint32_t* rowp = f.lab + (size_t)yw_lo * W;          // wave-uniform base, lane offset x
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            pix[r] = (okx && r < nrows) ? rowp[(uint32_t)x] : 0u;
+            rowp += (size_t)STRIDE * W;
+        }
+    }
+
+    if (wave == 0) {
+        // 2a. the block's candidate list
+        const uint32_t novf = *f.ovf_cnt[0];
+        const int sh = f.cs_shift;
+        const ClusterRec* __restrict__ citems = f.cell_items[0];
+        const ClusterRec* __restrict__ oitems = f.ovf_items[0];
+        const unsigned long long lowmask = (1ull << lane) - 1ull;
+        TileWindow win;
+        const int vlast = min(vrow_b0 + BH - 1, Hv - 1);
+        win.wy_lo = rem + vrow_b0 * STRIDE - S; win.wy_hi = rem + vlast * STRIDE + S;
+        win.wx_lo = x0 - S;                     win.wx_hi = min(x0 + kTileW - 1, W - 1) + S;
+        const int cxa = max(win.wx_lo, 0) >> sh, cxb = min(win.wx_hi, W - 1) >> sh;
+        const int cya = max(win.wy_lo, 0) >> sh, cyb = min(win.wy_hi, f.H - 1) >> sh;
+        const int ncxr = cxb - cxa + 1;
+        int cnt = 0;
+        auto visit = [&](const ClusterRec& rec, bool keep) {
+            const unsigned long long m = __ballot(keep);
+            const int pos = cnt + __popcll(m & lowmask);
+            if (keep && pos < 64) { s_braw[pos] = rec.yx; s_braw[64 + pos] = rec.lab; s_braw[128 + pos] = rec.tag; }
+            cnt += __popcll(m);
+        };
+        // lane -> (cell column, slot); a cell row of up to 8 cells is one 16-byte load per lane, six cell rows in flight
+        for (int cx0 = 0; cx0 < ncxr; cx0 += 8) {
+            const int cxi = cx0 + (lane >> 3);
+            const bool colok = cxi < ncxr;
+            const ClusterRec* base = citems + ((size_t)cya * f.ncx + cxa + cxi) * kCellCap + (lane & 7);
+            for (int cy0 = cya; cy0 <= cyb; cy0 += 6) {
+                ClusterRec rr[6];
+                bool okr[6];
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    okr[u] = colok && (cy0 + u) <= cyb;
+                    rr[u].yx = 0; rr[u].lab = 0; rr[u].tag = 0; rr[u].pad = 0;
+                    if (okr[u]) rr[u] = base[(size_t)u * f.ncx * kCellCap];
+                }
+                base += 6 * (size_t)f.ncx * kCellCap;
+#pragma unroll
+                for (int u = 0; u < 6; ++u) visit(rr[u], okr[u] && rr[u].pad == f.gen && in_window(rr[u], win));
+            }
+        }
+        for (uint32_t i0 = 0; i0 < novf; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            ClusterRec rec;
+            rec.yx = 0; rec.lab = 0; rec.tag = 0; rec.pad = 0;
+            if (i < novf) rec = oitems[i];
+            visit(rec, i < novf && in_window(rec, win));
+        }
+        __builtin_amdgcn_wave_barrier();
+        // rank by (phase, k): list order == visit order of the reference's scatter (src/context.cpp:214-242)
+        const int bn = cnt;
+        if (bn <= 64) {
+            const bool act = lane < bn;
+            const uint32_t yx_j = act ? s_braw[lane] : 0u;
+            const uint32_t lab_j = act ? s_braw[64 + lane] : 0u;
+            const uint32_t tag_j = act ? s_braw[128 + lane] : 0xFFFFFFFFu;
+            int rank = 0;
+            for (int i = 0; i < bn; ++i) rank += (int)(__builtin_amdgcn_readlane(tag_j, i) < tag_j);
+            uint32_t entry = kNoSlot;
+            if (FUSE) {
+                const uint32_t k = tag_j & 0xFFFFu;
+                const SlotGeom g = slot_geom((int)(yx_j >> 16), (int)(yx_j & 0xFFFFu), S, f.H, W, rem, STRIDE, BH, Hv);
+                const int by = (int)blockIdx.y, bx = (int)blockIdx.x;
+                if (g.any && by >= g.by0 && by <= g.by1)
+                    entry = (k * (uint32_t)f.cpart_ns + (uint32_t)((by - g.by0) * f.nbx + (bx - g.bx0))) * 6u;
+            }
+            if (act) s_list[rank] = make_uint4(yx_j, lab_j, tag_j & 0xFFFFu, entry);
+        }
+        if (lane == 0) s_bn = (uint32_t)bn;
+    } else {
+        // 2b. spatial table -> LDS, four 16-byte loads in flight per thread; centroid accumulators <- 0
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(f.tab);
+        uint4* dst = reinterpret_cast<uint4*>(s_dyn);
+        const int nq = f.tab_words >> 2;
+        const int t = tid - 64;
+        for (int b0 = 0; b0 < nq; b0 += 4 * 192) {
+            uint4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = b0 + u * 192 + t;
+                q[u] = make_uint4(0, 0, 0, 0);
+                if (i < nq) q[u] = src[i];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = b0 + u * 192 + t;
+                if (i < nq) dst[i] = q[u];
+            }
+        }
+        if (FUSE) {
+#pragma unroll
+            for (int i = 0; i < 64 * 6 * kBlkCopies / 192; ++i) s_acc[i * 192 + t] = 0u;
+        }
+    }
+    __syncthreads();
+    FSLIC_STAMP(1);
+    const int bn = (int)rfl(s_bn);
+    if (bn > 64) {                            // more live candidates than idx bits: the host redoes the frame generically
+        if (tid == 0) *f.err_flag = 1u;
+        return;
+    }
+
+    // 3. the block list in registers: lane j = candidate j; candidates whose window reaches this wavefront's rows
+    const uint4 mine = s_list[min(lane, 63)];
+    const uint32_t yx_j = mine.x, lab_j = mine.y;
+    const int yw_hi = yw_lo + (nrows - 1) * STRIDE;
+    unsigned long long todo;
+    {
+        const int cyj = (int)(yx_j >> 16);
+        todo = __ballot(lane < bn && nrows > 0 && cyj + S >= yw_lo && cyj - S <= yw_hi);
+    }
+    FSLIC_STAMP(2);
+
+    // 4. the argmin, two rows per instruction
+    us2 best[R / 2];
+#pragma unroll
+    for (int q = 0; q < R / 2; ++q) best[q] = (us2){0xFFFF, 0xFFFF};
+    const uint32_t nrpad = (uint32_t)f.tab_nrpad;
+    const int dyoff = f.tab_dyoff;
+#pragma unroll 1
+    while (todo) {
+        const int c = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const uint32_t cyx = __builtin_amdgcn_readlane(yx_j, c);
+        const uint32_t clab = __builtin_amdgcn_readlane(lab_j, c);
+        const int cy = (int)(cyx >> 16), cx = (int)(cyx & 0xFFFFu);
+        const uint32_t ux = __builtin_amdgcn_sad_u16((uint32_t)x, (uint32_t)cx, 0u);      // |x - cx|
+        const uint32_t uxc = min(ux, (uint32_t)(S + 1));
+        const uint32_t a0 = __umul24(uxc, nrpad) + (uint32_t)(yw_lo - cy + dyoff);        // element index of row 0
+        const uint32_t idx01 = (uint32_t)c | ((uint32_t)c << 16);
+#pragma unroll
+        for (int q = 0; q < R / 2; ++q) {
+            const us2 sp = (us2){s_tab[a0 + (2 * q) * STRIDE], s_tab[a0 + (2 * q + 1) * STRIDE]};
+            const uint32_t s0 = __builtin_amdgcn_sad_u8(pix[2 * q], clab, 0u);
+            const uint32_t s01 = __builtin_amdgcn_sad_hi_u8(pix[2 * q + 1], clab, s0);
+            const uint32_t t = (s01 << 6) + idx01;
+            const us2 key = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, t), sp);
+            best[q] = __builtin_elementwise_min(best[q], key);
+        }
+    }
+    FSLIC_STAMP(3);
+
+    // 5. write labels (+ fused centroid sums)
+    uint32_t slot[R];
+    {
+        uint32_t kk[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t key = (r & 1) ? (uint32_t)best[r / 2].y : (uint32_t)best[r / 2].x;
+            kk[r] = s_list[key & 63u].z;                            // idx 63 when not found: read, never used
+        }
+        uint16_t* rowp = f.labels + (size_t)yw_lo * W;
+        const uint32_t xo = (uint32_t)x;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool ok = okx && r < nrows;
+            const uint32_t key = (r & 1) ? (uint32_t)best[r / 2].y : (uint32_t)best[r / 2].x;
+            const bool found = key != 0xFFFFu;
+            slot[r] = kNoSlot;
+            if (ok && found) rowp[xo] = (uint16_t)kk[r];
+            if (FUSE && ok) {
+                if (found) slot[r] = key & 63u;
+                else {
+                    const uint32_t old = rowp[xo];     // stale label still takes part in update()
+                    if (old != 0xFFFFu) global_accumulate(f.sums[0], old, (uint32_t)(yw_lo + r * STRIDE), xo, pix[r]);
+                }
+            }
+            rowp += (size_t)STRIDE * W;
+        }
+    }
+    FSLIC_STAMP(4);
+    if (FUSE) {
+        if (!(f.exp_flags & 2)) {
+            bool uni = slot[0] != kNoSlot;
+#pragma unroll
+            for (int r = 1; r < R; ++r) uni = uni && (slot[r] == slot[0]);
+            const uint32_t copy = (uint32_t)lane & (kBlkCopies - 1);
+            if (uni) {   // whole column in one superpixel: one set of LDS atomics for R pixels
+                uint32_t sL = 0, sa = 0, sb = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) { sL += pix[r] & 255u; sa += (pix[r] >> 8) & 255u; sb += (pix[r] >> 16) & 255u; }
+                uint32_t* a = s_acc + (slot[0] * 6) * kBlkCopies + copy;
+                atomicAdd(a + 0 * kBlkCopies, (uint32_t)R);
+                atomicAdd(a + 1 * kBlkCopies, (uint32_t)(R * yw_lo + STRIDE * (R * (R - 1) / 2)));
+                atomicAdd(a + 2 * kBlkCopies, (uint32_t)(R * x));
+                atomicAdd(a + 3 * kBlkCopies, sL);
+                atomicAdd(a + 4 * kBlkCopies, sa);
+                atomicAdd(a + 5 * kBlkCopies, sb);
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (slot[r] != kNoSlot) {
+                        uint32_t* a = s_acc + (slot[r] * 6) * kBlkCopies + copy;
+                        atomicAdd(a + 0 * kBlkCopies, 1u);
+                        atomicAdd(a + 1 * kBlkCopies, (uint32_t)(yw_lo + r * STRIDE));
+                        atomicAdd(a + 2 * kBlkCopies, (uint32_t)x);
+                        atomicAdd(a + 3 * kBlkCopies, pix[r] & 255u);
+                        atomicAdd(a + 4 * kBlkCopies, (pix[r] >> 8) & 255u);
+                        atomicAdd(a + 5 * kBlkCopies, (pix[r] >> 16) & 255u);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // one plain store per (candidate, quantity): entry reserved for (cluster, this block), zeros included
+        for (int i = tid; i < bn * 6; i += 256) {
+            const int c = i / 6;
+            const uint32_t entry = s_list[c].w;
+            if (entry != kNoSlot) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int cpy = 0; cpy < kBlkCopies; ++cpy) v += s_acc[i * kBlkCopies + cpy];
+                f.cpart[(size_t)entry + (uint32_t)(i - c * 6)] = v;
+            }
+        }
+    }
+    FSLIC_STAMP(5);
+    if (f.dbg && lane == 0) {
+        const size_t o = ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kWavesPerBlock + wave) * 8;
+        f.dbg[o + 6] = (unsigned long long)bn;
+        f.dbg[o + 7] = (unsigned long long)bn;
+    }
+#undef FSLIC_STAMP
+}
+
+template <int R, bool FUSE, int STRIDE>
+static void launch_assign_blk_t(const FrameDev& f, int nframes, int rem, int Hv, hipStream_t st) {
+    dim3 grid((f.W + kTileW - 1) / kTileW, (Hv + kWavesPerBlock * R - 1) / (kWavesPerBlock * R), nframes);
+    const size_t lds = (size_t)f.tab_words * sizeof(uint32_t);
+    hipLaunchKernelGGL((k_assign_blk<R, FUSE, STRIDE>), grid, dim3(256), lds, st, f, rem, Hv);
 }
 
 template <int R, bool FUSE, int STRIDE>
@@ -846,23 +1189,41 @@ static void launch_assign_r(const FrameDev& f, int nframes, int rem, int stride,
     }
 }
 
-void launch_assign(const FrameDev& f_, int nframes, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st) {
+PassGeom launch_assign(const FrameDev& f_, int nframes, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st) {
     const FrameDev f = rotated(f_, buf, sbuf);
     const int Hv = (f.H - rem + stride - 1) / stride;
-    if (Hv <= 0) return;
-    if (f.tab_words > 0 && stride >= 1 && stride <= 3) {       // packed 16-bit kernel
+    PassGeom pg;
+    pg.rem = rem; pg.stride = stride; pg.Hv = Hv; pg.BH = kWavesPerBlock * 8; pg.use_slots = 0;
+    if (Hv <= 0) return pg;
+    static const int which = getenv("FSLIC_ASSIGN") ? atoi(getenv("FSLIC_ASSIGN")) : 0;   // 16 / 32: older kernels (A/B timing)
+    if (f.tab_words > 0 && stride >= 1 && stride <= 3 && which == 0) {       // block-level packed kernel
+        if (!fuse_update && stride == 1) {
+            if (assign_rows_per_wave(f, nframes, Hv, false) == 16) launch_assign_blk_t<16, false, 1>(f, nframes, rem, Hv, st);
+            else launch_assign_blk_t<8, false, 1>(f, nframes, rem, Hv, st);
+            return pg;
+        }
+        if (fuse_update) {
+            pg.use_slots = 1;
+            if (stride == 1) launch_assign_blk_t<8, true, 1>(f, nframes, rem, Hv, st);
+            else if (stride == 2) launch_assign_blk_t<8, true, 2>(f, nframes, rem, Hv, st);
+            else launch_assign_blk_t<8, true, 3>(f, nframes, rem, Hv, st);
+            return pg;
+        }
+    }
+    if (f.tab_words > 0 && stride >= 1 && stride <= 3 && which != 32) {       // per-wavefront packed kernel
         const int R = assign_rows_per_wave(f, nframes, Hv, fuse_update);
         if (!fuse_update) {
-            if (stride == 1 && R == 16) { launch_assign16_t<16, false, 1>(f, nframes, rem, Hv, buf, sbuf, st); return; }
-            if (stride == 1) { launch_assign16_t<8, false, 1>(f, nframes, rem, Hv, buf, sbuf, st); return; }
+            if (stride == 1 && R == 16) { launch_assign16_t<16, false, 1>(f, nframes, rem, Hv, buf, sbuf, st); return pg; }
+            if (stride == 1) { launch_assign16_t<8, false, 1>(f, nframes, rem, Hv, buf, sbuf, st); return pg; }
         } else {
-            if (stride == 1) { launch_assign16_t<8, true, 1>(f, nframes, rem, Hv, buf, sbuf, st); return; }
-            if (stride == 2) { launch_assign16_t<8, true, 2>(f, nframes, rem, Hv, buf, sbuf, st); return; }
-            if (stride == 3) { launch_assign16_t<8, true, 3>(f, nframes, rem, Hv, buf, sbuf, st); return; }
+            if (stride == 1) { launch_assign16_t<8, true, 1>(f, nframes, rem, Hv, buf, sbuf, st); return pg; }
+            if (stride == 2) { launch_assign16_t<8, true, 2>(f, nframes, rem, Hv, buf, sbuf, st); return pg; }
+            if (stride == 3) { launch_assign16_t<8, true, 3>(f, nframes, rem, Hv, buf, sbuf, st); return pg; }
         }
     }
     if (assign_rows_per_wave(f, nframes, Hv, fuse_update) == 16) launch_assign_r<16>(f, nframes, rem, stride, Hv, buf, sbuf, fuse_update, st);
     else launch_assign_r<8>(f, nframes, rem, stride, Hv, buf, sbuf, fuse_update, st);
+    return pg;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1221,10 +1582,16 @@ __global__ __launch_bounds__(256) void k_cca_densify(CcaDev c, int32_t* __restri
 //                       redoes the step with std::partial_sort itself.
 // Kept leaders are sorted (bitonic, LDS) and final_lab[leader] = rank, i.e. labels 0,1,2.. in raster order
 // of each component's first pixel (src/cca.cpp:229-237).
-// status word: 0 = done here, 1 = host path required.
+// status word (counters[3]): 0 = done here; 1 = area tie at the cut: the candidates have been written to
+// dense_leader / dense_area SORTED BY LEADER (counters[1] = M), which is the order the reference feeds to
+// std::partial_sort, and the host only has to run that one call; 2 = too many candidates for this block, the
+// host gathers and sorts them itself.
 // ---------------------------------------------------------------------------------------------
 constexpr int kSelCap = 12288;    // candidates the device path holds in LDS (3 x 48 KB)
-__global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int ntiles) {
+constexpr int kSelSortCap = 8192;   // candidates the tie path sorts in LDS (power of two <= kSelCap)
+__global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int ntiles, int32_t* dense_leader, uint32_t* dense_area, int dense_cap) {
+    FrameDev::adv(dense_leader, (size_t)blockIdx.x * c.frame_bytes);
+    FrameDev::adv(dense_area, (size_t)blockIdx.x * c.frame_bytes);
     c.select(blockIdx.x);
     constexpr int TT = kCcaTilePx;
     extern __shared__ uint32_t s_dyn[];
@@ -1252,7 +1619,7 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int ntiles) {
     uint32_t off0 = s_scan[tid] - mine;
     if (tid == 0) { c.counters[2] = M; s_v[3] = 0; }
     if (M > (uint32_t)kSelCap) {
-        if (tid == 0) c.counters[3] = 1u;
+        if (tid == 0) c.counters[3] = 2u;
         return;
     }
     for (int t = tid; t < ntiles; t += 1024) {
@@ -1309,7 +1676,34 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int ntiles) {
         if (eq) atomicAdd(&s_hist[0], eq);
         __syncthreads();
         if (s_hist[0] != kk) {
-            if (tid == 0) c.counters[3] = 1u;
+            // tie at the cut: hand the host the candidates in ascending-leader order (bitonic sort of the pairs)
+            uint32_t P2 = 1;
+            while (P2 < M) P2 <<= 1;
+            if (P2 > (uint32_t)kSelSortCap || M > (uint32_t)dense_cap) {
+                if (tid == 0) c.counters[3] = 2u;
+                return;
+            }
+            __syncthreads();
+            for (uint32_t i = M + tid; i < P2; i += 1024) { s_lead[i] = 0xFFFFFFFFu; s_area[i] = 0u; }
+            __syncthreads();
+            for (uint32_t k2 = 2; k2 <= P2; k2 <<= 1) {
+                for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+                    for (uint32_t i = tid; i < P2; i += 1024) {
+                        const uint32_t ixj = i ^ j;
+                        if (ixj > i) {
+                            const uint32_t a = s_lead[i], b = s_lead[ixj];
+                            const bool up = ((i & k2) == 0);
+                            if ((a > b) == up) {
+                                s_lead[i] = b; s_lead[ixj] = a;
+                                const uint32_t t = s_area[i]; s_area[i] = s_area[ixj]; s_area[ixj] = t;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            for (uint32_t i = tid; i < M; i += 1024) { dense_leader[i] = (int32_t)s_lead[i]; dense_area[i] = s_area[i]; }
+            if (tid == 0) { c.counters[1] = M; c.counters[3] = 1u; }
             return;
         }
     }
@@ -1360,12 +1754,12 @@ void launch_cca_phase1(const CcaDev& c, int nframes, hipStream_t st) {
     hipLaunchKernelGGL(k_cca_collect, dim3(tx * ty, nframes), dim3(256), 0, st, c);
 }
 
-void launch_cca_select(const CcaDev& c, int nframes, hipStream_t st) {
+void launch_cca_select(const CcaDev& c, int nframes, int32_t* dense_leader, uint32_t* dense_area, int dense_cap, hipStream_t st) {
     constexpr int T = kCcaTile;
     const int ntiles = ((c.W + T - 1) / T) * ((c.H + kCcaTileH - 1) / kCcaTileH);
     const size_t lds = 3 * (size_t)kSelCap * sizeof(uint32_t);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cca_select), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_cca_select, dim3(nframes), dim3(1024), lds, st, c, ntiles);
+    hipLaunchKernelGGL(k_cca_select, dim3(nframes), dim3(1024), lds, st, c, ntiles, dense_leader, dense_area, dense_cap);
 }
 
 void launch_cca_densify(const CcaDev& c, int32_t* d_leader, uint32_t* d_area, hipStream_t st) {
