@@ -4,9 +4,13 @@
 One *step* = one pass of fast_slic.Slic.iterate() (max_iter=10, defaults) over one batch of synthetic
 frames per GPU: 8 frames of 1280x720 RGB, K=1600 (BASELINE.json configs[1]; 8 frames/GPU is the sharding of
 configs[3], so --gpus 8 is exactly the 64-frame batch).  Frames and label maps are resident in HBM when the
-timed region starts (torch tensors; the C ABI gets raw device pointers).  One process per GPU, frames are
-independent so there is no data-path collective; torch.distributed (RCCL) carries only the barrier and the
-max-over-ranks of the elapsed time.
+timed region starts (torch tensors; the C ABI gets raw device pointers).  The 8 frames of a step form ONE launch
+group (every kernel covers all 8 frames); consecutive steps alternate between the engine's slots (streams)
+through the asynchronous submit/wait entry points, so the host side of a step (cluster upload and write-back,
+std::partial_sort on a top-K tie) overlaps the kernels of the next one.  Every step starts cold from the grid
+seeding and is complete (labels in HBM, clusters written back on the host) before the timed region ends.
+One process per GPU, frames are independent so there is no data-path collective; torch.distributed (RCCL)
+carries only the barrier and the max-over-ranks of the elapsed time.
 
 Prints ONE JSON line on rank 0.  Extra keys: "roofline" (dominant kernel = the full-assign launch, HIP-event
 timed on its own stream inside the engine), "cpu_baseline" (the unmodified reference, SlicAvx2 + OpenMP, on
@@ -113,27 +117,49 @@ def main():
     wl = WORKLOADS[args.workload]
     H, W, K = wl["H"], wl["W"], wl["K"]
     fpg = args.frames_per_gpu or (8 if args.workload == "720p" else 2)
-    eng = Engine(local_rank, max(1, min(args.slots, fpg)))   # groups of fpg/slots frames, one launch sequence each
+    nslots = max(1, args.slots)
+    eng = Engine(local_rank, nslots)
     params = make_params(10, 10.0, 0.25, 3)
 
     # this rank's shard of the synthetic frame stream: frames are independent, rank r owns seeds r*fpg .. r*fpg+fpg-1
     seeds = batch.weak_shard(fpg, rank)
     frames = [variant("A", H, W, seed=s) for s in seeds]
     d_rgb = [torch.from_numpy(f).cuda() for f in frames]
-    d_lab = [torch.empty((H, W), dtype=torch.int16, device="cuda") for _ in frames]
-    cl0 = []
-    for f in frames:
-        c = np.zeros(K, CLUSTER_DTYPE)
-        B.load_library().fslic_hip_initialize_clusters(H, W, K, f.ctypes.data, c.ctypes.data)
-        cl0.append(c)
-    rgb_ptrs = [t.data_ptr() for t in d_rgb]
-    lab_ptrs = [t.data_ptr() for t in d_lab]
+    cl0 = np.zeros((fpg, K), CLUSTER_DTYPE)
+    for i, f in enumerate(frames):
+        B.load_library().fslic_hip_initialize_clusters(H, W, K, f.ctypes.data, cl0[i].ctypes.data)
+    # per slot: its own output label maps and cluster blocks (a group stays in flight until its slot is reused)
+    d_lab = [[torch.empty((H, W), dtype=torch.int16, device="cuda") for _ in frames] for _ in range(nslots)]
+    cls = [np.zeros((fpg, K), CLUSTER_DTYPE) for _ in range(nslots)]
+    a_rgb = eng.pointer_array([t.data_ptr() for t in d_rgb])
+    a_lab = [eng.pointer_array([t.data_ptr() for t in d_lab[s]]) for s in range(nslots)]
+    a_cls = [eng.pointer_array([cls[s][i].ctypes.data for i in range(fpg)]) for s in range(nslots)]
     torch.cuda.synchronize()
+    fa_ms, tot_ms, grp = [], [], []
+    state = {"n": 0, "pending": [False] * nslots}
+
+    def collect(s):
+        eng.wait_group(s)
+        state["pending"][s] = False
+        g = eng.last_group_frames(s)
+        t, f = eng.last_device_times(s)         # HIP events on the slot's own stream, per group launch
+        tot_ms.append(t / g)
+        fa_ms.append(f)
+        grp.append(g)
 
     def step():
-        cls = [c.copy() for c in cl0]        # every step is a cold iterate() from the grid seeding
-        eng.iterate_batch(rgb_ptrs, cls, lab_ptrs, H, W, params, device_ptrs=True)
-        return cls
+        s = state["n"] % nslots
+        state["n"] += 1
+        if state["pending"][s]:
+            collect(s)
+        np.copyto(cls[s], cl0)                  # every step is a cold iterate() from the grid seeding
+        eng.submit_group(s, a_rgb, a_cls[s], a_lab[s], fpg, H, W, K, params)
+        state["pending"][s] = True
+
+    def drain():
+        for s in range(nslots):
+            if state["pending"][s]:
+                collect(s)
 
     def barrier():
         torch.cuda.synchronize()
@@ -143,18 +169,13 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    fa_ms, tot_ms, grp = [], [], []
+    drain()
+    del fa_ms[:], tot_ms[:], grp[:]
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        for s in range(eng.n_slots):
-            g = eng.last_group_frames(s)
-            if g > 0:
-                t, f = eng.last_device_times(s)     # HIP events on the slot's own stream, per group launch
-                tot_ms.append(t / g)
-                fa_ms.append(f)
-                grp.append(g)
+    drain()                                     # every step of the timed region is complete here
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = batch.max_over_ranks(elapsed, dist, "cuda")

@@ -38,7 +38,8 @@ class Params(C.Structure):
 
 EXPORTS = [
     "fslic_hip_device_count", "fslic_hip_create", "fslic_hip_destroy", "fslic_hip_initialize_clusters",
-    "fslic_hip_iterate", "fslic_hip_iterate_device", "fslic_hip_iterate_batch", "fslic_hip_rgb_to_lab",
+    "fslic_hip_iterate", "fslic_hip_iterate_device", "fslic_hip_iterate_batch", "fslic_hip_submit_group",
+    "fslic_hip_wait_group", "fslic_hip_rgb_to_lab",
     "fslic_hip_enforce_connectivity", "fslic_hip_last_prelabels", "fslic_hip_last_timing_report",
     "fslic_hip_last_device_times", "fslic_hip_last_group_frames", "fslic_hip_last_path", "fslic_hip_last_error", "fslic_hip_version",
 ]
@@ -100,6 +101,8 @@ def load_library():
         lib.fslic_hip_iterate.argtypes = [vp, C.POINTER(Params), i32, i32, i32, vp, vp, vp]
         lib.fslic_hip_iterate_device.argtypes = [vp, i32, C.POINTER(Params), i32, i32, i32, vp, vp, vp]
         lib.fslic_hip_iterate_batch.argtypes = [vp, C.POINTER(Params), i32, i32, i32, i32, vp, vp, vp, i32]
+        lib.fslic_hip_submit_group.argtypes = [vp, i32, C.POINTER(Params), i32, i32, i32, i32, vp, vp, vp]
+        lib.fslic_hip_wait_group.argtypes = [vp, i32]
         lib.fslic_hip_rgb_to_lab.argtypes = [vp, i32, i32, vp, i32, vp]
         lib.fslic_hip_enforce_connectivity.argtypes = [vp, vp, i32, i32, i32, i32]
         lib.fslic_hip_last_prelabels.argtypes = [vp, i32, vp]
@@ -189,6 +192,22 @@ class Engine(object):
         _check(load_library().fslic_hip_iterate_batch(self._h, C.byref(params), H, W, K, n,
                                                       C.cast(a_rgb, C.c_void_p), C.cast(a_cl, C.c_void_p),
                                                       C.cast(a_lab, C.c_void_p), int(bool(device_ptrs))))
+
+    @staticmethod
+    def pointer_array(ptrs):
+        """A C array of pointers (kept alive by the caller) for submit_group / iterate_batch."""
+        PA = C.c_void_p * len(ptrs)
+        return PA(*[C.c_void_p(int(p)) for p in ptrs])
+
+    def submit_group(self, slot, a_rgb, a_clusters, a_labels, n, H, W, K, params):
+        """Enqueue one group of n device-resident frames on `slot` and return immediately (pointer arrays from
+        pointer_array(); the cluster blocks they point to are updated by wait_group)."""
+        _check(load_library().fslic_hip_submit_group(self._h, int(slot), C.byref(params), H, W, K, n,
+                                                     C.cast(a_rgb, C.c_void_p), C.cast(a_clusters, C.c_void_p),
+                                                     C.cast(a_labels, C.c_void_p)))
+
+    def wait_group(self, slot):
+        _check(load_library().fslic_hip_wait_group(self._h, int(slot)))
 
     def last_prelabels(self, H, W, slot=0):
         out = np.empty((H, W), np.uint16)

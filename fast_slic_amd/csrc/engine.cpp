@@ -188,6 +188,7 @@ struct Slot {
     float total_ms = 0, fa_ms = 0, lab_ms = 0, loop_ms = 0, cca_ms = 0;
     int last_path = 0;
     bool have_pre = false;
+    bool pending = false;            // a group submitted with fslic_hip_submit_group has not been waited for yet
     // cached spatial configuration (configure_spatial)
     bool sp_valid = false, sp_tiled_ok = false, sp_manhattan = true, sp_patch_uploaded = false;
     int sp_S = 0, sp_shift = 0, sp_stride = 0;
@@ -917,9 +918,35 @@ int fslic_hip_iterate_device(fslic_engine* e, int slot, const fslic_params* p, i
     if (slot < 0 || slot >= (int)e->slots.size()) return fail(FSLIC_E_INVALID, "slot out of range");
     HIPCHK(hipSetDevice(e->device));
     Slot& s = e->slots[slot];
+    if (s.pending) return fail(FSLIC_E_INVALID, "the slot still owns an unfinished group");
     int rc = group_begin(e, s, p, H, W, K, 1, &d_rgb, &clusters, &d_labels);
     if (rc) return rc;
     rc = group_finish(e, s);
+    if (rc == FSLIC_OK && slot == 0) make_timing_report(e, s);
+    return rc;
+}
+
+int fslic_hip_submit_group(fslic_engine* e, int slot, const fslic_params* p, int H, int W, int K, int n_frames,
+                           const uint8_t* const* d_rgb, fslic_cluster* const* clusters, uint16_t* const* d_labels) {
+    if (!e) return fail(FSLIC_E_INVALID, "engine is NULL");
+    if (slot < 0 || slot >= (int)e->slots.size()) return fail(FSLIC_E_INVALID, "slot out of range");
+    if (n_frames < 1 || n_frames > (int)kMaxGroup || !d_rgb || !clusters || !d_labels) return fail(FSLIC_E_INVALID, "bad group arguments");
+    Slot& s = e->slots[slot];
+    if (s.pending) return fail(FSLIC_E_INVALID, "the slot still owns an unfinished group (call fslic_hip_wait_group first)");
+    HIPCHK(hipSetDevice(e->device));
+    int rc = group_begin(e, s, p, H, W, K, n_frames, d_rgb, clusters, d_labels);
+    if (rc == FSLIC_OK) s.pending = true;
+    return rc;
+}
+
+int fslic_hip_wait_group(fslic_engine* e, int slot) {
+    if (!e) return fail(FSLIC_E_INVALID, "engine is NULL");
+    if (slot < 0 || slot >= (int)e->slots.size()) return fail(FSLIC_E_INVALID, "slot out of range");
+    Slot& s = e->slots[slot];
+    if (!s.pending) return FSLIC_OK;
+    HIPCHK(hipSetDevice(e->device));
+    s.pending = false;
+    int rc = group_finish(e, s);
     if (rc == FSLIC_OK && slot == 0) make_timing_report(e, s);
     return rc;
 }
@@ -949,6 +976,8 @@ int fslic_hip_iterate_batch(fslic_engine* e, const fslic_params* p, int H, int W
     if (rc) return rc;
     for (int i = 0; i < n_frames; i++)
         if (!rgb[i] || !clusters[i] || !labels[i]) return fail(FSLIC_E_INVALID, "NULL pointer argument");
+    for (const Slot& sl : e->slots)
+        if (sl.pending) return fail(FSLIC_E_INVALID, "a slot still owns an unfinished group");
     // Frames are cut into groups of up to group_size; every launch of a group covers all of its frames (frame =
     // last grid dimension).  Groups rotate over the slots (one stream each), so the host-side tail of one group
     // (cluster write-back, rare host top-K) overlaps the kernels of the next.

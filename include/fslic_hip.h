@@ -102,6 +102,15 @@ int fslic_hip_iterate_batch(fslic_engine* e, const fslic_params* p, int H, int W
                             const uint8_t* const* rgb, fslic_cluster* const* clusters,
                             uint16_t* const* labels, int device_ptrs);
 
+/* Asynchronous form for pipelining groups across calls (NEW surface): submit enqueues ONE group of n_frames
+ * (1..16) device-resident frames on `slot` and returns without waiting; wait blocks until that group is complete,
+ * serves its host-side steps and writes the clusters back.  The pointer arrays are copied; clusters[i] and the
+ * device buffers must stay valid until the wait.  With two slots the host work of one group (cluster upload and
+ * write-back, std::partial_sort on a top-K tie) overlaps the kernels of the other. */
+int fslic_hip_submit_group(fslic_engine* e, int slot, const fslic_params* p, int H, int W, int K, int n_frames,
+                           const uint8_t* const* d_rgb, fslic_cluster* const* clusters, uint16_t* const* d_labels);
+int fslic_hip_wait_group(fslic_engine* e, int slot);
+
 /* Stage entry points (used by the parity tests; each mirrors one stage of iterate()). */
 
 /* rgb_to_cielab, src/cielab.h:337-353 (convert != 0) or the raw copy of src/context.cpp:117-127

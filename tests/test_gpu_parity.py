@@ -276,3 +276,37 @@ def test_group_of_eight_frames_in_one_launch_sequence():
                 assert cls[i].tobytes() == exp[i][1].tobytes(), (rep, i)
     finally:
         e.close()
+
+
+def test_async_submit_wait_two_slots_pipeline():
+    # groups submitted alternately on two slots; results must equal the synchronous path / oracle
+    import torch
+    from fast_slic_amd import Engine
+    H, W, K, n = 160, 200, 60, 3
+    frames = [variant("A", H, W, seed=10 + i) for i in range(2 * n)]
+    p = make_params(10, 10.0, 0.25, 3)
+    exp = [orc.slic_iterate(f, orc.initialize_clusters(f, K)) for f in frames]
+    e = Engine(0, 2)
+    try:
+        d_rgb = [torch.from_numpy(f).cuda() for f in frames]
+        d_lab = [torch.empty((H, W), dtype=torch.int16, device="cuda") for _ in frames]
+        cls = np.stack([orc.initialize_clusters(f, K) for f in frames])
+        torch.cuda.synchronize()
+        arrs = []
+        for s in range(2):
+            sl = slice(s * n, (s + 1) * n)
+            a = (e.pointer_array([t.data_ptr() for t in d_rgb[sl]]),
+                 e.pointer_array([cls[i].ctypes.data for i in range(s * n, (s + 1) * n)]),
+                 e.pointer_array([t.data_ptr() for t in d_lab[sl]]))
+            arrs.append(a)
+            e.submit_group(s, a[0], a[1], a[2], n, H, W, K, p)
+        with pytest.raises(ValueError):           # the slot is busy
+            e.submit_group(0, arrs[0][0], arrs[0][1], arrs[0][2], n, H, W, K, p)
+        e.wait_group(1)
+        e.wait_group(0)
+        e.wait_group(0)                           # idempotent
+        for i in range(2 * n):
+            assert np.array_equal(d_lab[i].cpu().numpy().view(np.uint16), exp[i][0]), i
+            assert cls[i].tobytes() == exp[i][1].tobytes(), i
+    finally:
+        e.close()
