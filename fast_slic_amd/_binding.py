@@ -41,7 +41,7 @@ EXPORTS = [
     "fslic_hip_iterate", "fslic_hip_iterate_device", "fslic_hip_iterate_batch", "fslic_hip_submit_group",
     "fslic_hip_wait_group", "fslic_hip_rgb_to_lab",
     "fslic_hip_enforce_connectivity", "fslic_hip_last_prelabels", "fslic_hip_last_timing_report",
-    "fslic_hip_last_device_times", "fslic_hip_last_group_frames", "fslic_hip_last_path", "fslic_hip_last_error", "fslic_hip_version",
+    "fslic_hip_last_device_times", "fslic_hip_set_launch_timing", "fslic_hip_last_assign_loop", "fslic_hip_last_group_frames", "fslic_hip_last_path", "fslic_hip_last_error", "fslic_hip_version",
 ]
 
 _lib = None
@@ -109,6 +109,8 @@ def load_library():
         lib.fslic_hip_last_timing_report.argtypes = [vp]
         lib.fslic_hip_last_timing_report.restype = C.c_char_p
         lib.fslic_hip_last_device_times.argtypes = [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        lib.fslic_hip_set_launch_timing.argtypes = [vp, i32]
+        lib.fslic_hip_last_assign_loop.argtypes = [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int)]
         lib.fslic_hip_last_group_frames.argtypes = [vp, i32]
         lib.fslic_hip_last_path.argtypes = [vp, i32]
         lib.fslic_hip_last_error.restype = C.c_char_p
@@ -221,6 +223,15 @@ class Engine(object):
         t, f = C.c_float(), C.c_float()
         _check(load_library().fslic_hip_last_device_times(self._h, int(slot), C.byref(t), C.byref(f)))
         return t.value, f.value
+
+    def set_launch_timing(self, on):
+        _check(load_library().fslic_hip_set_launch_timing(self._h, int(bool(on))))
+
+    def last_assign_loop(self, slot=0):
+        """(sum of the fused assign launches' durations in ms, pixels they visited, number of launches)."""
+        ms, px, n = C.c_float(), C.c_double(), C.c_int()
+        _check(load_library().fslic_hip_last_assign_loop(self._h, int(slot), C.byref(ms), C.byref(px), C.byref(n)))
+        return ms.value, px.value, n.value
 
     def last_group_frames(self, slot=0):
         return load_library().fslic_hip_last_group_frames(self._h, int(slot))

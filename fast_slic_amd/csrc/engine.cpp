@@ -132,6 +132,12 @@ constexpr size_t kLutMaxWords = 12288;   // 48 KB of LDS for the spatial table a
 struct Slot {
     hipStream_t st = nullptr;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // HIP events bracketing every subsampled assign launch of the loop (the roofline figure of bench.py sums them)
+    static constexpr int kMaxTimedIters = 16;
+    hipEvent_t ev_it[2 * kMaxTimedIters] = {};
+    int n_timed_iters = 0;
+    float assign_loop_ms = 0;        // sum of the fused assign launches' durations of the last group
+    double assign_loop_px = 0;       // pixels those launches visited (all frames of the group)
     // device: one arena = [shared spatial tables][frame 0][frame 1]...; f / c hold frame 0's pointers
     char* arena = nullptr;
     size_t arena_cap = 0;
@@ -143,6 +149,7 @@ struct Slot {
     char* zero_block = nullptr;
     size_t zero_bytes = 0;
     uint32_t* d_misc = nullptr;      // 64 B: ovf_cnt[2], err flag, pad, cca counters[4]
+    uint32_t* d_yx_alt[2] = {nullptr, nullptr};   // the cluster pass's alternating position buffers (frame 0)
     uint8_t* d_rgb_stage = nullptr;
     uint16_t* d_out_stage = nullptr;
     int32_t* d_keep_leader = nullptr;
@@ -202,6 +209,7 @@ struct Slot {
 struct fslic_engine {
     int device = 0;
     int group_size = 8;              // frames per launch group of iterate_batch (FSLIC_GROUP)
+    bool launch_timing = false;      // bracket every subsampled assign launch with HIP events (fslic_hip_set_launch_timing)
     std::vector<Slot> slots;
     uint16_t* d_gamma = nullptr;
     uint16_t* d_labtbl = nullptr;
@@ -228,6 +236,7 @@ void free_slot(Slot& s) {
     if (s.h_cand_leader) hipHostFree(s.h_cand_leader);
     if (s.h_cand_area) hipHostFree(s.h_cand_area);
     for (auto& e : s.ev) if (e) hipEventDestroy(e);
+    for (auto& e : s.ev_it) if (e) hipEventDestroy(e);
     if (s.st) hipStreamDestroy(s.st);
     s = Slot();
 }
@@ -281,7 +290,7 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     const size_t shared_bytes = off;
     off = 0;
     const size_t o_lab = take(N * 4), o_labels = take(N * 2);
-    const size_t o_cl = take((size_t)K * 4 * 6);                     // yx, lab, n, moved, tag, shadow (contiguous)
+    const size_t o_cl = take((size_t)K * 4 * 8);                     // yx, lab, n, moved, tag, shadow, yx', yx'' (contiguous)
     // partial centroid sums of the block kernel: one entry per (cluster, assign block its window can overlap);
     // blocks are 64 px wide and at least 32 visited rows (stride >= 1) tall
     const int nbx = 2 * S / 64 + 2, nby = 2 * S / 32 + 2;
@@ -321,6 +330,8 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     uint32_t* cl = (uint32_t*)(b + o_cl);
     f.cl_yx = cl; f.cl_lab = cl + K; f.cl_n = cl + 2 * (size_t)K; f.cl_moved = cl + 3 * (size_t)K; f.cl_tag = cl + 4 * (size_t)K;
     f.cl_shadow = cl + 5 * (size_t)K;
+    s.d_yx_alt[0] = cl + 6 * (size_t)K; s.d_yx_alt[1] = cl + 7 * (size_t)K;
+    f.cl_yx_out = s.d_yx_alt[0];
     f.cpart = (uint32_t*)(b + o_cpart); f.cpart_ns = nbx * nby; f.nbx = nbx;
     f.sums[0] = (uint32_t*)(b + o_sums); f.sums[1] = (uint32_t*)(b + o_sums1);
     f.cell_cnt[0] = (uint32_t*)(b + o_cc0); f.cell_cnt[1] = (uint32_t*)(b + o_cc1);
@@ -349,6 +360,9 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     s.keyH = H; s.keyW = W; s.keyK = K;
     s.sp_valid = false;    // device copies of the spatial tables live in the arena that was just re-carved
     (void)e;
+    // testing aid: a freshly carved arena normally holds whatever the previous geometry left behind; FSLIC_POISON
+    // makes that worst case deterministic (every byte 0xA5) so that reads of never-written memory show up in tests
+    if (getenv("FSLIC_POISON")) HIPCHK(hipMemsetAsync(s.arena, 0xA5, total, s.st));
     // Bin slots are validated by a generation stamp (ClusterRec::pad == FrameDev::gen, gen >= 1 and strictly
     // increasing per slot), so a freshly carved region must not contain bytes that could pass for a stamp.
     HIPCHK(hipMemset2DAsync(b + o_ci0, frame_bytes, 0, (o_ov0 - o_ci0), (size_t)G, s.st));
@@ -654,12 +668,18 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     HIPCHK(hipMemset2DAsync(s.at(s.zero_block, i0), fb, 0, s.zero_bytes, (size_t)n, s.st));
     HIPCHK(hipMemset2DAsync(f.cl_n, fb, 0, sizeof(uint32_t) * 2 * (size_t)K, (size_t)n, s.st));   // cl_n, cl_moved
 
-    if (timed) HIPCHK(hipEventRecord(s.ev[0], s.st));
+    if (timed) { HIPCHK(hipEventRecord(s.ev[0], s.st)); s.n_timed_iters = 0; s.assign_loop_px = 0; }
     launch_rgb_to_lab(f, n, p->convert_to_lab, e->tables, true, s.st);   // + labels <- 0xFFFF (src/context.cpp:138-145)
     if (timed) HIPCHK(hipEventRecord(s.ev[1], s.st));
     f.gen = ++s.gen_counter;
     PassGeom pg{};
+    // positions: the uploaded centres are in s.f.cl_yx; every cluster pass reads one buffer and writes the other
+    uint32_t* const yx_up = f.cl_yx;
+    uint32_t* const yx_a = yx_up + 6 * (size_t)K;       // this frame's d_yx_alt[0]
+    uint32_t* const yx_b = yx_up + 7 * (size_t)K;       // this frame's d_yx_alt[1]
+    f.cl_yx = yx_up; f.cl_yx_out = yx_a;
     launch_bin_clusters(f, n, 0, 0, 0, pg, s.st);
+    uint32_t* yx_cur = yx_a;
     const int stride = p->subsample_stride;
     int rem = 0;
     f.dbg = nullptr;
@@ -671,15 +691,24 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
             f.dbg = s.d_dbg;
         }
         pg = PassGeom{};
+        const bool tme = timed && e->launch_timing && it < Slot::kMaxTimedIters;
+        if (tme) HIPCHK(hipEventRecord(s.ev_it[2 * it], s.st));
         if (generic) launch_assign_generic(f, n, rem, stride, it & 1, it & 1, true, s.st);
         else pg = launch_assign(f, n, rem, stride, it & 1, it & 1, true, s.st);
+        if (tme) {
+            HIPCHK(hipEventRecord(s.ev_it[2 * it + 1], s.st));
+            s.n_timed_iters = it + 1;
+            s.assign_loop_px += (double)((H - rem + stride - 1) / stride) * W * n;
+        }
         if (f.dbg && dbg_mode == 2) {
             int rc2 = print_phase_stamps(s, "last fused assign");
             if (rc2) return rc2;
             f.dbg = nullptr;
         }
         f.gen = ++s.gen_counter;
+        f.cl_yx = yx_cur; f.cl_yx_out = (yx_cur == yx_a) ? yx_b : yx_a;
         launch_bin_clusters(f, n, 1, (it + 1) & 1, it & 1, pg, s.st);
+        yx_cur = f.cl_yx_out;
         rem = (rem + 1) % stride;
     }
     if (dbg_mode == 1) {
@@ -703,8 +732,10 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     cca_enqueue(s, c, i0, n);
     if (timed) HIPCHK(hipEventRecord(s.ev[4], s.st));
     // cluster state, overflow flag and connectivity status back to the host
-    HIPCHK(hipMemcpy2DAsync(s.h_cl + (size_t)i0 * 4 * K, sizeof(uint32_t) * 4 * (size_t)K, f.cl_yx, fb,
-                            sizeof(uint32_t) * 4 * (size_t)K, (size_t)n, hipMemcpyDeviceToHost, s.st));
+    HIPCHK(hipMemcpy2DAsync(s.h_cl + (size_t)i0 * 4 * K, sizeof(uint32_t) * 4 * (size_t)K, yx_cur, fb,
+                            sizeof(uint32_t) * (size_t)K, (size_t)n, hipMemcpyDeviceToHost, s.st));
+    HIPCHK(hipMemcpy2DAsync(s.h_cl + (size_t)i0 * 4 * K + K, sizeof(uint32_t) * 4 * (size_t)K, yx_up + K, fb,
+                            sizeof(uint32_t) * 3 * (size_t)K, (size_t)n, hipMemcpyDeviceToHost, s.st));
     HIPCHK(hipMemcpy2DAsync(s.h_misc + 16 * (size_t)i0, 64, s.at(s.d_misc, i0), fb, 64, (size_t)n, hipMemcpyDeviceToHost, s.st));
     return FSLIC_OK;
 }
@@ -753,6 +784,12 @@ int group_finish(fslic_engine* e, Slot& s) {
     hipEventElapsedTime(&s.loop_ms, s.ev[1], s.ev[2]);
     hipEventElapsedTime(&s.fa_ms, s.ev[2], s.ev[3]);
     hipEventElapsedTime(&s.cca_ms, s.ev[3], s.ev[4]);
+    s.assign_loop_ms = 0;
+    for (int it = 0; it < s.n_timed_iters; it++) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, s.ev_it[2 * it], s.ev_it[2 * it + 1]);
+        s.assign_loop_ms += ms;
+    }
     const int thres = (int)round((double)(s.S * s.S) * (double)s.p.min_size_factor);
     const double t_ev = now_us();
     int n_host_topk = 0;
@@ -843,6 +880,8 @@ int fslic_hip_create(int device, int n_slots, fslic_engine** out) {
     for (auto& s : e->slots) {
         if (hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) { fslic_hip_destroy(e); return fail(FSLIC_E_HIP, "hipStreamCreate failed"); }
         for (auto& ev : s.ev)
+            if (hipEventCreate(&ev) != hipSuccess) { fslic_hip_destroy(e); return fail(FSLIC_E_HIP, "hipEventCreate failed"); }
+        for (auto& ev : s.ev_it)
             if (hipEventCreate(&ev) != hipSuccess) { fslic_hip_destroy(e); return fail(FSLIC_E_HIP, "hipEventCreate failed"); }
         if (hipMalloc((void**)&s.d_ptrs, sizeof(void*) * 2 * kMaxGroup) != hipSuccess ||
             hipHostMalloc((void**)&s.h_ptrs, sizeof(void*) * 2 * kMaxGroup) != hipSuccess) { fslic_hip_destroy(e); return fail(FSLIC_E_HIP, "pointer table allocation failed"); }
@@ -1108,6 +1147,21 @@ int fslic_hip_last_device_times(fslic_engine* e, int slot, float* total_ms, floa
     if (!e || slot < 0 || slot >= (int)e->slots.size()) return fail(FSLIC_E_INVALID, "bad engine/slot");
     if (total_ms) *total_ms = e->slots[slot].total_ms;
     if (full_assign_ms) *full_assign_ms = e->slots[slot].fa_ms;
+    return FSLIC_OK;
+}
+
+int fslic_hip_set_launch_timing(fslic_engine* e, int on) {
+    if (!e) return fail(FSLIC_E_INVALID, "engine is NULL");
+    e->launch_timing = on != 0;
+    return FSLIC_OK;
+}
+
+int fslic_hip_last_assign_loop(fslic_engine* e, int slot, float* sum_ms, double* visited_px, int* launches) {
+    if (!e || slot < 0 || slot >= (int)e->slots.size()) return fail(FSLIC_E_INVALID, "bad engine/slot");
+    const Slot& s = e->slots[slot];
+    if (sum_ms) *sum_ms = s.assign_loop_ms;
+    if (visited_px) *visited_px = s.assign_loop_px;
+    if (launches) *launches = s.n_timed_iters;
     return FSLIC_OK;
 }
 

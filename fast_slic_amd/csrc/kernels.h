@@ -48,7 +48,9 @@ struct FrameDev {
     uint32_t* lab;       // N, L|a<<8|b<<16
     uint16_t* labels;    // N, pre-connectivity assignment (persists across iterations)
     // cluster state (SoA)
-    uint32_t* cl_yx;     // K
+    uint32_t* cl_yx;     // K  positions the cluster pass READS (pre-update; also the uploaded centres)
+    uint32_t* cl_yx_out; // K  positions the cluster pass WRITES (the two alternate per iteration: a pass may still be
+                         //    reading a neighbour's old position while its owner stores the new one)
     uint32_t* cl_lab;    // K
     uint32_t* cl_tag;    // K  phase << 16 | k of the current centres
     uint32_t* cl_n;      // K  num_members of the last update
@@ -86,7 +88,7 @@ struct FrameDev {
         rgb = rgbs ? rgbs[z] : nullptr;
         const size_t d = (size_t)z * frame_bytes;
         adv(lab, d); adv(labels, d);
-        adv(cl_yx, d); adv(cl_lab, d); adv(cl_tag, d); adv(cl_n, d); adv(cl_moved, d); adv(cl_shadow, d);
+        adv(cl_yx, d); adv(cl_yx_out, d); adv(cl_lab, d); adv(cl_tag, d); adv(cl_n, d); adv(cl_moved, d); adv(cl_shadow, d);
         adv(sums[0], d); adv(sums[1], d); adv(cpart, d);
         adv(cell_cnt[0], d); adv(cell_cnt[1], d); adv(cell_items[0], d); adv(cell_items[1], d);
         adv(ovf_cnt[0], d); adv(ovf_cnt[1], d); adv(ovf_items[0], d); adv(ovf_items[1], d);

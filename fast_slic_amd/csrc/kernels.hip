@@ -159,19 +159,22 @@ static __device__ __forceinline__ void gather_sums(const FrameDev& f, const Pass
     const uint32_t* cp = f.cpart + (size_t)k * f.cpart_ns * 6;
     for (int by = g.by0; by <= g.by1; ++by)
         for (int bx = g.bx0; bx <= g.bx1; ++bx) {
-            const uint32_t* e = cp + ((by - g.by0) * f.nbx + (bx - g.bx0)) * 6;
-#pragma unroll
-            for (int q = 0; q < 6; ++q) out[q] += e[q];
+            const uint2* e = reinterpret_cast<const uint2*>(cp + ((by - g.by0) * f.nbx + (bx - g.bx0)) * 6);   // 24-byte entries
+            const uint2 e0 = e[0], e1 = e[1], e2 = e[2];
+            out[0] += e0.x; out[1] += e0.y; out[2] += e1.x; out[3] += e1.y; out[4] += e2.x; out[5] += e2.y;
         }
 }
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg) {
     f.select(blockIdx.y);
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < f.ncell) f.cell_cnt[1][k] = 0;
-    if (k == 0) *f.ovf_cnt[1] = 0;
-    const bool live = k < f.K;
+    // mode 1: consecutive blocks overlap by one cluster: thread 0 of a block only computes the member count of the
+    // cluster before the block's first one (the shadow test below needs the predecessor's count)
+    const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi < f.ncell) f.cell_cnt[1][gi] = 0;
+    if (gi == 0) *f.ovf_cnt[1] = 0;
+    const int k = MODE == 0 ? gi : (int)(blockIdx.x * (blockDim.x - 1) + threadIdx.x) - 1;
+    const bool live = k >= 0 && k < f.K;
     uint32_t yx = live ? f.cl_yx[k] : 0u;
     int y = (int)(yx >> 16), x = (int)(yx & 0xFFFF);
     uint32_t lab;
@@ -186,20 +189,19 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg) {
         if (!live) return;
         lab = f.lab[(size_t)y * f.W + x] & 0x00FFFFFFu;
         f.cl_lab[k] = lab;
+        f.cl_yx_out[k] = yx;
         shadowed = k > 0 && f.cl_yx[k - 1] == yx;
         f.cl_shadow[k] = shadowed ? 1u : 0u;
     } else {
         // a shadowed cluster is in no candidate list: it received nothing and its cpart entries are stale
         uint32_t s[6] = {0u, 0u, 0u, 0u, 0u, 0u};
         if (live && !(pg.use_slots && f.cl_shadow[k])) gather_sums(f, pg, k, yx, s);
-        // member count of cluster k-1 (needed below): the neighbouring lane's, recomputed at wavefront starts
-        uint32_t n_prev = __shfl_up(s[0], 1);
-        if ((threadIdx.x & 63) == 0 && live && k > 0) {
-            uint32_t sp[6] = {0u, 0u, 0u, 0u, 0u, 0u};
-            if (!(pg.use_slots && f.cl_shadow[k - 1])) gather_sums(f, pg, k - 1, f.cl_yx[k - 1], sp);
-            n_prev = sp[0];
-        }
-        if (!live) return;
+        // member count of cluster k-1 (needed below): the previous thread's
+        __shared__ uint32_t s_n[256];
+        s_n[threadIdx.x] = s[0];
+        __syncthreads();
+        if (!live || threadIdx.x == 0) return;
+        const uint32_t n_prev = s_n[threadIdx.x - 1];
         lab = f.cl_lab[k];
         uint32_t* z0 = f.sums[1] + 6 * (size_t)k;    // the next pass accumulates here (sums[0] is still being read by neighbours)
         const int32_t n = (int32_t)s[0];
@@ -208,17 +210,22 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg) {
             const int32_t h = n / 2;
             y = ((int32_t)s[1] + h) / n;
             x = ((int32_t)s[2] + h) / n;
+            // A centroid of in-image pixels is in the image, so this is a no-op on valid sums.  It only matters for a
+            // frame whose tiled attempt overflowed a candidate list (some partial sums were then never written and
+            // the frame is about to be redone by the generic path): positions must stay addressable meanwhile.
+            y = min(max(y, 0), f.H - 1);
+            x = min(max(x, 0), f.W - 1);
             const int32_t L = ((int32_t)s[3] + h) / n;
             const int32_t a = ((int32_t)s[4] + h) / n;
             const int32_t b = ((int32_t)s[5] + h) / n;
             yx = ((uint32_t)y << 16) | (uint32_t)(x & 0xFFFF);
             lab = (uint32_t)(L & 255) | ((uint32_t)(a & 255) << 8) | ((uint32_t)(b & 255) << 16);
-            f.cl_yx[k] = yx;
             f.cl_lab[k] = lab;
             f.cl_moved[k] = 1;
         } else if (k > 0 && n_prev == 0u) {
             shadowed = f.cl_yx[k - 1] == yx && f.cl_lab[k - 1] == lab;
         }
+        f.cl_yx_out[k] = yx;
         f.cl_shadow[k] = shadowed ? 1u : 0u;
         z0[0] = 0; z0[1] = 0; z0[2] = 0; z0[3] = 0; z0[4] = 0; z0[5] = 0;
     }
@@ -240,10 +247,13 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg) {
 
 void launch_bin_clusters(const FrameDev& f_, int nframes, int mode, int buf, int sbuf, const PassGeom& pg, hipStream_t st) {
     const FrameDev f = rotated(f_, buf, sbuf);
-    const int n = f.K > f.ncell ? f.K : f.ncell;
-    const int blocks = (n + 255) / 256;
-    if (mode == 0) hipLaunchKernelGGL(k_bin_clusters<0>, dim3(blocks, nframes), dim3(256), 0, st, f, pg);
-    else hipLaunchKernelGGL(k_bin_clusters<1>, dim3(blocks, nframes), dim3(256), 0, st, f, pg);
+    if (mode == 0) {
+        const int n = f.K > f.ncell ? f.K : f.ncell;
+        hipLaunchKernelGGL(k_bin_clusters<0>, dim3((n + 255) / 256, nframes), dim3(256), 0, st, f, pg);
+    } else {
+        const int bk = (f.K + 254) / 255, bc = (f.ncell + 255) / 256;    // 255 clusters per block (see the kernel)
+        hipLaunchKernelGGL(k_bin_clusters<1>, dim3(bk > bc ? bk : bc, nframes), dim3(256), 0, st, f, pg);
+    }
 }
 
 // =============================================================================================
@@ -1587,8 +1597,33 @@ __global__ __launch_bounds__(256) void k_cca_densify(CcaDev c, int32_t* __restri
 // std::partial_sort, and the host only has to run that one call; 2 = too many candidates for this block, the
 // host gathers and sorts them itself.
 // ---------------------------------------------------------------------------------------------
-constexpr int kSelCap = 12288;    // candidates the device path holds in LDS (3 x 48 KB)
-constexpr int kSelSortCap = 8192;   // candidates the tie path sorts in LDS (power of two <= kSelCap)
+constexpr int kSelCap = 10240;     // candidates the device path holds in LDS (3 x 40 KB)
+constexpr int kSelSortCap = 8192;  // candidates the tie path sorts in LDS (power of two <= kSelCap)
+constexpr int kSelBuckets = 2048;  // ranking buckets (consecutive raster-index ranges)
+
+// block-wide exclusive scan of one value per thread (1024 threads): wave scans by shuffles, 16 wave totals in LDS
+static __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* s_w, uint32_t& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(inc, off);
+        if (lane >= off) inc += u;
+    }
+    __syncthreads();                 // s_w may still be read from a previous call
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const uint32_t t = s_w[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    total = tot;
+    return base + inc - v;
+}
+
 __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int ntiles, int32_t* dense_leader, uint32_t* dense_area, int dense_cap) {
     FrameDev::adv(dense_leader, (size_t)blockIdx.x * c.frame_bytes);
     FrameDev::adv(dense_area, (size_t)blockIdx.x * c.frame_bytes);
@@ -1598,84 +1633,91 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int ntiles, int32
     uint32_t* const s_area = s_dyn;
     uint32_t* const s_lead = s_dyn + kSelCap;
     uint32_t* const s_key = s_dyn + 2 * kSelCap;
+    uint32_t* const s_bcnt = s_dyn + 3 * kSelCap;
+    uint32_t* const s_bstart = s_bcnt + kSelBuckets;
+    uint32_t* const s_bfill = s_bstart + kSelBuckets;
     __shared__ uint32_t s_hist[256];
-    __shared__ uint32_t s_scan[1024];
-    __shared__ uint32_t s_v[4];     // [1] prefix (a*), [2] kk, [3] n_keep
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_v[8];     // [0] max area, [1] prefix, [2] kk, [3] n_keep, [4] ties
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int K = c.K;
-    // 1. candidates of all tiles -> LDS (offsets by a block-wide exclusive scan of per-thread counts)
+    // 1. candidates of all tiles -> LDS
     uint32_t mine = 0;
     for (int t = tid; t < ntiles; t += 1024) mine += c.tile_ccnt[t];
-    s_scan[tid] = mine;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
-        __syncthreads();
-        s_scan[tid] += v;
-        __syncthreads();
-    }
-    const uint32_t M = s_scan[1023];
-    uint32_t off0 = s_scan[tid] - mine;
-    if (tid == 0) { c.counters[2] = M; s_v[3] = 0; }
+    if (tid < 8) s_v[tid] = 0;
+    uint32_t M;
+    uint32_t off0 = block_excl_scan_1024(mine, s_w, M);
+    if (tid == 0) c.counters[2] = M;
     if (M > (uint32_t)kSelCap) {
         if (tid == 0) c.counters[3] = 2u;
         return;
     }
+    uint32_t amax = 0;
     for (int t = tid; t < ntiles; t += 1024) {
         const uint32_t n = c.tile_ccnt[t];
         for (uint32_t j = 0; j < n; ++j) {
-            s_area[off0 + j] = c.cand_area[(size_t)t * TT + j];
+            const uint32_t a = c.cand_area[(size_t)t * TT + j];
+            s_area[off0 + j] = a;
             s_lead[off0 + j] = (uint32_t)c.cand_leader[(size_t)t * TT + j];
+            amax = max(amax, a);
         }
         off0 += n;
     }
+    if (M > (uint32_t)K) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax = max(amax, (uint32_t)__shfl_xor(amax, off));
+        if (lane == 0 && amax) atomicMax(&s_v[0], amax);
+    }
     __syncthreads();
-    // 2. K-th largest area by an 8-bit radix select over LDS
+    // 2. K-th largest area by an 8-bit radix select over LDS, starting at the top non-zero byte
     uint32_t astar = 0;           // keep iff area >= astar
     if (M > (uint32_t)K) {
+        const uint32_t mx = s_v[0];
+        const int top = mx >= (1u << 24) ? 24 : (mx >= (1u << 16) ? 16 : (mx >= (1u << 8) ? 8 : 0));
         uint32_t prefix = 0, kk = (uint32_t)K;
-        for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int shift = top; shift >= 0; shift -= 8) {
             if (tid < 256) s_hist[tid] = 0;
             __syncthreads();
             for (uint32_t i = tid; i < M; i += 1024) {
                 const uint32_t a = s_area[i];
-                if (shift == 24 || (a >> (shift + 8)) == prefix) atomicAdd(&s_hist[(a >> shift) & 255u], 1u);
+                if (shift == top || (a >> (shift + 8)) == prefix) atomicAdd(&s_hist[(a >> shift) & 255u], 1u);
             }
             __syncthreads();
-            // bin search: largest b with sum(hist[b..255]) >= kk, by an inclusive scan over the reversed histogram
-            {
-                uint32_t v = tid < 256 ? s_hist[255 - tid] : 0u;
-                if (tid < 256) s_scan[tid] = v;
-                __syncthreads();
-                for (int off = 1; off < 256; off <<= 1) {
-                    const uint32_t u = (tid < 256 && tid >= off) ? s_scan[tid - off] : 0u;
-                    __syncthreads();
-                    if (tid < 256) s_scan[tid] += u;
-                    __syncthreads();
+            if (tid < 64) {
+                // lane l owns bins 255-4l .. 252-4l (descending); find the bin where the descending running count reaches kk
+                uint32_t h[4], tot = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { h[q] = s_hist[255 - 4 * lane - q]; tot += h[q]; }
+                uint32_t inc = tot;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t u = __shfl_up(inc, off);
+                    if (lane >= off) inc += u;
                 }
-                if (tid < 256) {
-                    const uint32_t incl = s_scan[tid], excl = incl - v;
-                    if (incl >= kk && excl < kk) {
-                        s_v[1] = (prefix << 8) | (uint32_t)(255 - tid);
-                        s_v[2] = kk - excl;
+                uint32_t run = inc - tot;      // count in bins above this lane's
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (run < kk && run + h[q] >= kk) {
+                        s_v[1] = (prefix << 8) | (uint32_t)(255 - 4 * lane - q);
+                        s_v[2] = kk - run;
                     }
+                    run += h[q];
                 }
             }
             __syncthreads();
             prefix = s_v[1];
             kk = s_v[2];
-            __syncthreads();
         }
         astar = prefix;
         // kk of the components with area == a* are needed; unless that is all of them the choice is libstdc++'s
-        if (tid == 0) s_hist[0] = 0;
-        __syncthreads();
         uint32_t eq = 0;
         for (uint32_t i = tid; i < M; i += 1024) eq += (uint32_t)(s_area[i] == astar);
-        if (eq) atomicAdd(&s_hist[0], eq);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) eq += (uint32_t)__shfl_xor(eq, off);
+        if (lane == 0 && eq) atomicAdd(&s_v[4], eq);
         __syncthreads();
-        if (s_hist[0] != kk) {
+        if (s_v[4] != kk) {
             // tie at the cut: hand the host the candidates in ascending-leader order (bitonic sort of the pairs)
             uint32_t P2 = 1;
             while (P2 < M) P2 <<= 1;
@@ -1683,7 +1725,6 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int ntiles, int32
                 if (tid == 0) c.counters[3] = 2u;
                 return;
             }
-            __syncthreads();
             for (uint32_t i = M + tid; i < P2; i += 1024) { s_lead[i] = 0xFFFFFFFFu; s_area[i] = 0u; }
             __syncthreads();
             for (uint32_t k2 = 2; k2 <= P2; k2 <<= 1) {
@@ -1707,39 +1748,37 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int ntiles, int32
             return;
         }
     }
-    // 3. kept leaders -> s_key (ballot compaction), bitonic sort, labels = rank
-    for (uint32_t i0 = 0; i0 < M; i0 += 1024) {
-        const uint32_t i = i0 + tid;
-        const bool keep = i < M && s_area[i] >= astar;
-        const unsigned long long m = __ballot(keep);
-        if (m) {
-            const int leader = __ffsll((long long)m) - 1;
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(&s_v[3], (uint32_t)__popcll(m));
-            base = __shfl(base, leader);
-            if (keep) s_key[base + __popcll(m & ((1ull << lane) - 1ull))] = s_lead[i];
-        }
+    // 3. rank of every kept leader among the kept leaders (labels 0,1,2.. in raster order of the first pixel,
+    //    src/cca.cpp:229-237): bucket by raster-index range, exclusive scan of the bucket sizes, rank inside the bucket
+    const uint32_t bw = ((uint32_t)c.N + kSelBuckets - 1) / kSelBuckets;
+    for (int i = tid; i < kSelBuckets; i += 1024) { s_bcnt[i] = 0; s_bfill[i] = 0; }
+    __syncthreads();
+    for (uint32_t i = tid; i < M; i += 1024)
+        if (s_area[i] >= astar) atomicAdd(&s_bcnt[s_lead[i] / bw], 1u);
+    __syncthreads();
+    {
+        const uint32_t a = s_bcnt[2 * tid], b = s_bcnt[2 * tid + 1];
+        uint32_t n_keep;
+        const uint32_t ex = block_excl_scan_1024(a + b, s_w, n_keep);
+        s_bstart[2 * tid] = ex;
+        s_bstart[2 * tid + 1] = ex + a;
     }
     __syncthreads();
-    const uint32_t n_keep = s_v[3];
-    uint32_t P2 = 1;
-    while (P2 < n_keep) P2 <<= 1;
-    for (uint32_t i = n_keep + tid; i < P2; i += 1024) s_key[i] = 0xFFFFFFFFu;
-    __syncthreads();
-    for (uint32_t k = 2; k <= P2; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = tid; i < P2; i += 1024) {
-                const uint32_t ixj = i ^ j;
-                if (ixj > i) {
-                    const uint32_t a = s_key[i], b = s_key[ixj];
-                    const bool up = ((i & k) == 0);
-                    if ((a > b) == up) { s_key[i] = b; s_key[ixj] = a; }
-                }
-            }
-            __syncthreads();
+    for (uint32_t i = tid; i < M; i += 1024)
+        if (s_area[i] >= astar) {
+            const uint32_t b = s_lead[i] / bw;
+            s_key[s_bstart[b] + atomicAdd(&s_bfill[b], 1u)] = s_lead[i];
         }
-    }
-    for (uint32_t i = tid; i < n_keep; i += 1024) c.final_lab[s_key[i]] = (uint16_t)i;
+    __syncthreads();
+    for (uint32_t i = tid; i < M; i += 1024)
+        if (s_area[i] >= astar) {
+            const uint32_t me = s_lead[i];
+            const uint32_t b = me / bw;
+            const uint32_t lo = s_bstart[b], hi = lo + s_bcnt[b];
+            uint32_t r = lo;
+            for (uint32_t j = lo; j < hi; ++j) r += (uint32_t)(s_key[j] < me);
+            c.final_lab[me] = (uint16_t)r;
+        }
     if (tid == 0) c.counters[3] = 0u;
 }
 
@@ -1757,7 +1796,7 @@ void launch_cca_phase1(const CcaDev& c, int nframes, hipStream_t st) {
 void launch_cca_select(const CcaDev& c, int nframes, int32_t* dense_leader, uint32_t* dense_area, int dense_cap, hipStream_t st) {
     constexpr int T = kCcaTile;
     const int ntiles = ((c.W + T - 1) / T) * ((c.H + kCcaTileH - 1) / kCcaTileH);
-    const size_t lds = 3 * (size_t)kSelCap * sizeof(uint32_t);
+    const size_t lds = (3 * (size_t)kSelCap + 3 * (size_t)kSelBuckets) * sizeof(uint32_t);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cca_select), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_cca_select, dim3(nframes), dim3(1024), lds, st, c, ntiles, dense_leader, dense_area, dense_cap);
 }

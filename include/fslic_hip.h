@@ -134,6 +134,13 @@ const char* fslic_hip_last_timing_report(fslic_engine* e);
  * the full-assign launch alone (the roofline kernel; it covers every frame of the group).  */
 int fslic_hip_last_device_times(fslic_engine* e, int slot, float* total_ms, float* full_assign_ms);
 
+/* Per-launch timing of the subsampled (fused assign + update) launches: when on, groups submitted afterwards bracket
+ * each of those launches with HIP events on the slot's stream (about 1 us of stream time per launch, hence opt-in).
+ * last_assign_loop: sum of their durations (ms), pixels they visited over all frames, number of launches timed
+ * (0 when the group was submitted with timing off). */
+int fslic_hip_set_launch_timing(fslic_engine* e, int on);
+int fslic_hip_last_assign_loop(fslic_engine* e, int slot, float* sum_ms, double* visited_px, int* launches);
+
 /* Number of frames in the last group on `slot` (1 for iterate / iterate_device). */
 int fslic_hip_last_group_frames(fslic_engine* e, int slot);
 

@@ -12,14 +12,15 @@ if [ "${SKIP_TESTS:-0}" != "1" ]; then
   timeout 1200 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
   tail -5 $OUT/pytest_gpu.log
 fi
-timeout 600 python bench.py ${BENCH_ARGS:-} > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
+timeout 600 python bench.py ${BENCH_ARGS:-} 2> $OUT/bench.err > $OUT/bench.json; echo "bench rc=$?"
 cat $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/prof_bench
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_bench -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/prof_bench.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_bench -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-4k > $OUT/prof_bench.log 2>&1
 echo "rocprof rc=$?"
-find $OUT/prof_bench -name '*kernel_stats*' | head
-f=$(find $OUT/prof_bench -name '*kernel_stats.csv' | head -1)
-[ -n "$f" ] && head -30 "$f"
-# keep the merge-back small: drop the raw trace, keep stats + a trimmed trace
-find $OUT/prof_bench -name '*kernel_trace.csv' -size +20M -delete
+DB=$(find $OUT/prof_bench -name '*_results.db' | head -1)
+if [ -n "$DB" ]; then
+  python $R/scripts/rocpd_stats.py stats $DB $OUT/bench_kernel_stats.csv | head -40
+  python $R/scripts/rocpd_stats.py timeline $DB > $OUT/bench_last_frame_timeline.txt
+fi
+rm -rf $OUT/prof_bench

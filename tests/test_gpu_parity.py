@@ -310,3 +310,21 @@ def test_async_submit_wait_two_slots_pipeline():
             assert cls[i].tobytes() == exp[i][1].tobytes(), i
     finally:
         e.close()
+
+
+def test_poisoned_arena_overflow_redo_and_small_shapes(monkeypatch):
+    # FSLIC_POISON fills every freshly carved arena with 0xA5: anything that reads memory no kernel has written yet
+    # (partial sums of a block that bailed out on a candidate-list overflow, bins, counters) shows up here.
+    # 480x640 K=3000 (S=10) overflows the 64-entry block list and is redone by the generic path.
+    from fast_slic_amd import Engine
+    monkeypatch.setenv("FSLIC_POISON", "1")
+    e = Engine(0, 1)
+    try:
+        for (H, W, K) in [(480, 640, 3000), (96, 128, 24), (300, 420, 96), (64, 64, 1)]:
+            img = variant("A", H, W, seed=4)
+            cl0 = orc.initialize_clusters(img, K)
+            labels, cl, pre, path = run_hip(e, img, cl0)
+            o_labels, o_cl, o_lab, o_pre = orc.slic_iterate(img, cl0, stages=True)
+            assert_same("poison %dx%d K=%d path=%d" % (H, W, K, path), (labels, cl, pre), (o_labels, o_cl, o_pre))
+    finally:
+        e.close()
