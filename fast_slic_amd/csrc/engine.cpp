@@ -126,7 +126,7 @@ bool find_multiplier(int S, float coef, const std::vector<uint16_t>& patch, uint
 }
 
 constexpr int kDenseCap = 8192;          // leader-sorted candidates the select kernel hands over on a tie (== its LDS sort capacity)
-constexpr size_t kTabMaxBytes = 40960;   // LDS budget of the packed kernel's spatial table
+constexpr size_t kTabMaxBytes = 40960;   // LDS budget of the packed kernel's spatial table (row-vector mode: per table)
 constexpr size_t kLutMaxWords = 12288;   // 48 KB of LDS for the spatial table at most
 
 struct Slot {
@@ -154,8 +154,6 @@ struct Slot {
     uint16_t* d_out_stage = nullptr;
     int32_t* d_keep_leader = nullptr;
     uint16_t* d_keep_label = nullptr;
-    int32_t* d_dense_leader = nullptr;
-    uint32_t* d_dense_area = nullptr;
     // per-frame caller pointers of the current group: [0, kMaxGroup) inputs, [kMaxGroup, 2*kMaxGroup) outputs
     void** d_ptrs = nullptr;         // device copy (allocated with the slot)
     void** h_ptrs = nullptr;         // pinned staging
@@ -273,7 +271,7 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     }
     if (!s.h_misc) HIPCHK(hipHostMalloc((void**)&s.h_misc, 64 * kMaxGroup));
     if (!s.h_lut) HIPCHK(hipHostMalloc((void**)&s.h_lut, kLutMaxWords * 4));
-    if (!s.h_tab) HIPCHK(hipHostMalloc((void**)&s.h_tab, kTabMaxBytes));
+    if (!s.h_tab) HIPCHK(hipHostMalloc((void**)&s.h_tab, 2 * kTabMaxBytes));
     if (s.h_patch_cap < P * P) {
         if (s.h_patch) hipHostFree(s.h_patch);
         s.h_patch = nullptr; s.h_patch_cap = 0;
@@ -286,7 +284,7 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_patch = take(P * P * 2);
     const size_t o_lut = take(kLutMaxWords * 4);
-    const size_t o_tab = take(kTabMaxBytes);
+    const size_t o_tab = take(2 * kTabMaxBytes);
     const size_t shared_bytes = off;
     off = 0;
     const size_t o_lab = take(N * 4), o_labels = take(N * 2);
@@ -306,8 +304,7 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     const size_t TT = (size_t)kCcaTilePx;
     const size_t o_parent = take(N * 4), o_area = take(N * 4), o_final = take(N * 2), o_roots = take(ntiles * TT * 4);
     const size_t o_candl = take(ntiles * TT * 4), o_canda = take(ntiles * TT * 4);
-    const size_t o_densel = take(ntiles * TT * 4), o_densea = take(ntiles * TT * 4);
-    const size_t o_tcnt = take(ntiles * 4), o_tccnt = take(ntiles * 4);
+    const size_t o_tcnt = take(ntiles * 4);
     const size_t o_keepl = take((size_t)K * 4), o_keepb = take((size_t)K * 2);
     const size_t o_rgb = take(N * 3), o_out = take(N * 2);
     const size_t frame_bytes = off;
@@ -353,8 +350,7 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     c.final_lab = (uint16_t*)(b + o_final); c.roots = (int32_t*)(b + o_roots);
     c.counters = misc + 4;
     c.cand_leader = (int32_t*)(b + o_candl); c.cand_area = (uint32_t*)(b + o_canda);
-    c.tile_cnt = (uint32_t*)(b + o_tcnt); c.tile_ccnt = (uint32_t*)(b + o_tccnt);
-    s.d_dense_leader = (int32_t*)(b + o_densel); s.d_dense_area = (uint32_t*)(b + o_densea);
+    c.tile_cnt = (uint32_t*)(b + o_tcnt);
     s.d_keep_leader = (int32_t*)(b + o_keepl); s.d_keep_label = (uint16_t*)(b + o_keepb);
     s.d_rgb_stage = (uint8_t*)(b + o_rgb); s.d_out_stage = (uint16_t*)(b + o_out);
     s.keyH = H; s.keyW = W; s.keyK = K;
@@ -434,7 +430,7 @@ CcaDev cca_view(const Slot& s, int i0, const uint16_t* d_in0, size_t in_stride, 
     FrameDev::adv(c.in, (size_t)i0 * in_stride);
     const size_t d = (size_t)i0 * c.frame_bytes;
     FrameDev::adv(c.parent, d); FrameDev::adv(c.area, d); FrameDev::adv(c.final_lab, d); FrameDev::adv(c.roots, d);
-    FrameDev::adv(c.tile_cnt, d); FrameDev::adv(c.tile_ccnt, d); FrameDev::adv(c.counters, d);
+    FrameDev::adv(c.tile_cnt, d); FrameDev::adv(c.counters, d);
     FrameDev::adv(c.cand_leader, d); FrameDev::adv(c.cand_area, d);
     c.outs = reinterpret_cast<uint16_t* const*>(s.d_ptrs + kMaxGroup + i0);
     return c;
@@ -454,8 +450,18 @@ int upload_ptrs(Slot& s, int n, const uint8_t* const* d_rgb, uint16_t* const* d_
 // top-K + ranking, chain, relabel, for frames [i0, i0+n) (c = cca_view(s, i0, ...)).  The select status of every
 // frame ends up in its misc words; cca_finish_group() serves the frames whose status is not 0.
 void cca_enqueue(Slot& s, const CcaDev& c, int i0, int n) {
+    (void)i0;
     launch_cca_phase1(c, n, s.st);
-    launch_cca_select(c, n, s.at(s.d_dense_leader, i0), s.at(s.d_dense_area, i0), kDenseCap, s.st);
+    const bool dbg3 = getenv("FSLIC_DEBUG_TIMING") && atoi(getenv("FSLIC_DEBUG_TIMING")) == 3;
+    if (dbg3 && !s.d_dbg) hipMalloc((void**)&s.d_dbg, sizeof(unsigned long long) * 8 * 65536);
+    launch_cca_select(c, n, s.st, dbg3 ? s.d_dbg : nullptr);
+    if (dbg3) {
+        unsigned long long h[6];
+        hipStreamSynchronize(s.st);
+        hipMemcpy(h, s.d_dbg, sizeof h, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[fslic dbg] select ticks: load %llu  select+ties %llu  buckets+scan %llu  scatter %llu  rank+store %llu\n",
+                h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4]);
+    }
     launch_cca_phase2(c, n, s.st);
 }
 
@@ -475,8 +481,8 @@ int cca_finish_group(Slot& s, int first, int n, const uint16_t* d_in0, size_t in
             const uint32_t* hm = s.h_misc + 16 * (size_t)i;
             if (hm[4 + 3] != 1) continue;
             const uint32_t M = hm[4 + 1];
-            HIPCHK(hipMemcpyAsync(s.h_dense_leader + (size_t)i * kDenseCap, s.at(s.d_dense_leader, i), sizeof(int32_t) * M, hipMemcpyDeviceToHost, s.st));
-            HIPCHK(hipMemcpyAsync(s.h_dense_area + (size_t)i * kDenseCap, s.at(s.d_dense_area, i), sizeof(uint32_t) * M, hipMemcpyDeviceToHost, s.st));
+            HIPCHK(hipMemcpyAsync(s.h_dense_leader + (size_t)i * kDenseCap, s.at(s.c.cand_leader, i), sizeof(int32_t) * M, hipMemcpyDeviceToHost, s.st));
+            HIPCHK(hipMemcpyAsync(s.h_dense_area + (size_t)i * kDenseCap, s.at(s.c.cand_area, i), sizeof(uint32_t) * M, hipMemcpyDeviceToHost, s.st));
         }
         HIPCHK(hipStreamSynchronize(s.st));
         for (int i = first; i < first + n; i++) {
@@ -502,11 +508,8 @@ int cca_finish_group(Slot& s, int first, int n, const uint16_t* d_in0, size_t in
         uint32_t* hm = s.h_misc + 16 * (size_t)i;
         if (hm[4 + 3] != 2) continue;
         const CcaDev c1 = cca_view(s, i, d_in0, in_stride, K, thres);
-        int32_t* d_dl = s.at(s.d_dense_leader, i);
-        uint32_t* d_da = s.at(s.d_dense_area, i);
-        launch_cca_densify(c1, d_dl, d_da, s.st);
-        HIPCHK(hipMemcpyAsync(hm + 4, c1.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s.st));
-        HIPCHK(hipStreamSynchronize(s.st));
+        int32_t* d_dl = s.at(s.c.cand_leader, i);      // dense already (k_cca_collect), unordered
+        uint32_t* d_da = s.at(s.c.cand_area, i);
         const uint32_t M = hm[4 + 1];
         int rc = ensure_cand_capacity(s, std::max<size_t>(M, 1) * 2);
         if (rc) return rc;
@@ -605,8 +608,43 @@ int configure_spatial(Slot& s, int S, const fslic_params* p) {
         }
     }
     if (!have_mc && f.lut_words == 0) tiled_ok = false;        // the 32-bit kernel has neither multiplier nor table
-    f.tab = s.d_tab; f.tab_words = 0; f.tab_nrpad = 0; f.tab_dyoff = 0;
-    if (S >= 8 && max_sp + 765u < 1024u) {
+    f.tab = s.d_tab; f.tab_words = 0; f.tab_nrpad = 0; f.tab_dyoff = 0; f.tab_vmode = 0; f.tab_xout = 0;
+    static const bool no_vtab = getenv("FSLIC_NO_VTAB") != nullptr;     // A/B aid: force the 2-D table
+    // The 2-D table costs (S+2) * (2(S+pad)+1) * 2 bytes of L2 -> LDS traffic per block (26 KB at S = 72); the V table
+    // a few hundred bytes, at the price of walking a candidate twice when its centre row lies inside the
+    // wavefront's rows (frequent when S is small).  Measured: V wins at S = 72 (4K, K = 1600), loses at S = 24.
+    const size_t tab2d_bytes = (size_t)(S + 2) * (2 * (S + std::max(7 * std::min(stride_it, 3), 15)) + 1) * 2;
+    static const int vtab_min = getenv("FSLIC_VTAB_MIN_BYTES") ? atoi(getenv("FSLIC_VTAB_MIN_BYTES")) : 12288;
+    f.tabs = s.d_tab + kTabMaxBytes / 2; f.tabs_words = 0; f.tabs_dyoff = 0;
+    if (manhattan && !no_vtab && tab2d_bytes > (size_t)vtab_min && S >= 8 && max_sp + 765u < 1024u) {
+        // Row-vector V tables (the Manhattan patch depends on |di| + |dj| only): one for the full pass (stride 1, up to
+        // 16 rows per wavefront) and one for the subsampled passes (stride_it, 8 rows per wavefront).
+        const int xout = 2 * S + 1;
+        auto build = [&](int stride, int rows, uint16_t* dst, int& words, int& cc) -> bool {
+            const int pad = (rows - 1) * stride;
+            const int Cc = xout + S + pad;
+            const int tlen = 2 * Cc + 1 + 8 * stride;            // entries that can be addressed: t0 + 8*stride for the upper half
+            if ((size_t)tlen * 16 > kTabMaxBytes) return false;
+            auto V = [&](int t) -> uint16_t {
+                const int d = std::abs(t - Cc);
+                if (d > 2 * S) return 0xFFFFu;
+                const int di = std::min(d, S), dj = d - di;
+                return (uint16_t)(patch[(size_t)(S - di) * Pp + (S + dj)] << 6);
+            };
+            for (int t = 0; t < tlen; t++)
+                for (int k = 0; k < 8; k++) dst[(size_t)t * 8 + k] = V(t + k * stride);
+            words = tlen * 4; cc = Cc;
+            return true;
+        };
+        int w1 = 0, c1 = 0, ws = 0, cs = 0;
+        const int st3 = std::min(stride_it, 3);
+        if (build(1, 16, s.h_tab, w1, c1) && build(st3, 8, s.h_tab + kTabMaxBytes / 2, ws, cs)) {
+            f.tab_words = w1; f.tab_dyoff = c1; f.tab_vmode = 1; f.tab_xout = xout;
+            f.tabs_words = ws; f.tabs_dyoff = cs;
+            tiled_ok = true;
+        }
+    }
+    if (!f.tab_vmode && S >= 8 && max_sp + 765u < 1024u) {
         const int pad = std::max(7 * std::min(stride_it, 3), 15);   // (R-1)*stride of the kernels launch_assign picks
         const int dyoff = S + pad, NR = 2 * dyoff + 1;
         int nrpad = NR;
@@ -625,10 +663,13 @@ int configure_spatial(Slot& s, int S, const fslic_params* p) {
             tiled_ok = true;
         }
     }
+    if (stride_it > 3 && !have_mc && f.lut_words == 0) tiled_ok = false;   // strides the packed kernel does not take need the 32-bit kernel
     f.M = M;
     f.C = Coff;
     if (f.tab_words > 0)
         HIPCHK(hipMemcpyAsync(s.d_tab, s.h_tab, (size_t)f.tab_words * 4, hipMemcpyHostToDevice, s.st));
+    if (f.tabs_words > 0)
+        HIPCHK(hipMemcpyAsync(const_cast<uint16_t*>(f.tabs), s.h_tab + kTabMaxBytes / 2, (size_t)f.tabs_words * 4, hipMemcpyHostToDevice, s.st));
     if (f.lut_words > 0)
         HIPCHK(hipMemcpyAsync(s.d_lut, s.h_lut, (size_t)f.lut_words * 4, hipMemcpyHostToDevice, s.st));
     s.sp_tiled_ok = tiled_ok;

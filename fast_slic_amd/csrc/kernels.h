@@ -75,6 +75,11 @@ struct FrameDev {
     // packed 16-bit kernel: column-major spatial table tab[ux'][dy + tab_dyoff], (patch << 6) or 0xffff
     const uint16_t* tab;       // tab_words * 2 entries (tab_words == 0: packed kernel not applicable)
     int tab_words, tab_nrpad, tab_dyoff;
+    int tab_vmode, tab_xout;   // tab_vmode: `tab` is the row-vector form of the V-shaped 1-D table V[t] = patch(|t - tab_dyoff|) << 6
+                               // (Manhattan patch): 16-byte entry t = V[t + k*stride], k = 0..7; lanes outside the x window use
+                               // |dx| = tab_xout.  `tab` serves the full (stride 1) pass, `tabs` the subsampled passes
+    const uint16_t* tabs;
+    int tabs_words, tabs_dyoff;
     // generic-path tables
     const uint16_t* patch2d;   // (2S+1)^2, src/context.cpp:22-40
 
@@ -117,17 +122,16 @@ struct CcaDev {
     uint16_t* final_lab;  // N (sparse: valid at global roots)
     int32_t* roots;       // ntiles * kCcaTilePx: tile t's tile-local roots at [t*kCcaTilePx, +tile_cnt[t])
     uint32_t* tile_cnt;   // ntiles
-    uint32_t* tile_ccnt;  // ntiles: candidates (global roots with area >= threshold) of tile t
-    uint32_t* counters;   // [1] dense candidate count (host path), [2] M, [3] select status (0 done, 1 host)
-    int32_t* cand_leader; // ntiles * kCcaTilePx, per-tile slices
-    uint32_t* cand_area;  // ntiles * kCcaTilePx
+    uint32_t* counters;   // [1] M = number of candidates (append cursor of k_cca_collect), [2] M again, [3] select status
+    int32_t* cand_leader; // dense candidate list (global roots with area >= threshold): leaders,
+    uint32_t* cand_area;  //   and areas; capacity ntiles * kCcaTilePx >= N.  Unordered unless the select status is 1
 
     __host__ __device__ __forceinline__ void select(int z) {
         out = outs[z];
         FrameDev::adv(in, (size_t)z * in_stride);
         const size_t d = (size_t)z * frame_bytes;
         FrameDev::adv(parent, d); FrameDev::adv(area, d); FrameDev::adv(final_lab, d); FrameDev::adv(roots, d);
-        FrameDev::adv(tile_cnt, d); FrameDev::adv(tile_ccnt, d); FrameDev::adv(counters, d);
+        FrameDev::adv(tile_cnt, d); FrameDev::adv(counters, d);
         FrameDev::adv(cand_leader, d); FrameDev::adv(cand_area, d);
     }
 };
@@ -150,12 +154,11 @@ PassGeom launch_assign(const FrameDev& f, int nframes, int rem, int stride, int 
 void launch_assign_generic(const FrameDev& f, int nframes, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st);
 // connectivity
 void launch_cca_phase1(const CcaDev& c, int nframes, hipStream_t st);   // local CCL, border merge, compress, collect
-// device top-K + ranking; counters[3] = status (see k_cca_select).  dense_* are frame 0's buffers (frame stride =
-// c.frame_bytes) of dense_cap entries each: leader-sorted candidates for the host when the status is 1
-void launch_cca_select(const CcaDev& c, int nframes, int32_t* dense_leader, uint32_t* dense_area, int dense_cap, hipStream_t st);
+// device top-K + ranking; counters[3] = status (see k_cca_select).  On status 1 the candidate arrays are left
+// sorted by leader for the host.  dbg: 6 cycle stamps of block 0 (bring-up aid)
+void launch_cca_select(const CcaDev& c, int nframes, hipStream_t st, unsigned long long* dbg = nullptr);
 void launch_cca_phase2(const CcaDev& c, int nframes, hipStream_t st);   // chain resolution + relabel
-// host top-K path, one frame at a time (the CcaDev passed in is already select()ed to that frame)
-void launch_cca_densify(const CcaDev& c, int32_t* d_leader, uint32_t* d_area, hipStream_t st);
+// host top-K path, one frame at a time (the CcaDev passed in is already advanced to that frame)
 void launch_cca_set_kept(const CcaDev& c, const int32_t* d_leaders, const uint16_t* d_labels, int n, hipStream_t st);
 
 }  // namespace fslic

@@ -899,8 +899,42 @@ __global__ __launch_bounds__(256) void k_assign16(FrameDev f, int rem, int Hv, i
 // =============================================================================================
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 
-template <int R, bool FUSE, int STRIDE>
-__global__ __launch_bounds__(256) void k_assign_blk(FrameDev f, int rem, int Hv) {
+// s_bitreplicate_b64_b32: every bit of the source twice, in order (bit i -> bits 2i, 2i+1)
+static __device__ __forceinline__ unsigned long long sbitrep(uint32_t v) {
+    unsigned long long r;
+    asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(r) : "s"(v));
+    return r;
+}
+// One 32-bit word per pair of rows: 0xffff in the half of every row whose bit is set in `inv` (R bits), each bit
+// replicated 16 times by four rounds of s_bitreplicate (scalar unit only).
+template <int R>
+static __device__ __forceinline__ void row_masks(uint32_t inv, uint32_t (&m)[R / 2]) {
+    static_assert(R == 8 || R == 16, "row masks are built for 8 or 16 rows");
+    const unsigned long long r1 = sbitrep(inv);                 // x2
+    const unsigned long long r2 = sbitrep((uint32_t)r1);        // x4  (R <= 16: 32 significant bits of r1)
+    if (R == 8) {
+        const unsigned long long r3 = sbitrep((uint32_t)r2);    // x8: 64 bits
+        const unsigned long long a = sbitrep((uint32_t)r3), b = sbitrep((uint32_t)(r3 >> 32));
+        m[0] = (uint32_t)a; m[1] = (uint32_t)(a >> 32); m[2] = (uint32_t)b; m[3] = (uint32_t)(b >> 32);
+    } else {
+        const unsigned long long r3a = sbitrep((uint32_t)r2), r3b = sbitrep((uint32_t)(r2 >> 32));   // x8: 128 bits
+        const unsigned long long q0 = sbitrep((uint32_t)r3a), q1 = sbitrep((uint32_t)(r3a >> 32));
+        const unsigned long long q2 = sbitrep((uint32_t)r3b), q3 = sbitrep((uint32_t)(r3b >> 32));
+        m[0] = (uint32_t)q0; m[1] = (uint32_t)(q0 >> 32); m[2] = (uint32_t)q1; m[3] = (uint32_t)(q1 >> 32);
+        m[R / 2 - 4] = (uint32_t)q2; m[R / 2 - 3] = (uint32_t)(q2 >> 32); m[R / 2 - 2] = (uint32_t)q3; m[R / 2 - 1] = (uint32_t)(q3 >> 32);
+    }
+}
+
+// VT (Manhattan patch only): the spatial term is a function of d = |dx| + |dy| alone, so the LDS table derives from the
+// one-dimensional, V-shaped  V[t] = patch(|t - Cc|) << 6  (0xffff beyond 2S) instead of the (S+2) x (2S+2pad+1)
+// column-major patch copy (26 KB at S = 72, re-read by every block).  Row r of a candidate reads V[Cc + dy_r + ux]
+// when dy_r >= 0 and V[Cc + dy_r - ux] when dy_r < 0: either way the index advances with the row, so the rows are
+// still fixed offsets from ONE per-lane base as long as they lie on one side of the centre; a candidate whose centre
+// row lies inside the wavefront's rows is walked twice (rows above, rows below).  Lanes outside the x window use
+// ux = 2S+1, which lands beyond 2S for every row; rows outside the y window are switched off by a per-pair scalar
+// mask OR-ed in together with idx (v_lshl_or_b32: no extra VALU).
+template <int R, bool FUSE, int STRIDE, bool VT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_assign_blk(FrameDev f, int rem, int Hv) {
     extern __shared__ uint32_t s_dyn[];                  // spatial table (u16), f.tab_words dwords
     const uint16_t* const s_tab = reinterpret_cast<const uint16_t*>(s_dyn);
     __shared__ uint32_t s_braw[3 * 64];
@@ -1049,6 +1083,8 @@ __global__ __launch_bounds__(256) void k_assign_blk(FrameDev f, int rem, int Hv)
     {
         const int cyj = (int)(yx_j >> 16);
         todo = __ballot(lane < bn && nrows > 0 && cyj + S >= yw_lo && cyj - S <= yw_hi);
+        if (f.exp_flags & 4) todo = 0;        // timing experiment: no argmin
+        if (f.exp_flags & 8) todo &= 1ull;    // timing experiment: one candidate
     }
     FSLIC_STAMP(2);
 
@@ -1058,6 +1094,72 @@ __global__ __launch_bounds__(256) void k_assign_blk(FrameDev f, int rem, int Hv)
     for (int q = 0; q < R / 2; ++q) best[q] = (us2){0xFFFF, 0xFFFF};
     const uint32_t nrpad = (uint32_t)f.tab_nrpad;
     const int dyoff = f.tab_dyoff;
+    if (VT) {
+        const int Cc = f.tab_dyoff;                 // centre index of the V table
+        const uint32_t xout = (uint32_t)f.tab_xout;
+        constexpr int BIAS = 32768;                 // makes the numerators of the row-range divisions positive
+        constexpr uint32_t full = (1u << R) - 1u;
+        // Per-candidate row ranges, computed ONCE in the vector unit with lane j = candidate j (the scalar unit is
+        // shared by the whole CU and issues about as many instructions per clock as the four SIMDs together).
+        //   rows r with dy_r = dy0 + r*STRIDE: above the centre r < rs, inside the window ra <= r <= rb
+        uint32_t vab_j;                             // rows above (low half) | rows at/below (high half) that are in the window
+        {
+            const int dy0 = yw_lo - (int)(yx_j >> 16);
+            const int rs = min(max((-dy0 + STRIDE * BIAS + STRIDE - 1) / STRIDE - BIAS, 0), R);
+            const int ra = min(max((-S - dy0 + STRIDE * BIAS + STRIDE - 1) / STRIDE - BIAS, 0), R);
+            const int rb = min(max((S - dy0 + STRIDE * BIAS) / STRIDE - BIAS, -1), R - 1);
+            const uint32_t upto_rs = (1u << rs) - 1u;
+            const uint32_t in_win = rb < 0 ? 0u : (((2u << rb) - 1u) & ~((1u << ra) - 1u) & full);
+            vab_j = (in_win & upto_rs) | ((in_win & ~upto_rs) << 16);
+        }
+        // row-vector table: entry t = (V[t], V[t+STRIDE], .. V[t+7*STRIDE]) as one 16-byte word, so the spatial terms of
+        // eight rows are ONE 16-byte-ALIGNED ds_read_b128 (a 2-byte-aligned b128 read costs 64 clk of the CU's LDS pipe
+        // instead of 8, scripts/microbench/lds_unaligned.hip)
+        const uint4* const s_rv = reinterpret_cast<const uint4*>(s_dyn);
+        auto pass = [&](uint32_t clab, uint32_t base, uint32_t idx01, const uint32_t* mq) {
+            uint32_t spw[R / 2];
+            {
+                const uint4 e0 = s_rv[base];
+                spw[0] = e0.x; spw[1] = e0.y; spw[2] = e0.z; spw[3] = e0.w;
+                if (R == 16) {
+                    const uint4 e1 = s_rv[base + 8 * STRIDE];
+                    spw[R / 2 - 4] = e1.x; spw[R / 2 - 3] = e1.y; spw[R / 2 - 2] = e1.z; spw[R / 2 - 1] = e1.w;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < R / 2; ++q) {
+                const us2 sp = __builtin_bit_cast(us2, spw[q]);
+                const uint32_t s0 = __builtin_amdgcn_sad_u8(pix[2 * q], clab, 0u);
+                const uint32_t s01 = __builtin_amdgcn_sad_hi_u8(pix[2 * q + 1], clab, s0);
+                const uint32_t t = (s01 << 6) | (mq ? (mq[q] | idx01) : idx01);                // v_lshl_or_b32, scalar 3rd operand
+                const us2 key = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, t), sp);
+                best[q] = __builtin_elementwise_min(best[q], key);
+            }
+        };
+#pragma unroll 1
+        while (todo) {
+            const int c = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const uint32_t cyx = __builtin_amdgcn_readlane(yx_j, c);
+            const uint32_t clab = __builtin_amdgcn_readlane(lab_j, c);
+            const uint32_t vab = __builtin_amdgcn_readlane(vab_j, c);
+            const int cy = (int)(cyx >> 16), cx = (int)(cyx & 0xFFFFu);
+            const uint32_t ux = __builtin_amdgcn_sad_u16((uint32_t)x, (uint32_t)cx, 0u);      // |x - cx|
+            const uint32_t uxc = ux <= (uint32_t)S ? ux : xout;
+            const uint32_t k0 = (uint32_t)(Cc + yw_lo - cy);                                   // wave-uniform
+            const uint32_t idx01 = (uint32_t)c | ((uint32_t)c << 16);
+            if (vab == (full << 16)) {                    // every row at/below the centre and inside the window
+                pass(clab, k0 + uxc, idx01, nullptr);
+            } else if (vab == full) {                     // every row above the centre and inside the window
+                pass(clab, k0 - uxc, idx01, nullptr);
+            } else {                                      // window edge and / or centre row inside this wavefront's rows
+                const uint32_t va = vab & 0xFFFFu, vb = vab >> 16;
+                uint32_t mq[R / 2];
+                if (va) { row_masks<R>(~va & full, mq); pass(clab, k0 - uxc, idx01, mq); }
+                if (vb) { row_masks<R>(~vb & full, mq); pass(clab, k0 + uxc, idx01, mq); }
+            }
+        }
+    } else {
 #pragma unroll 1
     while (todo) {
         const int c = __builtin_ctzll(todo);
@@ -1078,6 +1180,7 @@ __global__ __launch_bounds__(256) void k_assign_blk(FrameDev f, int rem, int Hv)
             const us2 key = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, t), sp);
             best[q] = __builtin_elementwise_min(best[q], key);
         }
+    }
     }
     FSLIC_STAMP(3);
 
@@ -1165,10 +1268,13 @@ __global__ __launch_bounds__(256) void k_assign_blk(FrameDev f, int rem, int Hv)
 }
 
 template <int R, bool FUSE, int STRIDE>
-static void launch_assign_blk_t(const FrameDev& f, int nframes, int rem, int Hv, hipStream_t st) {
+static void launch_assign_blk_t(const FrameDev& f_, int nframes, int rem, int Hv, hipStream_t st) {
+    FrameDev f = f_;
+    if (f.tab_vmode && FUSE) { f.tab = f.tabs; f.tab_words = f.tabs_words; f.tab_dyoff = f.tabs_dyoff; }   // row vectors of the subsampled stride
     dim3 grid((f.W + kTileW - 1) / kTileW, (Hv + kWavesPerBlock * R - 1) / (kWavesPerBlock * R), nframes);
     const size_t lds = (size_t)f.tab_words * sizeof(uint32_t);
-    hipLaunchKernelGGL((k_assign_blk<R, FUSE, STRIDE>), grid, dim3(256), lds, st, f, rem, Hv);
+    if (f.tab_vmode) hipLaunchKernelGGL((k_assign_blk<R, FUSE, STRIDE, true>), grid, dim3(256), lds, st, f, rem, Hv);
+    else hipLaunchKernelGGL((k_assign_blk<R, FUSE, STRIDE, false>), grid, dim3(256), lds, st, f, rem, Hv);
 }
 
 template <int R, bool FUSE, int STRIDE>
@@ -1541,45 +1647,49 @@ __global__ __launch_bounds__(256) void k_cca_compress(CcaDev c) {
     }
 }
 
-// Global roots: reset their final label; those with area >= threshold (src/cca.cpp:213-217) become
-// candidates in this tile's candidate slice (no global atomic).
+// Global roots: reset their final label; those with area >= threshold (src/cca.cpp:213-217) become candidates,
+// appended to the frame's dense candidate arrays (one returning atomic per tile on counters[1], which ends up as M).
 __global__ __launch_bounds__(256) void k_cca_collect(CcaDev c) {
     c.select(blockIdx.y);
     constexpr int TT = kCcaTilePx;
-    __shared__ uint32_t s_n;
+    __shared__ uint32_t s_n, s_base;
+    __shared__ int32_t s_cl[256];
+    __shared__ uint32_t s_ca[256];
     const int tile = blockIdx.x;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
     const uint32_t n = c.tile_cnt[tile];
     const int32_t* __restrict__ my_roots = c.roots + (size_t)tile * TT;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const int32_t r = my_roots[i];
-        if (c.parent[r] != r) continue;
-        c.final_lab[r] = 0xFFFFu;
-        const uint32_t a = c.area[r];
-        if ((int64_t)a >= (int64_t)c.min_threshold) {
-            const uint32_t pos = atomicAdd(&s_n, 1u);
-            c.cand_leader[(size_t)tile * TT + pos] = r;
-            c.cand_area[(size_t)tile * TT + pos] = a;
+    for (uint32_t i0 = 0; i0 < n; i0 += blockDim.x) {
+        const uint32_t i = i0 + threadIdx.x;
+        bool cand = false;
+        int32_t r = 0;
+        uint32_t a = 0;
+        if (i < n) {
+            r = my_roots[i];
+            if (c.parent[r] == r) {
+                c.final_lab[r] = 0xFFFFu;
+                a = c.area[r];
+                cand = (int64_t)a >= (int64_t)c.min_threshold;
+            }
         }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) c.tile_ccnt[tile] = s_n;
-}
-
-// Dense candidate list for the host top-K path (rare: area tie at the cut, or more kept components than the
-// device path sorts).  counters[1] = M.
-__global__ __launch_bounds__(256) void k_cca_densify(CcaDev c, int32_t* __restrict__ out_leader, uint32_t* __restrict__ out_area) {
-    constexpr int TT = kCcaTilePx;
-    __shared__ uint32_t s_base;
-    const int tile = blockIdx.x;
-    const uint32_t n = c.tile_ccnt[tile];
-    if (n == 0) return;
-    if (threadIdx.x == 0) s_base = atomicAdd(&c.counters[1], n);
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        out_leader[s_base + i] = c.cand_leader[(size_t)tile * TT + i];
-        out_area[s_base + i] = c.cand_area[(size_t)tile * TT + i];
+        if (cand) {
+            const uint32_t pos = atomicAdd(&s_n, 1u);
+            s_cl[pos] = r; s_ca[pos] = a;
+        }
+        __syncthreads();
+        const uint32_t m = s_n;
+        if (m) {
+            if (threadIdx.x == 0) s_base = atomicAdd(&c.counters[1], m);
+            __syncthreads();
+            if (threadIdx.x < m) {
+                c.cand_leader[s_base + threadIdx.x] = s_cl[threadIdx.x];
+                c.cand_area[s_base + threadIdx.x] = s_ca[threadIdx.x];
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) s_n = 0;
+            __syncthreads();
+        }
     }
 }
 
@@ -1600,6 +1710,7 @@ __global__ __launch_bounds__(256) void k_cca_densify(CcaDev c, int32_t* __restri
 constexpr int kSelCap = 10240;     // candidates the device path holds in LDS (3 x 40 KB)
 constexpr int kSelSortCap = 8192;  // candidates the tie path sorts in LDS (power of two <= kSelCap)
 constexpr int kSelBuckets = 2048;  // ranking buckets (consecutive raster-index ranges)
+constexpr int kSelBins = 4096;     // histogram bins of the selection
 
 // block-wide exclusive scan of one value per thread (1024 threads): wave scans by shuffles, 16 wave totals in LDS
 static __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* s_w, uint32_t& total) {
@@ -1624,90 +1735,90 @@ static __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint
     return base + inc - v;
 }
 
-__global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int ntiles, int32_t* dense_leader, uint32_t* dense_area, int dense_cap) {
-    FrameDev::adv(dense_leader, (size_t)blockIdx.x * c.frame_bytes);
-    FrameDev::adv(dense_area, (size_t)blockIdx.x * c.frame_bytes);
+// K-th largest of s_area[0..M) restricted to values v with (v >> (sh + 12)) == prefix (all values when first):
+// histogram of (v >> sh) & 4095 (areas spread over many bins: few same-address LDS atomics), descending scan.
+// Returns through s_v[1] the bin holding the kk-th largest, through s_v[2] the rank left inside that bin.
+static __device__ __forceinline__ void select_pass(const uint32_t* s_area, uint32_t M, int sh, bool first, uint32_t prefix,
+                                                   uint32_t kk, uint32_t* s_hist, uint32_t* s_w, uint32_t* s_v) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < kSelBins; i += 1024) s_hist[i] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < M; i += 1024) {
+        const uint32_t a = s_area[i];
+        if (first || (a >> (sh + 12)) == prefix) atomicAdd(&s_hist[(a >> sh) & (kSelBins - 1)], 1u);
+    }
+    __syncthreads();
+    // thread t owns bins 4095-4t .. 4092-4t (descending order)
+    uint32_t h[4], tot = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { h[q] = s_hist[kSelBins - 1 - 4 * tid - q]; tot += h[q]; }
+    uint32_t total;
+    uint32_t run = block_excl_scan_1024(tot, s_w, total);    // count in bins above this thread's
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (run < kk && run + h[q] >= kk) {
+            s_v[1] = (uint32_t)(kSelBins - 1 - 4 * tid - q);
+            s_v[2] = kk - run;
+        }
+        run += h[q];
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, unsigned long long* dbg) {
+#define SEL_STAMP(i_) do { if (dbg && threadIdx.x == 0 && blockIdx.x == 0) dbg[i_] = __builtin_readcyclecounter(); } while (0)
+    SEL_STAMP(0);
     c.select(blockIdx.x);
-    constexpr int TT = kCcaTilePx;
     extern __shared__ uint32_t s_dyn[];
     uint32_t* const s_area = s_dyn;
     uint32_t* const s_lead = s_dyn + kSelCap;
     uint32_t* const s_key = s_dyn + 2 * kSelCap;
-    uint32_t* const s_bcnt = s_dyn + 3 * kSelCap;
+    uint32_t* const s_bcnt = s_dyn + 3 * kSelCap;       // ranking buckets; the selection's histogram lives here first
     uint32_t* const s_bstart = s_bcnt + kSelBuckets;
     uint32_t* const s_bfill = s_bstart + kSelBuckets;
-    __shared__ uint32_t s_hist[256];
+    uint32_t* const s_hist = s_bcnt;                    // kSelBins <= 3 * kSelBuckets words
     __shared__ uint32_t s_w[16];
-    __shared__ uint32_t s_v[8];     // [0] max area, [1] prefix, [2] kk, [3] n_keep, [4] ties
+    __shared__ uint32_t s_v[8];     // [0] max area, [1] bin, [2] kk, [4] ties
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int K = c.K;
-    // 1. candidates of all tiles -> LDS
-    uint32_t mine = 0;
-    for (int t = tid; t < ntiles; t += 1024) mine += c.tile_ccnt[t];
+    // 1. the frame's candidates -> LDS
+    const uint32_t M = c.counters[1];
     if (tid < 8) s_v[tid] = 0;
-    uint32_t M;
-    uint32_t off0 = block_excl_scan_1024(mine, s_w, M);
     if (tid == 0) c.counters[2] = M;
     if (M > (uint32_t)kSelCap) {
         if (tid == 0) c.counters[3] = 2u;
         return;
     }
     uint32_t amax = 0;
-    for (int t = tid; t < ntiles; t += 1024) {
-        const uint32_t n = c.tile_ccnt[t];
-        for (uint32_t j = 0; j < n; ++j) {
-            const uint32_t a = c.cand_area[(size_t)t * TT + j];
-            s_area[off0 + j] = a;
-            s_lead[off0 + j] = (uint32_t)c.cand_leader[(size_t)t * TT + j];
-            amax = max(amax, a);
-        }
-        off0 += n;
+    for (uint32_t i = tid; i < M; i += 1024) {
+        const uint32_t a = c.cand_area[i];
+        s_area[i] = a;
+        s_lead[i] = (uint32_t)c.cand_leader[i];
+        amax = max(amax, a);
     }
+    __syncthreads();
     if (M > (uint32_t)K) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) amax = max(amax, (uint32_t)__shfl_xor(amax, off));
         if (lane == 0 && amax) atomicMax(&s_v[0], amax);
+        __syncthreads();
     }
-    __syncthreads();
-    // 2. K-th largest area by an 8-bit radix select over LDS, starting at the top non-zero byte
+    SEL_STAMP(1);
+    // 2. K-th largest area: 12 bits per pass, starting just above the top bit of the largest area
     uint32_t astar = 0;           // keep iff area >= astar
     if (M > (uint32_t)K) {
         const uint32_t mx = s_v[0];
-        const int top = mx >= (1u << 24) ? 24 : (mx >= (1u << 16) ? 16 : (mx >= (1u << 8) ? 8 : 0));
+        int sh = 0;
+        while ((mx >> sh) >= (uint32_t)kSelBins) sh += 12;
         uint32_t prefix = 0, kk = (uint32_t)K;
-        for (int shift = top; shift >= 0; shift -= 8) {
-            if (tid < 256) s_hist[tid] = 0;
-            __syncthreads();
-            for (uint32_t i = tid; i < M; i += 1024) {
-                const uint32_t a = s_area[i];
-                if (shift == top || (a >> (shift + 8)) == prefix) atomicAdd(&s_hist[(a >> shift) & 255u], 1u);
-            }
-            __syncthreads();
-            if (tid < 64) {
-                // lane l owns bins 255-4l .. 252-4l (descending); find the bin where the descending running count reaches kk
-                uint32_t h[4], tot = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { h[q] = s_hist[255 - 4 * lane - q]; tot += h[q]; }
-                uint32_t inc = tot;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const uint32_t u = __shfl_up(inc, off);
-                    if (lane >= off) inc += u;
-                }
-                uint32_t run = inc - tot;      // count in bins above this lane's
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (run < kk && run + h[q] >= kk) {
-                        s_v[1] = (prefix << 8) | (uint32_t)(255 - 4 * lane - q);
-                        s_v[2] = kk - run;
-                    }
-                    run += h[q];
-                }
-            }
-            __syncthreads();
-            prefix = s_v[1];
+        bool first = true;
+        for (; sh >= 0; sh -= 12) {
+            select_pass(s_area, M, sh, first, prefix, kk, s_hist, s_w, s_v);
+            prefix = (prefix << 12) | s_v[1];
             kk = s_v[2];
+            first = false;
+            __syncthreads();
         }
         astar = prefix;
         // kk of the components with area == a* are needed; unless that is all of them the choice is libstdc++'s
@@ -1721,7 +1832,7 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int ntiles, int32
             // tie at the cut: hand the host the candidates in ascending-leader order (bitonic sort of the pairs)
             uint32_t P2 = 1;
             while (P2 < M) P2 <<= 1;
-            if (P2 > (uint32_t)kSelSortCap || M > (uint32_t)dense_cap) {
+            if (P2 > (uint32_t)kSelSortCap) {
                 if (tid == 0) c.counters[3] = 2u;
                 return;
             }
@@ -1743,18 +1854,20 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int ntiles, int32
                     __syncthreads();
                 }
             }
-            for (uint32_t i = tid; i < M; i += 1024) { dense_leader[i] = (int32_t)s_lead[i]; dense_area[i] = s_area[i]; }
-            if (tid == 0) { c.counters[1] = M; c.counters[3] = 1u; }
+            for (uint32_t i = tid; i < M; i += 1024) { c.cand_leader[i] = (int32_t)s_lead[i]; c.cand_area[i] = s_area[i]; }
+            if (tid == 0) c.counters[3] = 1u;
             return;
         }
     }
+    SEL_STAMP(2);
     // 3. rank of every kept leader among the kept leaders (labels 0,1,2.. in raster order of the first pixel,
     //    src/cca.cpp:229-237): bucket by raster-index range, exclusive scan of the bucket sizes, rank inside the bucket
-    const uint32_t bw = ((uint32_t)c.N + kSelBuckets - 1) / kSelBuckets;
-    for (int i = tid; i < kSelBuckets; i += 1024) { s_bcnt[i] = 0; s_bfill[i] = 0; }
+    int bsh = 0;
+    while ((((uint32_t)c.N - 1u) >> bsh) >= (uint32_t)kSelBuckets) bsh++;
+    for (int i = tid; i < 3 * kSelBuckets; i += 1024) s_bcnt[i] = 0;     // bcnt, bstart, bfill (the histogram is dead)
     __syncthreads();
     for (uint32_t i = tid; i < M; i += 1024)
-        if (s_area[i] >= astar) atomicAdd(&s_bcnt[s_lead[i] / bw], 1u);
+        if (s_area[i] >= astar) atomicAdd(&s_bcnt[s_lead[i] >> bsh], 1u);
     __syncthreads();
     {
         const uint32_t a = s_bcnt[2 * tid], b = s_bcnt[2 * tid + 1];
@@ -1764,22 +1877,26 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int ntiles, int32
         s_bstart[2 * tid + 1] = ex + a;
     }
     __syncthreads();
+    SEL_STAMP(3);
     for (uint32_t i = tid; i < M; i += 1024)
         if (s_area[i] >= astar) {
-            const uint32_t b = s_lead[i] / bw;
+            const uint32_t b = s_lead[i] >> bsh;
             s_key[s_bstart[b] + atomicAdd(&s_bfill[b], 1u)] = s_lead[i];
         }
     __syncthreads();
+    SEL_STAMP(4);
     for (uint32_t i = tid; i < M; i += 1024)
         if (s_area[i] >= astar) {
             const uint32_t me = s_lead[i];
-            const uint32_t b = me / bw;
+            const uint32_t b = me >> bsh;
             const uint32_t lo = s_bstart[b], hi = lo + s_bcnt[b];
             uint32_t r = lo;
             for (uint32_t j = lo; j < hi; ++j) r += (uint32_t)(s_key[j] < me);
             c.final_lab[me] = (uint16_t)r;
         }
     if (tid == 0) c.counters[3] = 0u;
+    SEL_STAMP(5);
+#undef SEL_STAMP
 }
 
 void launch_cca_phase1(const CcaDev& c, int nframes, hipStream_t st) {
@@ -1793,18 +1910,11 @@ void launch_cca_phase1(const CcaDev& c, int nframes, hipStream_t st) {
     hipLaunchKernelGGL(k_cca_collect, dim3(tx * ty, nframes), dim3(256), 0, st, c);
 }
 
-void launch_cca_select(const CcaDev& c, int nframes, int32_t* dense_leader, uint32_t* dense_area, int dense_cap, hipStream_t st) {
-    constexpr int T = kCcaTile;
-    const int ntiles = ((c.W + T - 1) / T) * ((c.H + kCcaTileH - 1) / kCcaTileH);
+void launch_cca_select(const CcaDev& c, int nframes, hipStream_t st, unsigned long long* dbg) {
     const size_t lds = (3 * (size_t)kSelCap + 3 * (size_t)kSelBuckets) * sizeof(uint32_t);
+    static_assert(kSelBins <= 3 * kSelBuckets, "the selection histogram reuses the ranking buckets");
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cca_select), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_cca_select, dim3(nframes), dim3(1024), lds, st, c, ntiles, dense_leader, dense_area, dense_cap);
-}
-
-void launch_cca_densify(const CcaDev& c, int32_t* d_leader, uint32_t* d_area, hipStream_t st) {
-    constexpr int T = kCcaTile;
-    const int ntiles = ((c.W + T - 1) / T) * ((c.H + kCcaTileH - 1) / kCcaTileH);
-    hipLaunchKernelGGL(k_cca_densify, dim3(ntiles), dim3(256), 0, st, c, d_leader, d_area);
+    hipLaunchKernelGGL(k_cca_select, dim3(nframes), dim3(1024), lds, st, c, dbg);
 }
 
 // Host path only: forget what the device select / chain wrote, then set the host's choice.
