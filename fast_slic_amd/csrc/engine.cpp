@@ -645,21 +645,33 @@ int configure_spatial(Slot& s, int S, const fslic_params* p) {
         }
     }
     if (!f.tab_vmode && S >= 8 && max_sp + 765u < 1024u) {
-        const int pad = std::max(7 * std::min(stride_it, 3), 15);   // (R-1)*stride of the kernels launch_assign picks
-        const int dyoff = S + pad, NR = 2 * dyoff + 1;
-        int nrpad = NR;
-        while ((nrpad & 3) != 2) nrpad++;                        // odd dword pitch: conflict-free columns
-        const size_t bytes = ((size_t)(S + 2) * nrpad * 2 + 15) / 16 * 16;
-        if (bytes <= kTabMaxBytes) {
+        // Pair-packed column-major copy of the patch: dword [ux][j] = (e(j), e(j + stride)), e(j) = patch[dy = j - dyoff][ux] << 6
+        // or 0xffff outside the window.  A pair of rows is then ONE 4-byte-aligned ds_read_b32 with an immediate offset
+        // (the u16 layout needed either a v_perm per pair or, at stride 1, 2-byte-aligned b128 reads, which cost 64 clk of
+        // the CU's LDS pipe each).  One table per stride: `tab` for the full pass, `tabs` for the subsampled passes.
+        auto build2d = [&](int stride, int rows, uint32_t* dst, int& words, int& nrpad_out, int& dyoff_out) -> bool {
+            const int pad = (rows - 1) * stride;
+            const int dyoff = S + pad, NR = 2 * dyoff + 1;
+            int nrpad = NR | 1;                                       // odd dword pitch: conflict-free columns
+            const size_t bytes = ((size_t)(S + 2) * nrpad * 4 + 15) / 16 * 16;
+            if (bytes > kTabMaxBytes) return false;
+            auto e = [&](int ux, int j) -> uint32_t {
+                const int dy = j - dyoff;
+                if (j < 0 || j >= NR || dy < -S || dy > S || ux > S) return 0xFFFFu;
+                return (uint32_t)(uint16_t)(patch[(size_t)(S + dy) * Pp + (S + ux)] << 6);
+            };
             for (int ux = 0; ux <= S + 1; ux++)
-                for (int dyi = 0; dyi < nrpad; dyi++) {
-                    const int dy = dyi - dyoff;
-                    uint16_t v = 0xFFFFu;
-                    if (dyi < NR && dy >= -S && dy <= S && ux <= S) v = (uint16_t)(patch[(size_t)(S + dy) * Pp + (S + ux)] << 6);
-                    s.h_tab[(size_t)ux * nrpad + dyi] = v;
-                }
-            for (size_t i = (size_t)(S + 2) * nrpad; i < bytes / 2; i++) s.h_tab[i] = 0xFFFFu;
-            f.tab_words = (int)(bytes / 4); f.tab_nrpad = nrpad; f.tab_dyoff = dyoff;
+                for (int j = 0; j < nrpad; j++) dst[(size_t)ux * nrpad + j] = e(ux, j) | (e(ux, j + stride) << 16);
+            for (size_t i = (size_t)(S + 2) * nrpad; i < bytes / 4; i++) dst[i] = 0xFFFFFFFFu;
+            words = (int)(bytes / 4); nrpad_out = nrpad; dyoff_out = dyoff;
+            return true;
+        };
+        int w1 = 0, n1 = 0, d1 = 0, ws = 0, ns = 0, ds = 0;
+        const int st3 = std::min(stride_it, 3);
+        if (build2d(1, 16, reinterpret_cast<uint32_t*>(s.h_tab), w1, n1, d1) &&
+            build2d(st3, 8, reinterpret_cast<uint32_t*>(s.h_tab + kTabMaxBytes / 2), ws, ns, ds)) {
+            f.tab_words = w1; f.tab_nrpad = n1; f.tab_dyoff = d1;
+            f.tabs_words = ws; f.tabs_nrpad = ns; f.tabs_dyoff = ds;
             tiled_ok = true;
         }
     }

@@ -79,7 +79,9 @@ struct FrameDev {
                                // (Manhattan patch): 16-byte entry t = V[t + k*stride], k = 0..7; lanes outside the x window use
                                // |dx| = tab_xout.  `tab` serves the full (stride 1) pass, `tabs` the subsampled passes
     const uint16_t* tabs;
-    int tabs_words, tabs_dyoff;
+    int tabs_words, tabs_dyoff, tabs_nrpad;
+    // tab_vmode == 0: pair-packed column-major patch copy, dword [ux'][j] = (e(j), e(j+stride)) with e = patch << 6 or 0xffff
+    // outside the window, row pitch tab_nrpad dwords, j = dy + tab_dyoff
     // generic-path tables
     const uint16_t* patch2d;   // (2S+1)^2, src/context.cpp:22-40
 

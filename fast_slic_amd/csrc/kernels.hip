@@ -593,296 +593,21 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
 #undef FSLIC_STAMP
 }
 
-// =============================================================================================
-// Packed 16-bit assign kernel (the default): two rows per VALU instruction.
-// The key of a pixel-candidate is 16 bits, (distance << 6) | idx, idx = rank of the candidate in (phase, k)
-// order within the wavefront's list (<= 64 entries), distance < 1024.  The spatial term comes from an LDS
-// copy of the reference's patch (src/context.cpp:22-40), stored column-major as tab[ux'][dy + DYOFF],
-// pre-shifted by 6, with 0xffff wherever |dy| > S or ux' = S+1 (window test folded in, saturating add keeps
-// it at 0xffff).  Column-major makes the address of row r  a0 + r*STRIDE  with a0 per lane and candidate, so
-// rows are DS *immediate offsets*: no per-row VALU or SALU work at all.  Per pair of rows:
-//     s   = v_sad_u8 (pix[r],   clab, 0)
-//     s   = v_sad_hi_u8(pix[r+1], clab, s)           two colour distances packed
-//     t   = v_lshl_add_u32(s, 6, idx|idx<<16)
-//     key = v_pk_add_u16(t, tab pair) clamp
-//     best= v_pk_min_u16(best, key)
-// i.e. 2.5 VALU + 1 LDS read per pixel-candidate (the 32-bit kernel above: 4 VALU + 5 SALU).
-// Exactness: the table IS the patch, so no fixed-point condition; ordering of (distance, idx) is unchanged.
-// The candidate list of a wavefront is filtered from a block-level list gathered once by wavefront 0.
-// =============================================================================================
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-
-template <int R, bool FUSE, int STRIDE>
-__global__ __launch_bounds__(256) void k_assign16(FrameDev f, int rem, int Hv, int buf, int sbuf) {
-    extern __shared__ uint32_t s_dyn[];                  // spatial table (u16), f.tab_words dwords
-    const uint16_t* const s_tab = reinterpret_cast<const uint16_t*>(s_dyn);
-    __shared__ uint32_t s_braw[3 * 64];
-    __shared__ uint32_t s_bn;
-    __shared__ uint32_t s_rawbuf[kWavesPerBlock][3 * 64];
-    __shared__ uint4 s_listbuf[kWavesPerBlock][64];
-    __shared__ uint32_t s_accbuf[FUSE ? kWavesPerBlock * kAccSlots * 6 * kAccCopies : 1];
-    static_assert(R % 2 == 0, "rows are processed in pairs");
-
-    f.select(blockIdx.z);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = (int)rfl((uint32_t)(tid >> 6));
-    uint32_t* const s_raw = s_rawbuf[wave];
-    uint4* const s_list = s_listbuf[wave];
-    uint32_t* const s_acc = s_accbuf + (FUSE ? wave * (kAccSlots * 6 * kAccCopies) : 0);
-    const int W = f.W, S = f.S;
-    const int x0 = blockIdx.x * kTileW;
-    const int x = x0 + lane;
-    const int vrow_b0 = blockIdx.y * (kWavesPerBlock * R);
-    const int vrow_w0 = vrow_b0 + wave * R;
-    const bool okx = x < W;
-    const bool wave_live = vrow_w0 < Hv;
-    const int yw_lo = rem + vrow_w0 * STRIDE;
-    const int nrows = wave_live ? min(R, Hv - vrow_w0) : 0;
-#define FSLIC_STAMP(slot_)                                                                              \
-    do {                                                                                                 \
-        if (f.dbg && lane == 0)                                                                          \
-            f.dbg[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kWavesPerBlock + wave) * 8 + (slot_)] = __builtin_readcyclecounter(); \
-    } while (0)
-    FSLIC_STAMP(0);
-    const uint32_t novf = *f.ovf_cnt[0];
-
-    // 1. pixel loads first; nothing below depends on them until the argmin
-    uint32_t pix[R];
-    {
-        const uint32_t* rowp = f.lab + (size_t)yw_lo * W;          // wave-uniform base, lane offset x
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            pix[r] = (okx && r < nrows) ? rowp[(uint32_t)x] : 0u;
-            rowp += (size_t)STRIDE * W;
-        }
-    }
-    if (FUSE) {
-#pragma unroll
-        for (int i = 0; i < kAccSlots * 6 * kAccCopies / 64; ++i) s_acc[i * 64 + lane] = 0u;
-    }
-
-    // 2. gather into 64 LDS slots: returns the number of live records inside `win` (may exceed 64)
-    const int sh = f.cs_shift;
-    const ClusterRec* __restrict__ citems = f.cell_items[0];
-    const ClusterRec* __restrict__ oitems = f.ovf_items[0];
-    const unsigned long long lowmask = (1ull << lane) - 1ull;
-    auto gather = [&](const TileWindow& win, uint32_t* dst) -> int {
-        const int cxa = max(win.wx_lo, 0) >> sh, cxb = min(win.wx_hi, W - 1) >> sh;
-        const int cya = max(win.wy_lo, 0) >> sh, cyb = min(win.wy_hi, f.H - 1) >> sh;
-        const int ncxr = cxb - cxa + 1;
-        int cnt = 0;
-        auto visit = [&](const ClusterRec& rec, bool keep) {
-            const unsigned long long m = __ballot(keep);
-            const int pos = cnt + __popcll(m & lowmask);
-            if (keep && pos < 64) { dst[pos] = rec.yx; dst[64 + pos] = rec.lab; dst[128 + pos] = rec.tag; }
-            cnt += __popcll(m);
-        };
-        // lane -> (cell column, slot); a cell row of up to 8 cells is one 16-byte load per lane.  Up to six cell
-        // rows are fetched before the first one is examined, so the whole gather is one memory round trip.
-        for (int cx0 = 0; cx0 < ncxr; cx0 += 8) {
-            const int cxi = cx0 + (lane >> 3);
-            const bool colok = cxi < ncxr;
-            const ClusterRec* base = citems + ((size_t)cya * f.ncx + cxa + cxi) * kCellCap + (lane & 7);
-            for (int cy0 = cya; cy0 <= cyb; cy0 += 6) {
-                ClusterRec rr[6];
-                bool okr[6];
-#pragma unroll
-                for (int u = 0; u < 6; ++u) {
-                    okr[u] = colok && (cy0 + u) <= cyb;
-                    rr[u].yx = 0; rr[u].lab = 0; rr[u].tag = 0; rr[u].pad = 0;
-                    if (okr[u]) rr[u] = base[(size_t)u * f.ncx * kCellCap];
-                }
-                base += 6 * (size_t)f.ncx * kCellCap;
-#pragma unroll
-                for (int u = 0; u < 6; ++u) visit(rr[u], okr[u] && rr[u].pad == f.gen && in_window(rr[u], win));
-            }
-        }
-        for (uint32_t i0 = 0; i0 < novf; i0 += 64) {
-            const uint32_t i = i0 + lane;
-            ClusterRec rec;
-            rec.yx = 0; rec.lab = 0; rec.tag = 0; rec.pad = 0;
-            if (i < novf) rec = oitems[i];
-            visit(rec, i < novf && in_window(rec, win));
-        }
-        return cnt;
-    };
-    if (wave == 0) {
-        TileWindow bw;
-        const int vlast = min(vrow_b0 + kWavesPerBlock * R - 1, Hv - 1);
-        bw.wy_lo = rem + vrow_b0 * STRIDE - S; bw.wy_hi = rem + vlast * STRIDE + S;
-        bw.wx_lo = x0 - S;                     bw.wx_hi = min(x0 + kTileW - 1, W - 1) + S;
-        const int bn = gather(bw, s_braw);
-        if (lane == 0) s_bn = (uint32_t)bn;
-    }
-    // spatial table -> LDS (all wavefronts)
-    {
-        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(f.tab);
-        uint4* dst = reinterpret_cast<uint4*>(s_dyn);
-        for (int i = tid; i < (f.tab_words >> 2); i += 256) dst[i] = src[i];
-    }
-    __syncthreads();                          // the only barrier
-    if (!wave_live) return;
-    FSLIC_STAMP(1);
-
-    // 3. this wavefront's candidates: block list filtered to the wavefront's rows (own gather if it overflowed)
-    TileWindow win;
-    win.wy_lo = yw_lo - S; win.wy_hi = yw_lo + (nrows - 1) * STRIDE + S;
-    win.wx_lo = x0 - S;    win.wx_hi = min(x0 + kTileW - 1, W - 1) + S;
-    int nraw;
-    const int bn = (int)rfl(s_bn);
-    if (bn <= 64) {
-        ClusterRec rec;
-        rec.yx = lane < bn ? s_braw[lane] : 0u;
-        rec.lab = lane < bn ? s_braw[64 + lane] : 0u;
-        rec.tag = lane < bn ? s_braw[128 + lane] : 0u;
-        rec.pad = 0;
-        const bool keep = lane < bn && in_window(rec, win);
-        const unsigned long long m = __ballot(keep);
-        const int pos = __popcll(m & lowmask);
-        if (keep) { s_raw[pos] = rec.yx; s_raw[64 + pos] = rec.lab; s_raw[128 + pos] = rec.tag; }
-        nraw = __popcll(m);
-    } else {
-        nraw = gather(win, s_raw);
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (nraw > 64) {                          // more live candidates than idx bits: the host redoes the frame generically
-        if (lane == 0) *f.err_flag = 1u;
-        return;
-    }
-    // rank by (phase, k): list index order == visit order of the reference scatter.  Clusters with identical
-    // state are kept out of the bins by k_bin_clusters; one that slips through only costs a list slot (it has
-    // the same distance as its earlier twin and loses the tie on idx).
-    const int n = nraw;
-    {
-        const bool act = lane < nraw;
-        const uint32_t tag_j = act ? s_raw[128 + lane] : 0xFFFFFFFFu;
-        int rank = 0;
-        for (int i = 0; i < nraw; ++i) rank += (int)(__builtin_amdgcn_readlane(tag_j, i) < tag_j);
-        if (act) s_list[rank] = make_uint4(s_raw[lane], s_raw[64 + lane], tag_j & 0xFFFFu, 0u);
-    }
-    __builtin_amdgcn_wave_barrier();
-    FSLIC_STAMP(2);
-
-    // 4. the argmin, two rows per instruction
-    us2 best[R / 2];
-#pragma unroll
-    for (int q = 0; q < R / 2; ++q) best[q] = (us2){0xFFFF, 0xFFFF};
-    const uint32_t nrpad = (uint32_t)f.tab_nrpad;
-    const int dyoff = f.tab_dyoff;
-    uint2 nxt = *reinterpret_cast<const uint2*>(&s_list[0]);
-#pragma unroll 1
-    for (int c = 0; c < n; ++c) {
-        const uint2 rec = nxt;
-        nxt = *reinterpret_cast<const uint2*>(&s_list[min(c + 1, 63)]);
-        const uint32_t cyx = rfl(rec.x);
-        const uint32_t clab = rfl(rec.y);
-        const int cy = (int)(cyx >> 16), cx = (int)(cyx & 0xFFFFu);
-        const uint32_t ux = __builtin_amdgcn_sad_u16((uint32_t)x, (uint32_t)cx, 0u);      // |x - cx|
-        const uint32_t uxc = min(ux, (uint32_t)(S + 1));
-        const uint32_t a0 = __umul24(uxc, nrpad) + (uint32_t)(yw_lo - cy + dyoff);        // element index of row 0
-        const uint32_t idx01 = (uint32_t)c | ((uint32_t)c << 16);
-#pragma unroll
-        for (int q = 0; q < R / 2; ++q) {
-            const us2 sp = (us2){s_tab[a0 + (2 * q) * STRIDE], s_tab[a0 + (2 * q + 1) * STRIDE]};
-            const uint32_t s0 = __builtin_amdgcn_sad_u8(pix[2 * q], clab, 0u);
-            const uint32_t s01 = __builtin_amdgcn_sad_hi_u8(pix[2 * q + 1], clab, s0);
-            const uint32_t t = (s01 << 6) + idx01;
-            const us2 key = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, t), sp);
-            best[q] = __builtin_elementwise_min(best[q], key);
-        }
-    }
-    FSLIC_STAMP(3);
-
-    // 5. write labels (+ fused centroid sums).  All idx -> k lookups are issued before the first store so their
-    //    LDS latency overlaps; rows are addressed as wave-uniform row pointer + unsigned lane offset (saddr form).
-    uint32_t slot[R];
-    {
-        uint32_t kk[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t key = (r & 1) ? (uint32_t)best[r / 2].y : (uint32_t)best[r / 2].x;
-            kk[r] = s_list[key & 63u].z;                            // idx 63 when not found: read, never used
-        }
-        uint16_t* rowp = f.labels + (size_t)yw_lo * W;
-        const uint32_t xo = (uint32_t)x;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const bool ok = okx && r < nrows;
-            const uint32_t key = (r & 1) ? (uint32_t)best[r / 2].y : (uint32_t)best[r / 2].x;
-            const bool found = key != 0xFFFFu;
-            slot[r] = 0xFFFFFFFFu;
-            if (ok && found) rowp[xo] = (uint16_t)kk[r];
-            if (FUSE && ok) {
-                const uint32_t idx = key & 63u;
-                if (found) {
-                    if (idx < (uint32_t)kAccSlots) slot[r] = idx;
-                    else global_accumulate(f.sums[0], kk[r], (uint32_t)(yw_lo + r * STRIDE), xo, pix[r]);
-                } else {
-                    const uint32_t old = rowp[xo];     // stale label still takes part in update()
-                    if (old != 0xFFFFu) global_accumulate(f.sums[0], old, (uint32_t)(yw_lo + r * STRIDE), xo, pix[r]);
-                }
-            }
-            rowp += (size_t)STRIDE * W;
-        }
-    }
-    FSLIC_STAMP(4);
-    if (FUSE && !(f.exp_flags & 2)) {
-        bool uni = slot[0] != 0xFFFFFFFFu;
-#pragma unroll
-        for (int r = 1; r < R; ++r) uni = uni && (slot[r] == slot[0]);
-        const uint32_t copy = (uint32_t)lane & (kAccCopies - 1);
-        if (uni) {
-            uint32_t sL = 0, sa = 0, sb = 0;
-#pragma unroll
-            for (int r = 0; r < R; ++r) { sL += pix[r] & 255u; sa += (pix[r] >> 8) & 255u; sb += (pix[r] >> 16) & 255u; }
-            uint32_t* a = s_acc + (slot[0] * 6) * kAccCopies + copy;
-            atomicAdd(a + 0 * kAccCopies, (uint32_t)R);
-            atomicAdd(a + 1 * kAccCopies, (uint32_t)(R * yw_lo + STRIDE * (R * (R - 1) / 2)));
-            atomicAdd(a + 2 * kAccCopies, (uint32_t)(R * x));
-            atomicAdd(a + 3 * kAccCopies, sL);
-            atomicAdd(a + 4 * kAccCopies, sa);
-            atomicAdd(a + 5 * kAccCopies, sb);
-        } else {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (slot[r] != 0xFFFFFFFFu) {
-                    uint32_t* a = s_acc + (slot[r] * 6) * kAccCopies + copy;
-                    atomicAdd(a + 0 * kAccCopies, 1u);
-                    atomicAdd(a + 1 * kAccCopies, (uint32_t)(yw_lo + r * STRIDE));
-                    atomicAdd(a + 2 * kAccCopies, (uint32_t)x);
-                    atomicAdd(a + 3 * kAccCopies, pix[r] & 255u);
-                    atomicAdd(a + 4 * kAccCopies, (pix[r] >> 8) & 255u);
-                    atomicAdd(a + 5 * kAccCopies, (pix[r] >> 16) & 255u);
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int nacc = (f.exp_flags & 1) ? 0 : min(n, kAccSlots) * 6;
-        for (int i = lane; i < nacc; i += 64) {
-            uint32_t v = 0;
-#pragma unroll
-            for (int c = 0; c < kAccCopies; ++c) v += s_acc[i * kAccCopies + c];
-            if (v) {
-                const int sl = i / 6;
-                atomicAdd(f.sums[0] + 6 * (size_t)s_list[sl].z + (i - sl * 6), v);
-            }
-        }
-    }
-    FSLIC_STAMP(5);
-    if (f.dbg && lane == 0) {
-        const size_t o = ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kWavesPerBlock + wave) * 8;
-        f.dbg[o + 6] = (unsigned long long)nraw;
-        f.dbg[o + 7] = (unsigned long long)n;
-    }
-#undef FSLIC_STAMP
-}
 
 // =============================================================================================
 // Block-level packed assign kernel (the default, and the roofline kernel).
-// One block = 64 columns x (4 wavefronts x R) visited rows.  Same 16-bit key arithmetic as k_assign16 above
-// ((distance << 6) | idx, two rows per VALU instruction, spatial term from the column-major LDS copy of the
-// reference's patch), but the prologue is paid once per BLOCK and costs one memory round trip:
+// One block = 64 columns x (4 wavefronts x R) visited rows.  The key of a pixel-candidate is 16 bits,
+// (distance << 6) | idx, idx = rank of the candidate in (phase, k) order within the block's list (<= 64 entries),
+// distance < 1024; two rows share one VALU instruction:
+//     s   = v_sad_u8 (pix[r],   clab, 0)
+//     s   = v_sad_hi_u8(pix[r+1], clab, s)           two colour distances packed
+//     t   = v_lshl_add_u32(s, 6, idx|idx<<16)
+//     key = v_pk_add_u16(t, spatial pair) clamp      0xffff outside the window: saturates, never wins
+//     best= v_pk_min_u16(best, key)
+// i.e. 2.5 VALU + one aligned LDS read per pixel-candidate pair.  The spatial pair comes from an LDS copy of the
+// reference's patch (src/context.cpp:22-40) laid out so that the rows of a wavefront are immediate offsets from one
+// per-lane address (two layouts, see VT below).  The prologue is paid once per BLOCK and costs one memory round trip:
 //   wavefront 0   fetches every bin slot the block's pixels can see (all loads in flight at once), compacts the
 //                 live records by ballot, ranks them by (phase, k) with readlane broadcasts and writes the sorted
 //                 block list to LDS: idx = position in that list = visit order of the reference's scatter
@@ -936,7 +661,6 @@ static __device__ __forceinline__ void row_masks(uint32_t inv, uint32_t (&m)[R /
 template <int R, bool FUSE, int STRIDE, bool VT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_assign_blk(FrameDev f, int rem, int Hv) {
     extern __shared__ uint32_t s_dyn[];                  // spatial table (u16), f.tab_words dwords
-    const uint16_t* const s_tab = reinterpret_cast<const uint16_t*>(s_dyn);
     __shared__ uint32_t s_braw[3 * 64];
     __shared__ uint4 s_list[64];                         // {yx, lab, k, cpart entry | kNoSlot}
     __shared__ uint32_t s_bn;
@@ -1169,11 +893,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
         const int cy = (int)(cyx >> 16), cx = (int)(cyx & 0xFFFFu);
         const uint32_t ux = __builtin_amdgcn_sad_u16((uint32_t)x, (uint32_t)cx, 0u);      // |x - cx|
         const uint32_t uxc = min(ux, (uint32_t)(S + 1));
-        const uint32_t a0 = __umul24(uxc, nrpad) + (uint32_t)(yw_lo - cy + dyoff);        // element index of row 0
+        const uint32_t a0 = __umul24(uxc, nrpad) + (uint32_t)(yw_lo - cy + dyoff);        // dword index of the pair (row 0, row 1)
         const uint32_t idx01 = (uint32_t)c | ((uint32_t)c << 16);
 #pragma unroll
         for (int q = 0; q < R / 2; ++q) {
-            const us2 sp = (us2){s_tab[a0 + (2 * q) * STRIDE], s_tab[a0 + (2 * q + 1) * STRIDE]};
+            const us2 sp = __builtin_bit_cast(us2, s_dyn[a0 + (2 * q) * STRIDE]);            // one aligned ds_read_b32 per row pair
             const uint32_t s0 = __builtin_amdgcn_sad_u8(pix[2 * q], clab, 0u);
             const uint32_t s01 = __builtin_amdgcn_sad_hi_u8(pix[2 * q + 1], clab, s0);
             const uint32_t t = (s01 << 6) + idx01;
@@ -1270,18 +994,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
 template <int R, bool FUSE, int STRIDE>
 static void launch_assign_blk_t(const FrameDev& f_, int nframes, int rem, int Hv, hipStream_t st) {
     FrameDev f = f_;
-    if (f.tab_vmode && FUSE) { f.tab = f.tabs; f.tab_words = f.tabs_words; f.tab_dyoff = f.tabs_dyoff; }   // row vectors of the subsampled stride
+    if (FUSE) { f.tab = f.tabs; f.tab_words = f.tabs_words; f.tab_dyoff = f.tabs_dyoff; f.tab_nrpad = f.tabs_nrpad; }   // table of the subsampled stride
     dim3 grid((f.W + kTileW - 1) / kTileW, (Hv + kWavesPerBlock * R - 1) / (kWavesPerBlock * R), nframes);
-    const size_t lds = (size_t)f.tab_words * sizeof(uint32_t);
+    static const size_t lds_pad = getenv("FSLIC_LDS_PAD") ? (size_t)atoi(getenv("FSLIC_LDS_PAD")) : 0;   // experiment: caps blocks per CU
+    const size_t lds = (size_t)f.tab_words * sizeof(uint32_t) + lds_pad;
+    if (lds_pad) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_assign_blk<R, FUSE, STRIDE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_assign_blk<R, FUSE, STRIDE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     if (f.tab_vmode) hipLaunchKernelGGL((k_assign_blk<R, FUSE, STRIDE, true>), grid, dim3(256), lds, st, f, rem, Hv);
     else hipLaunchKernelGGL((k_assign_blk<R, FUSE, STRIDE, false>), grid, dim3(256), lds, st, f, rem, Hv);
-}
-
-template <int R, bool FUSE, int STRIDE>
-static void launch_assign16_t(const FrameDev& f, int nframes, int rem, int Hv, int buf, int sbuf, hipStream_t st) {
-    dim3 grid((f.W + kTileW - 1) / kTileW, (Hv + kWavesPerBlock * R - 1) / (kWavesPerBlock * R), nframes);
-    const size_t lds = (size_t)f.tab_words * sizeof(uint32_t);
-    hipLaunchKernelGGL((k_assign16<R, FUSE, STRIDE>), grid, dim3(256), lds, st, f, rem, Hv, buf, sbuf);
 }
 
 static int assign_rows_per_wave(const FrameDev& f, int nframes, int Hv, bool fuse_update) {
@@ -1311,7 +1033,7 @@ PassGeom launch_assign(const FrameDev& f_, int nframes, int rem, int stride, int
     PassGeom pg;
     pg.rem = rem; pg.stride = stride; pg.Hv = Hv; pg.BH = kWavesPerBlock * 8; pg.use_slots = 0;
     if (Hv <= 0) return pg;
-    static const int which = getenv("FSLIC_ASSIGN") ? atoi(getenv("FSLIC_ASSIGN")) : 0;   // 16 / 32: older kernels (A/B timing)
+    static const int which = getenv("FSLIC_ASSIGN") ? atoi(getenv("FSLIC_ASSIGN")) : 0;   // 32: force the 32-bit kernel (A/B timing)
     if (f.tab_words > 0 && stride >= 1 && stride <= 3 && which == 0) {       // block-level packed kernel
         if (!fuse_update && stride == 1) {
             if (assign_rows_per_wave(f, nframes, Hv, false) == 16) launch_assign_blk_t<16, false, 1>(f, nframes, rem, Hv, st);
@@ -1324,17 +1046,6 @@ PassGeom launch_assign(const FrameDev& f_, int nframes, int rem, int stride, int
             else if (stride == 2) launch_assign_blk_t<8, true, 2>(f, nframes, rem, Hv, st);
             else launch_assign_blk_t<8, true, 3>(f, nframes, rem, Hv, st);
             return pg;
-        }
-    }
-    if (f.tab_words > 0 && stride >= 1 && stride <= 3 && which != 32) {       // per-wavefront packed kernel
-        const int R = assign_rows_per_wave(f, nframes, Hv, fuse_update);
-        if (!fuse_update) {
-            if (stride == 1 && R == 16) { launch_assign16_t<16, false, 1>(f, nframes, rem, Hv, buf, sbuf, st); return pg; }
-            if (stride == 1) { launch_assign16_t<8, false, 1>(f, nframes, rem, Hv, buf, sbuf, st); return pg; }
-        } else {
-            if (stride == 1) { launch_assign16_t<8, true, 1>(f, nframes, rem, Hv, buf, sbuf, st); return pg; }
-            if (stride == 2) { launch_assign16_t<8, true, 2>(f, nframes, rem, Hv, buf, sbuf, st); return pg; }
-            if (stride == 3) { launch_assign16_t<8, true, 3>(f, nframes, rem, Hv, buf, sbuf, st); return pg; }
         }
     }
     if (assign_rows_per_wave(f, nframes, Hv, fuse_update) == 16) launch_assign_r<16>(f, nframes, rem, stride, Hv, buf, sbuf, fuse_update, st);

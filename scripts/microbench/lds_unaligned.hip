@@ -63,6 +63,15 @@ int main() {
     uint32_t* d_out;
     CHK(hipMalloc(&d_out, 256 * 8 * 256 * 4));
     run<10>("2 x b128, 16B aligned (lane*32)", 32, 0, d_out);
+    run<10>("2 x b128, 16B aligned (lane*16: RV table)", 16, 0, d_out);
+    run<10>("2 x b128, 16B aligned (lane*176: 2-D, pitch 44 banks)", 176, 0, d_out);
+    run<10>("2 x b128, 4B aligned  (lane*176 + 4)", 176, 4, d_out);
+    run<10>("2 x b128, 8B aligned  (lane*176 + 8)", 176, 8, d_out);
+    run<10>("2 x b128, 2B aligned  (lane*176 + 2)", 176, 2, d_out);
+    run<11>("4 x b64,  8B aligned  (lane*176 + 8)", 176, 8, d_out);
+    run<11>("4 x b64,  4B aligned  (lane*176 + 4)", 176, 4, d_out);
+    run<12>("8 x b32,  4B aligned  (lane*176 + 4)", 176, 4, d_out);
+    run<12>("8 x b32,  2B aligned  (lane*176 + 2)", 176, 2, d_out);
     run<0>("2 x b128, lane*2 bytes (+0..14 phase)", 2, 0, d_out);
     run<0>("2 x b128, lane*2 bytes, base+2", 2, 2, d_out);
     run<0>("2 x b128, lane*(178*2) bytes (2-D table)", 356, 0, d_out);
