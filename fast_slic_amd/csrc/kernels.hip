@@ -1476,15 +1476,15 @@ static __device__ __forceinline__ void select_pass(const uint32_t* s_area, uint3
     __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, unsigned long long* dbg) {
-#define SEL_STAMP(i_) do { if (dbg && threadIdx.x == 0 && blockIdx.x == 0) dbg[i_] = __builtin_readcyclecounter(); } while (0)
+__global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int cap, unsigned long long* dbg) {
+#define SEL_STAMP(i_) do { if (dbg && threadIdx.x == 0 && blockIdx.x == 0) dbg[i_] = __builtin_amdgcn_s_memrealtime(); } while (0)   // 100 MHz
     SEL_STAMP(0);
     c.select(blockIdx.x);
     extern __shared__ uint32_t s_dyn[];
     uint32_t* const s_area = s_dyn;
-    uint32_t* const s_lead = s_dyn + kSelCap;
-    uint32_t* const s_key = s_dyn + 2 * kSelCap;
-    uint32_t* const s_bcnt = s_dyn + 3 * kSelCap;       // ranking buckets; the selection's histogram lives here first
+    uint32_t* const s_lead = s_dyn + cap;
+    uint32_t* const s_key = s_dyn + 2 * cap;
+    uint32_t* const s_bcnt = s_dyn + 3 * cap;           // ranking buckets; the selection's histogram lives here first
     uint32_t* const s_bstart = s_bcnt + kSelBuckets;
     uint32_t* const s_bfill = s_bstart + kSelBuckets;
     uint32_t* const s_hist = s_bcnt;                    // kSelBins <= 3 * kSelBuckets words
@@ -1497,7 +1497,7 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, unsigned long lon
     const uint32_t M = c.counters[1];
     if (tid < 8) s_v[tid] = 0;
     if (tid == 0) c.counters[2] = M;
-    if (M > (uint32_t)kSelCap) {
+    if (M > (uint32_t)cap) {
         if (tid == 0) c.counters[3] = 2u;
         return;
     }
@@ -1540,32 +1540,41 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, unsigned long lon
         if (lane == 0 && eq) atomicAdd(&s_v[4], eq);
         __syncthreads();
         if (s_v[4] != kk) {
-            // tie at the cut: hand the host the candidates in ascending-leader order (bitonic sort of the pairs)
-            uint32_t P2 = 1;
-            while (P2 < M) P2 <<= 1;
-            if (P2 > (uint32_t)kSelSortCap) {
+            // tie at the cut: hand the host the candidates in ascending-leader order.  Same bucket ranking as step 3
+            // below, applied to every candidate: rank = position in the leader-sorted list (a bitonic sort of the
+            // pairs took 30 us here).
+            if (M > (uint32_t)kSelSortCap) {
                 if (tid == 0) c.counters[3] = 2u;
                 return;
             }
-            for (uint32_t i = M + tid; i < P2; i += 1024) { s_lead[i] = 0xFFFFFFFFu; s_area[i] = 0u; }
+            int bsh = 0;
+            while ((((uint32_t)c.N - 1u) >> bsh) >= (uint32_t)kSelBuckets) bsh++;
+            for (int i = tid; i < 3 * kSelBuckets; i += 1024) s_bcnt[i] = 0;
             __syncthreads();
-            for (uint32_t k2 = 2; k2 <= P2; k2 <<= 1) {
-                for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
-                    for (uint32_t i = tid; i < P2; i += 1024) {
-                        const uint32_t ixj = i ^ j;
-                        if (ixj > i) {
-                            const uint32_t a = s_lead[i], b = s_lead[ixj];
-                            const bool up = ((i & k2) == 0);
-                            if ((a > b) == up) {
-                                s_lead[i] = b; s_lead[ixj] = a;
-                                const uint32_t t = s_area[i]; s_area[i] = s_area[ixj]; s_area[ixj] = t;
-                            }
-                        }
-                    }
-                    __syncthreads();
-                }
+            for (uint32_t i = tid; i < M; i += 1024) atomicAdd(&s_bcnt[s_lead[i] >> bsh], 1u);
+            __syncthreads();
+            {
+                const uint32_t a = s_bcnt[2 * tid], b = s_bcnt[2 * tid + 1];
+                uint32_t tot;
+                const uint32_t ex = block_excl_scan_1024(a + b, s_w, tot);
+                s_bstart[2 * tid] = ex;
+                s_bstart[2 * tid + 1] = ex + a;
             }
-            for (uint32_t i = tid; i < M; i += 1024) { c.cand_leader[i] = (int32_t)s_lead[i]; c.cand_area[i] = s_area[i]; }
+            __syncthreads();
+            for (uint32_t i = tid; i < M; i += 1024) {
+                const uint32_t b = s_lead[i] >> bsh;
+                s_key[s_bstart[b] + atomicAdd(&s_bfill[b], 1u)] = s_lead[i];
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < M; i += 1024) {
+                const uint32_t me = s_lead[i];
+                const uint32_t b = me >> bsh;
+                const uint32_t lo = s_bstart[b], hi = lo + s_bcnt[b];
+                uint32_t r = lo;
+                for (uint32_t j = lo; j < hi; ++j) r += (uint32_t)(s_key[j] < me);
+                c.cand_leader[r] = (int32_t)me;
+                c.cand_area[r] = s_area[i];
+            }
             if (tid == 0) c.counters[3] = 1u;
             return;
         }
@@ -1622,10 +1631,15 @@ void launch_cca_phase1(const CcaDev& c, int nframes, hipStream_t st) {
 }
 
 void launch_cca_select(const CcaDev& c, int nframes, hipStream_t st, unsigned long long* dbg) {
-    const size_t lds = (3 * (size_t)kSelCap + 3 * (size_t)kSelBuckets) * sizeof(uint32_t);
+    // LDS capacity: no frame has more candidates than N / max(threshold, 1)
+    long long need = (long long)c.N / (c.min_threshold > 1 ? c.min_threshold : 1) + 1;
+    int cap = 1024;
+    while (cap < need && cap < kSelCap) cap <<= 1;
+    if (cap > kSelCap) cap = kSelCap;
+    const size_t lds = (3 * (size_t)cap + 3 * (size_t)kSelBuckets) * sizeof(uint32_t);
     static_assert(kSelBins <= 3 * kSelBuckets, "the selection histogram reuses the ranking buckets");
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cca_select), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_cca_select, dim3(nframes), dim3(1024), lds, st, c, dbg);
+    hipLaunchKernelGGL(k_cca_select, dim3(nframes), dim3(1024), lds, st, c, cap, dbg);
 }
 
 // Host path only: forget what the device select / chain wrote, then set the host's choice.
