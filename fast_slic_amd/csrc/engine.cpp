@@ -13,7 +13,10 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -194,6 +197,22 @@ struct Slot {
     int last_path = 0;
     bool have_pre = false;
     bool pending = false;            // a group submitted with fslic_hip_submit_group has not been waited for yet
+    // asynchronous groups run on the slot's own host thread (launches, stream sync, std::partial_sort on ties,
+    // cluster write-back), so the host work of one slot overlaps that of the others and the caller's
+    struct Async {
+        std::thread worker;
+        std::mutex m;
+        std::condition_variable cv;
+        bool has_job = false, done = false, quit = false;
+        fslic_params p{};
+        int H = 0, W = 0, K = 0, n = 0;
+        const uint8_t* d_rgb[kMaxGroup] = {};
+        fslic_cluster* clusters[kMaxGroup] = {};
+        uint16_t* d_out[kMaxGroup] = {};
+        int rc = 0;
+        std::string err;
+    };
+    std::unique_ptr<Async> async;
     // cached spatial configuration (configure_spatial)
     bool sp_valid = false, sp_tiled_ok = false, sp_manhattan = true, sp_patch_uploaded = false;
     int sp_S = 0, sp_shift = 0, sp_stride = 0;
@@ -218,6 +237,15 @@ struct fslic_engine {
 namespace {
 
 void free_slot(Slot& s) {
+    if (s.async) {
+        {
+            std::lock_guard<std::mutex> lk(s.async->m);
+            s.async->quit = true;
+        }
+        s.async->cv.notify_all();
+        if (s.async->worker.joinable()) s.async->worker.join();
+        s.async.reset();
+    }
     if (s.arena) hipFree(s.arena);
     if (s.d_dbg) hipFree(s.d_dbg);
     if (s.d_ptrs) hipFree(s.d_ptrs);
@@ -1018,6 +1046,27 @@ int fslic_hip_iterate_device(fslic_engine* e, int slot, const fslic_params* p, i
     return rc;
 }
 
+// The slot's host thread: one group at a time, begin + finish.
+static void slot_worker(fslic_engine* e, Slot* s) {
+    Slot::Async& a = *s->async;
+    (void)hipSetDevice(e->device);
+    for (;;) {
+        std::unique_lock<std::mutex> lk(a.m);
+        a.cv.wait(lk, [&] { return a.has_job || a.quit; });
+        if (a.quit) return;
+        lk.unlock();
+        int rc = group_begin(e, *s, &a.p, a.H, a.W, a.K, a.n, a.d_rgb, a.clusters, a.d_out);
+        if (rc == FSLIC_OK) rc = group_finish(e, *s);
+        lk.lock();
+        a.rc = rc;
+        a.err = rc ? g_err : std::string();
+        a.has_job = false;
+        a.done = true;
+        lk.unlock();
+        a.cv.notify_all();
+    }
+}
+
 int fslic_hip_submit_group(fslic_engine* e, int slot, const fslic_params* p, int H, int W, int K, int n_frames,
                            const uint8_t* const* d_rgb, fslic_cluster* const* clusters, uint16_t* const* d_labels) {
     if (!e) return fail(FSLIC_E_INVALID, "engine is NULL");
@@ -1025,10 +1074,26 @@ int fslic_hip_submit_group(fslic_engine* e, int slot, const fslic_params* p, int
     if (n_frames < 1 || n_frames > (int)kMaxGroup || !d_rgb || !clusters || !d_labels) return fail(FSLIC_E_INVALID, "bad group arguments");
     Slot& s = e->slots[slot];
     if (s.pending) return fail(FSLIC_E_INVALID, "the slot still owns an unfinished group (call fslic_hip_wait_group first)");
-    HIPCHK(hipSetDevice(e->device));
-    int rc = group_begin(e, s, p, H, W, K, n_frames, d_rgb, clusters, d_labels);
-    if (rc == FSLIC_OK) s.pending = true;
-    return rc;
+    int S = 0;
+    int rc = validate(p, H, W, K, S);          // argument errors surface here, on the caller's thread
+    if (rc) return rc;
+    for (int i = 0; i < n_frames; i++)
+        if (!clusters[i] || !d_rgb[i] || !d_labels[i]) return fail(FSLIC_E_INVALID, "NULL pointer argument");
+    if (!s.async) {
+        s.async.reset(new Slot::Async());
+        s.async->worker = std::thread(slot_worker, e, &s);
+    }
+    Slot::Async& a = *s.async;
+    {
+        std::lock_guard<std::mutex> lk(a.m);
+        a.p = *p; a.H = H; a.W = W; a.K = K; a.n = n_frames;
+        for (int i = 0; i < n_frames; i++) { a.d_rgb[i] = d_rgb[i]; a.clusters[i] = clusters[i]; a.d_out[i] = d_labels[i]; }
+        a.done = false;
+        a.has_job = true;
+    }
+    a.cv.notify_all();
+    s.pending = true;
+    return FSLIC_OK;
 }
 
 int fslic_hip_wait_group(fslic_engine* e, int slot) {
@@ -1036,9 +1101,15 @@ int fslic_hip_wait_group(fslic_engine* e, int slot) {
     if (slot < 0 || slot >= (int)e->slots.size()) return fail(FSLIC_E_INVALID, "slot out of range");
     Slot& s = e->slots[slot];
     if (!s.pending) return FSLIC_OK;
-    HIPCHK(hipSetDevice(e->device));
+    Slot::Async& a = *s.async;
+    int rc;
+    {
+        std::unique_lock<std::mutex> lk(a.m);
+        a.cv.wait(lk, [&] { return a.done; });
+        rc = a.rc;
+        if (rc) g_err = a.err;
+    }
     s.pending = false;
-    int rc = group_finish(e, s);
     if (rc == FSLIC_OK && slot == 0) make_timing_report(e, s);
     return rc;
 }
