@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="720p", choices=sorted(WORKLOADS))
     ap.add_argument("--frames-per-gpu", type=int, default=0)
-    ap.add_argument("--slots", type=int, default=2, help="streams per GPU; the frames of a step are cut into one group per slot")
+    ap.add_argument("--slots", type=int, default=4, help="streams per GPU; the frames of a step are cut into one group per slot")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-4k", action="store_true")
     args = ap.parse_args()

@@ -664,9 +664,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
     __shared__ uint32_t s_braw[3 * 64];
     __shared__ uint4 s_list[64];                         // {yx, lab, k, cpart entry | kNoSlot}
     __shared__ uint32_t s_bn;
-    __shared__ uint32_t s_acc[FUSE ? 64 * 6 * kBlkCopies : 1];
+    // centroid accumulators: per (candidate, copy) two 64-bit words of three 20-bit-spaced fields each,
+    //   A = sum L | sum a << 20 | sum b << 40        B = sum (x - x0) | sum (y - y0) << 20 | count << 40
+    // so a pixel (or a whole column) costs two ds_add_u64 instead of six ds_add_u32.  No field can carry into its
+    // neighbour: a block has 2048 pixels, channels <= 255, x - x0 <= 63, y - y0 <= 93.
+    __shared__ unsigned long long s_acc[FUSE ? 64 * kBlkCopies * 2 : 1];
     static_assert(R % 2 == 0, "rows are processed in pairs");
     constexpr int BH = kWavesPerBlock * R;
+    static_assert(!FUSE || (BH * 64 * 255 < (1 << 20) && (BH - 1) * STRIDE * BH * 64 < (1 << 20)), "accumulator fields overflow");
 
     f.select(blockIdx.z);
     const int tid = threadIdx.x;
@@ -787,8 +792,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
             }
         }
         if (FUSE) {
-#pragma unroll
-            for (int i = 0; i < 64 * 6 * kBlkCopies / 192; ++i) s_acc[i * 192 + t] = 0u;
+            for (int i = t; i < 64 * kBlkCopies * 2; i += 192) s_acc[i] = 0ull;
         }
     }
     __syncthreads();
@@ -943,42 +947,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
 #pragma unroll
             for (int r = 1; r < R; ++r) uni = uni && (slot[r] == slot[0]);
             const uint32_t copy = (uint32_t)lane & (kBlkCopies - 1);
-            if (uni) {   // whole column in one superpixel: one set of LDS atomics for R pixels
+            const uint32_t dyw = (uint32_t)(wave * R * STRIDE);            // first row of this wavefront relative to the block's
+            if (uni) {   // whole column in one superpixel: one pair of LDS atomics for R pixels
                 uint32_t sL = 0, sa = 0, sb = 0;
 #pragma unroll
                 for (int r = 0; r < R; ++r) { sL += pix[r] & 255u; sa += (pix[r] >> 8) & 255u; sb += (pix[r] >> 16) & 255u; }
-                uint32_t* a = s_acc + (slot[0] * 6) * kBlkCopies + copy;
-                atomicAdd(a + 0 * kBlkCopies, (uint32_t)R);
-                atomicAdd(a + 1 * kBlkCopies, (uint32_t)(R * yw_lo + STRIDE * (R * (R - 1) / 2)));
-                atomicAdd(a + 2 * kBlkCopies, (uint32_t)(R * x));
-                atomicAdd(a + 3 * kBlkCopies, sL);
-                atomicAdd(a + 4 * kBlkCopies, sa);
-                atomicAdd(a + 5 * kBlkCopies, sb);
+                unsigned long long* a = s_acc + (slot[0] * kBlkCopies + copy) * 2;
+                const unsigned long long A = (unsigned long long)(sL | (sa << 20)) | ((unsigned long long)(sb << 8) << 32);
+                const uint32_t sdy = (uint32_t)R * dyw + (uint32_t)(STRIDE * (R * (R - 1) / 2));
+                const unsigned long long B = (unsigned long long)((uint32_t)R * (uint32_t)lane | (sdy << 20)) | ((unsigned long long)((uint32_t)R << 8) << 32);
+                atomicAdd(a, A);
+                atomicAdd(a + 1, B);
             } else {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     if (slot[r] != kNoSlot) {
-                        uint32_t* a = s_acc + (slot[r] * 6) * kBlkCopies + copy;
-                        atomicAdd(a + 0 * kBlkCopies, 1u);
-                        atomicAdd(a + 1 * kBlkCopies, (uint32_t)(yw_lo + r * STRIDE));
-                        atomicAdd(a + 2 * kBlkCopies, (uint32_t)x);
-                        atomicAdd(a + 3 * kBlkCopies, pix[r] & 255u);
-                        atomicAdd(a + 4 * kBlkCopies, (pix[r] >> 8) & 255u);
-                        atomicAdd(a + 5 * kBlkCopies, (pix[r] >> 16) & 255u);
+                        unsigned long long* a = s_acc + (slot[r] * kBlkCopies + copy) * 2;
+                        const uint32_t p = pix[r];
+                        const unsigned long long A = (unsigned long long)((p & 255u) | ((p & 0xFF00u) << 12)) | ((unsigned long long)((p >> 8) & 0xFF00u) << 32);
+                        const unsigned long long B = (unsigned long long)((uint32_t)lane | ((dyw + (uint32_t)(r * STRIDE)) << 20)) | (256ull << 32);
+                        atomicAdd(a, A);
+                        atomicAdd(a + 1, B);
                     }
                 }
             }
         }
         __syncthreads();
         // one plain store per (candidate, quantity): entry reserved for (cluster, this block), zeros included
+        const uint32_t yb0 = (uint32_t)(rem + vrow_b0 * STRIDE);
         for (int i = tid; i < bn * 6; i += 256) {
-            const int c = i / 6;
+            const int c = i / 6, q = i - c * 6;
             const uint32_t entry = s_list[c].w;
             if (entry != kNoSlot) {
-                uint32_t v = 0;
+                unsigned long long A = 0, B = 0;
 #pragma unroll
-                for (int cpy = 0; cpy < kBlkCopies; ++cpy) v += s_acc[i * kBlkCopies + cpy];
-                f.cpart[(size_t)entry + (uint32_t)(i - c * 6)] = v;
+                for (int cpy = 0; cpy < kBlkCopies; ++cpy) { A += s_acc[(c * kBlkCopies + cpy) * 2]; B += s_acc[(c * kBlkCopies + cpy) * 2 + 1]; }
+                const uint32_t cnt = (uint32_t)(B >> 40);
+                uint32_t v;
+                if (q == 0) v = cnt;
+                else if (q == 1) v = ((uint32_t)(B >> 20) & 0xFFFFFu) + yb0 * cnt;
+                else if (q == 2) v = ((uint32_t)B & 0xFFFFFu) + (uint32_t)x0 * cnt;
+                else if (q == 3) v = (uint32_t)A & 0xFFFFFu;
+                else if (q == 4) v = (uint32_t)(A >> 20) & 0xFFFFFu;
+                else v = (uint32_t)(A >> 40);
+                f.cpart[(size_t)entry + (uint32_t)q] = v;
             }
         }
     }
