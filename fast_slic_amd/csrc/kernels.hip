@@ -157,12 +157,26 @@ static __device__ __forceinline__ void gather_sums(const FrameDev& f, const Pass
     const SlotGeom g = slot_geom((int)(yx >> 16), (int)(yx & 0xFFFFu), f.S, f.H, f.W, pg.rem, pg.stride, pg.BH, pg.Hv);
     if (!g.any) return;
     const uint32_t* cp = f.cpart + (size_t)k * f.cpart_ns * 6;
-    for (int by = g.by0; by <= g.by1; ++by)
-        for (int bx = g.bx0; bx <= g.bx1; ++bx) {
-            const uint2* e = reinterpret_cast<const uint2*>(cp + ((by - g.by0) * f.nbx + (bx - g.bx0)) * 6);   // 24-byte entries
-            const uint2 e0 = e[0], e1 = e[1], e2 = e[2];
-            out[0] += e0.x; out[1] += e0.y; out[2] += e1.x; out[3] += e1.y; out[4] += e2.x; out[5] += e2.y;
+    // entries (by, bx) in [by0, by1] x [bx0, bx1], four at a time with all their loads in flight (one memory round trip
+    // per four entries instead of one per entry: this pass is a chain of dependent loads on a handful of blocks)
+    const int nx = g.bx1 - g.bx0 + 1, ne = nx * (g.by1 - g.by0 + 1);
+    for (int e0 = 0; e0 < ne; e0 += 4) {
+        uint2 v[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u;
+            const int ey = e / nx, ex = e - ey * nx;
+            v[u][0] = v[u][1] = v[u][2] = make_uint2(0u, 0u);
+            if (e < ne) {
+                const uint2* p = reinterpret_cast<const uint2*>(cp + (ey * f.nbx + ex) * 6);   // 24-byte entries
+                v[u][0] = p[0]; v[u][1] = p[1]; v[u][2] = p[2];
+            }
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            out[0] += v[u][0].x; out[1] += v[u][0].y; out[2] += v[u][1].x; out[3] += v[u][1].y; out[4] += v[u][2].x; out[5] += v[u][2].y;
+        }
+    }
 }
 
 template <int MODE>
