@@ -707,14 +707,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
     FSLIC_STAMP(0);
 
     // 1. pixel loads first; nothing below depends on them until the argmin
+    // Out-of-image lanes and rows re-read the last valid column / row instead of being masked off: no exec juggling
+    // around the loads (their results are never stored and never reach the centroid sums).
     uint32_t pix[R];
-    {
-        const uint32_t* rowp = f.lab + (size_t)yw_lo * W;          // wave-uniform base, lane offset x
+    if (nrows > 0) {
+        const uint32_t xc = (uint32_t)min(x, W - 1);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            pix[r] = (okx && r < nrows) ? rowp[(uint32_t)x] : 0u;
-            rowp += (size_t)STRIDE * W;
+            const uint32_t* rowp = f.lab + (size_t)(yw_lo + min(r, nrows - 1) * STRIDE) * W;   // wave-uniform base
+            pix[r] = rowp[xc];
         }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) pix[r] = 0u;
     }
 
     if (wave == 0) {
@@ -742,15 +747,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
         for (int cx0 = 0; cx0 < ncxr; cx0 += 8) {
             const int cxi = cx0 + (lane >> 3);
             const bool colok = cxi < ncxr;
-            const ClusterRec* base = citems + ((size_t)cya * f.ncx + cxa + cxi) * kCellCap + (lane & 7);
+            const ClusterRec* base = citems + ((size_t)cya * f.ncx + cxa + min(cxi, ncxr - 1)) * kCellCap + (lane & 7);
             for (int cy0 = cya; cy0 <= cyb; cy0 += 6) {
                 ClusterRec rr[6];
                 bool okr[6];
 #pragma unroll
-                for (int u = 0; u < 6; ++u) {
+                for (int u = 0; u < 6; ++u) {      // unconditional loads (rows past the range re-read the last one)
                     okr[u] = colok && (cy0 + u) <= cyb;
-                    rr[u].yx = 0; rr[u].lab = 0; rr[u].tag = 0; rr[u].pad = 0;
-                    if (okr[u]) rr[u] = base[(size_t)u * f.ncx * kCellCap];
+                    rr[u] = base[(size_t)min(u, cyb - cy0) * f.ncx * kCellCap];
                 }
                 base += 6 * (size_t)f.ncx * kCellCap;
 #pragma unroll
@@ -791,22 +795,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
         uint4* dst = reinterpret_cast<uint4*>(s_dyn);
         const int nq = f.tab_words >> 2;
         const int t = tid - 64;
-        for (int b0 = 0; b0 < nq; b0 += 4 * 192) {
+        for (int b0 = 0; b0 < nq; b0 += 4 * 192) {     // indices past the end are clamped: the last quad is rewritten, no masking
             uint4 q[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = b0 + u * 192 + t;
-                q[u] = make_uint4(0, 0, 0, 0);
-                if (i < nq) q[u] = src[i];
-            }
+            for (int u = 0; u < 4; ++u) q[u] = src[min(b0 + u * 192 + t, nq - 1)];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = b0 + u * 192 + t;
-                if (i < nq) dst[i] = q[u];
-            }
+            for (int u = 0; u < 4; ++u) dst[min(b0 + u * 192 + t, nq - 1)] = q[u];
         }
         if (FUSE) {
-            for (int i = t; i < 64 * kBlkCopies * 2; i += 192) s_acc[i] = 0ull;
+#pragma unroll
+            for (int i = 0; i < (64 * kBlkCopies * 2 + 191) / 192; ++i) s_acc[min(i * 192 + t, 64 * kBlkCopies * 2 - 1)] = 0ull;
         }
     }
     __syncthreads();
