@@ -1374,9 +1374,17 @@ __global__ __launch_bounds__(256) void k_cca_compress(CcaDev c) {
     const int32_t* __restrict__ my_roots = c.roots + (size_t)tile * TT;
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
         const int32_t r = my_roots[i];
-        const int32_t g = g_find(c.parent, r);
+        // READ-ONLY walk: a path-halving store of another thread (parent[r] = some ancestor) could land after this
+        // thread's parent[r] = g and leave r one level short of flat, and chain / relabel rely on parent[parent[p]]
+        // being the global root (an intermittent wrong label at 4K, about one run in six, was exactly that)
+        int32_t g = r;
+        for (;;) {
+            const int32_t p = g_load(c.parent + g);
+            if (p == g) break;
+            g = p;
+        }
         if (g != r) {
-            c.parent[r] = g;
+            __hip_atomic_store(c.parent + r, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             atomicAdd(&c.area[g], c.area[r]);
         }
     }
@@ -1662,7 +1670,9 @@ void launch_cca_select(const CcaDev& c, int nframes, hipStream_t st, unsigned lo
     if (cap > kSelCap) cap = kSelCap;
     const size_t lds = (3 * (size_t)cap + 3 * (size_t)kSelBuckets) * sizeof(uint32_t);
     static_assert(kSelBins <= 3 * kSelBuckets, "the selection histogram reuses the ranking buckets");
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_cca_select), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(k_cca_select), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                           (int)((3 * (size_t)kSelCap + 3 * (size_t)kSelBuckets) * sizeof(uint32_t)));
+    (void)attr_once;
     hipLaunchKernelGGL(k_cca_select, dim3(nframes), dim3(1024), lds, st, c, cap, dbg);
 }
 
