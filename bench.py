@@ -38,7 +38,17 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(H, W, K, budget_s=8.0):
+def pmc_traffic(key):
+    """HBM bytes per launch of the assign kernels from the committed rocprofv3 --pmc passes of this workload
+    (profiles/r01_pmc_assign_traffic.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE); None when the file is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_assign_traffic.json")) as f:
+            return json.load(f)[key]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def cpu_baseline(H, W, K, budget_s=12.0):
     """Reference timed on this host: iterate(img, 10) only, fresh clusters per frame (the reference
     re-allocates its context per call anyway), frames of the same synthetic stream as the GPU leg.
     The OpenMP thread count is chosen by a short sweep (the reference's per-iteration `omp critical`
@@ -194,6 +204,8 @@ def main():
         lp_ms = float(np.mean(loop_ms))
         gbs = lambda b, ms: b / (ms * 1e-3) / 1e9
         achieved = gbs(fa_bytes + lp_bytes, fa_avg_ms + lp_ms)
+        pmc = pmc_traffic("720p_x8") if (args.workload == "720p" and frames_per_launch == 8) else None
+        traffic = (pmc["full_assign"]["bytes"] + 10.0 * pmc["fused_assign_update"]["bytes"]) if pmc else None
         out = {
             "metric": "megapixels/sec @10 iters (1280x720 & 4K, K=1600); % HBM roofline",
             "value": round(total_px / elapsed / 1e6, 2),
@@ -210,7 +222,8 @@ def main():
             # centroid update) + the full-assign launch; achieved = sum of algorithmic bytes / sum of durations
             "roofline": {"kernel": "k_assign_blk, all 11 launches of a group (%dx%d x %g frames per launch)" % (W, H, frames_per_launch),
                          "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, profiles/r01_pmc_assign_traffic.json" if pmc else None,
                          "bytes_per_group": fa_bytes + lp_bytes, "ms_per_group": round(fa_avg_ms + lp_ms, 5),
                          "full_assign": {"bytes_per_launch": fa_bytes, "avg_launch_ms": round(fa_avg_ms, 5),
                                          "achieved": round(gbs(fa_bytes, fa_avg_ms), 2),
@@ -241,9 +254,10 @@ def main():
                     l4px.append(lp)
             a4 = ASSIGN_BYTES_PER_PX * H4 * W4 / (float(np.mean(f4)) * 1e-3) / 1e9
             b4 = ASSIGN_BYTES_PER_PX * float(np.mean(l4px)) / (float(np.mean(l4ms)) * 1e-3) / 1e9
+            pmc4 = pmc_traffic("4k_k1600")
             out["roofline_4k"] = {"kernel": "k_assign_blk<16,false,1> (full_assign launch, 3840x2160, K=1600, 1 frame)", "bound": "hbm",
                                   "achieved": round(a4, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": round(a4 / HBM_PEAK_GBS, 4), "traffic": None,
+                                  "frac": round(a4 / HBM_PEAK_GBS, 4), "traffic": pmc4["full_assign"]["bytes"] if pmc4 else None,
                                   "avg_launch_ms": round(float(np.mean(f4)), 5),
                                   "fused_assign_update": {"avg_launch_ms": round(float(np.mean(l4ms)) / 10.0, 5),
                                                           "achieved": round(b4, 2), "frac": round(b4 / HBM_PEAK_GBS, 4)},
