@@ -182,6 +182,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # setup, not a step: every slot allocates and carves its arena on first use (hipMalloc + table upload), so touch
+    # each slot once before the warm-up steps; otherwise a small --warmup would leave allocations in the timed region
+    for _ in range(nslots):
+        step()
+    drain()
     for _ in range(args.warmup):
         step()
     drain()
