@@ -341,3 +341,20 @@ def test_repeated_runs_are_identical_at_4k(engine, golden_digests):
         assert digest(pre) == d["prelabels"], rep
         assert digest(orc.to_int16(labels)) == d["labels_int16"], rep
         assert digest(orc.cluster_table(cl)) == d["clusters_f32"], rep
+
+
+def test_randomized_shapes_and_options_against_oracle(engine):
+    # many small random cases: ragged sizes, every option combination the tiled and generic kernels take
+    rng = np.random.default_rng(20260926)
+    for trial in range(40):
+        H, W = int(rng.integers(24, 260)), int(rng.integers(24, 300))
+        K = int(rng.integers(1, max(2, H * W // 90)))
+        var = "ABCD"[int(rng.integers(0, 4))]
+        kw = dict(max_iter=int(rng.integers(0, 7)), compactness=float(rng.choice([1.0, 5.0, 10.0, 30.0, 80.0])),
+                  min_size_factor=float(rng.choice([0.0, 0.1, 0.25, 0.6])), subsample_stride=int(rng.integers(1, 5)),
+                  convert_to_lab=bool(rng.integers(0, 2)), manhattan=bool(rng.integers(0, 4)))
+        img = variant(var, H, W, seed=trial)
+        cl0 = orc.initialize_clusters(img, K)
+        labels, cl, pre, path = run_hip(engine, img, cl0, **kw)
+        o_labels, o_cl, o_lab, o_pre = orc.slic_iterate(img, cl0, stages=True, **kw)
+        assert_same("trial %d %dx%d K=%d %s %s path=%d" % (trial, H, W, K, var, kw, path), (labels, cl, pre), (o_labels, o_cl, o_pre))
