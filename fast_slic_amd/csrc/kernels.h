@@ -85,8 +85,10 @@ struct FrameDev {
     // generic-path tables
     const uint16_t* patch2d;   // (2S+1)^2, src/context.cpp:22-40
 
+    // byte offset by POINTER arithmetic (not through an integer): the compiler then still knows the pointer came from a
+    // kernel argument, i.e. points to global memory, and emits global_load / global_store instead of FLAT instructions
     template <class T> static __host__ __device__ __forceinline__ void adv(T*& p, size_t d) {
-        p = reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + d);
+        p = reinterpret_cast<T*>(const_cast<char*>(reinterpret_cast<const volatile char*>(p)) + d);
     }
     // advance every per-frame pointer to frame z of the group (tables lut / tab / patch2d are shared)
     __host__ __device__ __forceinline__ void select(int z) {
