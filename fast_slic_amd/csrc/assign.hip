@@ -1,277 +1,22 @@
-// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the SLIC hot path.
-//
-// Nothing here is a translation of the reference's AVX2/NEON code.  The reference *scatters*:
-// each cluster min-updates a (2S+1)^2 window, clusters visited in (phase, k) order
-// (src/context.cpp:199-298, src/arch/x64/avx2.h:89-187).  These kernels *gather*: every pixel
-// takes the lexicographic minimum of (distance, phase, k) over the clusters whose window covers
-// it, which is the same function of the inputs and needs no min_dists plane in memory.
-//
-// All arithmetic on this path is integer, so the results are bit-identical to the reference.
-#include "kernels.h"
-#include <cstdlib>
+// assign.hip -- assign / fused update kernels (src/context.cpp:199-354, src/arch/x64/avx2.h)
+// Hand-written gfx950 (CDNA4, wave64) kernels of the SLIC hot path; see kernels.h for the launch interface and
+// DESIGN.md for the design.  All arithmetic on this path is integer, so results are bit-identical to the reference.
+#include "device_common.h"
 
 namespace fslic {
 
-#define LANE() (threadIdx.x & 63)
-
-// Kernels index the double-buffered members with the constants 0 (this pass) and 1 (the other parity): a
-// run-time index into the by-value FrameDev argument would push the whole struct into scratch memory once
-// select() has modified it.  The launchers rotate the arrays accordingly.
-static FrameDev rotated(const FrameDev& f, int buf, int sbuf) {
-    FrameDev g = f;
-    g.cell_cnt[0] = f.cell_cnt[buf]; g.cell_cnt[1] = f.cell_cnt[buf ^ 1];
-    g.cell_items[0] = f.cell_items[buf]; g.cell_items[1] = f.cell_items[buf ^ 1];
-    g.ovf_cnt[0] = f.ovf_cnt[buf]; g.ovf_cnt[1] = f.ovf_cnt[buf ^ 1];
-    g.ovf_items[0] = f.ovf_items[buf]; g.ovf_items[1] = f.ovf_items[buf ^ 1];
-    g.sums[0] = f.sums[sbuf]; g.sums[1] = f.sums[sbuf ^ 1];
-    return g;
-}
-
-static __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-
+// Nothing here is a translation of the reference's AVX2/NEON code.  The reference *scatters*: each cluster
+// min-updates a (2S+1)^2 window, clusters visited in (phase, k) order (src/context.cpp:199-298,
+// src/arch/x64/avx2.h:89-187).  These kernels *gather*: every pixel takes the lexicographic minimum of
+// (distance, phase, k) over the clusters whose window covers it, which is the same function of the inputs and needs
+// no min_dists plane in memory.
+//   k_assign_blk      the default and the roofline kernel (block-level candidate list, packed 16-bit keys)
+//   k_assign          32-bit keys, one wavefront per tile: serves what the packed kernel does not take (distances
+//                     >= 1024, spatial table too large for LDS, subsample_stride > 3)
+//   k_assign_generic  one thread per pixel straight from the coarse bins: fallback (S < 8, candidate-list
+//                     overflow) and independent cross-check in the tests
 // =============================================================================================
-// RGB -> CIELAB prepass.  Restates FastCIELabCvt::convert (src/cielab.h:309-325) with both lookup
-// tables staged in LDS (16.5 KB); 4 pixels per thread: 3 dword loads in, one 16-byte store out.
-// Algorithmic traffic: 3 B read + 4 B written per pixel.
-// =============================================================================================
-struct LabConst { int cb[9]; };
-
-static __device__ __forceinline__ uint32_t lab_px(uint32_t R, uint32_t G, uint32_t B,
-                                                  const uint16_t* sg, const uint16_t* sl, const LabConst& k) {
-    const int sr = sg[R], sgv = sg[G], sb = sg[B];
-    const int xr = (k.cb[0] * sr + k.cb[1] * sgv + k.cb[2] * sb) >> 16;
-    const int yr = (k.cb[3] * sr + k.cb[4] * sgv + k.cb[5] * sb) >> 16;
-    const int zr = (k.cb[6] * sr + k.cb[7] * sgv + k.cb[8] * sb) >> 16;
-    const int fx = sl[xr], fy = sl[yr], fz = sl[zr];
-    const int ciel = 116 * fy - (16 << 13);
-    const int ciea = 500 * (fx - fy) + (128 << 13);
-    const int cieb = 200 * (fy - fz) + (128 << 13);
-    int l = (int)((unsigned)ciel >> 12);
-    int a = (int)((unsigned)ciea >> 12) - 128;
-    int b = (int)((unsigned)cieb >> 12) - 128;
-    l = min(max(l, 0), 255);
-    a = min(max(a, 0), 255);
-    b = min(max(b, 0), 255);
-    return (uint32_t)l | ((uint32_t)a << 8) | ((uint32_t)b << 16);
-}
-
-template <bool CONVERT>
-__global__ __launch_bounds__(1024) void k_rgb_to_lab(FrameDev f, const uint16_t* __restrict__ g_gamma,
-                                                     const uint16_t* __restrict__ g_labtbl, LabConst kc, int init_labels) {
-    __shared__ uint16_t s_gamma[256];
-    __shared__ uint16_t s_lab[8194];
-    f.select(blockIdx.y);
-    const uint8_t* __restrict__ rgb = f.rgb;
-    uint32_t* __restrict__ lab = f.lab;
-    uint16_t* __restrict__ labels_init = init_labels ? f.labels : nullptr;
-    const int N = f.N;
-    const int aligned4 = ((reinterpret_cast<uintptr_t>(rgb) & 3) == 0) ? 1 : 0;
-    if (CONVERT) {
-        for (int i = threadIdx.x; i < 128; i += blockDim.x)
-            reinterpret_cast<uint32_t*>(s_gamma)[i] = reinterpret_cast<const uint32_t*>(g_gamma)[i];
-        for (int i = threadIdx.x; i < 4097; i += blockDim.x)   // 8194 entries (last one padding)
-            reinterpret_cast<uint32_t*>(s_lab)[i] = reinterpret_cast<const uint32_t*>(g_labtbl)[i];
-        __syncthreads();
-    }
-    const int nquad = aligned4 ? (N >> 2) : 0;
-    const int gstride = gridDim.x * blockDim.x;
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += gstride) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(rgb) + 3 * (size_t)q;
-        const uint32_t w0 = src[0], w1 = src[1], w2 = src[2];
-        uint32_t r0 = w0 & 255, g0 = (w0 >> 8) & 255, b0 = (w0 >> 16) & 255;
-        uint32_t r1 = w0 >> 24, g1 = w1 & 255, b1 = (w1 >> 8) & 255;
-        uint32_t r2 = (w1 >> 16) & 255, g2 = w1 >> 24, b2 = w2 & 255;
-        uint32_t r3 = (w2 >> 8) & 255, g3 = (w2 >> 16) & 255, b3 = w2 >> 24;
-        uint4 o;
-        if (CONVERT) {
-            o.x = lab_px(r0, g0, b0, s_gamma, s_lab, kc);
-            o.y = lab_px(r1, g1, b1, s_gamma, s_lab, kc);
-            o.z = lab_px(r2, g2, b2, s_gamma, s_lab, kc);
-            o.w = lab_px(r3, g3, b3, s_gamma, s_lab, kc);
-        } else {   // raw copy, src/context.cpp:117-127
-            o.x = r0 | (g0 << 8) | (b0 << 16);
-            o.y = r1 | (g1 << 8) | (b1 << 16);
-            o.z = r2 | (g2 << 8) | (b2 << 16);
-            o.w = r3 | (g3 << 8) | (b3 << 16);
-        }
-        reinterpret_cast<uint4*>(lab)[q] = o;
-        // assignment plane <- 0xFFFF once per call (src/context.cpp:138-145)
-        if (labels_init) reinterpret_cast<uint2*>(labels_init)[q] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-    }
-    // tail (and the whole image when the source pointer is not 4-byte aligned)
-    for (int p = (nquad << 2) + blockIdx.x * blockDim.x + threadIdx.x; p < N; p += gstride) {
-        const uint32_t r = rgb[3 * (size_t)p], g = rgb[3 * (size_t)p + 1], b = rgb[3 * (size_t)p + 2];
-        lab[p] = CONVERT ? lab_px(r, g, b, s_gamma, s_lab, kc) : (r | (g << 8) | (b << 16));
-        if (labels_init) labels_init[p] = 0xFFFFu;
-    }
-}
-
-void launch_rgb_to_lab(const FrameDev& f, int nframes, int convert, const LabTables& t, bool init_labels, hipStream_t st) {
-    LabConst kc;
-    for (int i = 0; i < 9; i++) kc.cb[i] = t.cb[i];
-    int blocks = (f.N / 4 + 1023) / 1024;
-    const int cap = (512 + nframes - 1) / nframes;   // about two resident blocks per CU over the whole group, grid-stride
-    if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
-    if (convert)
-        hipLaunchKernelGGL(k_rgb_to_lab<true>, dim3(blocks, nframes), dim3(1024), 0, st, f, t.gamma, t.labtbl, kc, init_labels ? 1 : 0);
-    else
-        hipLaunchKernelGGL(k_rgb_to_lab<false>, dim3(blocks, nframes), dim3(1024), 0, st, f, t.gamma, t.labtbl, kc, init_labels ? 1 : 0);
-}
-
-// =============================================================================================
-// Cluster pass (K threads): centroid finalisation + coarse binning.
-//   mode 0: colour resample at the centre, src/context.cpp:128-135
-//   mode 1: integer mean of the accumulated sums, src/context.cpp:356-373 (round_int,
-//           src/fast-slic-common.h:62-65), num_members written even when it is 0 (:362-364)
-// Then every cluster record {yx, lab, phase<<16|k} is appended to the coarse cell containing
-// its centre (spill list when a cell is full).  The other parity's counters are cleared for the
-// next iteration, so no per-iteration memset launch is needed.
-// =============================================================================================
-// Which assign blocks (64 px x BH visited rows) can hold pixels of a cluster centred at (cy, cx): the blocks its
-// (2S+1)^2 window overlaps, in block columns [bx0, bx1] and block rows [by0, by1] (any == false: no visited row).
-// The block kernel and the cluster pass evaluate this identically, which is what pairs writer and reader of
-// FrameDev::cpart.
-struct SlotGeom { int bx0, bx1, by0, by1; bool any; };
-static __device__ __forceinline__ SlotGeom slot_geom(int cy, int cx, int S, int H, int W, int rem, int stride, int BH, int Hv) {
-    SlotGeom g;
-    g.bx0 = max(cx - S, 0) >> 6;
-    g.bx1 = min(cx + S, W - 1) >> 6;
-    const int t = max(cy - S, 0) - rem;
-    const int v0 = t <= 0 ? 0 : (t + stride - 1) / stride;
-    const int u = min(cy + S, H - 1) - rem;
-    const int v1 = u < 0 ? -1 : min(u / stride, Hv - 1);
-    g.any = v0 <= v1;
-    g.by0 = v0 / BH;
-    g.by1 = g.any ? v1 / BH : -1;
-    return g;
-}
-
-// Sums of cluster k over the pass: the block kernel's partial sums (one entry per overlapping block) plus whatever
-// went through global atomics.  out[0..5] = count, sum y, sum x, sum L, sum a, sum b.
-static __device__ __forceinline__ void gather_sums(const FrameDev& f, const PassGeom& pg, int k, uint32_t yx, uint32_t* out) {
-    const uint32_t* s = f.sums[0] + 6 * (size_t)k;
-#pragma unroll
-    for (int q = 0; q < 6; ++q) out[q] = s[q];
-    if (!pg.use_slots) return;
-    const SlotGeom g = slot_geom((int)(yx >> 16), (int)(yx & 0xFFFFu), f.S, f.H, f.W, pg.rem, pg.stride, pg.BH, pg.Hv);
-    if (!g.any) return;
-    const uint32_t* cp = f.cpart + (size_t)k * f.cpart_ns * 6;
-    // entries (by, bx) in [by0, by1] x [bx0, bx1], four at a time with all their loads in flight (one memory round trip
-    // per four entries instead of one per entry: this pass is a chain of dependent loads on a handful of blocks)
-    const int nx = g.bx1 - g.bx0 + 1, ne = nx * (g.by1 - g.by0 + 1);
-    for (int e0 = 0; e0 < ne; e0 += 4) {
-        uint2 v[4][3];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = e0 + u;
-            const int ey = e / nx, ex = e - ey * nx;
-            v[u][0] = v[u][1] = v[u][2] = make_uint2(0u, 0u);
-            if (e < ne) {
-                const uint2* p = reinterpret_cast<const uint2*>(cp + (ey * f.nbx + ex) * 6);   // 24-byte entries
-                v[u][0] = p[0]; v[u][1] = p[1]; v[u][2] = p[2];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            out[0] += v[u][0].x; out[1] += v[u][0].y; out[2] += v[u][1].x; out[3] += v[u][1].y; out[4] += v[u][2].x; out[5] += v[u][2].y;
-        }
-    }
-}
-
-template <int MODE>
-__global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg) {
-    f.select(blockIdx.y);
-    // mode 1: consecutive blocks overlap by one cluster: thread 0 of a block only computes the member count of the
-    // cluster before the block's first one (the shadow test below needs the predecessor's count)
-    const int gi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gi < f.ncell) f.cell_cnt[1][gi] = 0;
-    if (gi == 0) *f.ovf_cnt[1] = 0;
-    const int k = MODE == 0 ? gi : (int)(blockIdx.x * (blockDim.x - 1) + threadIdx.x) - 1;
-    const bool live = k >= 0 && k < f.K;
-    uint32_t yx = live ? f.cl_yx[k] : 0u;
-    int y = (int)(yx >> 16), x = (int)(yx & 0xFFFF);
-    uint32_t lab;
-    // A cluster whose integer state (y, x, L, a, b) equals that of cluster k-1 has the same distance to every
-    // pixel and the same phase, and k-1 is visited first: it can never win a pixel.  Such runs come from
-    // initialize_clusters piling its leftover seeds on the image centre (src/context.cpp:80-86; 225 of 6000
-    // at 4K) and stay identical for ever because they never receive members.  They are kept out of the bins
-    // (exact), which keeps every candidate list short.  Detected only where it is race-free: both clusters
-    // unchanged by this pass (mode 1), or equal uploaded centres (mode 0).
-    bool shadowed = false;
-    if (MODE == 0) {
-        if (!live) return;
-        lab = f.lab[(size_t)y * f.W + x] & 0x00FFFFFFu;
-        f.cl_lab[k] = lab;
-        f.cl_yx_out[k] = yx;
-        shadowed = k > 0 && f.cl_yx[k - 1] == yx;
-        f.cl_shadow[k] = shadowed ? 1u : 0u;
-    } else {
-        // a shadowed cluster is in no candidate list: it received nothing and its cpart entries are stale
-        uint32_t s[6] = {0u, 0u, 0u, 0u, 0u, 0u};
-        if (live && !(pg.use_slots && f.cl_shadow[k])) gather_sums(f, pg, k, yx, s);
-        // member count of cluster k-1 (needed below): the previous thread's
-        __shared__ uint32_t s_n[256];
-        s_n[threadIdx.x] = s[0];
-        __syncthreads();
-        if (!live || threadIdx.x == 0) return;
-        const uint32_t n_prev = s_n[threadIdx.x - 1];
-        lab = f.cl_lab[k];
-        uint32_t* z0 = f.sums[1] + 6 * (size_t)k;    // the next pass accumulates here (sums[0] is still being read by neighbours)
-        const int32_t n = (int32_t)s[0];
-        f.cl_n[k] = (uint32_t)n;
-        if (n != 0) {
-            const int32_t h = n / 2;
-            y = ((int32_t)s[1] + h) / n;
-            x = ((int32_t)s[2] + h) / n;
-            // A centroid of in-image pixels is in the image, so this is a no-op on valid sums.  It only matters for a
-            // frame whose tiled attempt overflowed a candidate list (some partial sums were then never written and
-            // the frame is about to be redone by the generic path): positions must stay addressable meanwhile.
-            y = min(max(y, 0), f.H - 1);
-            x = min(max(x, 0), f.W - 1);
-            const int32_t L = ((int32_t)s[3] + h) / n;
-            const int32_t a = ((int32_t)s[4] + h) / n;
-            const int32_t b = ((int32_t)s[5] + h) / n;
-            yx = ((uint32_t)y << 16) | (uint32_t)(x & 0xFFFF);
-            lab = (uint32_t)(L & 255) | ((uint32_t)(a & 255) << 8) | ((uint32_t)(b & 255) << 16);
-            f.cl_lab[k] = lab;
-            f.cl_moved[k] = 1;
-        } else if (k > 0 && n_prev == 0u) {
-            shadowed = f.cl_yx[k - 1] == yx && f.cl_lab[k - 1] == lab;
-        }
-        f.cl_yx_out[k] = yx;
-        f.cl_shadow[k] = shadowed ? 1u : 0u;
-        z0[0] = 0; z0[1] = 0; z0[2] = 0; z0[3] = 0; z0[4] = 0; z0[5] = 0;
-    }
-    // visit order of the reference scatter: phase = 2*((cy/T)&1) + ((cx/T)&1), then k
-    const uint32_t phase = (uint32_t)(2 * ((y / f.T) & 1) + ((x / f.T) & 1));
-    ClusterRec rec;
-    rec.yx = yx; rec.lab = lab; rec.tag = (phase << 16) | (uint32_t)k; rec.pad = f.gen;
-    f.cl_tag[k] = rec.tag;
-    if (shadowed) return;
-    const int cell = (y >> f.cs_shift) * f.ncx + (x >> f.cs_shift);
-    const uint32_t slot = atomicAdd(&f.cell_cnt[0][cell], 1u);
-    if (slot < (uint32_t)kCellCap) {
-        f.cell_items[0][(size_t)cell * kCellCap + slot] = rec;
-    } else {
-        const uint32_t o = atomicAdd(f.ovf_cnt[0], 1u);
-        f.ovf_items[0][o] = rec;
-    }
-}
-
-void launch_bin_clusters(const FrameDev& f_, int nframes, int mode, int buf, int sbuf, const PassGeom& pg, hipStream_t st) {
-    const FrameDev f = rotated(f_, buf, sbuf);
-    if (mode == 0) {
-        const int n = f.K > f.ncell ? f.K : f.ncell;
-        hipLaunchKernelGGL(k_bin_clusters<0>, dim3((n + 255) / 256, nframes), dim3(256), 0, st, f, pg);
-    } else {
-        const int bk = (f.K + 254) / 255, bc = (f.ncell + 255) / 256;    // 255 clusters per block (see the kernel)
-        hipLaunchKernelGGL(k_bin_clusters<1>, dim3(bk > bc ? bk : bc, nframes), dim3(256), 0, st, f, pg);
-    }
-}
-
-// =============================================================================================
-// Assign kernel (the roofline kernel).  One WAVEFRONT = one tile of 64 columns x R visited rows; the four
+// 32-bit assign kernel.  One WAVEFRONT = one tile of 64 columns x R visited rows; the four
 // wavefronts of a block are independent (no barrier, no shared list), so they drift apart in time and the
 // loads of one overlap the argmin of another.
 // Lane = column, so |x - cx| and the x window test are per-lane-per-candidate, while |y - cy| and the y window
@@ -823,8 +568,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
     {
         const int cyj = (int)(yx_j >> 16);
         todo = __ballot(lane < bn && nrows > 0 && cyj + S >= yw_lo && cyj - S <= yw_hi);
-        if (f.exp_flags & 4) todo = 0;        // timing experiment: no argmin
-        if (f.exp_flags & 8) todo &= 1ull;    // timing experiment: one candidate
     }
     FSLIC_STAMP(2);
 
@@ -954,7 +697,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
     }
     FSLIC_STAMP(4);
     if (FUSE) {
-        if (!(f.exp_flags & 2)) {
+        {
             bool uni = slot[0] != kNoSlot;
 #pragma unroll
             for (int r = 1; r < R; ++r) uni = uni && (slot[r] == slot[0]);
@@ -1020,12 +763,7 @@ static void launch_assign_blk_t(const FrameDev& f_, int nframes, int rem, int Hv
     FrameDev f = f_;
     if (FUSE) { f.tab = f.tabs; f.tab_words = f.tabs_words; f.tab_dyoff = f.tabs_dyoff; f.tab_nrpad = f.tabs_nrpad; }   // table of the subsampled stride
     dim3 grid((f.W + kTileW - 1) / kTileW, (Hv + kWavesPerBlock * R - 1) / (kWavesPerBlock * R), nframes);
-    static const size_t lds_pad = getenv("FSLIC_LDS_PAD") ? (size_t)atoi(getenv("FSLIC_LDS_PAD")) : 0;   // experiment: caps blocks per CU
-    const size_t lds = (size_t)f.tab_words * sizeof(uint32_t) + lds_pad;
-    if (lds_pad) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_assign_blk<R, FUSE, STRIDE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_assign_blk<R, FUSE, STRIDE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
+    const size_t lds = (size_t)f.tab_words * sizeof(uint32_t);
     if (f.tab_vmode) hipLaunchKernelGGL((k_assign_blk<R, FUSE, STRIDE, true>), grid, dim3(256), lds, st, f, rem, Hv);
     else hipLaunchKernelGGL((k_assign_blk<R, FUSE, STRIDE, false>), grid, dim3(256), lds, st, f, rem, Hv);
 }
@@ -1130,628 +868,6 @@ void launch_assign_generic(const FrameDev& f_, int nframes, int rem, int stride,
     const int blocks = (int)((n + 255) / 256);
     if (fuse_update) hipLaunchKernelGGL(k_assign_generic<true>, dim3(blocks, nframes), dim3(256), 0, st, f, rem, stride, Hv, buf, sbuf);
     else hipLaunchKernelGGL(k_assign_generic<false>, dim3(blocks, nframes), dim3(256), 0, st, f, rem, stride, Hv, buf, sbuf);
-}
-
-// =============================================================================================
-// Connectivity / min-size pass (src/cca.cpp).  GPU union-find whose roots are the minimum raster
-// index of each component, exactly the "leader" the reference ends up with (src/cca.h:36-57).
-//   k_cca_local    64x64 tiles resolved entirely in LDS (row runs by ballot, vertical unions by LDS
-//                  atomicMin), writes parent[p] = global index of the tile-local root, tile-local
-//                  areas, and appends tile-local roots to a list
-//   k_cca_border   unions across tile borders (global atomicMin)
-//   k_cca_compress tile-local roots -> global roots, areas summed into the global root
-//   k_cca_collect  global roots with area >= threshold -> candidate list for the top-K step
-//   (host)         std::partial_sort / ranking of <= few thousand (leader, area) pairs
-//   k_cca_chain    every other component takes the final label of the component left of (or
-//                  above) its leader, src/cca.cpp:240-254, resolved by chasing toward smaller leaders
-//   k_cca_relabel  out[p] = final[root(p)]
-// =============================================================================================
-// LDS accessors.  They are relaxed workgroup-scope atomics rather than `volatile` accesses on purpose:
-// volatile blocks the address-space inference and the accesses become FLAT instructions, which reach the LDS
-// through the vector-memory path at global-memory latency (measured: 1.2 ms instead of tens of us for the
-// tile kernel); atomics still lower to ds_read_b32 / ds_write_b32 and are re-read on every loop trip.
-static __device__ __forceinline__ uint32_t lds_ld(uint32_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-static __device__ __forceinline__ void lds_st(uint32_t* p, uint32_t v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-// find with path halving.  The halving store races with concurrent atomicMin hooks, which is safe:
-// it only ever replaces a parent by one of its ancestors (cf. ECL-CC style concurrent union-find).
-static __device__ __forceinline__ uint32_t lds_find(uint32_t* par, uint32_t x) {
-    for (;;) {
-        const uint32_t p = lds_ld(par + x);
-        if (p == x) return x;
-        const uint32_t gp = lds_ld(par + p);
-        if (gp == p) return p;
-        lds_st(par + x, gp);
-        x = gp;
-    }
-}
-static __device__ __forceinline__ void lds_union(uint32_t* par, uint32_t a, uint32_t b) {
-    for (;;) {
-        a = lds_find(par, a);
-        b = lds_find(par, b);
-        if (a == b) return;
-        if (a < b) { const uint32_t t = a; a = b; b = t; }
-        const uint32_t old = atomicMin(par + a, b);
-        if (old == a) return;
-        a = old;
-    }
-}
-
-// read-only find (no halving stores), unrolled for the flatten pass
-static __device__ __forceinline__ uint32_t lds_find_ro(uint32_t* par, uint32_t x) {
-    uint32_t p = lds_ld(par + x);
-    while (p != x) { x = p; p = lds_ld(par + x); }
-    return x;
-}
-
-// One block = one 64x64 tile = 4 wavefronts x 16 rows.  Lane = column.
-//  A  each wavefront resolves its own 16-row strip top-down: horizontal runs by ballot, one LDS union per
-//     horizontal overlap with the row above; the (possibly stale) root of the pixel above travels in a VGPR,
-//     so a row costs a handful of dependent LDS operations instead of chain walks
-//  B  the three strip seams inside the tile are merged in LDS
-//  C  flatten: every pixel -> tile-local root (min raster index), parent plane written, run lengths added
-//     to the root's area
-//  D  tile-local roots appended to the root list (one global atomic per wavefront row)
-__global__ __launch_bounds__(256) void k_cca_local(CcaDev c) {
-    c.select(blockIdx.z);
-    constexpr int T = kCcaTile;
-    constexpr int TH = kCcaTileH;
-    constexpr int RW = TH / 4;
-    __shared__ uint16_t s_lbl[T * TH];
-    __shared__ uint32_t s_par[T * TH];
-    __shared__ uint32_t s_area[T * TH];
-    const int lane = LANE();
-    const int wave = (int)rfl((uint32_t)(threadIdx.x >> 6));
-    const int tx0 = blockIdx.x * T, ty0 = blockIdx.y * TH;
-    const int x = tx0 + lane;
-    const bool okx = x < c.W;
-    const int ly0 = wave * RW;
-    const unsigned long long lowmask = (2ull << lane) - 1ull;
-
-    uint32_t lbl[RW];
-#pragma unroll
-    for (int i = 0; i < RW; ++i) {
-        const int y = ty0 + ly0 + i;
-        lbl[i] = (okx && y < c.H) ? (uint32_t)c.in[(size_t)y * c.W + x] : 0x10000u;
-    }
-    // ---- A ----
-    // Per row: every pixel whose upper neighbour has the same label folds the (possibly stale) root carried in
-    // its VGPR into its run's node with a non-returning ds_min; one dependent ds_read then yields the run's
-    // root.  Only where a run joins two so-far distinct components (U shapes) is a real union needed.
-    uint32_t up_root = 0;
-#pragma unroll
-    for (int i = 0; i < RW; ++i) {
-        const int ly = ly0 + i;
-        const bool ok = okx && (ty0 + ly) < c.H;
-        const int p = ly * T + lane;
-        const uint32_t l = lbl[i];
-        const uint32_t left = __shfl_up(l, 1);
-        const bool start = (lane == 0) || (l != left) || !ok;
-        const unsigned long long m = __ballot(start);
-        const uint32_t node = (uint32_t)(ly * T + (63 - __clzll(m & lowmask)));
-        s_lbl[p] = (uint16_t)l;
-        s_area[p] = 0u;
-        s_par[p] = node;
-        uint32_t cur_root = node;
-        if (i > 0) {
-            const bool up_same = ok && (lbl[i - 1] == l);
-            if (up_same) __hip_atomic_fetch_min(s_par + node, up_root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (ok) cur_root = lds_ld(s_par + node);
-            if (up_same && up_root != cur_root) lds_union(s_par, up_root, cur_root);
-        }
-        up_root = cur_root;
-    }
-    __syncthreads();
-    // ---- B ----
-    if (wave > 0) {
-        const int p = ly0 * T + lane;
-        const bool ok = okx && (ty0 + ly0) < c.H;
-        const uint32_t l = lbl[0];
-        const uint32_t left = __shfl_up(l, 1);
-        if (ok && (uint32_t)s_lbl[p - T] == l) {
-            const bool first = (lane == 0) || (left != l) || ((uint32_t)s_lbl[p - T - 1] != l);
-            if (first) lds_union(s_par, (uint32_t)p, (uint32_t)(p - T));
-        }
-    }
-    __syncthreads();
-    // ---- C ----
-    uint32_t root[RW];
-#pragma unroll
-    for (int i = 0; i < RW; ++i) root[i] = s_par[(ly0 + i) * T + lane];
-#pragma unroll
-    for (int i = 0; i < RW; ++i) root[i] = s_par[root[i]];
-#pragma unroll
-    for (int i = 0; i < RW; ++i) root[i] = lds_find_ro(s_par, root[i]);
-#pragma unroll
-    for (int i = 0; i < RW; ++i) {
-        const int ly = ly0 + i;
-        const int y = ty0 + ly;
-        const bool ok = okx && y < c.H;
-        const uint32_t r = ok ? root[i] : 0xFFFFFFFFu;
-        if (ok) c.parent[(size_t)y * c.W + x] = (int32_t)((size_t)(ty0 + (int)(r / T)) * c.W + tx0 + (int)(r % T));
-        const uint32_t rl = __shfl_up(r, 1);
-        const bool start = (lane == 0) || (r != rl) || !ok;
-        const unsigned long long m = __ballot(start);
-        if (ok && start) {
-            const unsigned long long higher = (lane == 63) ? 0ull : (m >> (lane + 1));
-            const int len = higher ? __ffsll((long long)higher) : (64 - lane);
-            atomicAdd(&s_area[r], (uint32_t)len);
-        }
-    }
-    __syncthreads();
-    // ---- D ---- tile-local roots -> this tile's slice of the root list.  No global atomic: a single
-    // returning atomic word saturates near 88 ops/us on this chip, which at one append per wavefront-row
-    // (130k at 4K) cost 1.2 ms in the first version of this kernel.
-    __shared__ uint32_t s_nroots;
-    if (threadIdx.x == 0) s_nroots = 0;
-    __syncthreads();
-    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
-    int32_t* const my_roots = c.roots + (size_t)tile * (T * TH);
-#pragma unroll 4
-    for (int i = 0; i < RW; ++i) {
-        const int ly = ly0 + i;
-        const int y = ty0 + ly;
-        const bool ok = okx && y < c.H;
-        const int p = ly * T + lane;
-        const bool isroot = ok && root[i] == (uint32_t)p;
-        const unsigned long long m = __ballot(isroot);
-        if (m) {
-            const int leader = __ffsll((long long)m) - 1;
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(&s_nroots, (uint32_t)__popcll(m));
-            base = __shfl(base, leader);
-            if (isroot) {
-                const int32_t g = (int32_t)((size_t)y * c.W + x);
-                c.area[g] = s_area[p];
-                my_roots[base + __popcll(m & ((1ull << lane) - 1ull))] = g;
-            }
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) c.tile_cnt[tile] = s_nroots;
-}
-
-static __device__ __forceinline__ int32_t g_load(int32_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-static __device__ __forceinline__ int32_t g_find(int32_t* parent, int32_t x) {
-    for (;;) {
-        const int32_t p = g_load(parent + x);
-        if (p == x) return x;
-        const int32_t gp = g_load(parent + p);
-        if (gp == p) return p;
-        __hip_atomic_store(parent + x, gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        x = gp;
-    }
-}
-static __device__ __forceinline__ void g_union(int32_t* parent, int32_t a, int32_t b) {
-    for (;;) {
-        a = g_find(parent, a);
-        b = g_find(parent, b);
-        if (a == b) return;
-        if (a < b) { const int32_t t = a; a = b; b = t; }
-        const int32_t old = atomicMin(parent + a, b);
-        if (old == a) return;
-        a = old;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_cca_border(CcaDev c, int nh, int nv) {
-    c.select(blockIdx.y);
-    constexpr int T = kCcaTile;
-    constexpr int TH = kCcaTileH;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int W = c.W, H = c.H;
-    if (i < nh) {            // pixel on the first row of a tile row, merge with the pixel above
-        const int by = i / W + 1, x = i - (by - 1) * W;
-        const int p = by * TH * W + x;
-        const uint16_t lbl = c.in[p];
-        if (c.in[p - W] == lbl) {
-            const bool first = (x % T == 0) || c.in[p - 1] != lbl || c.in[p - W - 1] != lbl;
-            if (first) g_union(c.parent, p, p - W);
-        }
-    } else if (i < nh + nv) { // pixel on the first column of a tile column, merge with the pixel to the left
-        const int j = i - nh;
-        const int bx = j / H + 1, y = j - (bx - 1) * H;
-        const int p = y * W + bx * T;
-        const uint16_t lbl = c.in[p];
-        if (c.in[p - 1] == lbl) {
-            const bool first = (y % TH == 0) || c.in[p - W] != lbl || c.in[p - W - 1] != lbl;
-            if (first) g_union(c.parent, p, p - 1);
-        }
-    }
-}
-
-// One block per tile for the passes over tile-local roots.
-__global__ __launch_bounds__(256) void k_cca_compress(CcaDev c) {
-    c.select(blockIdx.y);
-    constexpr int TT = kCcaTilePx;
-    const int tile = blockIdx.x;
-    const uint32_t n = c.tile_cnt[tile];
-    const int32_t* __restrict__ my_roots = c.roots + (size_t)tile * TT;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const int32_t r = my_roots[i];
-        // READ-ONLY walk: a path-halving store of another thread (parent[r] = some ancestor) could land after this
-        // thread's parent[r] = g and leave r one level short of flat, and chain / relabel rely on parent[parent[p]]
-        // being the global root (an intermittent wrong label at 4K, about one run in six, was exactly that)
-        int32_t g = r;
-        for (;;) {
-            const int32_t p = g_load(c.parent + g);
-            if (p == g) break;
-            g = p;
-        }
-        if (g != r) {
-            __hip_atomic_store(c.parent + r, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            atomicAdd(&c.area[g], c.area[r]);
-        }
-    }
-}
-
-// Global roots: reset their final label; those with area >= threshold (src/cca.cpp:213-217) become candidates,
-// appended to the frame's dense candidate arrays (one returning atomic per tile on counters[1], which ends up as M).
-__global__ __launch_bounds__(256) void k_cca_collect(CcaDev c) {
-    c.select(blockIdx.y);
-    constexpr int TT = kCcaTilePx;
-    __shared__ uint32_t s_n, s_base;
-    __shared__ int32_t s_cl[256];
-    __shared__ uint32_t s_ca[256];
-    const int tile = blockIdx.x;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    const uint32_t n = c.tile_cnt[tile];
-    const int32_t* __restrict__ my_roots = c.roots + (size_t)tile * TT;
-    for (uint32_t i0 = 0; i0 < n; i0 += blockDim.x) {
-        const uint32_t i = i0 + threadIdx.x;
-        bool cand = false;
-        int32_t r = 0;
-        uint32_t a = 0;
-        if (i < n) {
-            r = my_roots[i];
-            if (c.parent[r] == r) {
-                c.final_lab[r] = 0xFFFFu;
-                a = c.area[r];
-                cand = (int64_t)a >= (int64_t)c.min_threshold;
-            }
-        }
-        if (cand) {
-            const uint32_t pos = atomicAdd(&s_n, 1u);
-            s_cl[pos] = r; s_ca[pos] = a;
-        }
-        __syncthreads();
-        const uint32_t m = s_n;
-        if (m) {
-            if (threadIdx.x == 0) s_base = atomicAdd(&c.counters[1], m);
-            __syncthreads();
-            if (threadIdx.x < m) {
-                c.cand_leader[s_base + threadIdx.x] = s_cl[threadIdx.x];
-                c.cand_area[s_base + threadIdx.x] = s_ca[threadIdx.x];
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) s_n = 0;
-            __syncthreads();
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Device top-K + ranking (src/cca.cpp:205-237) in ONE block, for the unambiguous case:
-//   M <= K            : every candidate is kept
-//   M >  K            : the K largest areas are kept; the K-th largest area a* is found by an 8-bit radix
-//                       select.  If only part of the components with area == a* fit, which ones
-//                       std::partial_sort keeps depends on libstdc++'s heap order -> status = 1 and the host
-//                       redoes the step with std::partial_sort itself.
-// Kept leaders are sorted (bitonic, LDS) and final_lab[leader] = rank, i.e. labels 0,1,2.. in raster order
-// of each component's first pixel (src/cca.cpp:229-237).
-// status word (counters[3]): 0 = done here; 1 = area tie at the cut: the candidates have been written to
-// dense_leader / dense_area SORTED BY LEADER (counters[1] = M), which is the order the reference feeds to
-// std::partial_sort, and the host only has to run that one call; 2 = too many candidates for this block, the
-// host gathers and sorts them itself.
-// ---------------------------------------------------------------------------------------------
-constexpr int kSelCap = 10240;     // candidates the device path holds in LDS (3 x 40 KB)
-constexpr int kSelSortCap = 8192;  // candidates the tie path sorts in LDS (power of two <= kSelCap)
-constexpr int kSelBuckets = 2048;  // ranking buckets (consecutive raster-index ranges)
-constexpr int kSelBins = 4096;     // histogram bins of the selection
-
-// block-wide exclusive scan of one value per thread (1024 threads): wave scans by shuffles, 16 wave totals in LDS
-static __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* s_w, uint32_t& total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t u = __shfl_up(inc, off);
-        if (lane >= off) inc += u;
-    }
-    __syncthreads();                 // s_w may still be read from a previous call
-    if (lane == 63) s_w[wave] = inc;
-    __syncthreads();
-    uint32_t base = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) {
-        const uint32_t t = s_w[w];
-        if (w < wave) base += t;
-        tot += t;
-    }
-    total = tot;
-    return base + inc - v;
-}
-
-// K-th largest of s_area[0..M) restricted to values v with (v >> (sh + 12)) == prefix (all values when first):
-// histogram of (v >> sh) & 4095 (areas spread over many bins: few same-address LDS atomics), descending scan.
-// Returns through s_v[1] the bin holding the kk-th largest, through s_v[2] the rank left inside that bin.
-static __device__ __forceinline__ void select_pass(const uint32_t* s_area, uint32_t M, int sh, bool first, uint32_t prefix,
-                                                   uint32_t kk, uint32_t* s_hist, uint32_t* s_w, uint32_t* s_v) {
-    const int tid = threadIdx.x;
-    for (int i = tid; i < kSelBins; i += 1024) s_hist[i] = 0;
-    __syncthreads();
-    for (uint32_t i = tid; i < M; i += 1024) {
-        const uint32_t a = s_area[i];
-        if (first || (a >> (sh + 12)) == prefix) atomicAdd(&s_hist[(a >> sh) & (kSelBins - 1)], 1u);
-    }
-    __syncthreads();
-    // thread t owns bins 4095-4t .. 4092-4t (descending order)
-    uint32_t h[4], tot = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { h[q] = s_hist[kSelBins - 1 - 4 * tid - q]; tot += h[q]; }
-    uint32_t total;
-    uint32_t run = block_excl_scan_1024(tot, s_w, total);    // count in bins above this thread's
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (run < kk && run + h[q] >= kk) {
-            s_v[1] = (uint32_t)(kSelBins - 1 - 4 * tid - q);
-            s_v[2] = kk - run;
-        }
-        run += h[q];
-    }
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int cap, unsigned long long* dbg) {
-#define SEL_STAMP(i_) do { if (dbg && threadIdx.x == 0 && blockIdx.x == 0) dbg[i_] = __builtin_amdgcn_s_memrealtime(); } while (0)   // 100 MHz
-    SEL_STAMP(0);
-    c.select(blockIdx.x);
-    extern __shared__ uint32_t s_dyn[];
-    uint32_t* const s_area = s_dyn;
-    uint32_t* const s_lead = s_dyn + cap;
-    uint32_t* const s_key = s_dyn + 2 * cap;
-    uint32_t* const s_bcnt = s_dyn + 3 * cap;           // ranking buckets; the selection's histogram lives here first
-    uint32_t* const s_bstart = s_bcnt + kSelBuckets;
-    uint32_t* const s_bfill = s_bstart + kSelBuckets;
-    uint32_t* const s_hist = s_bcnt;                    // kSelBins <= 3 * kSelBuckets words
-    __shared__ uint32_t s_w[16];
-    __shared__ uint32_t s_v[8];     // [0] max area, [1] bin, [2] kk, [4] ties
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int K = c.K;
-    // 1. the frame's candidates -> LDS
-    const uint32_t M = c.counters[1];
-    if (tid < 8) s_v[tid] = 0;
-    if (tid == 0) c.counters[2] = M;
-    if (M > (uint32_t)cap) {
-        if (tid == 0) c.counters[3] = 2u;
-        return;
-    }
-    uint32_t amax = 0;
-    for (uint32_t i = tid; i < M; i += 1024) {
-        const uint32_t a = c.cand_area[i];
-        s_area[i] = a;
-        s_lead[i] = (uint32_t)c.cand_leader[i];
-        amax = max(amax, a);
-    }
-    __syncthreads();
-    if (M > (uint32_t)K) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) amax = max(amax, (uint32_t)__shfl_xor(amax, off));
-        if (lane == 0 && amax) atomicMax(&s_v[0], amax);
-        __syncthreads();
-    }
-    SEL_STAMP(1);
-    // 2. K-th largest area: 12 bits per pass, starting just above the top bit of the largest area
-    uint32_t astar = 0;           // keep iff area >= astar
-    if (M > (uint32_t)K) {
-        const uint32_t mx = s_v[0];
-        int sh = 0;
-        while ((mx >> sh) >= (uint32_t)kSelBins) sh += 12;
-        uint32_t prefix = 0, kk = (uint32_t)K;
-        bool first = true;
-        for (; sh >= 0; sh -= 12) {
-            select_pass(s_area, M, sh, first, prefix, kk, s_hist, s_w, s_v);
-            prefix = (prefix << 12) | s_v[1];
-            kk = s_v[2];
-            first = false;
-            __syncthreads();
-        }
-        astar = prefix;
-        // kk of the components with area == a* are needed; unless that is all of them the choice is libstdc++'s
-        uint32_t eq = 0;
-        for (uint32_t i = tid; i < M; i += 1024) eq += (uint32_t)(s_area[i] == astar);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) eq += (uint32_t)__shfl_xor(eq, off);
-        if (lane == 0 && eq) atomicAdd(&s_v[4], eq);
-        __syncthreads();
-        if (s_v[4] != kk) {
-            // tie at the cut: hand the host the candidates in ascending-leader order.  Same bucket ranking as step 3
-            // below, applied to every candidate: rank = position in the leader-sorted list (a bitonic sort of the
-            // pairs took 30 us here).
-            if (M > (uint32_t)kSelSortCap) {
-                if (tid == 0) c.counters[3] = 2u;
-                return;
-            }
-            int bsh = 0;
-            while ((((uint32_t)c.N - 1u) >> bsh) >= (uint32_t)kSelBuckets) bsh++;
-            for (int i = tid; i < 3 * kSelBuckets; i += 1024) s_bcnt[i] = 0;
-            __syncthreads();
-            for (uint32_t i = tid; i < M; i += 1024) atomicAdd(&s_bcnt[s_lead[i] >> bsh], 1u);
-            __syncthreads();
-            {
-                const uint32_t a = s_bcnt[2 * tid], b = s_bcnt[2 * tid + 1];
-                uint32_t tot;
-                const uint32_t ex = block_excl_scan_1024(a + b, s_w, tot);
-                s_bstart[2 * tid] = ex;
-                s_bstart[2 * tid + 1] = ex + a;
-            }
-            __syncthreads();
-            for (uint32_t i = tid; i < M; i += 1024) {
-                const uint32_t b = s_lead[i] >> bsh;
-                s_key[s_bstart[b] + atomicAdd(&s_bfill[b], 1u)] = s_lead[i];
-            }
-            __syncthreads();
-            for (uint32_t i = tid; i < M; i += 1024) {
-                const uint32_t me = s_lead[i];
-                const uint32_t b = me >> bsh;
-                const uint32_t lo = s_bstart[b], hi = lo + s_bcnt[b];
-                uint32_t r = lo;
-                for (uint32_t j = lo; j < hi; ++j) r += (uint32_t)(s_key[j] < me);
-                c.cand_leader[r] = (int32_t)me;
-                c.cand_area[r] = s_area[i];
-            }
-            if (tid == 0) c.counters[3] = 1u;
-            return;
-        }
-    }
-    SEL_STAMP(2);
-    // 3. rank of every kept leader among the kept leaders (labels 0,1,2.. in raster order of the first pixel,
-    //    src/cca.cpp:229-237): bucket by raster-index range, exclusive scan of the bucket sizes, rank inside the bucket
-    int bsh = 0;
-    while ((((uint32_t)c.N - 1u) >> bsh) >= (uint32_t)kSelBuckets) bsh++;
-    for (int i = tid; i < 3 * kSelBuckets; i += 1024) s_bcnt[i] = 0;     // bcnt, bstart, bfill (the histogram is dead)
-    __syncthreads();
-    for (uint32_t i = tid; i < M; i += 1024)
-        if (s_area[i] >= astar) atomicAdd(&s_bcnt[s_lead[i] >> bsh], 1u);
-    __syncthreads();
-    {
-        const uint32_t a = s_bcnt[2 * tid], b = s_bcnt[2 * tid + 1];
-        uint32_t n_keep;
-        const uint32_t ex = block_excl_scan_1024(a + b, s_w, n_keep);
-        s_bstart[2 * tid] = ex;
-        s_bstart[2 * tid + 1] = ex + a;
-    }
-    __syncthreads();
-    SEL_STAMP(3);
-    for (uint32_t i = tid; i < M; i += 1024)
-        if (s_area[i] >= astar) {
-            const uint32_t b = s_lead[i] >> bsh;
-            s_key[s_bstart[b] + atomicAdd(&s_bfill[b], 1u)] = s_lead[i];
-        }
-    __syncthreads();
-    SEL_STAMP(4);
-    for (uint32_t i = tid; i < M; i += 1024)
-        if (s_area[i] >= astar) {
-            const uint32_t me = s_lead[i];
-            const uint32_t b = me >> bsh;
-            const uint32_t lo = s_bstart[b], hi = lo + s_bcnt[b];
-            uint32_t r = lo;
-            for (uint32_t j = lo; j < hi; ++j) r += (uint32_t)(s_key[j] < me);
-            c.final_lab[me] = (uint16_t)r;
-        }
-    if (tid == 0) c.counters[3] = 0u;
-    SEL_STAMP(5);
-#undef SEL_STAMP
-}
-
-void launch_cca_phase1(const CcaDev& c, int nframes, hipStream_t st) {
-    constexpr int T = kCcaTile;
-    const int tx = (c.W + T - 1) / T, ty = (c.H + kCcaTileH - 1) / kCcaTileH;
-    hipLaunchKernelGGL(k_cca_local, dim3(tx, ty, nframes), dim3(256), 0, st, c);
-    const int nh = (ty - 1) * c.W, nv = (tx - 1) * c.H;
-    if (nh + nv > 0)
-        hipLaunchKernelGGL(k_cca_border, dim3((nh + nv + 255) / 256, nframes), dim3(256), 0, st, c, nh, nv);
-    hipLaunchKernelGGL(k_cca_compress, dim3(tx * ty, nframes), dim3(256), 0, st, c);
-    hipLaunchKernelGGL(k_cca_collect, dim3(tx * ty, nframes), dim3(256), 0, st, c);
-}
-
-void launch_cca_select(const CcaDev& c, int nframes, hipStream_t st, unsigned long long* dbg) {
-    // LDS capacity: no frame has more candidates than N / max(threshold, 1)
-    long long need = (long long)c.N / (c.min_threshold > 1 ? c.min_threshold : 1) + 1;
-    int cap = 1024;
-    while (cap < need && cap < kSelCap) cap <<= 1;
-    if (cap > kSelCap) cap = kSelCap;
-    const size_t lds = (3 * (size_t)cap + 3 * (size_t)kSelBuckets) * sizeof(uint32_t);
-    static_assert(kSelBins <= 3 * kSelBuckets, "the selection histogram reuses the ranking buckets");
-    static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(k_cca_select), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                           (int)((3 * (size_t)kSelCap + 3 * (size_t)kSelBuckets) * sizeof(uint32_t)));
-    (void)attr_once;
-    hipLaunchKernelGGL(k_cca_select, dim3(nframes), dim3(1024), lds, st, c, cap, dbg);
-}
-
-// Host path only: forget what the device select / chain wrote, then set the host's choice.
-__global__ __launch_bounds__(256) void k_cca_reset_final(CcaDev c) {
-    constexpr int TT = kCcaTilePx;
-    const int tile = blockIdx.x;
-    const uint32_t n = c.tile_cnt[tile];
-    const int32_t* __restrict__ my_roots = c.roots + (size_t)tile * TT;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const int32_t r = my_roots[i];
-        if (c.parent[r] == r) c.final_lab[r] = 0xFFFFu;
-    }
-}
-__global__ void k_cca_set_kept(CcaDev c, const int32_t* __restrict__ leaders, const uint16_t* __restrict__ labels, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) c.final_lab[leaders[i]] = labels[i];
-}
-void launch_cca_set_kept(const CcaDev& c, const int32_t* d_leaders, const uint16_t* d_labels, int n, hipStream_t st) {
-    constexpr int T = kCcaTile;
-    const int ntiles = ((c.W + T - 1) / T) * ((c.H + kCcaTileH - 1) / kCcaTileH);
-    hipLaunchKernelGGL(k_cca_reset_final, dim3(ntiles), dim3(256), 0, st, c);
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_cca_set_kept, dim3((n + 255) / 256), dim3(256), 0, st, c, d_leaders, d_labels, n);
-}
-
-// Every component that was not kept takes the final label of the component left of (or, in column 0,
-// above) its leader (src/cca.cpp:240-254).  Leaders strictly decrease along the chase, so it terminates.
-__global__ __launch_bounds__(256) void k_cca_chain(CcaDev c) {
-    c.select(blockIdx.y);
-    constexpr int TT = kCcaTilePx;
-    const int tile = blockIdx.x;
-    const uint32_t n = c.tile_cnt[tile];
-    const int32_t* __restrict__ my_roots = c.roots + (size_t)tile * TT;
-    const int W = c.W;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const int32_t r = my_roots[i];
-        if (c.parent[r] != r) continue;
-        if (__hip_atomic_load(c.final_lab + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0xFFFFu) continue;   // kept
-        int32_t cur = r;
-        uint32_t f;
-        for (;;) {
-            if (cur == 0) { f = 0; break; }        // src/cca.cpp:238
-            const int32_t t = (cur % W > 0) ? cur - 1 : cur - W;   // src/cca.cpp:243-248
-            const int32_t g = c.parent[c.parent[t]];
-            f = __hip_atomic_load(c.final_lab + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (f != 0xFFFFu) break;
-            cur = g;
-        }
-        __hip_atomic_store(c.final_lab + r, (uint16_t)f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-__global__ __launch_bounds__(256) void k_cca_relabel(CcaDev c) {
-    c.select(blockIdx.y);
-    const int gstride = gridDim.x * blockDim.x;
-    const int nquad = c.N >> 2;
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += gstride) {
-        const int4 lr = reinterpret_cast<const int4*>(c.parent)[q];
-        const uint32_t a = c.final_lab[c.parent[lr.x]], b = c.final_lab[c.parent[lr.y]];
-        const uint32_t d = c.final_lab[c.parent[lr.z]], e = c.final_lab[c.parent[lr.w]];
-        uint2 o;
-        o.x = a | (b << 16);
-        o.y = d | (e << 16);
-        reinterpret_cast<uint2*>(c.out)[q] = o;
-    }
-    for (int p = (nquad << 2) + blockIdx.x * blockDim.x + threadIdx.x; p < c.N; p += gstride)
-        c.out[p] = c.final_lab[c.parent[c.parent[p]]];
-}
-
-void launch_cca_phase2(const CcaDev& c, int nframes, hipStream_t st) {
-    constexpr int T = kCcaTile;
-    const int ntiles = ((c.W + T - 1) / T) * ((c.H + kCcaTileH - 1) / kCcaTileH);
-    hipLaunchKernelGGL(k_cca_chain, dim3(ntiles, nframes), dim3(256), 0, st, c);
-    int blocks = (c.N / 4 + 255) / 256;
-    const int cap = (4096 + nframes - 1) / nframes;
-    if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_cca_relabel, dim3(blocks, nframes), dim3(256), 0, st, c);
 }
 
 }  // namespace fslic

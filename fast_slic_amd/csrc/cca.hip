@@ -1,0 +1,630 @@
+// cca.hip -- connectivity / minimum-size pass (src/cca.cpp)
+// Hand-written gfx950 (CDNA4, wave64) kernels of the SLIC hot path; see kernels.h for the launch interface and
+// DESIGN.md for the design.  All arithmetic on this path is integer, so results are bit-identical to the reference.
+#include "device_common.h"
+
+namespace fslic {
+
+// =============================================================================================
+// Connectivity / min-size pass (src/cca.cpp).  GPU union-find whose roots are the minimum raster
+// index of each component, exactly the "leader" the reference ends up with (src/cca.h:36-57).
+//   k_cca_local    64x64 tiles resolved entirely in LDS (row runs by ballot, vertical unions by LDS
+//                  atomicMin), writes parent[p] = global index of the tile-local root, tile-local
+//                  areas, and appends tile-local roots to a list
+//   k_cca_border   unions across tile borders (global atomicMin)
+//   k_cca_compress tile-local roots -> global roots, areas summed into the global root
+//   k_cca_collect  global roots with area >= threshold -> candidate list for the top-K step
+//   (host)         std::partial_sort / ranking of <= few thousand (leader, area) pairs
+//   k_cca_chain    every other component takes the final label of the component left of (or
+//                  above) its leader, src/cca.cpp:240-254, resolved by chasing toward smaller leaders
+//   k_cca_relabel  out[p] = final[root(p)]
+// =============================================================================================
+// LDS accessors.  They are relaxed workgroup-scope atomics rather than `volatile` accesses on purpose:
+// volatile blocks the address-space inference and the accesses become FLAT instructions, which reach the LDS
+// through the vector-memory path at global-memory latency (measured: 1.2 ms instead of tens of us for the
+// tile kernel); atomics still lower to ds_read_b32 / ds_write_b32 and are re-read on every loop trip.
+static __device__ __forceinline__ uint32_t lds_ld(uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+static __device__ __forceinline__ void lds_st(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// find with path halving.  The halving store races with concurrent atomicMin hooks, which is safe:
+// it only ever replaces a parent by one of its ancestors (cf. ECL-CC style concurrent union-find).
+static __device__ __forceinline__ uint32_t lds_find(uint32_t* par, uint32_t x) {
+    for (;;) {
+        const uint32_t p = lds_ld(par + x);
+        if (p == x) return x;
+        const uint32_t gp = lds_ld(par + p);
+        if (gp == p) return p;
+        lds_st(par + x, gp);
+        x = gp;
+    }
+}
+static __device__ __forceinline__ void lds_union(uint32_t* par, uint32_t a, uint32_t b) {
+    for (;;) {
+        a = lds_find(par, a);
+        b = lds_find(par, b);
+        if (a == b) return;
+        if (a < b) { const uint32_t t = a; a = b; b = t; }
+        const uint32_t old = atomicMin(par + a, b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+// read-only find (no halving stores), unrolled for the flatten pass
+static __device__ __forceinline__ uint32_t lds_find_ro(uint32_t* par, uint32_t x) {
+    uint32_t p = lds_ld(par + x);
+    while (p != x) { x = p; p = lds_ld(par + x); }
+    return x;
+}
+
+// One block = one 64x64 tile = 4 wavefronts x 16 rows.  Lane = column.
+//  A  each wavefront resolves its own 16-row strip top-down: horizontal runs by ballot, one LDS union per
+//     horizontal overlap with the row above; the (possibly stale) root of the pixel above travels in a VGPR,
+//     so a row costs a handful of dependent LDS operations instead of chain walks
+//  B  the three strip seams inside the tile are merged in LDS
+//  C  flatten: every pixel -> tile-local root (min raster index), parent plane written, run lengths added
+//     to the root's area
+//  D  tile-local roots appended to the root list (one global atomic per wavefront row)
+__global__ __launch_bounds__(256) void k_cca_local(CcaDev c) {
+    c.select(blockIdx.z);
+    constexpr int T = kCcaTile;
+    constexpr int TH = kCcaTileH;
+    constexpr int RW = TH / 4;
+    __shared__ uint16_t s_lbl[T * TH];
+    __shared__ uint32_t s_par[T * TH];
+    __shared__ uint32_t s_area[T * TH];
+    const int lane = LANE();
+    const int wave = (int)rfl((uint32_t)(threadIdx.x >> 6));
+    const int tx0 = blockIdx.x * T, ty0 = blockIdx.y * TH;
+    const int x = tx0 + lane;
+    const bool okx = x < c.W;
+    const int ly0 = wave * RW;
+    const unsigned long long lowmask = (2ull << lane) - 1ull;
+
+    uint32_t lbl[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int y = ty0 + ly0 + i;
+        lbl[i] = (okx && y < c.H) ? (uint32_t)c.in[(size_t)y * c.W + x] : 0x10000u;
+    }
+    // ---- A ----
+    // Per row: every pixel whose upper neighbour has the same label folds the (possibly stale) root carried in
+    // its VGPR into its run's node with a non-returning ds_min; one dependent ds_read then yields the run's
+    // root.  Only where a run joins two so-far distinct components (U shapes) is a real union needed.
+    uint32_t up_root = 0;
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int ly = ly0 + i;
+        const bool ok = okx && (ty0 + ly) < c.H;
+        const int p = ly * T + lane;
+        const uint32_t l = lbl[i];
+        const uint32_t left = __shfl_up(l, 1);
+        const bool start = (lane == 0) || (l != left) || !ok;
+        const unsigned long long m = __ballot(start);
+        const uint32_t node = (uint32_t)(ly * T + (63 - __clzll(m & lowmask)));
+        s_lbl[p] = (uint16_t)l;
+        s_area[p] = 0u;
+        s_par[p] = node;
+        uint32_t cur_root = node;
+        if (i > 0) {
+            const bool up_same = ok && (lbl[i - 1] == l);
+            if (up_same) __hip_atomic_fetch_min(s_par + node, up_root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (ok) cur_root = lds_ld(s_par + node);
+            if (up_same && up_root != cur_root) lds_union(s_par, up_root, cur_root);
+        }
+        up_root = cur_root;
+    }
+    __syncthreads();
+    // ---- B ----
+    if (wave > 0) {
+        const int p = ly0 * T + lane;
+        const bool ok = okx && (ty0 + ly0) < c.H;
+        const uint32_t l = lbl[0];
+        const uint32_t left = __shfl_up(l, 1);
+        if (ok && (uint32_t)s_lbl[p - T] == l) {
+            const bool first = (lane == 0) || (left != l) || ((uint32_t)s_lbl[p - T - 1] != l);
+            if (first) lds_union(s_par, (uint32_t)p, (uint32_t)(p - T));
+        }
+    }
+    __syncthreads();
+    // ---- C ----
+    uint32_t root[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) root[i] = s_par[(ly0 + i) * T + lane];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) root[i] = s_par[root[i]];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) root[i] = lds_find_ro(s_par, root[i]);
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int ly = ly0 + i;
+        const int y = ty0 + ly;
+        const bool ok = okx && y < c.H;
+        const uint32_t r = ok ? root[i] : 0xFFFFFFFFu;
+        if (ok) c.parent[(size_t)y * c.W + x] = (int32_t)((size_t)(ty0 + (int)(r / T)) * c.W + tx0 + (int)(r % T));
+        const uint32_t rl = __shfl_up(r, 1);
+        const bool start = (lane == 0) || (r != rl) || !ok;
+        const unsigned long long m = __ballot(start);
+        if (ok && start) {
+            const unsigned long long higher = (lane == 63) ? 0ull : (m >> (lane + 1));
+            const int len = higher ? __ffsll((long long)higher) : (64 - lane);
+            atomicAdd(&s_area[r], (uint32_t)len);
+        }
+    }
+    __syncthreads();
+    // ---- D ---- tile-local roots -> this tile's slice of the root list.  No global atomic: a single
+    // returning atomic word saturates near 88 ops/us on this chip, which at one append per wavefront-row
+    // (130k at 4K) cost 1.2 ms in the first version of this kernel.
+    __shared__ uint32_t s_nroots;
+    if (threadIdx.x == 0) s_nroots = 0;
+    __syncthreads();
+    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+    int32_t* const my_roots = c.roots + (size_t)tile * (T * TH);
+#pragma unroll 4
+    for (int i = 0; i < RW; ++i) {
+        const int ly = ly0 + i;
+        const int y = ty0 + ly;
+        const bool ok = okx && y < c.H;
+        const int p = ly * T + lane;
+        const bool isroot = ok && root[i] == (uint32_t)p;
+        const unsigned long long m = __ballot(isroot);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&s_nroots, (uint32_t)__popcll(m));
+            base = __shfl(base, leader);
+            if (isroot) {
+                const int32_t g = (int32_t)((size_t)y * c.W + x);
+                c.area[g] = s_area[p];
+                my_roots[base + __popcll(m & ((1ull << lane) - 1ull))] = g;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) c.tile_cnt[tile] = s_nroots;
+}
+
+static __device__ __forceinline__ int32_t g_load(int32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static __device__ __forceinline__ int32_t g_find(int32_t* parent, int32_t x) {
+    for (;;) {
+        const int32_t p = g_load(parent + x);
+        if (p == x) return x;
+        const int32_t gp = g_load(parent + p);
+        if (gp == p) return p;
+        __hip_atomic_store(parent + x, gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x = gp;
+    }
+}
+static __device__ __forceinline__ void g_union(int32_t* parent, int32_t a, int32_t b) {
+    for (;;) {
+        a = g_find(parent, a);
+        b = g_find(parent, b);
+        if (a == b) return;
+        if (a < b) { const int32_t t = a; a = b; b = t; }
+        const int32_t old = atomicMin(parent + a, b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cca_border(CcaDev c, int nh, int nv) {
+    c.select(blockIdx.y);
+    constexpr int T = kCcaTile;
+    constexpr int TH = kCcaTileH;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int W = c.W, H = c.H;
+    if (i < nh) {            // pixel on the first row of a tile row, merge with the pixel above
+        const int by = i / W + 1, x = i - (by - 1) * W;
+        const int p = by * TH * W + x;
+        const uint16_t lbl = c.in[p];
+        if (c.in[p - W] == lbl) {
+            const bool first = (x % T == 0) || c.in[p - 1] != lbl || c.in[p - W - 1] != lbl;
+            if (first) g_union(c.parent, p, p - W);
+        }
+    } else if (i < nh + nv) { // pixel on the first column of a tile column, merge with the pixel to the left
+        const int j = i - nh;
+        const int bx = j / H + 1, y = j - (bx - 1) * H;
+        const int p = y * W + bx * T;
+        const uint16_t lbl = c.in[p];
+        if (c.in[p - 1] == lbl) {
+            const bool first = (y % TH == 0) || c.in[p - W] != lbl || c.in[p - W - 1] != lbl;
+            if (first) g_union(c.parent, p, p - 1);
+        }
+    }
+}
+
+// One block per tile for the passes over tile-local roots.
+__global__ __launch_bounds__(256) void k_cca_compress(CcaDev c) {
+    c.select(blockIdx.y);
+    constexpr int TT = kCcaTilePx;
+    const int tile = blockIdx.x;
+    const uint32_t n = c.tile_cnt[tile];
+    const int32_t* __restrict__ my_roots = c.roots + (size_t)tile * TT;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const int32_t r = my_roots[i];
+        // READ-ONLY walk: a path-halving store of another thread (parent[r] = some ancestor) could land after this
+        // thread's parent[r] = g and leave r one level short of flat, and chain / relabel rely on parent[parent[p]]
+        // being the global root (an intermittent wrong label at 4K, about one run in six, was exactly that)
+        int32_t g = r;
+        for (;;) {
+            const int32_t p = g_load(c.parent + g);
+            if (p == g) break;
+            g = p;
+        }
+        if (g != r) {
+            __hip_atomic_store(c.parent + r, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicAdd(&c.area[g], c.area[r]);
+        }
+    }
+}
+
+// Global roots: reset their final label; those with area >= threshold (src/cca.cpp:213-217) become candidates,
+// appended to the frame's dense candidate arrays (one returning atomic per tile on counters[1], which ends up as M).
+__global__ __launch_bounds__(256) void k_cca_collect(CcaDev c) {
+    c.select(blockIdx.y);
+    constexpr int TT = kCcaTilePx;
+    __shared__ uint32_t s_n, s_base;
+    __shared__ int32_t s_cl[256];
+    __shared__ uint32_t s_ca[256];
+    const int tile = blockIdx.x;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const uint32_t n = c.tile_cnt[tile];
+    const int32_t* __restrict__ my_roots = c.roots + (size_t)tile * TT;
+    for (uint32_t i0 = 0; i0 < n; i0 += blockDim.x) {
+        const uint32_t i = i0 + threadIdx.x;
+        bool cand = false;
+        int32_t r = 0;
+        uint32_t a = 0;
+        if (i < n) {
+            r = my_roots[i];
+            if (c.parent[r] == r) {
+                c.final_lab[r] = 0xFFFFu;
+                a = c.area[r];
+                cand = (int64_t)a >= (int64_t)c.min_threshold;
+            }
+        }
+        if (cand) {
+            const uint32_t pos = atomicAdd(&s_n, 1u);
+            s_cl[pos] = r; s_ca[pos] = a;
+        }
+        __syncthreads();
+        const uint32_t m = s_n;
+        if (m) {
+            if (threadIdx.x == 0) s_base = atomicAdd(&c.counters[1], m);
+            __syncthreads();
+            if (threadIdx.x < m) {
+                c.cand_leader[s_base + threadIdx.x] = s_cl[threadIdx.x];
+                c.cand_area[s_base + threadIdx.x] = s_ca[threadIdx.x];
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) s_n = 0;
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device top-K + ranking (src/cca.cpp:205-237) in ONE block, for the unambiguous case:
+//   M <= K            : every candidate is kept
+//   M >  K            : the K largest areas are kept; the K-th largest area a* is found by an 8-bit radix
+//                       select.  If only part of the components with area == a* fit, which ones
+//                       std::partial_sort keeps depends on libstdc++'s heap order -> status = 1 and the host
+//                       redoes the step with std::partial_sort itself.
+// Kept leaders are sorted (bitonic, LDS) and final_lab[leader] = rank, i.e. labels 0,1,2.. in raster order
+// of each component's first pixel (src/cca.cpp:229-237).
+// status word (counters[3]): 0 = done here; 1 = area tie at the cut: the candidates have been written to
+// dense_leader / dense_area SORTED BY LEADER (counters[1] = M), which is the order the reference feeds to
+// std::partial_sort, and the host only has to run that one call; 2 = too many candidates for this block, the
+// host gathers and sorts them itself.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSelCap = 10240;     // candidates the device path holds in LDS (3 x 40 KB)
+constexpr int kSelSortCap = 8192;  // candidates the tie path sorts in LDS (power of two <= kSelCap)
+constexpr int kSelBuckets = 2048;  // ranking buckets (consecutive raster-index ranges)
+constexpr int kSelBins = 4096;     // histogram bins of the selection
+
+// block-wide exclusive scan of one value per thread (1024 threads): wave scans by shuffles, 16 wave totals in LDS
+static __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t* s_w, uint32_t& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = __shfl_up(inc, off);
+        if (lane >= off) inc += u;
+    }
+    __syncthreads();                 // s_w may still be read from a previous call
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const uint32_t t = s_w[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    total = tot;
+    return base + inc - v;
+}
+
+// K-th largest of s_area[0..M) restricted to values v with (v >> (sh + 12)) == prefix (all values when first):
+// histogram of (v >> sh) & 4095 (areas spread over many bins: few same-address LDS atomics), descending scan.
+// Returns through s_v[1] the bin holding the kk-th largest, through s_v[2] the rank left inside that bin.
+static __device__ __forceinline__ void select_pass(const uint32_t* s_area, uint32_t M, int sh, bool first, uint32_t prefix,
+                                                   uint32_t kk, uint32_t* s_hist, uint32_t* s_w, uint32_t* s_v) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < kSelBins; i += 1024) s_hist[i] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < M; i += 1024) {
+        const uint32_t a = s_area[i];
+        if (first || (a >> (sh + 12)) == prefix) atomicAdd(&s_hist[(a >> sh) & (kSelBins - 1)], 1u);
+    }
+    __syncthreads();
+    // thread t owns bins 4095-4t .. 4092-4t (descending order)
+    uint32_t h[4], tot = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { h[q] = s_hist[kSelBins - 1 - 4 * tid - q]; tot += h[q]; }
+    uint32_t total;
+    uint32_t run = block_excl_scan_1024(tot, s_w, total);    // count in bins above this thread's
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (run < kk && run + h[q] >= kk) {
+            s_v[1] = (uint32_t)(kSelBins - 1 - 4 * tid - q);
+            s_v[2] = kk - run;
+        }
+        run += h[q];
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int cap, unsigned long long* dbg) {
+#define SEL_STAMP(i_) do { if (dbg && threadIdx.x == 0 && blockIdx.x == 0) dbg[i_] = __builtin_amdgcn_s_memrealtime(); } while (0)   // 100 MHz
+    SEL_STAMP(0);
+    c.select(blockIdx.x);
+    extern __shared__ uint32_t s_dyn[];
+    uint32_t* const s_area = s_dyn;
+    uint32_t* const s_lead = s_dyn + cap;
+    uint32_t* const s_key = s_dyn + 2 * cap;
+    uint32_t* const s_bcnt = s_dyn + 3 * cap;           // ranking buckets; the selection's histogram lives here first
+    uint32_t* const s_bstart = s_bcnt + kSelBuckets;
+    uint32_t* const s_bfill = s_bstart + kSelBuckets;
+    uint32_t* const s_hist = s_bcnt;                    // kSelBins <= 3 * kSelBuckets words
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_v[8];     // [0] max area, [1] bin, [2] kk, [4] ties
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int K = c.K;
+    // 1. the frame's candidates -> LDS
+    const uint32_t M = c.counters[1];
+    if (tid < 8) s_v[tid] = 0;
+    if (tid == 0) c.counters[2] = M;
+    if (M > (uint32_t)cap) {
+        if (tid == 0) c.counters[3] = 2u;
+        return;
+    }
+    uint32_t amax = 0;
+    for (uint32_t i = tid; i < M; i += 1024) {
+        const uint32_t a = c.cand_area[i];
+        s_area[i] = a;
+        s_lead[i] = (uint32_t)c.cand_leader[i];
+        amax = max(amax, a);
+    }
+    __syncthreads();
+    if (M > (uint32_t)K) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax = max(amax, (uint32_t)__shfl_xor(amax, off));
+        if (lane == 0 && amax) atomicMax(&s_v[0], amax);
+        __syncthreads();
+    }
+    SEL_STAMP(1);
+    // 2. K-th largest area: 12 bits per pass, starting just above the top bit of the largest area
+    uint32_t astar = 0;           // keep iff area >= astar
+    if (M > (uint32_t)K) {
+        const uint32_t mx = s_v[0];
+        int sh = 0;
+        while ((mx >> sh) >= (uint32_t)kSelBins) sh += 12;
+        uint32_t prefix = 0, kk = (uint32_t)K;
+        bool first = true;
+        for (; sh >= 0; sh -= 12) {
+            select_pass(s_area, M, sh, first, prefix, kk, s_hist, s_w, s_v);
+            prefix = (prefix << 12) | s_v[1];
+            kk = s_v[2];
+            first = false;
+            __syncthreads();
+        }
+        astar = prefix;
+        // kk of the components with area == a* are needed; unless that is all of them the choice is libstdc++'s
+        uint32_t eq = 0;
+        for (uint32_t i = tid; i < M; i += 1024) eq += (uint32_t)(s_area[i] == astar);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) eq += (uint32_t)__shfl_xor(eq, off);
+        if (lane == 0 && eq) atomicAdd(&s_v[4], eq);
+        __syncthreads();
+        if (s_v[4] != kk) {
+            // tie at the cut: hand the host the candidates in ascending-leader order.  Same bucket ranking as step 3
+            // below, applied to every candidate: rank = position in the leader-sorted list (a bitonic sort of the
+            // pairs took 30 us here).
+            if (M > (uint32_t)kSelSortCap) {
+                if (tid == 0) c.counters[3] = 2u;
+                return;
+            }
+            int bsh = 0;
+            while ((((uint32_t)c.N - 1u) >> bsh) >= (uint32_t)kSelBuckets) bsh++;
+            for (int i = tid; i < 3 * kSelBuckets; i += 1024) s_bcnt[i] = 0;
+            __syncthreads();
+            for (uint32_t i = tid; i < M; i += 1024) atomicAdd(&s_bcnt[s_lead[i] >> bsh], 1u);
+            __syncthreads();
+            {
+                const uint32_t a = s_bcnt[2 * tid], b = s_bcnt[2 * tid + 1];
+                uint32_t tot;
+                const uint32_t ex = block_excl_scan_1024(a + b, s_w, tot);
+                s_bstart[2 * tid] = ex;
+                s_bstart[2 * tid + 1] = ex + a;
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < M; i += 1024) {
+                const uint32_t b = s_lead[i] >> bsh;
+                s_key[s_bstart[b] + atomicAdd(&s_bfill[b], 1u)] = s_lead[i];
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < M; i += 1024) {
+                const uint32_t me = s_lead[i];
+                const uint32_t b = me >> bsh;
+                const uint32_t lo = s_bstart[b], hi = lo + s_bcnt[b];
+                uint32_t r = lo;
+                for (uint32_t j = lo; j < hi; ++j) r += (uint32_t)(s_key[j] < me);
+                c.cand_leader[r] = (int32_t)me;
+                c.cand_area[r] = s_area[i];
+            }
+            if (tid == 0) c.counters[3] = 1u;
+            return;
+        }
+    }
+    SEL_STAMP(2);
+    // 3. rank of every kept leader among the kept leaders (labels 0,1,2.. in raster order of the first pixel,
+    //    src/cca.cpp:229-237): bucket by raster-index range, exclusive scan of the bucket sizes, rank inside the bucket
+    int bsh = 0;
+    while ((((uint32_t)c.N - 1u) >> bsh) >= (uint32_t)kSelBuckets) bsh++;
+    for (int i = tid; i < 3 * kSelBuckets; i += 1024) s_bcnt[i] = 0;     // bcnt, bstart, bfill (the histogram is dead)
+    __syncthreads();
+    for (uint32_t i = tid; i < M; i += 1024)
+        if (s_area[i] >= astar) atomicAdd(&s_bcnt[s_lead[i] >> bsh], 1u);
+    __syncthreads();
+    {
+        const uint32_t a = s_bcnt[2 * tid], b = s_bcnt[2 * tid + 1];
+        uint32_t n_keep;
+        const uint32_t ex = block_excl_scan_1024(a + b, s_w, n_keep);
+        s_bstart[2 * tid] = ex;
+        s_bstart[2 * tid + 1] = ex + a;
+    }
+    __syncthreads();
+    SEL_STAMP(3);
+    for (uint32_t i = tid; i < M; i += 1024)
+        if (s_area[i] >= astar) {
+            const uint32_t b = s_lead[i] >> bsh;
+            s_key[s_bstart[b] + atomicAdd(&s_bfill[b], 1u)] = s_lead[i];
+        }
+    __syncthreads();
+    SEL_STAMP(4);
+    for (uint32_t i = tid; i < M; i += 1024)
+        if (s_area[i] >= astar) {
+            const uint32_t me = s_lead[i];
+            const uint32_t b = me >> bsh;
+            const uint32_t lo = s_bstart[b], hi = lo + s_bcnt[b];
+            uint32_t r = lo;
+            for (uint32_t j = lo; j < hi; ++j) r += (uint32_t)(s_key[j] < me);
+            c.final_lab[me] = (uint16_t)r;
+        }
+    if (tid == 0) c.counters[3] = 0u;
+    SEL_STAMP(5);
+#undef SEL_STAMP
+}
+
+void launch_cca_phase1(const CcaDev& c, int nframes, hipStream_t st) {
+    constexpr int T = kCcaTile;
+    const int tx = (c.W + T - 1) / T, ty = (c.H + kCcaTileH - 1) / kCcaTileH;
+    hipLaunchKernelGGL(k_cca_local, dim3(tx, ty, nframes), dim3(256), 0, st, c);
+    const int nh = (ty - 1) * c.W, nv = (tx - 1) * c.H;
+    if (nh + nv > 0)
+        hipLaunchKernelGGL(k_cca_border, dim3((nh + nv + 255) / 256, nframes), dim3(256), 0, st, c, nh, nv);
+    hipLaunchKernelGGL(k_cca_compress, dim3(tx * ty, nframes), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_cca_collect, dim3(tx * ty, nframes), dim3(256), 0, st, c);
+}
+
+void launch_cca_select(const CcaDev& c, int nframes, hipStream_t st, unsigned long long* dbg) {
+    // LDS capacity: no frame has more candidates than N / max(threshold, 1)
+    long long need = (long long)c.N / (c.min_threshold > 1 ? c.min_threshold : 1) + 1;
+    int cap = 1024;
+    while (cap < need && cap < kSelCap) cap <<= 1;
+    if (cap > kSelCap) cap = kSelCap;
+    const size_t lds = (3 * (size_t)cap + 3 * (size_t)kSelBuckets) * sizeof(uint32_t);
+    static_assert(kSelBins <= 3 * kSelBuckets, "the selection histogram reuses the ranking buckets");
+    static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(k_cca_select), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                           (int)((3 * (size_t)kSelCap + 3 * (size_t)kSelBuckets) * sizeof(uint32_t)));
+    (void)attr_once;
+    hipLaunchKernelGGL(k_cca_select, dim3(nframes), dim3(1024), lds, st, c, cap, dbg);
+}
+
+// Host path only: forget what the device select / chain wrote, then set the host's choice.
+__global__ __launch_bounds__(256) void k_cca_reset_final(CcaDev c) {
+    constexpr int TT = kCcaTilePx;
+    const int tile = blockIdx.x;
+    const uint32_t n = c.tile_cnt[tile];
+    const int32_t* __restrict__ my_roots = c.roots + (size_t)tile * TT;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const int32_t r = my_roots[i];
+        if (c.parent[r] == r) c.final_lab[r] = 0xFFFFu;
+    }
+}
+__global__ void k_cca_set_kept(CcaDev c, const int32_t* __restrict__ leaders, const uint16_t* __restrict__ labels, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) c.final_lab[leaders[i]] = labels[i];
+}
+void launch_cca_set_kept(const CcaDev& c, const int32_t* d_leaders, const uint16_t* d_labels, int n, hipStream_t st) {
+    constexpr int T = kCcaTile;
+    const int ntiles = ((c.W + T - 1) / T) * ((c.H + kCcaTileH - 1) / kCcaTileH);
+    hipLaunchKernelGGL(k_cca_reset_final, dim3(ntiles), dim3(256), 0, st, c);
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_cca_set_kept, dim3((n + 255) / 256), dim3(256), 0, st, c, d_leaders, d_labels, n);
+}
+
+// Every component that was not kept takes the final label of the component left of (or, in column 0,
+// above) its leader (src/cca.cpp:240-254).  Leaders strictly decrease along the chase, so it terminates.
+__global__ __launch_bounds__(256) void k_cca_chain(CcaDev c) {
+    c.select(blockIdx.y);
+    constexpr int TT = kCcaTilePx;
+    const int tile = blockIdx.x;
+    const uint32_t n = c.tile_cnt[tile];
+    const int32_t* __restrict__ my_roots = c.roots + (size_t)tile * TT;
+    const int W = c.W;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const int32_t r = my_roots[i];
+        if (c.parent[r] != r) continue;
+        if (__hip_atomic_load(c.final_lab + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0xFFFFu) continue;   // kept
+        int32_t cur = r;
+        uint32_t f;
+        for (;;) {
+            if (cur == 0) { f = 0; break; }        // src/cca.cpp:238
+            const int32_t t = (cur % W > 0) ? cur - 1 : cur - W;   // src/cca.cpp:243-248
+            const int32_t g = c.parent[c.parent[t]];
+            f = __hip_atomic_load(c.final_lab + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (f != 0xFFFFu) break;
+            cur = g;
+        }
+        __hip_atomic_store(c.final_lab + r, (uint16_t)f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cca_relabel(CcaDev c) {
+    c.select(blockIdx.y);
+    const int gstride = gridDim.x * blockDim.x;
+    const int nquad = c.N >> 2;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += gstride) {
+        const int4 lr = reinterpret_cast<const int4*>(c.parent)[q];
+        const uint32_t a = c.final_lab[c.parent[lr.x]], b = c.final_lab[c.parent[lr.y]];
+        const uint32_t d = c.final_lab[c.parent[lr.z]], e = c.final_lab[c.parent[lr.w]];
+        uint2 o;
+        o.x = a | (b << 16);
+        o.y = d | (e << 16);
+        reinterpret_cast<uint2*>(c.out)[q] = o;
+    }
+    for (int p = (nquad << 2) + blockIdx.x * blockDim.x + threadIdx.x; p < c.N; p += gstride)
+        c.out[p] = c.final_lab[c.parent[c.parent[p]]];
+}
+
+void launch_cca_phase2(const CcaDev& c, int nframes, hipStream_t st) {
+    constexpr int T = kCcaTile;
+    const int ntiles = ((c.W + T - 1) / T) * ((c.H + kCcaTileH - 1) / kCcaTileH);
+    hipLaunchKernelGGL(k_cca_chain, dim3(ntiles, nframes), dim3(256), 0, st, c);
+    int blocks = (c.N / 4 + 255) / 256;
+    const int cap = (4096 + nframes - 1) / nframes;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_cca_relabel, dim3(blocks, nframes), dim3(256), 0, st, c);
+}
+
+}  // namespace fslic

@@ -1,0 +1,140 @@
+// clusters.hip -- cluster pass: centroid finalisation and coarse binning (src/context.cpp:128-135, 356-373)
+// Hand-written gfx950 (CDNA4, wave64) kernels of the SLIC hot path; see kernels.h for the launch interface and
+// DESIGN.md for the design.  All arithmetic on this path is integer, so results are bit-identical to the reference.
+#include "device_common.h"
+
+namespace fslic {
+
+// =============================================================================================
+// Cluster pass (K threads): centroid finalisation + coarse binning.
+//   mode 0: colour resample at the centre, src/context.cpp:128-135
+//   mode 1: integer mean of the accumulated sums, src/context.cpp:356-373 (round_int,
+//           src/fast-slic-common.h:62-65), num_members written even when it is 0 (:362-364)
+// Then every cluster record {yx, lab, phase<<16|k} is appended to the coarse cell containing
+// its centre (spill list when a cell is full).  The other parity's counters are cleared for the
+// next iteration, so no per-iteration memset launch is needed.
+// =============================================================================================
+// Sums of cluster k over the pass: the block kernel's partial sums (one entry per overlapping block) plus whatever
+// went through global atomics.  out[0..5] = count, sum y, sum x, sum L, sum a, sum b.
+static __device__ __forceinline__ void gather_sums(const FrameDev& f, const PassGeom& pg, int k, uint32_t yx, uint32_t* out) {
+    const uint32_t* s = f.sums[0] + 6 * (size_t)k;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) out[q] = s[q];
+    if (!pg.use_slots) return;
+    const SlotGeom g = slot_geom((int)(yx >> 16), (int)(yx & 0xFFFFu), f.S, f.H, f.W, pg.rem, pg.stride, pg.BH, pg.Hv);
+    if (!g.any) return;
+    const uint32_t* cp = f.cpart + (size_t)k * f.cpart_ns * 6;
+    // entries (by, bx) in [by0, by1] x [bx0, bx1], four at a time with all their loads in flight (one memory round trip
+    // per four entries instead of one per entry: this pass is a chain of dependent loads on a handful of blocks)
+    const int nx = g.bx1 - g.bx0 + 1, ne = nx * (g.by1 - g.by0 + 1);
+    for (int e0 = 0; e0 < ne; e0 += 4) {
+        uint2 v[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u;
+            const int ey = e / nx, ex = e - ey * nx;
+            v[u][0] = v[u][1] = v[u][2] = make_uint2(0u, 0u);
+            if (e < ne) {
+                const uint2* p = reinterpret_cast<const uint2*>(cp + (ey * f.nbx + ex) * 6);   // 24-byte entries
+                v[u][0] = p[0]; v[u][1] = p[1]; v[u][2] = p[2];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            out[0] += v[u][0].x; out[1] += v[u][0].y; out[2] += v[u][1].x; out[3] += v[u][1].y; out[4] += v[u][2].x; out[5] += v[u][2].y;
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg) {
+    f.select(blockIdx.y);
+    // mode 1: consecutive blocks overlap by one cluster: thread 0 of a block only computes the member count of the
+    // cluster before the block's first one (the shadow test below needs the predecessor's count)
+    const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi < f.ncell) f.cell_cnt[1][gi] = 0;
+    if (gi == 0) *f.ovf_cnt[1] = 0;
+    const int k = MODE == 0 ? gi : (int)(blockIdx.x * (blockDim.x - 1) + threadIdx.x) - 1;
+    const bool live = k >= 0 && k < f.K;
+    uint32_t yx = live ? f.cl_yx[k] : 0u;
+    int y = (int)(yx >> 16), x = (int)(yx & 0xFFFF);
+    uint32_t lab;
+    // A cluster whose integer state (y, x, L, a, b) equals that of cluster k-1 has the same distance to every
+    // pixel and the same phase, and k-1 is visited first: it can never win a pixel.  Such runs come from
+    // initialize_clusters piling its leftover seeds on the image centre (src/context.cpp:80-86; 225 of 6000
+    // at 4K) and stay identical for ever because they never receive members.  They are kept out of the bins
+    // (exact), which keeps every candidate list short.  Detected only where it is race-free: both clusters
+    // unchanged by this pass (mode 1), or equal uploaded centres (mode 0).
+    bool shadowed = false;
+    if (MODE == 0) {
+        if (!live) return;
+        lab = f.lab[(size_t)y * f.W + x] & 0x00FFFFFFu;
+        f.cl_lab[k] = lab;
+        f.cl_yx_out[k] = yx;
+        shadowed = k > 0 && f.cl_yx[k - 1] == yx;
+        f.cl_shadow[k] = shadowed ? 1u : 0u;
+    } else {
+        // a shadowed cluster is in no candidate list: it received nothing and its cpart entries are stale
+        uint32_t s[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+        if (live && !(pg.use_slots && f.cl_shadow[k])) gather_sums(f, pg, k, yx, s);
+        // member count of cluster k-1 (needed below): the previous thread's
+        __shared__ uint32_t s_n[256];
+        s_n[threadIdx.x] = s[0];
+        __syncthreads();
+        if (!live || threadIdx.x == 0) return;
+        const uint32_t n_prev = s_n[threadIdx.x - 1];
+        lab = f.cl_lab[k];
+        uint32_t* z0 = f.sums[1] + 6 * (size_t)k;    // the next pass accumulates here (sums[0] is still being read by neighbours)
+        const int32_t n = (int32_t)s[0];
+        f.cl_n[k] = (uint32_t)n;
+        if (n != 0) {
+            const int32_t h = n / 2;
+            y = ((int32_t)s[1] + h) / n;
+            x = ((int32_t)s[2] + h) / n;
+            // A centroid of in-image pixels is in the image, so this is a no-op on valid sums.  It only matters for a
+            // frame whose tiled attempt overflowed a candidate list (some partial sums were then never written and
+            // the frame is about to be redone by the generic path): positions must stay addressable meanwhile.
+            y = min(max(y, 0), f.H - 1);
+            x = min(max(x, 0), f.W - 1);
+            const int32_t L = ((int32_t)s[3] + h) / n;
+            const int32_t a = ((int32_t)s[4] + h) / n;
+            const int32_t b = ((int32_t)s[5] + h) / n;
+            yx = ((uint32_t)y << 16) | (uint32_t)(x & 0xFFFF);
+            lab = (uint32_t)(L & 255) | ((uint32_t)(a & 255) << 8) | ((uint32_t)(b & 255) << 16);
+            f.cl_lab[k] = lab;
+            f.cl_moved[k] = 1;
+        } else if (k > 0 && n_prev == 0u) {
+            shadowed = f.cl_yx[k - 1] == yx && f.cl_lab[k - 1] == lab;
+        }
+        f.cl_yx_out[k] = yx;
+        f.cl_shadow[k] = shadowed ? 1u : 0u;
+        z0[0] = 0; z0[1] = 0; z0[2] = 0; z0[3] = 0; z0[4] = 0; z0[5] = 0;
+    }
+    // visit order of the reference scatter: phase = 2*((cy/T)&1) + ((cx/T)&1), then k
+    const uint32_t phase = (uint32_t)(2 * ((y / f.T) & 1) + ((x / f.T) & 1));
+    ClusterRec rec;
+    rec.yx = yx; rec.lab = lab; rec.tag = (phase << 16) | (uint32_t)k; rec.pad = f.gen;
+    f.cl_tag[k] = rec.tag;
+    if (shadowed) return;
+    const int cell = (y >> f.cs_shift) * f.ncx + (x >> f.cs_shift);
+    const uint32_t slot = atomicAdd(&f.cell_cnt[0][cell], 1u);
+    if (slot < (uint32_t)kCellCap) {
+        f.cell_items[0][(size_t)cell * kCellCap + slot] = rec;
+    } else {
+        const uint32_t o = atomicAdd(f.ovf_cnt[0], 1u);
+        f.ovf_items[0][o] = rec;
+    }
+}
+
+void launch_bin_clusters(const FrameDev& f_, int nframes, int mode, int buf, int sbuf, const PassGeom& pg, hipStream_t st) {
+    const FrameDev f = rotated(f_, buf, sbuf);
+    if (mode == 0) {
+        const int n = f.K > f.ncell ? f.K : f.ncell;
+        hipLaunchKernelGGL(k_bin_clusters<0>, dim3((n + 255) / 256, nframes), dim3(256), 0, st, f, pg);
+    } else {
+        const int bk = (f.K + 254) / 255, bc = (f.ncell + 255) / 256;    // 255 clusters per block (see the kernel)
+        hipLaunchKernelGGL(k_bin_clusters<1>, dim3(bk > bc ? bk : bc, nframes), dim3(256), 0, st, f, pg);
+    }
+}
+
+}  // namespace fslic

@@ -728,7 +728,6 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     f.rgbs = nullptr;
     f.select(i0);                                  // host-side: pointers of frame i0
     f.rgbs = reinterpret_cast<const uint8_t* const*>(s.d_ptrs + i0);
-    f.exp_flags = getenv("FSLIC_EXP") ? atoi(getenv("FSLIC_EXP")) : 0;
     const size_t fb = s.frame_bytes;
 
     if (generic && !s.sp_patch_uploaded) {

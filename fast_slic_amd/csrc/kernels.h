@@ -40,7 +40,6 @@ struct FrameDev {
     int T;               // 2S + 32, phase cell side (src/context.cpp:213)
     int cs_shift;        // coarse bin side = 1 << cs_shift
     int ncx, ncy, ncell;
-    int exp_flags;       // timing experiments only (FSLIC_EXP): 1 = skip the global flush, 2 = skip the whole fused update
     uint32_t gen;        // generation stamp of the bin pass that filled cell_items[buf] (ClusterRec::pad)
     uint32_t M, C;       // spatial fixed point: patch[d] == (d * M + C) >> 16 for d in [0, 2S]
     // image planes

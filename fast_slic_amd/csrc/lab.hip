@@ -1,0 +1,98 @@
+// lab.hip -- RGB -> CIELAB prepass (src/cielab.h)
+// Hand-written gfx950 (CDNA4, wave64) kernels of the SLIC hot path; see kernels.h for the launch interface and
+// DESIGN.md for the design.  All arithmetic on this path is integer, so results are bit-identical to the reference.
+#include "device_common.h"
+
+namespace fslic {
+
+// =============================================================================================
+// RGB -> CIELAB prepass.  Restates FastCIELabCvt::convert (src/cielab.h:309-325) with both lookup
+// tables staged in LDS (16.5 KB); 4 pixels per thread: 3 dword loads in, one 16-byte store out.
+// Algorithmic traffic: 3 B read + 4 B written per pixel.
+// =============================================================================================
+struct LabConst { int cb[9]; };
+
+static __device__ __forceinline__ uint32_t lab_px(uint32_t R, uint32_t G, uint32_t B,
+                                                  const uint16_t* sg, const uint16_t* sl, const LabConst& k) {
+    const int sr = sg[R], sgv = sg[G], sb = sg[B];
+    const int xr = (k.cb[0] * sr + k.cb[1] * sgv + k.cb[2] * sb) >> 16;
+    const int yr = (k.cb[3] * sr + k.cb[4] * sgv + k.cb[5] * sb) >> 16;
+    const int zr = (k.cb[6] * sr + k.cb[7] * sgv + k.cb[8] * sb) >> 16;
+    const int fx = sl[xr], fy = sl[yr], fz = sl[zr];
+    const int ciel = 116 * fy - (16 << 13);
+    const int ciea = 500 * (fx - fy) + (128 << 13);
+    const int cieb = 200 * (fy - fz) + (128 << 13);
+    int l = (int)((unsigned)ciel >> 12);
+    int a = (int)((unsigned)ciea >> 12) - 128;
+    int b = (int)((unsigned)cieb >> 12) - 128;
+    l = min(max(l, 0), 255);
+    a = min(max(a, 0), 255);
+    b = min(max(b, 0), 255);
+    return (uint32_t)l | ((uint32_t)a << 8) | ((uint32_t)b << 16);
+}
+
+template <bool CONVERT>
+__global__ __launch_bounds__(1024) void k_rgb_to_lab(FrameDev f, const uint16_t* __restrict__ g_gamma,
+                                                     const uint16_t* __restrict__ g_labtbl, LabConst kc, int init_labels) {
+    __shared__ uint16_t s_gamma[256];
+    __shared__ uint16_t s_lab[8194];
+    f.select(blockIdx.y);
+    const uint8_t* __restrict__ rgb = f.rgb;
+    uint32_t* __restrict__ lab = f.lab;
+    uint16_t* __restrict__ labels_init = init_labels ? f.labels : nullptr;
+    const int N = f.N;
+    const int aligned4 = ((reinterpret_cast<uintptr_t>(rgb) & 3) == 0) ? 1 : 0;
+    if (CONVERT) {
+        for (int i = threadIdx.x; i < 128; i += blockDim.x)
+            reinterpret_cast<uint32_t*>(s_gamma)[i] = reinterpret_cast<const uint32_t*>(g_gamma)[i];
+        for (int i = threadIdx.x; i < 4097; i += blockDim.x)   // 8194 entries (last one padding)
+            reinterpret_cast<uint32_t*>(s_lab)[i] = reinterpret_cast<const uint32_t*>(g_labtbl)[i];
+        __syncthreads();
+    }
+    const int nquad = aligned4 ? (N >> 2) : 0;
+    const int gstride = gridDim.x * blockDim.x;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += gstride) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(rgb) + 3 * (size_t)q;
+        const uint32_t w0 = src[0], w1 = src[1], w2 = src[2];
+        uint32_t r0 = w0 & 255, g0 = (w0 >> 8) & 255, b0 = (w0 >> 16) & 255;
+        uint32_t r1 = w0 >> 24, g1 = w1 & 255, b1 = (w1 >> 8) & 255;
+        uint32_t r2 = (w1 >> 16) & 255, g2 = w1 >> 24, b2 = w2 & 255;
+        uint32_t r3 = (w2 >> 8) & 255, g3 = (w2 >> 16) & 255, b3 = w2 >> 24;
+        uint4 o;
+        if (CONVERT) {
+            o.x = lab_px(r0, g0, b0, s_gamma, s_lab, kc);
+            o.y = lab_px(r1, g1, b1, s_gamma, s_lab, kc);
+            o.z = lab_px(r2, g2, b2, s_gamma, s_lab, kc);
+            o.w = lab_px(r3, g3, b3, s_gamma, s_lab, kc);
+        } else {   // raw copy, src/context.cpp:117-127
+            o.x = r0 | (g0 << 8) | (b0 << 16);
+            o.y = r1 | (g1 << 8) | (b1 << 16);
+            o.z = r2 | (g2 << 8) | (b2 << 16);
+            o.w = r3 | (g3 << 8) | (b3 << 16);
+        }
+        reinterpret_cast<uint4*>(lab)[q] = o;
+        // assignment plane <- 0xFFFF once per call (src/context.cpp:138-145)
+        if (labels_init) reinterpret_cast<uint2*>(labels_init)[q] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    }
+    // tail (and the whole image when the source pointer is not 4-byte aligned)
+    for (int p = (nquad << 2) + blockIdx.x * blockDim.x + threadIdx.x; p < N; p += gstride) {
+        const uint32_t r = rgb[3 * (size_t)p], g = rgb[3 * (size_t)p + 1], b = rgb[3 * (size_t)p + 2];
+        lab[p] = CONVERT ? lab_px(r, g, b, s_gamma, s_lab, kc) : (r | (g << 8) | (b << 16));
+        if (labels_init) labels_init[p] = 0xFFFFu;
+    }
+}
+
+void launch_rgb_to_lab(const FrameDev& f, int nframes, int convert, const LabTables& t, bool init_labels, hipStream_t st) {
+    LabConst kc;
+    for (int i = 0; i < 9; i++) kc.cb[i] = t.cb[i];
+    int blocks = (f.N / 4 + 1023) / 1024;
+    const int cap = (512 + nframes - 1) / nframes;   // about two resident blocks per CU over the whole group, grid-stride
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    if (convert)
+        hipLaunchKernelGGL(k_rgb_to_lab<true>, dim3(blocks, nframes), dim3(1024), 0, st, f, t.gamma, t.labtbl, kc, init_labels ? 1 : 0);
+    else
+        hipLaunchKernelGGL(k_rgb_to_lab<false>, dim3(blocks, nframes), dim3(1024), 0, st, f, t.gamma, t.labtbl, kc, init_labels ? 1 : 0);
+}
+
+}  // namespace fslic

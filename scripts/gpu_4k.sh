@@ -2,7 +2,7 @@
 # 4K K=1600 single-frame timing under a few knobs: prints full-assign / fused-assign event times
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
-for cfg in ${CFGS:-"" "FSLIC_ASSIGN_R=8" "FSLIC_NO_VTAB=1" "FSLIC_NO_VTAB=1 FSLIC_ASSIGN_R=8"}; do
+for cfg in ${CFGS:-"FSLIC_NOP=1" "FSLIC_ASSIGN_R=8" "FSLIC_NO_VTAB=1"}; do
   echo "== $cfg"
   env $cfg python - <<PY
 import os, sys

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for e in ${EXPS:-0 4}; do
+for e in ${EXPS:-0}; do
   rm -rf $OUT/pmc_i
   FSLIC_EXP=$e timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $OUT/pmc_i -o p -- python $R/scripts/frames.py ${PMC_H:-2160} ${PMC_W:-3840} ${PMC_K:-1600} 2 > $OUT/pmc_i.log 2>&1
   DB=$(find $OUT/pmc_i -name '*_results.db' | head -1)

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Per-kernel resource usage of kernels.hip (VGPRs, SGPRs, scratch, LDS, occupancy) from hipcc's remarks.
+# Per-kernel resource usage of one kernel file (default assign.hip) (VGPRs, SGPRs, scratch, LDS, occupancy) from hipcc's remarks.
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -x hip --cuda-device-only -c -o /dev/null \
-  $(dirname $0)/../fast_slic_amd/csrc/kernels.hip -Wno-unused-value -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c '
+  ${1:-$(dirname $0)/../fast_slic_amd/csrc/assign.hip} -Wno-unused-value -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c '
 import sys,re
 cur=None; rows=[]
 for line in sys.stdin:
