@@ -32,7 +32,7 @@ class Params(C.Structure):
         ("subsample_stride", C.c_int32), ("convert_to_lab", C.c_int32),
         ("manhattan_spatial_dist", C.c_int32), ("preemptive", C.c_int32),
         ("preemptive_thres", C.c_float), ("num_threads", C.c_int32), ("debug_mode", C.c_int32),
-        ("force_generic", C.c_int32), ("reserved", C.c_int32 * 5),
+        ("force_generic", C.c_int32), ("variant", C.c_int32), ("reserved", C.c_int32 * 4),
     ]
 
 
@@ -269,8 +269,9 @@ def get_supported_archs():
 
 def make_params(max_iter, compactness, min_size_factor, subsample_stride, convert_to_lab=True,
                 manhattan_spatial_dist=True, preemptive=False, preemptive_thres=0.05, num_threads=-1,
-                debug_mode=False, force_generic=False):
+                debug_mode=False, force_generic=False, variant=0):
     p = Params()
+    p.variant = int(variant)        # 0: Slic (Context), 1: LSC (ContextLSC)
     p.max_iter = int(max_iter)
     p.compactness = float(compactness)
     p.min_size_factor = float(min_size_factor)
@@ -283,6 +284,9 @@ def make_params(max_iter, compactness, min_size_factor, subsample_stride, conver
     p.debug_mode = int(bool(debug_mode))
     p.force_generic = int(bool(force_generic))
     return p
+
+
+VARIANT_SLIC, VARIANT_LSC = 0, 1     # fslic_params.variant
 
 
 class SlicModel(object):
@@ -319,6 +323,8 @@ class SlicModel(object):
     def copy(self):
         # cfast_slic.pyx:45-49 drops arch_name; here the arch is preserved.
         result = SlicModel(self.num_components, self.arch_name, device=self.device)
+        result.real_dist = self.real_dist
+        result.real_dist_type = self.real_dist_type
         result._clusters[:] = self._clusters
         result.initialized = self.initialized
         return result
@@ -382,11 +388,15 @@ class SlicModel(object):
         if not self.initialized:
             raise RuntimeError("Slic model is not initialized")                    # pyx:151-152
         image = self._check_image(image)
-        if self.real_dist:
-            raise NotImplementedError("real_dist variants are not implemented on " + ARCH_NAME)
+        variant = VARIANT_SLIC
+        if self.real_dist:                                                         # pyx:198-235
+            if self.real_dist_type != "lsc":
+                raise NotImplementedError("real_dist_type %r is not implemented on %s (only 'lsc')"
+                                          % (self.real_dist_type, ARCH_NAME))
+            variant = VARIANT_LSC
         p = make_params(max_iter, compactness, min_size_factor, subsample_stride, self.convert_to_lab,
                         self.manhattan_spatial_dist, self.preemptive, self.preemptive_thres,
-                        self.num_threads, self.debug_mode, self.force_generic)
+                        self.num_threads, self.debug_mode, self.force_generic, variant)
         labels = self._engine.iterate(image, self._clusters, p)
         self.last_timing_report = self._engine.last_timing_report()
         result = labels.astype(np.int16)                                           # pyx:258-260

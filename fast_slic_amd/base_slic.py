@@ -65,3 +65,15 @@ class BaseSlic(object):
 class SlicHip(BaseSlic):
     """Drop-in for fast_slic.Slic / fast_slic.avx2.SlicAvx2 (fast_slic/avx2.py:10-11) on MI355X."""
     arch_name = ARCH_NAME
+
+
+class LSCHip(BaseSlic):
+    """Drop-in for fast_slic.LSC / fast_slic.avx2.LSCAvx2 (fast_slic/base_slic.py:63-71,87-89; avx2.py:13-14)."""
+    arch_name = ARCH_NAME
+    real_dist_type = "lsc"
+
+    def make_slic_model(self, num_components):
+        model = SlicModel(num_components, self.arch_name)
+        model.real_dist = True
+        model.real_dist_type = self.real_dist_type
+        return model

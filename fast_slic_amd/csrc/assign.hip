@@ -38,21 +38,7 @@ namespace fslic {
 // With FUSE the centroid sums of update() (src/context.cpp:301-354) for the same rows are accumulated in a
 // wave-private LDS region (privatised copies) and flushed with one global atomic per (candidate, quantity).
 // =============================================================================================
-static __device__ __forceinline__ void global_accumulate(uint32_t* sums, uint32_t k, uint32_t y, uint32_t x, uint32_t pix) {
-    uint32_t* s = sums + 6 * (size_t)k;
-    atomicAdd(s + 0, 1u);
-    atomicAdd(s + 1, y);
-    atomicAdd(s + 2, x);
-    atomicAdd(s + 3, pix & 255u);
-    atomicAdd(s + 4, (pix >> 8) & 255u);
-    atomicAdd(s + 5, (pix >> 16) & 255u);
-}
 
-struct TileWindow { int wy_lo, wy_hi, wx_lo, wx_hi; };
-static __device__ __forceinline__ bool in_window(const ClusterRec& r, const TileWindow& w) {
-    const int cy = (int)(r.yx >> 16), cx = (int)(r.yx & 0xFFFF);
-    return cy >= w.wy_lo && cy <= w.wy_hi && cx >= w.wx_lo && cx <= w.wx_hi;
-}
 
 template <int R, bool FUSE, bool LUT>
 __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride, int Hv, int buf, int sbuf) {

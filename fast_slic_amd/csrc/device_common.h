@@ -42,4 +42,69 @@ static __device__ __forceinline__ SlotGeom slot_geom(int cy, int cx, int S, int 
     return g;
 }
 
+
+// integer centroid sums of one pixel through global atomics (generic kernels, stale-label pixels): count, y, x, L, a, b
+static __device__ __forceinline__ void global_accumulate(uint32_t* sums, uint32_t k, uint32_t y, uint32_t x, uint32_t pix) {
+    uint32_t* s = sums + 6 * (size_t)k;
+    atomicAdd(s + 0, 1u);
+    atomicAdd(s + 1, y);
+    atomicAdd(s + 2, x);
+    atomicAdd(s + 3, pix & 255u);
+    atomicAdd(s + 4, (pix >> 8) & 255u);
+    atomicAdd(s + 5, (pix >> 16) & 255u);
+}
+
+// pixel window of a tile widened by S: a cluster whose centre lies inside can own a pixel of the tile
+struct TileWindow { int wy_lo, wy_hi, wx_lo, wx_hi; };
+static __device__ __forceinline__ bool in_window(const ClusterRec& r, const TileWindow& w) {
+    const int cy = (int)(r.yx >> 16), cx = (int)(r.yx & 0xFFFF);
+    return cy >= w.wy_lo && cy <= w.wy_hi && cx >= w.wx_lo && cx <= w.wx_hi;
+}
+
+// The candidate list of a block of pixels, built by ONE wavefront: every live record of the coarse cells the window can
+// see plus the spill list, ballot-compacted into dst (3 x 64 words: yx, lab, tag) in arbitrary order.  Returns the
+// number of live records inside the window (more than 64: the list overflowed, only the first 64 were stored).
+static __device__ __forceinline__ int gather_candidates(const FrameDev& f, const TileWindow& win, uint32_t* dst, int lane) {
+    const uint32_t novf = *f.ovf_cnt[0];
+    const int sh = f.cs_shift;
+    const ClusterRec* __restrict__ citems = f.cell_items[0];
+    const ClusterRec* __restrict__ oitems = f.ovf_items[0];
+    const unsigned long long lowmask = (1ull << lane) - 1ull;
+    const int cxa = max(win.wx_lo, 0) >> sh, cxb = min(win.wx_hi, f.W - 1) >> sh;
+    const int cya = max(win.wy_lo, 0) >> sh, cyb = min(win.wy_hi, f.H - 1) >> sh;
+    const int ncxr = cxb - cxa + 1;
+    int cnt = 0;
+    auto visit = [&](const ClusterRec& rec, bool keep) {
+        const unsigned long long m = __ballot(keep);
+        const int pos = cnt + __popcll(m & lowmask);
+        if (keep && pos < 64) { dst[pos] = rec.yx; dst[64 + pos] = rec.lab; dst[128 + pos] = rec.tag; }
+        cnt += __popcll(m);
+    };
+    for (int cx0 = 0; cx0 < ncxr; cx0 += 8) {
+        const int cxi = cx0 + (lane >> 3);
+        const bool colok = cxi < ncxr;
+        const ClusterRec* base = citems + ((size_t)cya * f.ncx + cxa + min(cxi, ncxr - 1)) * kCellCap + (lane & 7);
+        for (int cy0 = cya; cy0 <= cyb; cy0 += 6) {
+            ClusterRec rr[6];
+            bool okr[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {      // unconditional loads (rows past the range re-read the last one)
+                okr[u] = colok && (cy0 + u) <= cyb;
+                rr[u] = base[(size_t)min(u, cyb - cy0) * f.ncx * kCellCap];
+            }
+            base += 6 * (size_t)f.ncx * kCellCap;
+#pragma unroll
+            for (int u = 0; u < 6; ++u) visit(rr[u], okr[u] && rr[u].pad == f.gen && in_window(rr[u], win));
+        }
+    }
+    for (uint32_t i0 = 0; i0 < novf; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        ClusterRec rec;
+        rec.yx = 0; rec.lab = 0; rec.tag = 0; rec.pad = 0;
+        if (i < novf) rec = oitems[i];
+        visit(rec, i < novf && in_window(rec, win));
+    }
+    return cnt;
+}
+
 }  // namespace fslic

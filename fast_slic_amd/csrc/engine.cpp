@@ -213,6 +213,15 @@ struct Slot {
         std::string err;
     };
     std::unique_ptr<Async> async;
+    // LSC variant: own arena = [shared tables][frame 0][frame 1]...; l holds frame 0's pointers
+    char* lsc_arena = nullptr;
+    size_t lsc_cap = 0, lsc_frame_bytes = 0, lsc_zero_bytes = 0;
+    char* lsc_zero = nullptr;
+    LscDev l{};
+    float* h_lsc_lut = nullptr;      // pinned staging of the tables: [4][256] colour, [2][W], [2][H]
+    size_t h_lsc_lut_cap = 0;
+    int lsc_H = 0, lsc_W = 0, lsc_K = 0, lsc_G = 0, lsc_S = 0;
+    float lsc_compactness = -1.0f;
     // cached spatial configuration (configure_spatial)
     bool sp_valid = false, sp_tiled_ok = false, sp_manhattan = true, sp_patch_uploaded = false;
     int sp_S = 0, sp_shift = 0, sp_stride = 0;
@@ -247,6 +256,8 @@ void free_slot(Slot& s) {
         s.async.reset();
     }
     if (s.arena) hipFree(s.arena);
+    if (s.lsc_arena) hipFree(s.lsc_arena);
+    if (s.h_lsc_lut) hipHostFree(s.h_lsc_lut);
     if (s.d_dbg) hipFree(s.d_dbg);
     if (s.d_ptrs) hipFree(s.d_ptrs);
     if (s.h_ptrs) hipHostFree(s.h_ptrs);
@@ -399,6 +410,81 @@ int ensure_prepared(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G)
     return prepare(e, s, H, W, K, S, G);
 }
 
+// LSC variant: carve the feature arena for groups of up to G frames and (re)build the tables.  The tables follow
+// src/lsc.cpp:24-27,76-101 expression by expression (float vs double evaluation included) and use the host libm,
+// like the reference.
+int prepare_lsc(Slot& s, int H, int W, int K, int S, int G, float compactness) {
+    const size_t N = (size_t)H * W;
+    const size_t lut_floats = 1024 + 2 * (size_t)W + 2 * (size_t)H;
+    if (s.lsc_H != H || s.lsc_W != W || s.lsc_K != K || s.lsc_G < G) {
+        G = std::max(G, (s.lsc_H == H && s.lsc_W == W && s.lsc_K == K) ? s.lsc_G : 0);
+        size_t off = 0;
+        auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+        const size_t o_lut = take(lut_floats * 4);
+        const size_t shared_bytes = off;
+        off = 0;
+        const size_t o_feat = take(N * 4 * kLscFeat), o_w = take(N * 4);
+        const size_t o_hist = take(768 * 4), o_extra = take((size_t)K * kLscExPitch * 8);
+        const size_t zero_bytes = off - o_hist;
+        const size_t o_means = take(64), o_cfeat = take((size_t)K * kLscCfPitch * 4);
+        const size_t frame_bytes = off, total = shared_bytes + frame_bytes * (size_t)G;
+        if (s.lsc_cap < total) {
+            if (s.lsc_arena) { hipFree(s.lsc_arena); s.lsc_arena = nullptr; s.lsc_cap = 0; }
+            HIPCHK(hipMalloc((void**)&s.lsc_arena, total));
+            s.lsc_cap = total;
+        }
+        if (s.h_lsc_lut_cap < lut_floats) {
+            if (s.h_lsc_lut) hipHostFree(s.h_lsc_lut);
+            s.h_lsc_lut = nullptr; s.h_lsc_lut_cap = 0;
+            HIPCHK(hipHostMalloc((void**)&s.h_lsc_lut, lut_floats * 4));
+            s.h_lsc_lut_cap = lut_floats;
+        }
+        char* b = s.lsc_arena + shared_bytes;
+        LscDev& l = s.l;
+        l.frame_bytes = frame_bytes;
+        l.feat = (float*)(b + o_feat); l.weight = (float*)(b + o_w);
+        l.hist = (uint32_t*)(b + o_hist); l.extra = (long long*)(b + o_extra);
+        l.means = (float*)(b + o_means); l.cfeat = (float*)(b + o_cfeat);
+        const float* lut = (const float*)(s.lsc_arena + o_lut);
+        l.lut_color = lut; l.lut_x = lut + 1024; l.lut_y = lut + 1024 + 2 * (size_t)W;
+        s.lsc_zero = b + o_hist; s.lsc_zero_bytes = zero_bytes; s.lsc_frame_bytes = frame_bytes;
+        s.lsc_H = H; s.lsc_W = W; s.lsc_K = K; s.lsc_G = G;
+        s.lsc_S = 0;                                   // tables live in the arena that was just carved
+        if (getenv("FSLIC_POISON")) HIPCHK(hipMemsetAsync(s.lsc_arena, 0xA5, total, s.st));
+    }
+    if (s.lsc_S != S || s.lsc_compactness != compactness) {
+        const float C_color = 20.0f;                   // src/lsc.h:8
+        const float PI = 3.1415926f, halfPI = PI / 2;
+        const float ratio = compactness / 100.0f;
+        const float C_spatial = C_color * ratio;
+        float* t = s.h_lsc_lut;
+        for (int X = 0; X < 256; X++) {
+            const float theta = halfPI * (X / 255.0f);
+            const float cosine = (float)cos((double)theta), sine = (float)sin((double)theta);
+            t[512 + X] = C_color * cosine * 2.55f;                       // a, b planes
+            t[768 + X] = C_color * sine * 2.55f;
+            t[X] = (float)((double)C_color * cos((double)theta));       // L plane: the product is formed in double
+            t[256 + X] = (float)((double)C_color * sin((double)theta));
+        }
+        float* tx = t + 1024;
+        float* ty = tx + 2 * (size_t)W;
+        const float step = halfPI / S;
+        for (int i = 0; i < W; i++) {
+            const float theta = i * step;
+            tx[i] = (float)((double)C_spatial * cos((double)theta));
+            tx[W + i] = (float)((double)C_spatial * sin((double)theta));
+        }
+        for (int i = 0; i < H; i++) {
+            const float theta = i * step;
+            ty[i] = (float)((double)C_spatial * cos((double)theta));
+            ty[H + i] = (float)((double)C_spatial * sin((double)theta));
+        }
+        HIPCHK(hipMemcpyAsync(const_cast<float*>(s.l.lut_color), t, lut_floats * 4, hipMemcpyHostToDevice, s.st));
+        s.lsc_S = S; s.lsc_compactness = compactness;
+    }
+    return FSLIC_OK;
+}
+
 int validate(const fslic_params* p, int H, int W, int K, int& S) {
     if (!p) return fail(FSLIC_E_INVALID, "params is NULL");
     if (H <= 0 || W <= 0) return fail(FSLIC_E_INVALID, "H and W must be positive");
@@ -408,6 +494,7 @@ int validate(const fslic_params* p, int H, int W, int K, int& S) {
     if (p->subsample_stride < 1 || p->subsample_stride > 255) return fail(FSLIC_E_INVALID, "subsample_stride must be in [1, 255]");
     if (p->max_iter < 0) return fail(FSLIC_E_INVALID, "max_iter must be >= 0");
     if (p->preemptive) return fail(FSLIC_E_UNSUPPORTED, "preemptive=True is not implemented on hip/gfx950");
+    if (p->variant != FSLIC_VARIANT_SLIC && p->variant != FSLIC_VARIANT_LSC) return fail(FSLIC_E_UNSUPPORTED, "unknown variant");
     if (!(p->compactness > 0.0f) || !std::isfinite(p->compactness)) return fail(FSLIC_E_INVALID, "compactness must be a positive finite number");
     S = (int)(int16_t)sqrt(H * W / K);   // src/context.h:60
     if (S < 1) return fail(FSLIC_E_INVALID, "num_components exceeds the number of pixels (S == 0)");
@@ -763,8 +850,32 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     const int stride = p->subsample_stride;
     int rem = 0;
     f.dbg = nullptr;
+    const bool lsc = p->variant == FSLIC_VARIANT_LSC;
+    LscDev l = s.l;
+    if (lsc) {
+        l.select(i0);
+        HIPCHK(hipMemset2DAsync(s.lsc_zero + (size_t)i0 * s.lsc_frame_bytes, s.lsc_frame_bytes, 0, s.lsc_zero_bytes, (size_t)n, s.st));
+        launch_lsc_prepare(f, l, n, s.st);                        // before_iteration, src/lsc.cpp:12-15
+    }
     const int dbg_mode = getenv("FSLIC_DEBUG_TIMING") ? atoi(getenv("FSLIC_DEBUG_TIMING")) : 0;
-    for (int it = 0; it < p->max_iter; it++) {                  // src/context.cpp:158-175
+    for (int it = 0; lsc && it < p->max_iter; it++) {           // src/context.cpp:158-175 with ContextLSC's hooks
+        const bool tme = timed && e->launch_timing && it < Slot::kMaxTimedIters;
+        f.cl_yx = yx_cur; f.cl_yx_out = (yx_cur == yx_a) ? yx_b : yx_a;
+        if (tme) HIPCHK(hipEventRecord(s.ev_it[2 * it], s.st));
+        launch_lsc_assign(f, l, n, rem, stride, it & 1, it & 1, true, s.st);
+        if (tme) {
+            HIPCHK(hipEventRecord(s.ev_it[2 * it + 1], s.st));
+            s.n_timed_iters = it + 1;
+            s.assign_loop_px += (double)((H - rem + stride - 1) / stride) * W * n;
+        }
+        launch_lsc_update(f, l, n, rem, stride, it & 1, s.st);   // update() sums + after_update()
+        f.gen = ++s.gen_counter;
+        pg = PassGeom{};                                          // use_slots = 0: everything is in FrameDev::sums
+        launch_bin_clusters(f, n, 1, (it + 1) & 1, it & 1, pg, s.st);
+        yx_cur = f.cl_yx_out;
+        rem = (rem + 1) % stride;
+    }
+    for (int it = 0; !lsc && it < p->max_iter; it++) {          // src/context.cpp:158-175
         if (it == p->max_iter - 1 && dbg_mode == 2) {
             if (!s.d_dbg) HIPCHK(hipMalloc((void**)&s.d_dbg, sizeof(unsigned long long) * 8 * 65536));
             HIPCHK(hipMemsetAsync(s.d_dbg, 0, sizeof(unsigned long long) * 8 * 65536, s.st));
@@ -798,7 +909,8 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     }
     if (timed) HIPCHK(hipEventRecord(s.ev[2], s.st));
     // full_assign: stride 1, rem 0, no update afterwards (src/context.cpp:246-256)
-    if (generic) launch_assign_generic(f, n, 0, 1, p->max_iter & 1, 0, false, s.st);
+    if (lsc) { f.cl_yx = yx_cur; launch_lsc_assign(f, l, n, 0, 1, p->max_iter & 1, 0, false, s.st); }
+    else if (generic) launch_assign_generic(f, n, 0, 1, p->max_iter & 1, 0, false, s.st);
     else (void)launch_assign(f, n, 0, 1, p->max_iter & 1, 0, false, s.st);
     if (timed) HIPCHK(hipEventRecord(s.ev[3], s.st));
     if (f.dbg) {
@@ -841,9 +953,13 @@ int group_begin(fslic_engine* e, Slot& s, const fslic_params* p, int H, int W, i
     for (int i = 0; i < n; i++) { s.clusters[i] = clusters[i]; s.d_rgb[i] = d_rgb[i]; s.d_out[i] = d_out[i]; }
     rc = configure_spatial(s, S, p);
     if (rc) return rc;
+    if (p->variant == FSLIC_VARIANT_LSC) {
+        rc = prepare_lsc(s, H, W, K, S, n, p->compactness);
+        if (rc) return rc;
+    }
     rc = upload_ptrs(s, n, d_rgb, d_out);
     if (rc) return rc;
-    s.generic = p->force_generic || !s.sp_tiled_ok;
+    s.generic = p->variant == FSLIC_VARIANT_SLIC && (p->force_generic || !s.sp_tiled_ok);
     rc = enqueue_frames(e, s, 0, n, s.generic, true);
     if (rc) return rc;
     s.have_pre = true;

@@ -139,6 +139,31 @@ struct CcaDev {
     }
 };
 
+// Device state of the LSC variant (src/lsc.cpp): the 10-D feature map of every frame of the group and the feature-space
+// centroids.  Same per-frame sub-arena scheme as FrameDev (own arena, own frame stride).
+constexpr int kLscFeat = 10;        // l1, l2, a1, a2, b1, b2, x1, x2, y1, y2 (src/lsc.h:12)
+constexpr int kLscCfPitch = 16;     // floats per centroid record (10 features, padded to 64 bytes)
+constexpr int kLscExPitch = 12;     // int64 per cluster of the stale-pixel accumulators (10 features, weight, pad)
+constexpr float kLscFixScale = 1048576.0f;   // fixed point of those accumulators (order-independent sums)
+struct LscDev {
+    size_t frame_bytes;
+    float* feat;         // [10][N] planar, already divided by the pixel weight (src/lsc.cpp:152-162)
+    float* weight;       // [N]
+    uint32_t* hist;      // 768: histograms of the L, a, b planes (feature means of the colour half, src/lsc.cpp:143-149)
+    float* means;        // 16 (10 used)
+    float* cfeat;        // K * kLscCfPitch
+    long long* extra;    // K * kLscExPitch: w*F and w of visited pixels that kept a label whose cluster window has left them
+    // shared tables (host-built with the reference's expressions, src/lsc.cpp:76-101)
+    const float* lut_color;   // [4][256]: L cos, L sin, a/b cos, a/b sin
+    const float* lut_x;       // [2][W]: cos, sin
+    const float* lut_y;       // [2][H]
+    __host__ __device__ __forceinline__ void select(int z) {
+        const size_t d = (size_t)z * frame_bytes;
+        FrameDev::adv(feat, d); FrameDev::adv(weight, d); FrameDev::adv(hist, d); FrameDev::adv(means, d);
+        FrameDev::adv(cfeat, d); FrameDev::adv(extra, d);
+    }
+};
+
 struct LabTables {
     const uint16_t* gamma;   // 256   src/cielab.h:298-299
     const uint16_t* labtbl;  // 8193  src/cielab.h:302-304
@@ -155,6 +180,12 @@ void launch_bin_clusters(const FrameDev& f, int nframes, int mode, int buf, int 
 // of src/context.cpp:301-354 for the same rows.  Returns the geometry the following cluster pass needs.
 PassGeom launch_assign(const FrameDev& f, int nframes, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st);
 void launch_assign_generic(const FrameDev& f, int nframes, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st);
+// LSC variant (lsc.hip).  prepare: feature map + seed centroids (src/lsc.cpp:12-15), after LAB and the mode-0 cluster pass.
+void launch_lsc_prepare(const FrameDev& f, const LscDev& l, int nframes, hipStream_t st);
+// 10-D assignment of rows == rem (mod stride) (src/lsc.cpp:197-224); stale_sums: an update follows
+void launch_lsc_assign(const FrameDev& f, const LscDev& l, int nframes, int rem, int stride, int buf, int sbuf, bool stale_sums, hipStream_t st);
+// per-cluster gather of the integer sums (into FrameDev::sums) and the weighted feature means (src/lsc.cpp:226-307)
+void launch_lsc_update(const FrameDev& f, const LscDev& l, int nframes, int rem, int stride, int sbuf, hipStream_t st);
 // connectivity
 void launch_cca_phase1(const CcaDev& c, int nframes, hipStream_t st);   // local CCL, border merge, compress, collect
 // device top-K + ranking; counters[3] = status (see k_cca_select).  On status 1 the candidate arrays are left

@@ -45,3 +45,29 @@ def cluster_fields_equal(a, b):
             msgs.append("cluster field %s differs at %d entries, first k=%d got %s expected %s"
                         % (f, len(bad), bad[0], a[f][bad[0]], b[f][bad[0]]))
     return msgs
+
+
+# ---- partition agreement (LSC: f32 path, tolerance-based parity) ----------------
+def best_overlap(a, b):
+    """Fraction of pixels whose segment in `a` lies in the segment of `b` that it overlaps most."""
+    a = np.asarray(a).astype(np.int64).ravel()
+    b = np.asarray(b).astype(np.int64).ravel()
+    nb = int(b.max()) + 1
+    u, c = np.unique(a * nb + b, return_counts=True)
+    ua = u // nb
+    best = np.zeros(int(ua.max()) + 1, np.int64)
+    np.maximum.at(best, ua, c)
+    return float(best.sum()) / a.size
+
+
+def boundary_mask(a):
+    a = np.asarray(a)
+    m = np.zeros(a.shape, bool)
+    m[:, :-1] |= a[:, :-1] != a[:, 1:]
+    m[:-1, :] |= a[:-1, :] != a[1:, :]
+    return m
+
+
+def boundary_iou(a, b):
+    ma, mb = boundary_mask(a), boundary_mask(b)
+    return float((ma & mb).sum()) / max(1, int((ma | mb).sum()))
