@@ -21,6 +21,15 @@ static inline FrameDev rotated(const FrameDev& f, int buf, int sbuf) {
     return g;
 }
 
+// Orders this wavefront's LDS traffic for lane-to-lane exchange through LDS: without it the compiler may move one
+// lane's read above another lane's write (it only has to respect a single thread's own accesses).  No instruction
+// is emitted beyond the waitcnt the hardware needs; LDS itself serves a wavefront's requests in order.
+static __device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 static __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // Which assign blocks (64 px x BH visited rows) can hold pixels of a cluster centred at (cy, cx): the blocks its

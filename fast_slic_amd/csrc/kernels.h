@@ -147,7 +147,7 @@ constexpr int kLscExPitch = 12;     // int64 per cluster of the stale-pixel accu
 constexpr float kLscFixScale = 1048576.0f;   // fixed point of those accumulators (order-independent sums)
 struct LscDev {
     size_t frame_bytes;
-    float* feat;         // [10][N] planar, already divided by the pixel weight (src/lsc.cpp:152-162)
+    float* feat;         // [10][N] planar: features already divided by the pixel weight (src/lsc.cpp:152-162)
     float* weight;       // [N]
     uint32_t* hist;      // 768: histograms of the L, a, b planes (feature means of the colour half, src/lsc.cpp:143-149)
     float* means;        // 16 (10 used)

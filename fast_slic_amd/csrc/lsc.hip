@@ -12,6 +12,7 @@
 
 namespace fslic {
 
+typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int kLscRows = 4;                               // visited rows per wavefront of the assign kernel
 constexpr int kLscBH = kWavesPerBlock * kLscRows;         // visited rows per block
 
@@ -21,23 +22,36 @@ constexpr int kLscBH = kWavesPerBlock * kLscRows;         // visited rows per bl
 __global__ __launch_bounds__(256) void k_lsc_hist(FrameDev f, LscDev l) {
     f.select(blockIdx.y);
     l.select(blockIdx.y);
-    __shared__ uint32_t h[768];
-    for (int i = threadIdx.x; i < 768; i += 256) h[i] = 0;
+    // eight lane-striped copies of every bin: neighbouring pixels mostly share their values, and same-address LDS
+    // atomics of one wavefront serialise
+    __shared__ uint32_t h[768 * 8];
+    for (int i = threadIdx.x; i < 768 * 8; i += 256) h[i] = 0;
     __syncthreads();
     const size_t base = (size_t)blockIdx.x * 4096;
-#pragma unroll 4
+    const uint32_t cp = threadIdx.x & 7u;
+    uint32_t px[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {                       // all loads in flight before the first atomic
+        const size_t i = base + (size_t)u * 256 + threadIdx.x;
+        px[u] = f.lab[i < (size_t)f.N ? i : (size_t)f.N - 1];
+    }
+#pragma unroll
     for (int u = 0; u < 16; ++u) {
         const size_t i = base + (size_t)u * 256 + threadIdx.x;
         if (i < (size_t)f.N) {
-            const uint32_t p = f.lab[i];
-            atomicAdd(&h[p & 255u], 1u);
-            atomicAdd(&h[256 + ((p >> 8) & 255u)], 1u);
-            atomicAdd(&h[512 + ((p >> 16) & 255u)], 1u);
+            const uint32_t p = px[u];
+            atomicAdd(&h[(p & 255u) * 8 + cp], 1u);
+            atomicAdd(&h[(256 + ((p >> 8) & 255u)) * 8 + cp], 1u);
+            atomicAdd(&h[(512 + ((p >> 16) & 255u)) * 8 + cp], 1u);
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 768; i += 256)
-        if (h[i]) atomicAdd(&l.hist[i], h[i]);
+    for (int i = threadIdx.x; i < 768; i += 256) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v += h[i * 8 + ((c + threadIdx.x) & 7)];
+        if (v) atomicAdd(&l.hist[i], v);
+    }
 }
 
 // The ten feature means (src/lsc.cpp:143-149; the reference sums sequentially in f32, this is the exact mean).
@@ -130,11 +144,23 @@ __global__ __launch_bounds__(256) void k_lsc_seed(FrameDev f, LscDev l) {
     float acc[kLscFeat];
 #pragma unroll
     for (int q = 0; q < kLscFeat; ++q) acc[q] = 0.0f;
-    for (int t = lane; t < n; t += 64) {
-        const int yy = y_lo + t / nw, xx = x_lo + t % nw;
-        const size_t i = (size_t)yy * f.W + xx;
+    for (int t0 = lane; t0 - lane < n; t0 += 192) {
+        float v[3][kLscFeat];
 #pragma unroll
-        for (int q = 0; q < kLscFeat; ++q) acc[q] += l.feat[(size_t)q * f.N + i];
+        for (int u = 0; u < 3; ++u) {                   // loads of three steps in flight (clamped index, masked below)
+            const int t = min(t0 + 64 * u, n - 1);
+            const int yy = y_lo + t / nw, xx = x_lo + t % nw;
+            const size_t i = (size_t)yy * f.W + xx;
+#pragma unroll
+            for (int q = 0; q < kLscFeat; ++q) v[u][q] = l.feat[(size_t)q * f.N + i];
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            if (t0 + 64 * u < n) {
+#pragma unroll
+                for (int q = 0; q < kLscFeat; ++q) acc[q] += v[u][q];
+            }
+        }
     }
 #pragma unroll
     for (int q = 0; q < kLscFeat; ++q) acc[q] = wave_sum(acc[q]);
@@ -171,6 +197,7 @@ __global__ __launch_bounds__(256) void k_lsc_assign(FrameDev f, LscDev l, int re
         win.wy_lo = rem + stride * v0 - S; win.wy_hi = rem + stride * v_last + S;
         win.wx_lo = x0 - S; win.wx_hi = min(x0 + 63, W - 1) + S;
         const int cnt = gather_candidates(f, win, s_raw, lane);
+        wave_lds_sync();
         if (cnt <= 64) {
             const uint32_t mytag = lane < cnt ? s_raw[128 + lane] : 0xFFFFFFFFu;
             int rank = 0;
@@ -186,39 +213,44 @@ __global__ __launch_bounds__(256) void k_lsc_assign(FrameDev f, LscDev l, int re
         }
         if (lane == 0) s_cnt = cnt;
     }
-    // this wavefront's pixels: column x0 + lane of kLscRows visited rows (clamped addresses, masked results)
+    // this wavefront's pixels: column x0 + lane of kLscRows visited rows (clamped addresses, masked results).  Rows are
+    // held in pairs (r, r+1) per feature: the distance chain then runs on packed f32 (v_pk_add_f32 / v_pk_fma_f32,
+    // two rows per instruction; each half is the same IEEE operation as the scalar form)
     const int x = x0 + lane;
     const bool xok = x < W;
-    const int xc = min(x, W - 1);
-    const int vw = v0 + wave * kLscRows;
-    float F[kLscRows][kLscFeat];
+    const int vw = (int)rfl((uint32_t)(v0 + wave * kLscRows));
+    f2 F[kLscRows / 2][kLscFeat];
     int yr[kLscRows];
+    const int xc = min(x, W - 1);
 #pragma unroll
     for (int r = 0; r < kLscRows; ++r) {
         yr[r] = rem + stride * min(vw + r, Hv - 1);
         const size_t p = (size_t)yr[r] * W + xc;
 #pragma unroll
-        for (int q = 0; q < kLscFeat; ++q) F[r][q] = l.feat[(size_t)q * N + p];
+        for (int q = 0; q < kLscFeat; ++q) F[r >> 1][q][r & 1] = l.feat[(size_t)q * N + p];
     }
     __syncthreads();
     const int cnt = s_cnt;
-    float best[kLscRows];
+    f2 best[kLscRows / 2];
     uint32_t bk[kLscRows];
 #pragma unroll
-    for (int r = 0; r < kLscRows; ++r) { best[r] = FLT_MAX; bk[r] = 0xFFFFu; }
+    for (int r = 0; r < kLscRows; ++r) { best[r >> 1][r & 1] = FLT_MAX; bk[r] = 0xFFFFu; }
     const int y_top = yr[0], y_bot = yr[kLscRows - 1];
     auto consider = [&](int cy, int cx, uint32_t k, const float* cf) {
         const bool inx = abs(x - cx) <= S;
 #pragma unroll
-        for (int r = 0; r < kLscRows; ++r) {
-            if (abs(yr[r] - cy) > S) continue;            // uniform
-            float d = 0.0f;
+        for (int h = 0; h < kLscRows / 2; ++h) {
+            const bool in0 = abs(yr[2 * h] - cy) <= S, in1 = abs(yr[2 * h + 1] - cy) <= S;   // uniform
+            if (!(in0 || in1)) continue;
+            f2 d = {0.0f, 0.0f};
 #pragma unroll
             for (int q = 0; q < kLscFeat; ++q) {
-                const float diff = F[r][q] - cf[q];
-                d = __builtin_fmaf(diff, diff, d);
+                const f2 c2 = {cf[q], cf[q]};
+                const f2 diff = F[h][q] - c2;
+                d = __builtin_elementwise_fma(diff, diff, d);
             }
-            if (inx && d < best[r]) { best[r] = d; bk[r] = k; }
+            if (in0 && inx && d[0] < best[h][0]) { best[h][0] = d[0]; bk[2 * h] = k; }
+            if (in1 && inx && d[1] < best[h][1]) { best[h][1] = d[1]; bk[2 * h + 1] = k; }
         }
     };
     if (cnt <= 64) {
@@ -259,7 +291,7 @@ __global__ __launch_bounds__(256) void k_lsc_assign(FrameDev f, LscDev l, int re
     for (int r = 0; r < kLscRows; ++r) {
         if (!xok || vw + r >= Hv) continue;
         const size_t p = (size_t)yr[r] * W + x;
-        if (best[r] < FLT_MAX) {
+        if (best[r >> 1][r & 1] < FLT_MAX) {
             f.labels[p] = (uint16_t)bk[r];
         } else if (stale_sums) {
             // Nothing accepted this pixel: it keeps its label (src/lsc.cpp:217-220 never touches it) and the update sums
@@ -274,7 +306,7 @@ __global__ __launch_bounds__(256) void k_lsc_assign(FrameDev f, LscDev l, int re
                     unsigned long long* e = reinterpret_cast<unsigned long long*>(l.extra + (size_t)old * kLscExPitch);
 #pragma unroll
                     for (int q = 0; q < kLscFeat; ++q)
-                        atomicAdd(e + q, (unsigned long long)(long long)__builtin_rintf(w * F[r][q] * kLscFixScale));
+                        atomicAdd(e + q, (unsigned long long)(long long)__builtin_rintf(w * F[r >> 1][q][r & 1] * kLscFixScale));
                     atomicAdd(e + kLscFeat, (unsigned long long)(long long)__builtin_rintf(w * kLscFixScale));
                 }
             }
@@ -298,21 +330,55 @@ __global__ __launch_bounds__(256) void k_lsc_update(FrameDev f, LscDev l, int re
     const int x_lo = max(cx - S, 0), x_hi = min(cx + S, W - 1);
     const int t = y_lo - rem;
     const int v_first = t <= 0 ? 0 : (t + stride - 1) / stride;
+    // the stale-pixel contributions of the assign pass, fetched now so that the tail does not wait for them
+    const int tq = threadIdx.x;
+    uint32_t pre_sum = 0;
+    long long pre_ex = 0;
+    if (tq < 6) pre_sum = f.sums[0][6 * (size_t)k + tq];
+    if (tq >= 64 && tq < 64 + kLscFeat + 1) pre_ex = l.extra[(size_t)k * kLscExPitch + (tq - 64)];
     uint32_t in[6] = {0u, 0u, 0u, 0u, 0u, 0u};
     float acc[kLscFeat + 1];
 #pragma unroll
     for (int q = 0; q <= kLscFeat; ++q) acc[q] = 0.0f;
-    for (int y = rem + stride * (v_first + wave); y <= y_hi; y += kWavesPerBlock * stride) {
-        for (int x = x_lo + lane; x <= x_hi; x += 64) {
-            const size_t p = (size_t)y * W + x;
-            if (f.labels[p] != (uint16_t)k) continue;
-            const uint32_t pix = f.lab[p];
-            const float w = l.weight[p];
-            in[0] += 1u; in[1] += (uint32_t)y; in[2] += (uint32_t)x;
-            in[3] += pix & 255u; in[4] += (pix >> 8) & 255u; in[5] += (pix >> 16) & 255u;
+    // Wavefront w takes window rows w, w+4, ... (visited rows only), kUpdRows of them per trip, lanes over the columns.
+    // Two memory round trips per trip: the labels of all rows, then the features of the matching pixels -- the loads
+    // of a non-matching lane are redirected to the window's first pixel (one cached line for all of them) so that they
+    // can be issued unconditionally and all at once.
+    constexpr int kUpdRows = 5;
+    const size_t p_first = (size_t)min(rem + stride * v_first, f.H - 1) * W + x_lo;
+    for (int y0 = rem + stride * (v_first + wave); y0 <= y_hi; y0 += kUpdRows * kWavesPerBlock * stride) {
+        for (int x = x_lo + lane; x - lane <= x_hi; x += 64) {
+            size_t p[kUpdRows];
+            uint32_t lb[kUpdRows];
 #pragma unroll
-            for (int q = 0; q < kLscFeat; ++q) acc[q] = __builtin_fmaf(w, l.feat[(size_t)q * N + p], acc[q]);
-            acc[kLscFeat] += w;
+            for (int u = 0; u < kUpdRows; ++u) {
+                const int y = y0 + u * kWavesPerBlock * stride;
+                p[u] = (y <= y_hi && x <= x_hi) ? (size_t)y * W + x : p_first;
+                lb[u] = f.labels[p[u]];
+            }
+            uint32_t pix[kUpdRows];
+            float w[kUpdRows], Fv[kUpdRows][kLscFeat];
+            bool m[kUpdRows];
+#pragma unroll
+            for (int u = 0; u < kUpdRows; ++u) {
+                const int y = y0 + u * kWavesPerBlock * stride;
+                m[u] = y <= y_hi && x <= x_hi && lb[u] == (uint32_t)k;
+                const size_t pp = m[u] ? p[u] : p_first;
+                pix[u] = f.lab[pp];
+                w[u] = l.weight[pp];
+#pragma unroll
+                for (int q = 0; q < kLscFeat; ++q) Fv[u][q] = l.feat[(size_t)q * N + pp];
+            }
+#pragma unroll
+            for (int u = 0; u < kUpdRows; ++u) {
+                if (!m[u]) continue;
+                const int y = y0 + u * kWavesPerBlock * stride;
+                in[0] += 1u; in[1] += (uint32_t)y; in[2] += (uint32_t)x;
+                in[3] += pix[u] & 255u; in[4] += (pix[u] >> 8) & 255u; in[5] += (pix[u] >> 16) & 255u;
+#pragma unroll
+                for (int q = 0; q < kLscFeat; ++q) acc[q] = __builtin_fmaf(w[u], Fv[u][q], acc[q]);
+                acc[kLscFeat] += w[u];
+            }
         }
     }
     __shared__ uint32_t s_in[kWavesPerBlock][6];
@@ -330,16 +396,14 @@ __global__ __launch_bounds__(256) void k_lsc_update(FrameDev f, LscDev l, int re
     __syncthreads();
     const int q = threadIdx.x;
     if (q < 6) {
-        uint32_t* s = f.sums[0] + 6 * (size_t)k + q;       // holds the stale-pixel contributions of the assign pass
-        *s += ((s_in[0][q] + s_in[1][q]) + s_in[2][q]) + s_in[3][q];
+        f.sums[0][6 * (size_t)k + q] = pre_sum + (((s_in[0][q] + s_in[1][q]) + s_in[2][q]) + s_in[3][q]);
     }
     __shared__ float s_tot[kLscFeat + 1];
     if (q >= 64 && q < 64 + kLscFeat + 1) {
         const int j = q - 64;
         long long* e = l.extra + (size_t)k * kLscExPitch + j;
         float v = ((s_acc[0][j] + s_acc[1][j]) + s_acc[2][j]) + s_acc[3][j];
-        const long long ex = *e;
-        if (ex != 0) { v += (float)((double)ex / (double)kLscFixScale); *e = 0; }
+        if (pre_ex != 0) { v += (float)((double)pre_ex / (double)kLscFixScale); *e = 0; }
         s_tot[j] = v;
     }
     __syncthreads();

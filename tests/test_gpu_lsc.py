@@ -41,7 +41,7 @@ def run_lsc(engine, img, K, **kw):
 
 
 # per case: (min pre-connectivity pixel agreement, min best-overlap both ways, min boundary IoU)
-FLOORS = {"default": (0.97, 0.95, 0.80)}
+FLOORS = {"default": (0.99, 0.99, 0.95)}
 
 
 def test_lsc_agrees_with_reference_fixtures(engine, lsc_cases):
