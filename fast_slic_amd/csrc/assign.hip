@@ -436,6 +436,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
             f.dbg[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kWavesPerBlock + wave) * 8 + (slot_)] = __builtin_readcyclecounter(); \
     } while (0)
     FSLIC_STAMP(0);
+    const unsigned long long wc0 = f.dbg ? wall_clock64() : 0ull;
 
     // 1. pixel loads first; nothing below depends on them until the argmin
     // Out-of-image lanes and rows re-read the last valid column / row instead of being masked off: no exec juggling
@@ -453,7 +454,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
         for (int r = 0; r < R; ++r) pix[r] = 0u;
     }
 
-    if (wave == 0) {
+    // The list is built by ONE wavefront while the other three stage the table.  A block's wavefront i runs on SIMD i, so
+    // with a fixed choice the list builders of all resident blocks of a CU would share one SIMD (measured: their ~800
+    // instructions then take 3-6 us, with the other three SIMDs idle at the barrier); the choice rotates with the block.
+    const int gwave = (int)((blockIdx.x + blockIdx.y + blockIdx.z) & 3u);
+    if (wave == gwave) {
         // 2a. the block's candidate list
         const uint32_t novf = *f.ovf_cnt[0];
         const int sh = f.cs_shift;
@@ -525,7 +530,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(f.tab);
         uint4* dst = reinterpret_cast<uint4*>(s_dyn);
         const int nq = f.tab_words >> 2;
-        const int t = tid - 64;
+        const int t = ((wave - gwave - 1) & 3) * 64 + lane;      // 0..191 over the three staging wavefronts
         for (int b0 = 0; b0 < nq; b0 += 4 * 192) {     // indices past the end are clamped: the last quad is rewritten, no masking
             uint4 q[4];
 #pragma unroll
@@ -670,7 +675,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
             const uint32_t key = (r & 1) ? (uint32_t)best[r / 2].y : (uint32_t)best[r / 2].x;
             const bool found = key != 0xFFFFu;
             slot[r] = kNoSlot;
-            if (ok && found) rowp[xo] = (uint16_t)kk[r];
+            if (ok && found) st_stream(rowp + xo, (uint16_t)kk[r]);
             if (FUSE && ok) {
                 if (found) slot[r] = key & 63u;
                 else {
@@ -739,7 +744,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
     if (f.dbg && lane == 0) {
         const size_t o = ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kWavesPerBlock + wave) * 8;
         f.dbg[o + 6] = (unsigned long long)bn;
-        f.dbg[o + 7] = (unsigned long long)bn;
+        f.dbg[o + 7] = wall_clock64() - wc0;          // 100 MHz reference clock over the wavefront's life
     }
 #undef FSLIC_STAMP
 }

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void k_cca_local(CcaDev c) {
         const int y = ty0 + ly;
         const bool ok = okx && y < c.H;
         const uint32_t r = ok ? root[i] : 0xFFFFFFFFu;
-        if (ok) c.parent[(size_t)y * c.W + x] = (int32_t)((size_t)(ty0 + (int)(r / T)) * c.W + tx0 + (int)(r % T));
+        if (ok) st_stream(c.parent + (size_t)y * c.W + x, (int32_t)((size_t)(ty0 + (int)(r / T)) * c.W + tx0 + (int)(r % T)));
         const uint32_t rl = __shfl_up(r, 1);
         const bool start = (lane == 0) || (r != rl) || !ok;
         const unsigned long long m = __ballot(start);
@@ -610,10 +610,10 @@ __global__ __launch_bounds__(256) void k_cca_relabel(CcaDev c) {
         uint2 o;
         o.x = a | (b << 16);
         o.y = d | (e << 16);
-        reinterpret_cast<uint2*>(c.out)[q] = o;
+        st_stream(reinterpret_cast<uint2*>(c.out) + q, o);
     }
     for (int p = (nquad << 2) + blockIdx.x * blockDim.x + threadIdx.x; p < c.N; p += gstride)
-        c.out[p] = c.final_lab[c.parent[c.parent[p]]];
+        st_stream(c.out + p, c.final_lab[c.parent[c.parent[p]]]);
 }
 
 void launch_cca_phase2(const CcaDev& c, int nframes, hipStream_t st) {

@@ -30,6 +30,24 @@ static __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Streaming stores for planes that are written once and read by a LATER kernel (LAB plane, label maps, parents,
+// feature planes): written through at agent scope (`sc1`) instead of staying dirty in the XCD's L2.  A kernel's
+// end-of-kernel release otherwise writes all dirty lines back in one burst that nothing overlaps -- measured
+// (scripts/microbench/kernel_boundary.hip): a kernel storing 16 MB takes 8.9 us with plain stores and 3.5 us with
+// sc1 stores (64 MB: 24.9 -> ~10 us).
+static __device__ __forceinline__ void st_stream(uint16_t* p, uint16_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static __device__ __forceinline__ void st_stream(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static __device__ __forceinline__ void st_stream(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static __device__ __forceinline__ void st_stream(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static __device__ __forceinline__ void st_stream(uint2* p, uint2 v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static __device__ __forceinline__ void st_stream(uint4* p, uint4 v) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 q = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(q) : "memory");
+}
+
 static __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // Which assign blocks (64 px x BH visited rows) can hold pixels of a cluster centred at (cy, cx): the blocks its

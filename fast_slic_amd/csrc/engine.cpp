@@ -669,9 +669,24 @@ int print_phase_stamps(Slot& s, const char* what) {
         for (int q = 0; q < 5; q++) ph[q] += (double)(h[(size_t)b * 8 + q + 1] - h[(size_t)b * 8 + q]);
         nr += (double)h[(size_t)b * 8 + 6]; nn += (double)h[(size_t)b * 8 + 7];
     }
+    {
+        std::vector<double> life, pro;
+        for (int b = 0; b < nw; b++) {
+            if (h[(size_t)b * 8] == 0 || h[(size_t)b * 8 + 5] == 0) continue;
+            life.push_back((double)(h[(size_t)b * 8 + 5] - h[(size_t)b * 8]));
+            pro.push_back((double)(h[(size_t)b * 8 + 1] - h[(size_t)b * 8]));
+        }
+        if (!life.empty()) {
+            std::sort(life.begin(), life.end()); std::sort(pro.begin(), pro.end());
+            auto q = [&](std::vector<double>& v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
+            fprintf(stderr, "[fslic dbg]   wavefront life (cycles): min %.0f p10 %.0f p50 %.0f p90 %.0f max %.0f | prologue: min %.0f p10 %.0f p50 %.0f p90 %.0f max %.0f\n",
+                    q(life, 0), q(life, 0.1), q(life, 0.5), q(life, 0.9), q(life, 1), q(pro, 0), q(pro, 0.1), q(pro, 0.5), q(pro, 0.9), q(pro, 1));
+        }
+    }
     if (cnt == 0) cnt = 1;
-    fprintf(stderr, "[fslic dbg] %s %dx%d waves=%d avg ticks: loads+gather+barrier %.0f  filter+rank %.0f  argmin %.0f  store %.0f  update %.0f | nraw %.1f n %.1f\n",
-            what, s.W, s.H, cnt, ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt, ph[4] / cnt, nr / cnt, nn / cnt);
+    const double tot = ph[0] + ph[1] + ph[2] + ph[3] + ph[4];
+    fprintf(stderr, "[fslic dbg] %s %dx%d waves=%d avg ticks: loads+gather+barrier %.0f  filter+rank %.0f  argmin %.0f  store %.0f  update %.0f | candidates %.1f | wavefront life %.2f us, shader clock %.2f GHz\n",
+            what, s.W, s.H, cnt, ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt, ph[4] / cnt, nr / cnt, nn / cnt * 0.01, nn > 0 ? tot / (nn * 10.0) : 0.0);
     return FSLIC_OK;
 }
 // Spatial-distance configuration of a frame: the reference's patch (src/context.cpp:22-40) and the three device

@@ -70,15 +70,15 @@ __global__ __launch_bounds__(1024) void k_rgb_to_lab(FrameDev f, const uint16_t*
             o.z = r2 | (g2 << 8) | (b2 << 16);
             o.w = r3 | (g3 << 8) | (b3 << 16);
         }
-        reinterpret_cast<uint4*>(lab)[q] = o;
+        st_stream(reinterpret_cast<uint4*>(lab) + q, o);
         // assignment plane <- 0xFFFF once per call (src/context.cpp:138-145)
-        if (labels_init) reinterpret_cast<uint2*>(labels_init)[q] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        if (labels_init) st_stream(reinterpret_cast<uint2*>(labels_init) + q, make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu));
     }
     // tail (and the whole image when the source pointer is not 4-byte aligned)
     for (int p = (nquad << 2) + blockIdx.x * blockDim.x + threadIdx.x; p < N; p += gstride) {
         const uint32_t r = rgb[3 * (size_t)p], g = rgb[3 * (size_t)p + 1], b = rgb[3 * (size_t)p + 2];
-        lab[p] = CONVERT ? lab_px(r, g, b, s_gamma, s_lab, kc) : (r | (g << 8) | (b << 16));
-        if (labels_init) labels_init[p] = 0xFFFFu;
+        st_stream(lab + p, CONVERT ? lab_px(r, g, b, s_gamma, s_lab, kc) : (r | (g << 8) | (b << 16)));
+        if (labels_init) st_stream(labels_init + p, (uint16_t)0xFFFFu);
     }
 }
 

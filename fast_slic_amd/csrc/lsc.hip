@@ -113,9 +113,9 @@ __global__ __launch_bounds__(256) void k_lsc_features(FrameDev f, LscDev l) {
     float w = 0.0f;
 #pragma unroll
     for (int q = 0; q < kLscFeat; ++q) w = __builtin_fmaf(mean[q], F[q], w);
-    l.weight[i] = w;
+    st_stream(l.weight + i, w);
 #pragma unroll
-    for (int q = 0; q < kLscFeat; ++q) l.feat[(size_t)q * f.N + i] = F[q] / w;
+    for (int q = 0; q < kLscFeat; ++q) st_stream(l.feat + (size_t)q * f.N + i, F[q] / w);
 }
 
 static __device__ __forceinline__ float wave_sum(float v) {
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void k_lsc_assign(FrameDev f, LscDev l, int re
         if (!xok || vw + r >= Hv) continue;
         const size_t p = (size_t)yr[r] * W + x;
         if (best[r >> 1][r & 1] < FLT_MAX) {
-            f.labels[p] = (uint16_t)bk[r];
+            st_stream(f.labels + p, (uint16_t)bk[r]);
         } else if (stale_sums) {
             // Nothing accepted this pixel: it keeps its label (src/lsc.cpp:217-220 never touches it) and the update sums
             // it under that label (src/context.cpp:301-354, src/lsc.cpp:256-269).  The update kernel gathers over
