@@ -41,7 +41,7 @@ EXPORTS = [
     "fslic_hip_iterate", "fslic_hip_iterate_device", "fslic_hip_iterate_batch", "fslic_hip_submit_group",
     "fslic_hip_wait_group", "fslic_hip_rgb_to_lab",
     "fslic_hip_enforce_connectivity", "fslic_hip_last_prelabels", "fslic_hip_last_timing_report",
-    "fslic_hip_last_device_times", "fslic_hip_set_launch_timing", "fslic_hip_last_assign_loop", "fslic_hip_last_group_frames", "fslic_hip_last_path", "fslic_hip_last_error", "fslic_hip_version",
+    "fslic_hip_last_device_times", "fslic_hip_set_launch_timing", "fslic_hip_last_assign_loop", "fslic_hip_last_group_frames", "fslic_hip_last_path", "fslic_hip_last_launch_mode", "fslic_hip_group_done", "fslic_hip_last_error", "fslic_hip_version",
 ]
 
 _lib = None
@@ -91,7 +91,7 @@ def load_library():
             raise ImportError(
                 "fast_slic_amd: %s is missing; build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C fast_slic_amd/csrc` (there is no CPU fallback)" % _LIB_PATH)
-        lib = C.CDLL(_LIB_PATH)
+        lib = C.CDLL(os.environ.get("FSLIC_LIB") or _LIB_PATH)      # FSLIC_LIB: A/B a second build of the same ABI (scripts/gpu_ab.sh)
         vp, i32 = C.c_void_p, C.c_int
         lib.fslic_hip_device_count.restype = i32
         lib.fslic_hip_create.argtypes = [i32, i32, C.POINTER(vp)]
@@ -103,6 +103,8 @@ def load_library():
         lib.fslic_hip_iterate_batch.argtypes = [vp, C.POINTER(Params), i32, i32, i32, i32, vp, vp, vp, i32]
         lib.fslic_hip_submit_group.argtypes = [vp, i32, C.POINTER(Params), i32, i32, i32, i32, vp, vp, vp]
         lib.fslic_hip_wait_group.argtypes = [vp, i32]
+        if hasattr(lib, "fslic_hip_group_done"):
+            lib.fslic_hip_group_done.argtypes = [vp, i32]
         lib.fslic_hip_rgb_to_lab.argtypes = [vp, i32, i32, vp, i32, vp]
         lib.fslic_hip_enforce_connectivity.argtypes = [vp, vp, i32, i32, i32, i32]
         lib.fslic_hip_last_prelabels.argtypes = [vp, i32, vp]
@@ -113,6 +115,8 @@ def load_library():
         lib.fslic_hip_last_assign_loop.argtypes = [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int)]
         lib.fslic_hip_last_group_frames.argtypes = [vp, i32]
         lib.fslic_hip_last_path.argtypes = [vp, i32]
+        if hasattr(lib, "fslic_hip_last_launch_mode"):      # absent in older builds loaded through FSLIC_LIB
+            lib.fslic_hip_last_launch_mode.argtypes = [vp, i32]
         lib.fslic_hip_last_error.restype = C.c_char_p
         lib.fslic_hip_version.restype = C.c_char_p
         _lib = lib
@@ -210,6 +214,14 @@ class Engine(object):
 
     def wait_group(self, slot):
         _check(load_library().fslic_hip_wait_group(self._h, int(slot)))
+
+    def group_done(self, slot):
+        """True when wait_group(slot) would not block."""
+        return load_library().fslic_hip_group_done(self._h, int(slot)) != 0
+
+    def last_launch_mode(self, slot=0):
+        """0 direct enqueue, 1 captured into a hipGraph during the call, 2 graph replay."""
+        return int(load_library().fslic_hip_last_launch_mode(self._h, int(slot)))
 
     def last_prelabels(self, H, W, slot=0):
         out = np.empty((H, W), np.uint16)

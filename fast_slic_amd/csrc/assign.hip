@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
     __shared__ uint32_t s_accbuf[FUSE ? kWavesPerBlock * kAccSlots * 6 * kAccCopies : 1];
 
     f.select(blockIdx.z);
+    const uint32_t gen = f.generation();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = (int)rfl((uint32_t)(tid >> 6));
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const bool keep = live[u] && rec[u].pad == f.gen && in_window(rec[u], win);
+            const bool keep = live[u] && rec[u].pad == gen && in_window(rec[u], win);
             const unsigned long long m = __ballot(keep);
             const int pos = nraw + __popcll(m & lowmask);
             if (keep && pos < 64) { s_raw[pos] = rec[u].yx; s_raw[64 + pos] = rec[u].lab; s_raw[128 + pos] = rec[u].tag; }
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
             ClusterRec rec;
             rec.yx = 0; rec.lab = 0; rec.tag = 0; rec.pad = 0;
             if (e < total) rec = citems[cell_slot(e)];
-            stream(rec, e < total && rec.pad == f.gen && in_window(rec, win));
+            stream(rec, e < total && rec.pad == gen && in_window(rec, win));
         }
         for (uint32_t i0 = 0; i0 < novf; i0 += 64) {
             const uint32_t i = i0 + lane;
@@ -419,6 +420,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
     static_assert(!FUSE || (BH * 64 * 255 < (1 << 20) && (BH - 1) * STRIDE * BH * 64 < (1 << 20)), "accumulator fields overflow");
 
     f.select(blockIdx.z);
+    const uint32_t gen = f.generation();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = (int)rfl((uint32_t)(tid >> 6));
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
                 }
                 base += 6 * (size_t)f.ncx * kCellCap;
 #pragma unroll
-                for (int u = 0; u < 6; ++u) visit(rr[u], okr[u] && rr[u].pad == f.gen && in_window(rr[u], win));
+                for (int u = 0; u < 6; ++u) visit(rr[u], okr[u] && rr[u].pad == gen && in_window(rr[u], win));
             }
         }
         for (uint32_t i0 = 0; i0 < novf; i0 += 64) {

@@ -479,6 +479,7 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int cap, unsigned
                 for (uint32_t j = lo; j < hi; ++j) r += (uint32_t)(s_key[j] < me);
                 c.cand_leader[r] = (int32_t)me;
                 c.cand_area[r] = s_area[i];
+                if (c.host_leader) { c.host_leader[r] = (int32_t)me; c.host_area[r] = s_area[i]; }
             }
             if (tid == 0) c.counters[3] = 1u;
             return;

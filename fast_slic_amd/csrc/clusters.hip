@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg) {
     // visit order of the reference scatter: phase = 2*((cy/T)&1) + ((cx/T)&1), then k
     const uint32_t phase = (uint32_t)(2 * ((y / f.T) & 1) + ((x / f.T) & 1));
     ClusterRec rec;
-    rec.yx = yx; rec.lab = lab; rec.tag = (phase << 16) | (uint32_t)k; rec.pad = f.gen;
+    rec.yx = yx; rec.lab = lab; rec.tag = (phase << 16) | (uint32_t)k; rec.pad = f.generation();
     f.cl_tag[k] = rec.tag;
     if (shadowed) return;
     const int cell = (y >> f.cs_shift) * f.ncx + (x >> f.cs_shift);

@@ -93,6 +93,7 @@ static __device__ __forceinline__ bool in_window(const ClusterRec& r, const Tile
 // number of live records inside the window (more than 64: the list overflowed, only the first 64 were stored).
 static __device__ __forceinline__ int gather_candidates(const FrameDev& f, const TileWindow& win, uint32_t* dst, int lane) {
     const uint32_t novf = *f.ovf_cnt[0];
+    const uint32_t gen = f.generation();
     const int sh = f.cs_shift;
     const ClusterRec* __restrict__ citems = f.cell_items[0];
     const ClusterRec* __restrict__ oitems = f.ovf_items[0];
@@ -121,7 +122,7 @@ static __device__ __forceinline__ int gather_candidates(const FrameDev& f, const
             }
             base += 6 * (size_t)f.ncx * kCellCap;
 #pragma unroll
-            for (int u = 0; u < 6; ++u) visit(rr[u], okr[u] && rr[u].pad == f.gen && in_window(rr[u], win));
+            for (int u = 0; u < 6; ++u) visit(rr[u], okr[u] && rr[u].pad == gen && in_window(rr[u], win));
         }
     }
     for (uint32_t i0 = 0; i0 < novf; i0 += 64) {

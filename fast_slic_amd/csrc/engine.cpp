@@ -182,9 +182,22 @@ struct Slot {
     uint32_t* h_cand_area = nullptr;
     size_t h_cand_cap = 0;
     int hKeep = 0;
-    uint32_t gen_counter = 0;
+    uint32_t* d_gen = nullptr;       // device word: base of the bin generation stamps (FrameDev::gen_base)
     unsigned long long* d_dbg = nullptr;
     int keyH = 0, keyW = 0, keyK = 0;
+    size_t cand_capacity = 0;        // entries of the per-frame candidate arrays (>= N)
+    // Captured launch sequences (hipGraph), one per distinct (geometry, options, group size, arena carving): a group
+    // start is ~45 stream operations at ~3 us of host time each when enqueued one by one, ~8 us as one graph launch
+    // (scripts/microbench/graph_launch.hip).  A key is captured the second time it is seen.
+    struct GraphEntry {
+        std::vector<unsigned char> key;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        int seen = 0;
+        bool failed = false;
+    };
+    std::vector<GraphEntry> graphs;
+    int last_launch_mode = 0;        // 0 direct, 1 captured this call, 2 replayed
     // per-call state
     int H = 0, W = 0, K = 0, S = 0;
     int nframes = 0;
@@ -255,11 +268,14 @@ void free_slot(Slot& s) {
         if (s.async->worker.joinable()) s.async->worker.join();
         s.async.reset();
     }
+    for (auto& g : s.graphs) { if (g.exec) hipGraphExecDestroy(g.exec); if (g.graph) hipGraphDestroy(g.graph); }
+    s.graphs.clear();
     if (s.arena) hipFree(s.arena);
     if (s.lsc_arena) hipFree(s.lsc_arena);
     if (s.h_lsc_lut) hipHostFree(s.h_lsc_lut);
     if (s.d_dbg) hipFree(s.d_dbg);
     if (s.d_ptrs) hipFree(s.d_ptrs);
+    if (s.d_gen) hipFree(s.d_gen);
     if (s.h_ptrs) hipHostFree(s.h_ptrs);
     if (s.h_cl) hipHostFree(s.h_cl);
     if (s.h_misc) hipHostFree(s.h_misc);
@@ -389,6 +405,7 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     c.final_lab = (uint16_t*)(b + o_final); c.roots = (int32_t*)(b + o_roots);
     c.counters = misc + 4;
     c.cand_leader = (int32_t*)(b + o_candl); c.cand_area = (uint32_t*)(b + o_canda);
+    s.cand_capacity = ntiles * TT;
     c.tile_cnt = (uint32_t*)(b + o_tcnt);
     s.d_keep_leader = (int32_t*)(b + o_keepl); s.d_keep_label = (uint16_t*)(b + o_keepb);
     s.d_rgb_stage = (uint8_t*)(b + o_rgb); s.d_out_stage = (uint16_t*)(b + o_out);
@@ -548,6 +565,10 @@ CcaDev cca_view(const Slot& s, int i0, const uint16_t* d_in0, size_t in_stride, 
     FrameDev::adv(c.tile_cnt, d); FrameDev::adv(c.counters, d);
     FrameDev::adv(c.cand_leader, d); FrameDev::adv(c.cand_area, d);
     c.outs = reinterpret_cast<uint16_t* const*>(s.d_ptrs + kMaxGroup + i0);
+    static const bool tie_copy = getenv("FSLIC_TIE_COPY") && atoi(getenv("FSLIC_TIE_COPY"));
+    c.host_leader = tie_copy ? nullptr : s.h_dense_leader + (size_t)i0 * kDenseCap;
+    c.host_area = tie_copy ? nullptr : s.h_dense_area + (size_t)i0 * kDenseCap;
+    c.host_stride = kDenseCap;
     return c;
 }
 
@@ -565,7 +586,6 @@ int upload_ptrs(Slot& s, int n, const uint8_t* const* d_rgb, uint16_t* const* d_
 // top-K + ranking, chain, relabel, for frames [i0, i0+n) (c = cca_view(s, i0, ...)).  The select status of every
 // frame ends up in its misc words; cca_finish_group() serves the frames whose status is not 0.
 void cca_enqueue(Slot& s, const CcaDev& c, int i0, int n) {
-    (void)i0;
     launch_cca_phase1(c, n, s.st);
     const bool dbg3 = getenv("FSLIC_DEBUG_TIMING") && atoi(getenv("FSLIC_DEBUG_TIMING")) == 3;
     if (dbg3 && !s.d_dbg) hipMalloc((void**)&s.d_dbg, sizeof(unsigned long long) * 8 * 65536);
@@ -592,15 +612,18 @@ int cca_finish_group(Slot& s, int first, int n, const uint16_t* d_in0, size_t in
     }
     if (n_tie == 0 && n_slow == 0) return FSLIC_OK;
     if (n_tie) {
-        for (int i = first; i < first + n; i++) {
-            const uint32_t* hm = s.h_misc + 16 * (size_t)i;
-            if (hm[4 + 3] != 1) continue;
-            const uint32_t M = hm[4 + 1];
-            HIPCHK(hipMemcpyAsync(s.h_dense_leader + (size_t)i * kDenseCap, s.at(s.c.cand_leader, i), sizeof(int32_t) * M, hipMemcpyDeviceToHost, s.st));
-            HIPCHK(hipMemcpyAsync(s.h_dense_area + (size_t)i * kDenseCap, s.at(s.c.cand_area, i), sizeof(uint32_t) * M, hipMemcpyDeviceToHost, s.st));
+        static const bool tie_copy = getenv("FSLIC_TIE_COPY") && atoi(getenv("FSLIC_TIE_COPY"));      // A/B: fetch the lists with copy commands instead
+        if (tie_copy) {
+            for (int i = first; i < first + n; i++) {
+                const uint32_t* hm = s.h_misc + 16 * (size_t)i;
+                if (hm[4 + 3] != 1) continue;
+                const uint32_t M = hm[4 + 1];
+                HIPCHK(hipMemcpyAsync(s.h_dense_leader + (size_t)i * kDenseCap, s.at(s.c.cand_leader, i), sizeof(int32_t) * M, hipMemcpyDeviceToHost, s.st));
+                HIPCHK(hipMemcpyAsync(s.h_dense_area + (size_t)i * kDenseCap, s.at(s.c.cand_area, i), sizeof(uint32_t) * M, hipMemcpyDeviceToHost, s.st));
+            }
+            HIPCHK(hipStreamSynchronize(s.st));
         }
-        HIPCHK(hipStreamSynchronize(s.st));
-        for (int i = first; i < first + n; i++) {
+        for (int i = first; i < first + n; i++) {      // the select kernel left the candidate lists in pinned host memory
             const uint32_t* hm = s.h_misc + 16 * (size_t)i;
             if (hm[4 + 3] != 1) continue;
             const uint32_t M = hm[4 + 1];
@@ -821,11 +844,38 @@ int configure_spatial(Slot& s, int S, const fslic_params* p) {
 }
 
 
-// Everything of iterate() for frames [i0, i0+n) of the slot's current group, enqueued asynchronously on the
-// slot's stream: cluster upload, LAB, the assign/update loop, full assign, connectivity, result download.
+// Host half of a group start: the integer part of the clamped centres (src/context.cpp:129-131,208-211,262) into the
+// pinned staging block, and what the launch-timing events of this call will cover.  Nothing here touches the stream, so
+// it runs on every call whether the device half below is enqueued directly or replayed as a graph.
+void stage_group(fslic_engine* e, Slot& s, int i0, int n, bool timed) {
+    const int H = s.H, W = s.W, K = s.K;
+    for (int z = 0; z < n; z++) {
+        const fslic_cluster* cl = s.clusters[i0 + z];
+        uint32_t* h = s.h_cl + (size_t)(i0 + z) * 4 * K;
+        for (int k = 0; k < K; k++) {
+            const int y = clampi((int)cl[k].y, 0, H - 1), x = clampi((int)cl[k].x, 0, W - 1);
+            h[k] = ((uint32_t)y << 16) | (uint32_t)x;
+        }
+    }
+    if (timed) {
+        s.n_timed_iters = 0; s.assign_loop_px = 0;
+        const int stride = s.p.subsample_stride;
+        int rem = 0;
+        for (int it = 0; it < s.p.max_iter && e->launch_timing && it < Slot::kMaxTimedIters; it++) {
+            s.n_timed_iters = it + 1;
+            s.assign_loop_px += (double)((H - rem + stride - 1) / stride) * W * n;
+            rem = (rem + 1) % stride;
+        }
+    }
+}
+
+// Device half: everything of iterate() for frames [i0, i0+n) of the slot's current group, enqueued asynchronously on
+// the slot's stream: cluster upload, LAB, the assign/update loop, full assign, connectivity, result download.  Pure
+// stream work with no per-call values in any launch argument (caller pointers sit in the device pointer table, bin
+// generations come from device memory), so the same sequence can be captured once and replayed (group_begin).
 int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool timed) {
     const fslic_params* p = &s.p;
-    const int H = s.H, W = s.W, K = s.K, S = s.S;
+    const int K = s.K, S = s.S;
     FrameDev f = s.f;
     f.rgbs = nullptr;
     f.select(i0);                                  // host-side: pointers of frame i0
@@ -836,24 +886,18 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
         HIPCHK(hipMemcpyAsync(s.d_patch, s.h_patch, (size_t)(2 * S + 1) * (2 * S + 1) * sizeof(uint16_t), hipMemcpyHostToDevice, s.st));
         s.sp_patch_uploaded = true;
     }
-    // cluster centres: integer part of the clamped position (src/context.cpp:129-131,208-211,262)
-    for (int z = 0; z < n; z++) {
-        const fslic_cluster* cl = s.clusters[i0 + z];
-        uint32_t* h = s.h_cl + (size_t)(i0 + z) * 4 * K;
-        for (int k = 0; k < K; k++) {
-            const int y = clampi((int)cl[k].y, 0, H - 1), x = clampi((int)cl[k].x, 0, W - 1);
-            h[k] = ((uint32_t)y << 16) | (uint32_t)x;
-        }
-    }
+    // cluster centres: staged by stage_group() into the pinned block this copy reads
     HIPCHK(hipMemcpy2DAsync(f.cl_yx, fb, s.h_cl + (size_t)i0 * 4 * K, sizeof(uint32_t) * 4 * (size_t)K,
                             sizeof(uint32_t) * (size_t)K, (size_t)n, hipMemcpyHostToDevice, s.st));
     HIPCHK(hipMemset2DAsync(s.at(s.zero_block, i0), fb, 0, s.zero_bytes, (size_t)n, s.st));
     HIPCHK(hipMemset2DAsync(f.cl_n, fb, 0, sizeof(uint32_t) * 2 * (size_t)K, (size_t)n, s.st));   // cl_n, cl_moved
 
-    if (timed) { HIPCHK(hipEventRecord(s.ev[0], s.st)); s.n_timed_iters = 0; s.assign_loop_px = 0; }
-    launch_rgb_to_lab(f, n, p->convert_to_lab, e->tables, true, s.st);   // + labels <- 0xFFFF (src/context.cpp:138-145)
+    if (timed) HIPCHK(hipEventRecord(s.ev[0], s.st));
+    // + labels <- 0xFFFF (src/context.cpp:138-145); + a fresh range of bin generation stamps for this group's passes
+    f.gen_base = s.d_gen;
+    launch_rgb_to_lab(f, n, p->convert_to_lab, e->tables, true, s.st, (uint32_t)p->max_iter + 2u);
     if (timed) HIPCHK(hipEventRecord(s.ev[1], s.st));
-    f.gen = ++s.gen_counter;
+    f.gen_off = 1;
     PassGeom pg{};
     // positions: the uploaded centres are in s.f.cl_yx; every cluster pass reads one buffer and writes the other
     uint32_t* const yx_up = f.cl_yx;
@@ -878,13 +922,9 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
         f.cl_yx = yx_cur; f.cl_yx_out = (yx_cur == yx_a) ? yx_b : yx_a;
         if (tme) HIPCHK(hipEventRecord(s.ev_it[2 * it], s.st));
         launch_lsc_assign(f, l, n, rem, stride, it & 1, it & 1, true, s.st);
-        if (tme) {
-            HIPCHK(hipEventRecord(s.ev_it[2 * it + 1], s.st));
-            s.n_timed_iters = it + 1;
-            s.assign_loop_px += (double)((H - rem + stride - 1) / stride) * W * n;
-        }
+        if (tme) HIPCHK(hipEventRecord(s.ev_it[2 * it + 1], s.st));
         launch_lsc_update(f, l, n, rem, stride, it & 1, s.st);   // update() sums + after_update()
-        f.gen = ++s.gen_counter;
+        f.gen_off++;
         pg = PassGeom{};                                          // use_slots = 0: everything is in FrameDev::sums
         launch_bin_clusters(f, n, 1, (it + 1) & 1, it & 1, pg, s.st);
         yx_cur = f.cl_yx_out;
@@ -901,17 +941,13 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
         if (tme) HIPCHK(hipEventRecord(s.ev_it[2 * it], s.st));
         if (generic) launch_assign_generic(f, n, rem, stride, it & 1, it & 1, true, s.st);
         else pg = launch_assign(f, n, rem, stride, it & 1, it & 1, true, s.st);
-        if (tme) {
-            HIPCHK(hipEventRecord(s.ev_it[2 * it + 1], s.st));
-            s.n_timed_iters = it + 1;
-            s.assign_loop_px += (double)((H - rem + stride - 1) / stride) * W * n;
-        }
+        if (tme) HIPCHK(hipEventRecord(s.ev_it[2 * it + 1], s.st));
         if (f.dbg && dbg_mode == 2) {
             int rc2 = print_phase_stamps(s, "last fused assign");
             if (rc2) return rc2;
             f.dbg = nullptr;
         }
-        f.gen = ++s.gen_counter;
+        f.gen_off++;
         f.cl_yx = yx_cur; f.cl_yx_out = (yx_cur == yx_a) ? yx_b : yx_a;
         launch_bin_clusters(f, n, 1, (it + 1) & 1, it & 1, pg, s.st);
         yx_cur = f.cl_yx_out;
@@ -953,6 +989,53 @@ double now_us() {
 }
 const bool g_host_timing = getenv("FSLIC_HOST_TIMING") != nullptr;
 
+// The device half of a group start, replayed from a captured graph when this exact sequence has been seen before.
+const bool g_use_graphs = !(getenv("FSLIC_GRAPH") && atoi(getenv("FSLIC_GRAPH")) == 0) && !getenv("FSLIC_DEBUG_TIMING");
+int launch_group(fslic_engine* e, Slot& s, int n) {
+    s.last_launch_mode = 0;
+    if (!g_use_graphs) return enqueue_frames(e, s, 0, n, s.generic, true);
+    // everything a launch argument can depend on
+    std::vector<unsigned char> key;
+    auto put = [&](const void* p, size_t bytes) { const unsigned char* b = (const unsigned char*)p; key.insert(key.end(), b, b + bytes); };
+    const int hdr[8] = {s.H, s.W, s.K, s.S, n, s.generic ? 1 : 0, e->launch_timing ? 1 : 0, s.sp_patch_uploaded ? 1 : 0};
+    const void* const ptrs[8] = {s.h_cl, s.h_misc, s.h_dense_leader, s.h_dense_area, s.d_ptrs, s.h_patch, s.d_gen, s.lsc_zero};   // baked into copy nodes / arguments
+    put(hdr, sizeof hdr); put(ptrs, sizeof ptrs); put(&s.p, sizeof s.p); put(&s.f, sizeof s.f); put(&s.c, sizeof s.c);
+    if (s.p.variant == FSLIC_VARIANT_LSC) put(&s.l, sizeof s.l);
+    Slot::GraphEntry* ge = nullptr;
+    for (auto& g : s.graphs) if (g.key == key) { ge = &g; break; }
+    if (!ge) {
+        if (s.graphs.size() >= 8) {                  // keep the cache small: drop the oldest entry
+            if (s.graphs.front().exec) hipGraphExecDestroy(s.graphs.front().exec);
+            if (s.graphs.front().graph) hipGraphDestroy(s.graphs.front().graph);
+            s.graphs.erase(s.graphs.begin());
+        }
+        s.graphs.emplace_back();
+        ge = &s.graphs.back();
+        ge->key = key;
+    }
+    if (ge->exec) {
+        HIPCHK(hipGraphLaunch(ge->exec, s.st));
+        s.last_launch_mode = 2;
+        return FSLIC_OK;
+    }
+    if (ge->failed || ge->seen++ == 0) return enqueue_frames(e, s, 0, n, s.generic, true);   // first sighting: direct (also warms one-time setup)
+    if (hipStreamBeginCapture(s.st, hipStreamCaptureModeThreadLocal) != hipSuccess) { ge->failed = true; (void)hipGetLastError(); return enqueue_frames(e, s, 0, n, s.generic, true); }
+    const int rc = enqueue_frames(e, s, 0, n, s.generic, true);
+    hipGraph_t g = nullptr;
+    const hipError_t ec = hipStreamEndCapture(s.st, &g);
+    if (rc != FSLIC_OK || ec != hipSuccess || !g || hipGraphInstantiate(&ge->exec, g, nullptr, nullptr, 0) != hipSuccess) {
+        if (g) hipGraphDestroy(g);
+        ge->exec = nullptr; ge->failed = true;
+        (void)hipGetLastError();
+        if (rc != FSLIC_OK) return rc;
+        return enqueue_frames(e, s, 0, n, s.generic, true);
+    }
+    ge->graph = g;
+    HIPCHK(hipGraphLaunch(ge->exec, s.st));
+    s.last_launch_mode = 1;
+    return FSLIC_OK;
+}
+
 int group_begin(fslic_engine* e, Slot& s, const fslic_params* p, int H, int W, int K, int n,
                 const uint8_t* const* d_rgb, fslic_cluster* const* clusters, uint16_t* const* d_out) {
     const double t_begin = now_us();
@@ -975,7 +1058,8 @@ int group_begin(fslic_engine* e, Slot& s, const fslic_params* p, int H, int W, i
     rc = upload_ptrs(s, n, d_rgb, d_out);
     if (rc) return rc;
     s.generic = p->variant == FSLIC_VARIANT_SLIC && (p->force_generic || !s.sp_tiled_ok);
-    rc = enqueue_frames(e, s, 0, n, s.generic, true);
+    stage_group(e, s, 0, n, true);
+    rc = launch_group(e, s, n);
     if (rc) return rc;
     s.have_pre = true;
     s.last_path = s.generic ? 1 : 0;
@@ -990,15 +1074,16 @@ int group_finish(fslic_engine* e, Slot& s) {
     HIPCHK(hipStreamSynchronize(s.st));
     const double t_sync = now_us();
     const int n = s.nframes, K = s.K, H = s.H, W = s.W;
-    hipEventElapsedTime(&s.total_ms, s.ev[0], s.ev[4]);
-    hipEventElapsedTime(&s.lab_ms, s.ev[0], s.ev[1]);
-    hipEventElapsedTime(&s.loop_ms, s.ev[1], s.ev[2]);
-    hipEventElapsedTime(&s.fa_ms, s.ev[2], s.ev[3]);
-    hipEventElapsedTime(&s.cca_ms, s.ev[3], s.ev[4]);
+    auto elapsed = [](float& ms, hipEvent_t a, hipEvent_t b) { if (hipEventElapsedTime(&ms, a, b) != hipSuccess) { ms = 0; (void)hipGetLastError(); } };
+    elapsed(s.total_ms, s.ev[0], s.ev[4]);
+    elapsed(s.lab_ms, s.ev[0], s.ev[1]);
+    elapsed(s.loop_ms, s.ev[1], s.ev[2]);
+    elapsed(s.fa_ms, s.ev[2], s.ev[3]);
+    elapsed(s.cca_ms, s.ev[3], s.ev[4]);
     s.assign_loop_ms = 0;
     for (int it = 0; it < s.n_timed_iters; it++) {
         float ms = 0;
-        hipEventElapsedTime(&ms, s.ev_it[2 * it], s.ev_it[2 * it + 1]);
+        elapsed(ms, s.ev_it[2 * it], s.ev_it[2 * it + 1]);
         s.assign_loop_ms += ms;
     }
     const int thres = (int)round((double)(s.S * s.S) * (double)s.p.min_size_factor);
@@ -1007,6 +1092,8 @@ int group_finish(fslic_engine* e, Slot& s) {
     for (int i = 0; i < n; i++) {
         n_host_topk += s.h_misc[16 * (size_t)i + 4 + 3] != 0;
         if (!s.generic && s.h_misc[16 * (size_t)i + 2] != 0) {     // the tiled kernel overflowed an LDS candidate list
+            if (g_host_timing) fprintf(stderr, "[fslic host] candidate-list overflow: frame %d redone with the generic kernel\n", i);
+            stage_group(e, s, i, 1, false);
             int rc = enqueue_frames(e, s, i, 1, true, false);
             if (rc) return rc;
             HIPCHK(hipStreamSynchronize(s.st));
@@ -1095,7 +1182,8 @@ int fslic_hip_create(int device, int n_slots, fslic_engine** out) {
         for (auto& ev : s.ev_it)
             if (hipEventCreate(&ev) != hipSuccess) { fslic_hip_destroy(e); return fail(FSLIC_E_HIP, "hipEventCreate failed"); }
         if (hipMalloc((void**)&s.d_ptrs, sizeof(void*) * 2 * kMaxGroup) != hipSuccess ||
-            hipHostMalloc((void**)&s.h_ptrs, sizeof(void*) * 2 * kMaxGroup) != hipSuccess) { fslic_hip_destroy(e); return fail(FSLIC_E_HIP, "pointer table allocation failed"); }
+            hipHostMalloc((void**)&s.h_ptrs, sizeof(void*) * 2 * kMaxGroup) != hipSuccess ||
+            hipMalloc((void**)&s.d_gen, 256) != hipSuccess || hipMemset(s.d_gen, 0, 256) != hipSuccess) { fslic_hip_destroy(e); return fail(FSLIC_E_HIP, "pointer table allocation failed"); }
     }
     if (hipMalloc((void**)&e->d_gamma, sizeof g_tables.gamma) != hipSuccess ||
         hipMalloc((void**)&e->d_labtbl, sizeof g_tables.lab) != hipSuccess) { fslic_hip_destroy(e); return fail(FSLIC_E_HIP, "hipMalloc(tables) failed"); }
@@ -1242,6 +1330,14 @@ int fslic_hip_wait_group(fslic_engine* e, int slot) {
     s.pending = false;
     if (rc == FSLIC_OK && slot == 0) make_timing_report(e, s);
     return rc;
+}
+
+int fslic_hip_group_done(fslic_engine* e, int slot) {
+    if (!e || slot < 0 || slot >= (int)e->slots.size()) return -1;
+    Slot& s = e->slots[slot];
+    if (!s.pending) return 1;
+    std::lock_guard<std::mutex> lk(s.async->m);
+    return s.async->done ? 1 : 0;
 }
 
 int fslic_hip_iterate(fslic_engine* e, const fslic_params* p, int H, int W, int K, const uint8_t* rgb,
@@ -1422,6 +1518,11 @@ int fslic_hip_last_assign_loop(fslic_engine* e, int slot, float* sum_ms, double*
 int fslic_hip_last_group_frames(fslic_engine* e, int slot) {
     if (!e || slot < 0 || slot >= (int)e->slots.size()) return -1;
     return e->slots[slot].nframes;
+}
+
+int fslic_hip_last_launch_mode(fslic_engine* e, int slot) {
+    if (!e || slot < 0 || slot >= (int)e->slots.size()) return -1;
+    return e->slots[slot].last_launch_mode;
 }
 
 int fslic_hip_last_path(fslic_engine* e, int slot) {

@@ -40,7 +40,12 @@ struct FrameDev {
     int T;               // 2S + 32, phase cell side (src/context.cpp:213)
     int cs_shift;        // coarse bin side = 1 << cs_shift
     int ncx, ncy, ncell;
-    uint32_t gen;        // generation stamp of the bin pass that filled cell_items[buf] (ClusterRec::pad)
+    // Generation stamp of the bin pass that filled cell_items[buf] (ClusterRec::pad) = *gen_base + gen_off.  The base
+    // lives in device memory and is advanced by the first kernel of every group, so that the launch sequence of a
+    // group carries no per-call value and can be replayed as a hipGraph.
+    uint32_t* gen_base;
+    uint32_t gen_off;
+    __device__ __forceinline__ uint32_t generation() const { return *gen_base + gen_off; }
     uint32_t M, C;       // spatial fixed point: patch[d] == (d * M + C) >> 16 for d in [0, 2S]
     // image planes
     const uint8_t* rgb;  // N*3 (set by select)
@@ -128,6 +133,11 @@ struct CcaDev {
     uint32_t* counters;   // [1] M = number of candidates (append cursor of k_cca_collect), [2] M again, [3] select status
     int32_t* cand_leader; // dense candidate list (global roots with area >= threshold): leaders,
     uint32_t* cand_area;  //   and areas; capacity ntiles * kCcaTilePx >= N.  Unordered unless the select status is 1
+    // pinned HOST memory (device-accessible), host_stride entries per frame: on a tie at the top-K cut the select kernel
+    // leaves the leader-sorted candidates here as well, so the host sort needs no copy command and no second wait
+    int32_t* host_leader;
+    uint32_t* host_area;
+    size_t host_stride;
 
     __host__ __device__ __forceinline__ void select(int z) {
         out = outs[z];
@@ -136,6 +146,7 @@ struct CcaDev {
         FrameDev::adv(parent, d); FrameDev::adv(area, d); FrameDev::adv(final_lab, d); FrameDev::adv(roots, d);
         FrameDev::adv(tile_cnt, d); FrameDev::adv(counters, d);
         FrameDev::adv(cand_leader, d); FrameDev::adv(cand_area, d);
+        host_leader += (size_t)z * host_stride; host_area += (size_t)z * host_stride;
     }
 };
 
@@ -172,7 +183,8 @@ struct LabTables {
 
 // ---- launches (all asynchronous on `st`) ----------------------------------------------------
 // labels_init != nullptr: also fill the N-entry label plane with 0xFFFF (src/context.cpp:138-145)
-void launch_rgb_to_lab(const FrameDev& f, int nframes, int convert, const LabTables& t, bool init_labels, hipStream_t st);
+// gen_step != 0: first kernel of a group, advances FrameDev::gen_base by gen_step (more than the group's bin passes)
+void launch_rgb_to_lab(const FrameDev& f, int nframes, int convert, const LabTables& t, bool init_labels, hipStream_t st, uint32_t gen_step = 0);
 // mode 0: resample colours at the current centres (src/context.cpp:128-135) and bin;
 // mode 1: integer centroid update from `sums` (src/context.cpp:356-373), zero sums, and bin.
 void launch_bin_clusters(const FrameDev& f, int nframes, int mode, int buf, int sbuf, const PassGeom& pg, hipStream_t st);

@@ -33,9 +33,11 @@ static __device__ __forceinline__ uint32_t lab_px(uint32_t R, uint32_t G, uint32
 
 template <bool CONVERT>
 __global__ __launch_bounds__(1024) void k_rgb_to_lab(FrameDev f, const uint16_t* __restrict__ g_gamma,
-                                                     const uint16_t* __restrict__ g_labtbl, LabConst kc, int init_labels) {
+                                                     const uint16_t* __restrict__ g_labtbl, LabConst kc, int init_labels, uint32_t gen_step) {
     __shared__ uint16_t s_gamma[256];
     __shared__ uint16_t s_lab[8194];
+    // first kernel of a group: new generation of bin stamps (nothing in this kernel reads them; the stream orders the rest)
+    if (gen_step && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *f.gen_base += gen_step;
     f.select(blockIdx.y);
     const uint8_t* __restrict__ rgb = f.rgb;
     uint32_t* __restrict__ lab = f.lab;
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(1024) void k_rgb_to_lab(FrameDev f, const uint16_t*
     }
 }
 
-void launch_rgb_to_lab(const FrameDev& f, int nframes, int convert, const LabTables& t, bool init_labels, hipStream_t st) {
+void launch_rgb_to_lab(const FrameDev& f, int nframes, int convert, const LabTables& t, bool init_labels, hipStream_t st, uint32_t gen_step) {
     LabConst kc;
     for (int i = 0; i < 9; i++) kc.cb[i] = t.cb[i];
     int blocks = (f.N / 4 + 1023) / 1024;
@@ -90,9 +92,9 @@ void launch_rgb_to_lab(const FrameDev& f, int nframes, int convert, const LabTab
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     if (convert)
-        hipLaunchKernelGGL(k_rgb_to_lab<true>, dim3(blocks, nframes), dim3(1024), 0, st, f, t.gamma, t.labtbl, kc, init_labels ? 1 : 0);
+        hipLaunchKernelGGL(k_rgb_to_lab<true>, dim3(blocks, nframes), dim3(1024), 0, st, f, t.gamma, t.labtbl, kc, init_labels ? 1 : 0, gen_step);
     else
-        hipLaunchKernelGGL(k_rgb_to_lab<false>, dim3(blocks, nframes), dim3(1024), 0, st, f, t.gamma, t.labtbl, kc, init_labels ? 1 : 0);
+        hipLaunchKernelGGL(k_rgb_to_lab<false>, dim3(blocks, nframes), dim3(1024), 0, st, f, t.gamma, t.labtbl, kc, init_labels ? 1 : 0, gen_step);
 }
 
 }  // namespace fslic

@@ -114,6 +114,10 @@ int fslic_hip_iterate_batch(fslic_engine* e, const fslic_params* p, int H, int W
 int fslic_hip_submit_group(fslic_engine* e, int slot, const fslic_params* p, int H, int W, int K, int n_frames,
                            const uint8_t* const* d_rgb, fslic_cluster* const* clusters, uint16_t* const* d_labels);
 int fslic_hip_wait_group(fslic_engine* e, int slot);
+/* Non-blocking: 1 when the group submitted on `slot` is complete (fslic_hip_wait_group will not block) or the slot is
+ * idle, 0 while it is in flight, -1 on a bad argument.  Lets a caller with several slots collect groups in completion
+ * order instead of submission order (groups with a top-K tie take longer than the others). */
+int fslic_hip_group_done(fslic_engine* e, int slot);
 
 /* Stage entry points (used by the parity tests; each mirrors one stage of iterate()). */
 
@@ -147,6 +151,11 @@ int fslic_hip_last_assign_loop(fslic_engine* e, int slot, float* sum_ms, double*
 
 /* Number of frames in the last group on `slot` (1 for iterate / iterate_device). */
 int fslic_hip_last_group_frames(fslic_engine* e, int slot);
+
+/* How the last group on `slot` reached the GPU: 0 = operations enqueued one by one, 1 = captured into a hipGraph during
+ * this call and launched, 2 = replay of a captured graph.  (The engine captures a launch sequence the second time it
+ * sees the same geometry / options / group size; FSLIC_GRAPH=0 disables that.)  Testing / diagnostics aid. */
+int fslic_hip_last_launch_mode(fslic_engine* e, int slot);
 
 /* Which kernel family served the last call on `slot`: 0 = tiled (LDS candidate lists), 1 = generic. */
 int fslic_hip_last_path(fslic_engine* e, int slot);

@@ -35,8 +35,52 @@ def timeline(db, marker="rgb_to_lab"):
               % ((st - t0) / 1e3, (en - t0) / 1e3, (en - st) / 1e3, n[:64], gx // max(wx, 1), gy, wx, lds, vg, sg, sid))
 
 
+def overlap(db, frac=0.5):
+    """Concurrency over the last `frac` of the trace: busy time (union of kernel intervals), summed kernel time, and
+    how both split between the streams."""
+    c = sqlite3.connect(db)
+    rows = c.execute("select name, start, end, stream_id from kernels order by start").fetchall()
+    t_lo = rows[0][1] + (rows[-1][2] - rows[0][1]) * (1.0 - frac)
+    rows = [r for r in rows if r[1] >= t_lo]
+    span = rows[-1][2] - rows[0][1]
+    ev = sorted([(r[1], 1) for r in rows] + [(r[2], -1) for r in rows])
+    busy = 0; depth = 0; last = ev[0][0]; hist = {}
+    for t, d in ev:
+        if depth > 0: busy += t - last
+        hist[depth] = hist.get(depth, 0) + (t - last)
+        depth += d; last = t
+    tot = sum(r[2] - r[1] for r in rows)
+    print("window %.1f us: busy (>=1 kernel running) %.1f us = %.1f %%, summed kernel time %.1f us = %.2f x window, %d kernels"
+          % (span / 1e3, busy / 1e3, 100.0 * busy / span, tot / 1e3, tot / span, len(rows)))
+    print("time at concurrency depth: " + "  ".join("%d: %.1f%%" % (k, 100.0 * v / span) for k, v in sorted(hist.items())))
+    per = {}
+    for n, st, en, sid in rows:
+        key = n.split("(")[0][-40:]
+        per[key] = per.get(key, 0) + (en - st)
+    for k, v in sorted(per.items(), key=lambda kv: -kv[1])[:14]:
+        print("  %-42s %8.1f us  %5.1f %% of summed" % (k, v / 1e3, 100.0 * v / tot))
+
+
+def window(db, back_us=8000.0, us=1200.0):
+    """All kernels of every stream in a window of `us` microseconds that starts `back_us` before the last kernel ends."""
+    c = sqlite3.connect(db)
+    rows = c.execute("select name, start, end, stream_id, queue_id from kernels order by start").fetchall()
+    t0 = rows[-1][2] - back_us * 1e3
+    prev_end = None
+    for n, st, en, sid, qid in rows:
+        if st < t0 or st > t0 + us * 1e3:
+            continue
+        gap = "" if prev_end is None else ("   idle %.1f" % ((st - prev_end) / 1e3) if st > prev_end else "")
+        print("%9.1f %7.1f  s%-3d q%-3d %s%s" % ((st - t0) / 1e3, (en - st) / 1e3, sid, qid, n.split("(")[0][-36:], gap))
+        prev_end = en if prev_end is None else max(prev_end, en)
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "window":
+        window(sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 8000.0, float(sys.argv[4]) if len(sys.argv) > 4 else 1200.0)
+    elif sys.argv[1] == "overlap":
+        overlap(sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 0.5)
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
     else:
         timeline(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "rgb_to_lab")

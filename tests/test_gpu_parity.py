@@ -358,3 +358,27 @@ def test_randomized_shapes_and_options_against_oracle(engine):
         labels, cl, pre, path = run_hip(engine, img, cl0, **kw)
         o_labels, o_cl, o_lab, o_pre = orc.slic_iterate(img, cl0, stages=True, **kw)
         assert_same("trial %d %dx%d K=%d %s %s path=%d" % (trial, H, W, K, var, kw, path), (labels, cl, pre), (o_labels, o_cl, o_pre))
+
+
+def test_graph_replay_equals_direct_launches():
+    # the engine captures a group's launch sequence the second time it sees it and replays it afterwards; every mode must
+    # give the same result, with different frames and clusters on every call (nothing per-call may be baked into the graph)
+    from fast_slic_amd import Engine
+    H, W, K = 240, 320, 150
+    p = make_params(10, 10.0, 0.25, 3)
+    e = Engine(0, 1)
+    try:
+        modes = []
+        for rep, kind in enumerate(["A", "B", "C", "A", "B"]):
+            img = variant(kind, H, W, seed=rep)
+            cl0 = orc.initialize_clusters(img, K)
+            exp = orc.slic_iterate(img, cl0)
+            cl = cl0.copy()
+            labels = e.iterate(np.ascontiguousarray(img), cl, p)
+            modes.append(e.last_launch_mode())
+            assert np.array_equal(labels, exp[0]), describe_mismatch("rep %d (launch mode %d)" % (rep, modes[-1]), labels, exp[0])
+            assert not cluster_fields_equal(cl, exp[1])
+            assert e.last_device_times()[0] > 0.0          # the events inside the captured sequence still time it
+        assert modes[0] == 0 and 1 in modes and modes[-1] == 2, modes
+    finally:
+        e.close()
