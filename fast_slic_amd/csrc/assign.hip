@@ -2,6 +2,9 @@
 // Hand-written gfx950 (CDNA4, wave64) kernels of the SLIC hot path; see kernels.h for the launch interface and
 // DESIGN.md for the design.  All arithmetic on this path is integer, so results are bit-identical to the reference.
 #include "device_common.h"
+#ifndef FSLIC_EXP
+#define FSLIC_EXP 0      // timing experiments (scripts/gpu_exp.sh): results are wrong when != 0
+#endif
 
 namespace fslic {
 
@@ -406,7 +409,7 @@ static __device__ __forceinline__ void row_masks(uint32_t inv, uint32_t (&m)[R /
 // mask OR-ed in together with idx (v_lshl_or_b32: no extra VALU).
 template <int R, bool FUSE, int STRIDE, bool VT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_assign_blk(FrameDev f, int rem, int Hv) {
-    extern __shared__ uint32_t s_dyn[];                  // spatial table (u16), f.tab_words dwords
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];   // spatial table (u16), f.tab_words dwords; 16-byte aligned: the row-vector reads are ds_read_b128
     __shared__ uint32_t s_braw[3 * 64];
     __shared__ uint4 s_list[64];                         // {yx, lab, k, cpart entry | kNoSlot}
     __shared__ uint32_t s_bn;
@@ -533,6 +536,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
         uint4* dst = reinterpret_cast<uint4*>(s_dyn);
         const int nq = f.tab_words >> 2;
         const int t = ((wave - gwave - 1) & 3) * 64 + lane;      // 0..191 over the three staging wavefronts
+#if FSLIC_EXP == 3
+        if (false)
+#endif
         for (int b0 = 0; b0 < nq; b0 += 4 * 192) {     // indices past the end are clamped: the last quad is rewritten, no masking
             uint4 q[4];
 #pragma unroll
@@ -592,28 +598,63 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
         // eight rows are ONE 16-byte-ALIGNED ds_read_b128 (a 2-byte-aligned b128 read costs 64 clk of the CU's LDS pipe
         // instead of 8, scripts/microbench/lds_unaligned.hip)
         const uint4* const s_rv = reinterpret_cast<const uint4*>(s_dyn);
-        auto pass = [&](uint32_t clab, uint32_t base, uint32_t idx01, const uint32_t* mq) {
-            uint32_t spw[R / 2];
-            {
-                const uint4 e0 = s_rv[base];
-                spw[0] = e0.x; spw[1] = e0.y; spw[2] = e0.z; spw[3] = e0.w;
-                if (R == 16) {
-                    const uint4 e1 = s_rv[base + 8 * STRIDE];
-                    spw[R / 2 - 4] = e1.x; spw[R / 2 - 3] = e1.y; spw[R / 2 - 2] = e1.z; spw[R / 2 - 1] = e1.w;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < R / 2; ++q) {
-                const us2 sp = __builtin_bit_cast(us2, spw[q]);
-                const uint32_t s0 = __builtin_amdgcn_sad_u8(pix[2 * q], clab, 0u);
-                const uint32_t s01 = __builtin_amdgcn_sad_hi_u8(pix[2 * q + 1], clab, s0);
-                const uint32_t t = (s01 << 6) | (mq ? (mq[q] | idx01) : idx01);                // v_lshl_or_b32, scalar 3rd operand
-                const us2 key = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, t), sp);
-                best[q] = __builtin_elementwise_min(best[q], key);
+        // One pass = one candidate over the rows on ONE side of its centre.  The loop is software-pipelined over passes:
+        // the table words of pass n+1 are requested before the arithmetic of pass n, so the LDS round trip (measured:
+        // 30 % of the kernel when it sits between the request and its first use) overlaps a whole pass of VALU work.
+        struct Pass { uint32_t clab, idx01, inv; bool valid; };
+        auto fetch = [&](uint32_t base, uint32_t (&spw)[R / 2]) {
+#if FSLIC_EXP == 1
+            for (int q = 0; q < R / 2; ++q) spw[q] = base;
+            return;
+#endif
+            const uint4 e0 = s_rv[base];
+            spw[0] = e0.x; spw[1] = e0.y; spw[2] = e0.z; spw[3] = e0.w;
+            if (R == 16) {
+                const uint4 e1 = s_rv[base + 8 * STRIDE];
+                spw[R / 2 - 4] = e1.x; spw[R / 2 - 3] = e1.y; spw[R / 2 - 2] = e1.z; spw[R / 2 - 1] = e1.w;
             }
         };
-#pragma unroll 1
-        while (todo) {
+        auto compute = [&](const Pass& ps_, const uint32_t (&spw)[R / 2]) {
+            Pass ps;       // wave-uniform by construction; say so, or the values travel in VGPRs after the loop's phis
+            ps.clab = rfl(ps_.clab); ps.idx01 = rfl(ps_.idx01); ps.inv = rfl(ps_.inv); ps.valid = true;
+            // three sweeps over the row pairs instead of one chain per pair: a packed op that consumes the result of the
+            // packed op issued just before it costs a wait state (s_nop) on this target
+            uint32_t t[R / 2];
+            if (ps.inv == 0u) {
+#pragma unroll
+                for (int q = 0; q < R / 2; ++q) {
+                    const uint32_t s0 = __builtin_amdgcn_sad_u8(pix[2 * q], ps.clab, 0u);
+                    const uint32_t s01 = __builtin_amdgcn_sad_hi_u8(pix[2 * q + 1], ps.clab, s0);
+                    t[q] = (s01 << 6) | ps.idx01;                                              // v_lshl_or_b32, scalar 3rd operand
+                }
+            } else {
+                uint32_t mq[R / 2];
+                row_masks<R>(ps.inv, mq);
+#pragma unroll
+                for (int q = 0; q < R / 2; ++q) {
+                    const uint32_t s0 = __builtin_amdgcn_sad_u8(pix[2 * q], ps.clab, 0u);
+                    const uint32_t s01 = __builtin_amdgcn_sad_hi_u8(pix[2 * q + 1], ps.clab, s0);
+                    t[q] = (s01 << 6) | (mq[q] | ps.idx01);
+                }
+            }
+            us2 key[R / 2];
+#pragma unroll
+            for (int q = 0; q < R / 2; ++q) key[q] = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, t[q]), __builtin_bit_cast(us2, spw[q]));
+#pragma unroll
+            for (int q = 0; q < R / 2; ++q) best[q] = __builtin_elementwise_min(best[q], key[q]);
+        };
+        // pass generator: pops candidates off `todo`; a candidate whose centre row lies inside this wavefront's rows
+        // yields two passes (rows above, then rows at/below)
+        bool pend = false;
+        uint32_t pend_clab = 0, pend_idx = 0, pend_inv = 0, pend_base = 0;      // pend_base is per lane
+        auto next = [&](Pass& ps, uint32_t& base) {
+            if (pend) {
+                pend = false;
+                ps.clab = pend_clab; ps.idx01 = pend_idx; ps.inv = pend_inv; ps.valid = true;
+                base = pend_base;
+                return;
+            }
+            if (!todo) { ps.valid = false; ps.clab = 0; ps.idx01 = 0; ps.inv = 0; base = 0; return; }
             const int c = __builtin_ctzll(todo);
             todo &= todo - 1ull;
             const uint32_t cyx = __builtin_amdgcn_readlane(yx_j, c);
@@ -624,15 +665,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
             const uint32_t uxc = ux <= (uint32_t)S ? ux : xout;
             const uint32_t k0 = (uint32_t)(Cc + yw_lo - cy);                                   // wave-uniform
             const uint32_t idx01 = (uint32_t)c | ((uint32_t)c << 16);
-            if (vab == (full << 16)) {                    // every row at/below the centre and inside the window
-                pass(clab, k0 + uxc, idx01, nullptr);
-            } else if (vab == full) {                     // every row above the centre and inside the window
-                pass(clab, k0 - uxc, idx01, nullptr);
-            } else {                                      // window edge and / or centre row inside this wavefront's rows
-                const uint32_t va = vab & 0xFFFFu, vb = vab >> 16;
-                uint32_t mq[R / 2];
-                if (va) { row_masks<R>(~va & full, mq); pass(clab, k0 - uxc, idx01, mq); }
-                if (vb) { row_masks<R>(~vb & full, mq); pass(clab, k0 + uxc, idx01, mq); }
+            const uint32_t va = vab & 0xFFFFu, vb = vab >> 16;
+            ps.clab = clab; ps.idx01 = idx01; ps.valid = true;
+            if (va) {
+                ps.inv = ~va & full;
+                base = k0 - uxc;
+                if (vb) { pend = true; pend_clab = clab; pend_idx = idx01; pend_inv = ~vb & full; pend_base = k0 + uxc; }
+            } else {
+                ps.inv = ~vb & full;
+                base = k0 + uxc;
+            }
+        };
+        {
+            Pass pa, pb;
+            uint32_t ba, bb;
+            uint32_t spa[R / 2], spb[R / 2];
+            next(pa, ba);
+            if (pa.valid) {
+                fetch(ba, spa);
+#pragma unroll 1
+                for (;;) {
+                    next(pb, bb);
+                    if (pb.valid) fetch(bb, spb);
+                    compute(pa, spa);
+                    if (!pb.valid) break;
+                    next(pa, ba);
+                    if (pa.valid) fetch(ba, spa);
+                    compute(pb, spb);
+                    if (!pa.valid) break;
+                }
             }
         }
     } else {
@@ -667,7 +728,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint32_t key = (r & 1) ? (uint32_t)best[r / 2].y : (uint32_t)best[r / 2].x;
+#if FSLIC_EXP == 2
+            kk[r] = key & 63u;
+#else
             kk[r] = s_list[key & 63u].z;                            // idx 63 when not found: read, never used
+#endif
         }
         uint16_t* rowp = f.labels + (size_t)yw_lo * W;
         const uint32_t xo = (uint32_t)x;

@@ -12,7 +12,12 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, int lane_stride_bytes, i
     for (int i = threadIdx.x; i < 16384; i += 256) s_tab[i] = (uint16_t)(i * 7);
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    uint32_t addr = (uint32_t)(base_off + lane * lane_stride_bytes);      // byte address inside s_tab
+    // lane -> table entry: 0 one entry per lane, 1 V shape |lane - 20| (the assign kernel's |x - cx|), 2 one entry for all
+    // lanes, 3 min(lane, 30) (lanes outside the window share an entry), 4 lane pairs share an entry
+    const int pattern = base_off >> 16;
+    base_off &= 0xffff;
+    const int li = pattern == 1 ? abs(lane - 20) : pattern == 2 ? 0 : pattern == 3 ? min(lane, 30) : pattern == 4 ? lane >> 1 : lane;
+    uint32_t addr = (uint32_t)(base_off + li * lane_stride_bytes);      // byte address inside s_tab
     uint32_t acc = 0;
     const char* basep = reinterpret_cast<const char*>(s_tab);
 #pragma unroll 1
@@ -72,6 +77,12 @@ int main() {
     run<11>("4 x b64,  4B aligned  (lane*176 + 4)", 176, 4, d_out);
     run<12>("8 x b32,  4B aligned  (lane*176 + 4)", 176, 4, d_out);
     run<12>("8 x b32,  2B aligned  (lane*176 + 2)", 176, 2, d_out);
+    run<10>("2 x b128, 16B entries, V shape |lane-20|", 16, 1 << 16, d_out);
+    run<10>("2 x b128, 16B entries, all lanes one entry", 16, 2 << 16, d_out);
+    run<10>("2 x b128, 16B entries, min(lane,30)", 16, 3 << 16, d_out);
+    run<10>("2 x b128, 16B entries, lane pairs share", 16, 4 << 16, d_out);
+    run<12>("8 x b32,  V shape, 16B entries", 16, 1 << 16, d_out);
+    run<12>("8 x b32,  all lanes one entry", 16, 2 << 16, d_out);
     run<0>("2 x b128, lane*2 bytes (+0..14 phase)", 2, 0, d_out);
     run<0>("2 x b128, lane*2 bytes, base+2", 2, 2, d_out);
     run<0>("2 x b128, lane*(178*2) bytes (2-D table)", 356, 0, d_out);
