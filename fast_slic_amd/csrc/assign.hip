@@ -598,63 +598,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
         // eight rows are ONE 16-byte-ALIGNED ds_read_b128 (a 2-byte-aligned b128 read costs 64 clk of the CU's LDS pipe
         // instead of 8, scripts/microbench/lds_unaligned.hip)
         const uint4* const s_rv = reinterpret_cast<const uint4*>(s_dyn);
-        // One pass = one candidate over the rows on ONE side of its centre.  The loop is software-pipelined over passes:
-        // the table words of pass n+1 are requested before the arithmetic of pass n, so the LDS round trip (measured:
-        // 30 % of the kernel when it sits between the request and its first use) overlaps a whole pass of VALU work.
-        struct Pass { uint32_t clab, idx01, inv; bool valid; };
-        auto fetch = [&](uint32_t base, uint32_t (&spw)[R / 2]) {
+        auto pass = [&](uint32_t clab, uint32_t base, uint32_t idx01, const uint32_t* mq) {
+            uint32_t spw[R / 2];
 #if FSLIC_EXP == 1
             for (int q = 0; q < R / 2; ++q) spw[q] = base;
-            return;
+            if (false)
 #endif
-            const uint4 e0 = s_rv[base];
-            spw[0] = e0.x; spw[1] = e0.y; spw[2] = e0.z; spw[3] = e0.w;
-            if (R == 16) {
-                const uint4 e1 = s_rv[base + 8 * STRIDE];
-                spw[R / 2 - 4] = e1.x; spw[R / 2 - 3] = e1.y; spw[R / 2 - 2] = e1.z; spw[R / 2 - 1] = e1.w;
+            {
+                const uint4 e0 = s_rv[base];
+                spw[0] = e0.x; spw[1] = e0.y; spw[2] = e0.z; spw[3] = e0.w;
+                if (R == 16) {
+                    const uint4 e1 = s_rv[base + 8 * STRIDE];
+                    spw[R / 2 - 4] = e1.x; spw[R / 2 - 3] = e1.y; spw[R / 2 - 2] = e1.z; spw[R / 2 - 1] = e1.w;
+                }
             }
-        };
-        auto compute = [&](const Pass& ps_, const uint32_t (&spw)[R / 2]) {
-            Pass ps;       // wave-uniform by construction; say so, or the values travel in VGPRs after the loop's phis
-            ps.clab = rfl(ps_.clab); ps.idx01 = rfl(ps_.idx01); ps.inv = rfl(ps_.inv); ps.valid = true;
+#if FSLIC_EXP == 4
+#pragma unroll
+            for (int q = 0; q < R / 2; ++q) {
+                const uint32_t s0 = __builtin_amdgcn_sad_u8(pix[2 * q], clab, 0u);
+                const uint32_t s01 = __builtin_amdgcn_sad_hi_u8(pix[2 * q + 1], clab, s0);
+                const uint32_t t = (s01 << 6) | (mq ? (mq[q] | idx01) : idx01);
+                best[q] = __builtin_elementwise_min(best[q], __builtin_elementwise_add_sat(__builtin_bit_cast(us2, t), __builtin_bit_cast(us2, spw[q])));
+            }
+#else
             // three sweeps over the row pairs instead of one chain per pair: a packed op that consumes the result of the
             // packed op issued just before it costs a wait state (s_nop) on this target
             uint32_t t[R / 2];
-            if (ps.inv == 0u) {
 #pragma unroll
-                for (int q = 0; q < R / 2; ++q) {
-                    const uint32_t s0 = __builtin_amdgcn_sad_u8(pix[2 * q], ps.clab, 0u);
-                    const uint32_t s01 = __builtin_amdgcn_sad_hi_u8(pix[2 * q + 1], ps.clab, s0);
-                    t[q] = (s01 << 6) | ps.idx01;                                              // v_lshl_or_b32, scalar 3rd operand
-                }
-            } else {
-                uint32_t mq[R / 2];
-                row_masks<R>(ps.inv, mq);
-#pragma unroll
-                for (int q = 0; q < R / 2; ++q) {
-                    const uint32_t s0 = __builtin_amdgcn_sad_u8(pix[2 * q], ps.clab, 0u);
-                    const uint32_t s01 = __builtin_amdgcn_sad_hi_u8(pix[2 * q + 1], ps.clab, s0);
-                    t[q] = (s01 << 6) | (mq[q] | ps.idx01);
-                }
+            for (int q = 0; q < R / 2; ++q) {
+                const uint32_t s0 = __builtin_amdgcn_sad_u8(pix[2 * q], clab, 0u);
+                const uint32_t s01 = __builtin_amdgcn_sad_hi_u8(pix[2 * q + 1], clab, s0);
+                t[q] = (s01 << 6) | (mq ? (mq[q] | idx01) : idx01);                            // v_lshl_or_b32, scalar 3rd operand
             }
             us2 key[R / 2];
 #pragma unroll
             for (int q = 0; q < R / 2; ++q) key[q] = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, t[q]), __builtin_bit_cast(us2, spw[q]));
 #pragma unroll
             for (int q = 0; q < R / 2; ++q) best[q] = __builtin_elementwise_min(best[q], key[q]);
+#endif
         };
-        // pass generator: pops candidates off `todo`; a candidate whose centre row lies inside this wavefront's rows
-        // yields two passes (rows above, then rows at/below)
-        bool pend = false;
-        uint32_t pend_clab = 0, pend_idx = 0, pend_inv = 0, pend_base = 0;      // pend_base is per lane
-        auto next = [&](Pass& ps, uint32_t& base) {
-            if (pend) {
-                pend = false;
-                ps.clab = pend_clab; ps.idx01 = pend_idx; ps.inv = pend_inv; ps.valid = true;
-                base = pend_base;
-                return;
-            }
-            if (!todo) { ps.valid = false; ps.clab = 0; ps.idx01 = 0; ps.inv = 0; base = 0; return; }
+#pragma unroll 1
+        while (todo) {
             const int c = __builtin_ctzll(todo);
             todo &= todo - 1ull;
             const uint32_t cyx = __builtin_amdgcn_readlane(yx_j, c);
@@ -665,35 +649,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
             const uint32_t uxc = ux <= (uint32_t)S ? ux : xout;
             const uint32_t k0 = (uint32_t)(Cc + yw_lo - cy);                                   // wave-uniform
             const uint32_t idx01 = (uint32_t)c | ((uint32_t)c << 16);
-            const uint32_t va = vab & 0xFFFFu, vb = vab >> 16;
-            ps.clab = clab; ps.idx01 = idx01; ps.valid = true;
-            if (va) {
-                ps.inv = ~va & full;
-                base = k0 - uxc;
-                if (vb) { pend = true; pend_clab = clab; pend_idx = idx01; pend_inv = ~vb & full; pend_base = k0 + uxc; }
-            } else {
-                ps.inv = ~vb & full;
-                base = k0 + uxc;
-            }
-        };
-        {
-            Pass pa, pb;
-            uint32_t ba, bb;
-            uint32_t spa[R / 2], spb[R / 2];
-            next(pa, ba);
-            if (pa.valid) {
-                fetch(ba, spa);
-#pragma unroll 1
-                for (;;) {
-                    next(pb, bb);
-                    if (pb.valid) fetch(bb, spb);
-                    compute(pa, spa);
-                    if (!pb.valid) break;
-                    next(pa, ba);
-                    if (pa.valid) fetch(ba, spa);
-                    compute(pb, spb);
-                    if (!pa.valid) break;
-                }
+            if (vab == (full << 16) || vab == full) {     // every row inside the window and on one side of the centre:
+                const int sgn = vab == full ? -1 : 1;     // at/below (+) or above (-); one code path for both
+                pass(clab, k0 + (uint32_t)__mul24((int)uxc, sgn), idx01, nullptr);
+            } else {                                      // window edge and / or centre row inside this wavefront's rows
+                const uint32_t va = vab & 0xFFFFu, vb = vab >> 16;
+                uint32_t mq[R / 2];
+                if (va) { row_masks<R>(~va & full, mq); pass(clab, k0 - uxc, idx01, mq); }
+                if (vb) { row_masks<R>(~vb & full, mq); pass(clab, k0 + uxc, idx01, mq); }
             }
         }
     } else {
