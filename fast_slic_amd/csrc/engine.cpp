@@ -198,6 +198,7 @@ struct Slot {
     };
     std::vector<GraphEntry> graphs;
     int last_launch_mode = 0;        // 0 direct, 1 captured this call, 2 replayed
+    bool launch_timing = false;      // the engine's flag as it stood when this slot's current group was submitted
     // per-call state
     int H = 0, W = 0, K = 0, S = 0;
     int nframes = 0;
@@ -861,7 +862,7 @@ void stage_group(fslic_engine* e, Slot& s, int i0, int n, bool timed) {
         s.n_timed_iters = 0; s.assign_loop_px = 0;
         const int stride = s.p.subsample_stride;
         int rem = 0;
-        for (int it = 0; it < s.p.max_iter && e->launch_timing && it < Slot::kMaxTimedIters; it++) {
+        for (int it = 0; it < s.p.max_iter && s.launch_timing && it < Slot::kMaxTimedIters; it++) {
             s.n_timed_iters = it + 1;
             s.assign_loop_px += (double)((H - rem + stride - 1) / stride) * W * n;
             rem = (rem + 1) % stride;
@@ -918,7 +919,7 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     }
     const int dbg_mode = getenv("FSLIC_DEBUG_TIMING") ? atoi(getenv("FSLIC_DEBUG_TIMING")) : 0;
     for (int it = 0; lsc && it < p->max_iter; it++) {           // src/context.cpp:158-175 with ContextLSC's hooks
-        const bool tme = timed && e->launch_timing && it < Slot::kMaxTimedIters;
+        const bool tme = timed && s.launch_timing && it < Slot::kMaxTimedIters;
         f.cl_yx = yx_cur; f.cl_yx_out = (yx_cur == yx_a) ? yx_b : yx_a;
         if (tme) HIPCHK(hipEventRecord(s.ev_it[2 * it], s.st));
         launch_lsc_assign(f, l, n, rem, stride, it & 1, it & 1, true, s.st);
@@ -937,7 +938,7 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
             f.dbg = s.d_dbg;
         }
         pg = PassGeom{};
-        const bool tme = timed && e->launch_timing && it < Slot::kMaxTimedIters;
+        const bool tme = timed && s.launch_timing && it < Slot::kMaxTimedIters;
         if (tme) HIPCHK(hipEventRecord(s.ev_it[2 * it], s.st));
         if (generic) launch_assign_generic(f, n, rem, stride, it & 1, it & 1, true, s.st);
         else pg = launch_assign(f, n, rem, stride, it & 1, it & 1, true, s.st);
@@ -993,11 +994,13 @@ const bool g_host_timing = getenv("FSLIC_HOST_TIMING") != nullptr;
 const bool g_use_graphs = !(getenv("FSLIC_GRAPH") && atoi(getenv("FSLIC_GRAPH")) == 0) && !getenv("FSLIC_DEBUG_TIMING");
 int launch_group(fslic_engine* e, Slot& s, int n) {
     s.last_launch_mode = 0;
-    if (!g_use_graphs) return enqueue_frames(e, s, 0, n, s.generic, true);
+    // Per-launch timing wants real event records between the launches; events replayed inside a graph keep the time
+    // stamps of an earlier execution.  Timed groups therefore take the direct path.
+    if (!g_use_graphs || s.launch_timing) return enqueue_frames(e, s, 0, n, s.generic, true);
     // everything a launch argument can depend on
     std::vector<unsigned char> key;
     auto put = [&](const void* p, size_t bytes) { const unsigned char* b = (const unsigned char*)p; key.insert(key.end(), b, b + bytes); };
-    const int hdr[8] = {s.H, s.W, s.K, s.S, n, s.generic ? 1 : 0, e->launch_timing ? 1 : 0, s.sp_patch_uploaded ? 1 : 0};
+    const int hdr[8] = {s.H, s.W, s.K, s.S, n, s.generic ? 1 : 0, 0, s.sp_patch_uploaded ? 1 : 0};
     const void* const ptrs[8] = {s.h_cl, s.h_misc, s.h_dense_leader, s.h_dense_area, s.d_ptrs, s.h_patch, s.d_gen, s.lsc_zero};   // baked into copy nodes / arguments
     put(hdr, sizeof hdr); put(ptrs, sizeof ptrs); put(&s.p, sizeof s.p); put(&s.f, sizeof s.f); put(&s.c, sizeof s.c);
     if (s.p.variant == FSLIC_VARIANT_LSC) put(&s.l, sizeof s.l);
@@ -1013,26 +1016,28 @@ int launch_group(fslic_engine* e, Slot& s, int n) {
         ge = &s.graphs.back();
         ge->key = key;
     }
-    if (ge->exec) {
-        HIPCHK(hipGraphLaunch(ge->exec, s.st));
+    if (!ge->exec) {
+        if (ge->failed || ge->seen++ == 0) return enqueue_frames(e, s, 0, n, s.generic, true);   // first sighting: direct (also warms one-time setup)
+        if (hipStreamBeginCapture(s.st, hipStreamCaptureModeThreadLocal) != hipSuccess) { ge->failed = true; (void)hipGetLastError(); return enqueue_frames(e, s, 0, n, s.generic, true); }
+        const int rc = enqueue_frames(e, s, 0, n, s.generic, false);     // no event records inside the graph
+        hipGraph_t g = nullptr;
+        const hipError_t ec = hipStreamEndCapture(s.st, &g);
+        if (rc != FSLIC_OK || ec != hipSuccess || !g || hipGraphInstantiate(&ge->exec, g, nullptr, nullptr, 0) != hipSuccess) {
+            if (g) hipGraphDestroy(g);
+            ge->exec = nullptr; ge->failed = true;
+            (void)hipGetLastError();
+            if (rc != FSLIC_OK) return rc;
+            return enqueue_frames(e, s, 0, n, s.generic, true);
+        }
+        ge->graph = g;
+        s.last_launch_mode = 1;
+    } else {
         s.last_launch_mode = 2;
-        return FSLIC_OK;
     }
-    if (ge->failed || ge->seen++ == 0) return enqueue_frames(e, s, 0, n, s.generic, true);   // first sighting: direct (also warms one-time setup)
-    if (hipStreamBeginCapture(s.st, hipStreamCaptureModeThreadLocal) != hipSuccess) { ge->failed = true; (void)hipGetLastError(); return enqueue_frames(e, s, 0, n, s.generic, true); }
-    const int rc = enqueue_frames(e, s, 0, n, s.generic, true);
-    hipGraph_t g = nullptr;
-    const hipError_t ec = hipStreamEndCapture(s.st, &g);
-    if (rc != FSLIC_OK || ec != hipSuccess || !g || hipGraphInstantiate(&ge->exec, g, nullptr, nullptr, 0) != hipSuccess) {
-        if (g) hipGraphDestroy(g);
-        ge->exec = nullptr; ge->failed = true;
-        (void)hipGetLastError();
-        if (rc != FSLIC_OK) return rc;
-        return enqueue_frames(e, s, 0, n, s.generic, true);
-    }
-    ge->graph = g;
+    // the whole group between two real event records: total device time stays available, the per-phase split does not
+    HIPCHK(hipEventRecord(s.ev[0], s.st));
     HIPCHK(hipGraphLaunch(ge->exec, s.st));
-    s.last_launch_mode = 1;
+    HIPCHK(hipEventRecord(s.ev[4], s.st));
     return FSLIC_OK;
 }
 
@@ -1076,10 +1081,14 @@ int group_finish(fslic_engine* e, Slot& s) {
     const int n = s.nframes, K = s.K, H = s.H, W = s.W;
     auto elapsed = [](float& ms, hipEvent_t a, hipEvent_t b) { if (hipEventElapsedTime(&ms, a, b) != hipSuccess) { ms = 0; (void)hipGetLastError(); } };
     elapsed(s.total_ms, s.ev[0], s.ev[4]);
-    elapsed(s.lab_ms, s.ev[0], s.ev[1]);
-    elapsed(s.loop_ms, s.ev[1], s.ev[2]);
-    elapsed(s.fa_ms, s.ev[2], s.ev[3]);
-    elapsed(s.cca_ms, s.ev[3], s.ev[4]);
+    if (s.last_launch_mode == 0) {
+        elapsed(s.lab_ms, s.ev[0], s.ev[1]);
+        elapsed(s.loop_ms, s.ev[1], s.ev[2]);
+        elapsed(s.fa_ms, s.ev[2], s.ev[3]);
+        elapsed(s.cca_ms, s.ev[3], s.ev[4]);
+    } else {
+        s.lab_ms = s.loop_ms = s.fa_ms = s.cca_ms = 0;       // graph replay: only the group total is event-timed
+    }
     s.assign_loop_ms = 0;
     for (int it = 0; it < s.n_timed_iters; it++) {
         float ms = 0;
@@ -1257,6 +1266,7 @@ int fslic_hip_iterate_device(fslic_engine* e, int slot, const fslic_params* p, i
     HIPCHK(hipSetDevice(e->device));
     Slot& s = e->slots[slot];
     if (s.pending) return fail(FSLIC_E_INVALID, "the slot still owns an unfinished group");
+    s.launch_timing = e->launch_timing;
     int rc = group_begin(e, s, p, H, W, K, 1, &d_rgb, &clusters, &d_labels);
     if (rc) return rc;
     rc = group_finish(e, s);
@@ -1305,6 +1315,7 @@ int fslic_hip_submit_group(fslic_engine* e, int slot, const fslic_params* p, int
     {
         std::lock_guard<std::mutex> lk(a.m);
         a.p = *p; a.H = H; a.W = W; a.K = K; a.n = n_frames;
+        s.launch_timing = e->launch_timing;      // sampled on the caller's thread: the worker may start later
         for (int i = 0; i < n_frames; i++) { a.d_rgb[i] = d_rgb[i]; a.clusters[i] = clusters[i]; a.d_out[i] = d_labels[i]; }
         a.done = false;
         a.has_job = true;
@@ -1412,6 +1423,7 @@ int fslic_hip_iterate_batch(fslic_engine* e, const fslic_params* p, int H, int W
         } else {
             for (int i = 0; i < n; i++) { d_rgb[i] = rgb[first + i]; d_out[i] = labels[first + i]; }
         }
+        s.launch_timing = e->launch_timing;
         rc = group_begin(e, s, p, H, W, K, n, d_rgb, clusters + first, d_out);
         if (rc) return rc;
         inflight.push_back({si, first, n});
