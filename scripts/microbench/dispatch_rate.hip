@@ -1,6 +1,7 @@
 // Microbenchmark: how fast does the hardware start the wavefronts of a grid that fits the chip in one round?
-// Every wavefront records its start time (s_memtime, shader clock, chip-wide counter) and then spins for `hold`
-// cycles so that no slot is reused; the spread of the start times is the dispatch ramp.
+// Every wavefront spins for `hold` shader cycles (s_memtime), so no slot is reused: event-timed kernel duration minus
+// the hold time is launch + dispatch ramp + completion.  (s_memtime is per XCD, not chip-wide: start stamps of
+// different XCDs cannot be compared, so only durations are reported.)
 //   hipcc --offload-arch=gfx950 -O3 -o dispatch_rate.out dispatch_rate.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -32,10 +33,9 @@ static int run(int blocks, int hold, int lds_bytes, unsigned long long* d_out) {
         CHK(hipEventElapsedTime(&ms, e0, e1));
     }
     CHK(hipMemcpy(h.data(), d_out, nw * 8, hipMemcpyDeviceToHost));
-    std::sort(h.begin(), h.end());
     const double ghz = 2.39;
-    printf("block %4d x %5d blocks (%5zu waves), lds %5d B, hold %5d cyc: start spread p50 %6.2f us  p90 %6.2f us  last %6.2f us | kernel %7.2f us (events)\n",
-           BLOCK, blocks, nw, lds_bytes, hold, (h[nw / 2] - h[0]) / ghz / 1e3, (h[nw * 9 / 10] - h[0]) / ghz / 1e3, (h[nw - 1] - h[0]) / ghz / 1e3, ms * 1e3);
+    printf("block %4d x %5d blocks (%5zu waves), lds %5d B, hold %5d cyc = %5.2f us: kernel %7.2f us (events) => launch + ramp + completion %5.2f us\n",
+           BLOCK, blocks, nw, lds_bytes, hold, hold / ghz / 1e3, ms * 1e3, ms * 1e3 - hold / ghz / 1e3);
     return 0;
 }
 
