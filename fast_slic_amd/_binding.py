@@ -298,7 +298,8 @@ def make_params(max_iter, compactness, min_size_factor, subsample_stride, conver
     return p
 
 
-VARIANT_SLIC, VARIANT_LSC = 0, 1     # fslic_params.variant
+VARIANT_SLIC, VARIANT_LSC, VARIANT_REALDIST, VARIANT_REALDIST_L2 = 0, 1, 2, 3     # fslic_params.variant
+_REAL_DIST_VARIANTS = {"standard": VARIANT_REALDIST, "l2": VARIANT_REALDIST_L2, "lsc": VARIANT_LSC}
 
 
 class SlicModel(object):
@@ -402,10 +403,11 @@ class SlicModel(object):
         image = self._check_image(image)
         variant = VARIANT_SLIC
         if self.real_dist:                                                         # pyx:198-235
-            if self.real_dist_type != "lsc":
-                raise NotImplementedError("real_dist_type %r is not implemented on %s (only 'lsc')"
-                                          % (self.real_dist_type, ARCH_NAME))
-            variant = VARIANT_LSC
+            if self.real_dist_type not in _REAL_DIST_VARIANTS:
+                if self.real_dist_type == "noq":
+                    raise NotImplementedError("real_dist_type 'noq' is not implemented on " + ARCH_NAME)
+                raise RuntimeError("No such real_dist_type " + repr(self.real_dist_type))      # pyx:236
+            variant = _REAL_DIST_VARIANTS[self.real_dist_type]
         p = make_params(max_iter, compactness, min_size_factor, subsample_stride, self.convert_to_lab,
                         self.manhattan_spatial_dist, self.preemptive, self.preemptive_thres,
                         self.num_threads, self.debug_mode, self.force_generic, variant)

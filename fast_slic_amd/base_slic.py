@@ -67,13 +67,23 @@ class SlicHip(BaseSlic):
     arch_name = ARCH_NAME
 
 
-class LSCHip(BaseSlic):
-    """Drop-in for fast_slic.LSC / fast_slic.avx2.LSCAvx2 (fast_slic/base_slic.py:63-71,87-89; avx2.py:13-14)."""
+class SlicRealDistHip(BaseSlic):
+    """fast_slic.SlicRealDist (fast_slic/base_slic.py:63-71): f32 distances, quantised centroids."""
     arch_name = ARCH_NAME
-    real_dist_type = "lsc"
+    real_dist_type = "standard"
 
     def make_slic_model(self, num_components):
         model = SlicModel(num_components, self.arch_name)
         model.real_dist = True
         model.real_dist_type = self.real_dist_type
         return model
+
+
+class SlicRealDistL2Hip(SlicRealDistHip):
+    """fast_slic.SlicRealDistL2 (fast_slic/base_slic.py:73-75): squared colour and spatial terms."""
+    real_dist_type = "l2"
+
+
+class LSCHip(SlicRealDistHip):
+    """Drop-in for fast_slic.LSC / fast_slic.avx2.LSCAvx2 (fast_slic/base_slic.py:87-89; avx2.py:13-14)."""
+    real_dist_type = "lsc"

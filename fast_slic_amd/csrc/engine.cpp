@@ -227,6 +227,13 @@ struct Slot {
         std::string err;
     };
     std::unique_ptr<Async> async;
+    // float-distance variants: f32 spatial patch (shared region of the arena) and its pinned staging
+    float* d_patchf = nullptr;
+    float* h_patchf = nullptr;
+    size_t h_patchf_cap = 0;
+    int pf_S = 0, pf_shift = -1, pf_variant = -1;
+    float pf_compactness = -1.0f;
+    bool pf_manhattan = true;
     // LSC variant: own arena = [shared tables][frame 0][frame 1]...; l holds frame 0's pointers
     char* lsc_arena = nullptr;
     size_t lsc_cap = 0, lsc_frame_bytes = 0, lsc_zero_bytes = 0;
@@ -274,6 +281,7 @@ void free_slot(Slot& s) {
     if (s.arena) hipFree(s.arena);
     if (s.lsc_arena) hipFree(s.lsc_arena);
     if (s.h_lsc_lut) hipHostFree(s.h_lsc_lut);
+    if (s.h_patchf) hipHostFree(s.h_patchf);
     if (s.d_dbg) hipFree(s.d_dbg);
     if (s.d_ptrs) hipFree(s.d_ptrs);
     if (s.d_gen) hipFree(s.d_gen);
@@ -328,6 +336,12 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     if (!s.h_misc) HIPCHK(hipHostMalloc((void**)&s.h_misc, 64 * kMaxGroup));
     if (!s.h_lut) HIPCHK(hipHostMalloc((void**)&s.h_lut, kLutMaxWords * 4));
     if (!s.h_tab) HIPCHK(hipHostMalloc((void**)&s.h_tab, 2 * kTabMaxBytes));
+    if (s.h_patchf_cap < P * P) {
+        if (s.h_patchf) hipHostFree(s.h_patchf);
+        s.h_patchf = nullptr; s.h_patchf_cap = 0;
+        HIPCHK(hipHostMalloc((void**)&s.h_patchf, sizeof(float) * P * P));
+        s.h_patchf_cap = P * P;
+    }
     if (s.h_patch_cap < P * P) {
         if (s.h_patch) hipHostFree(s.h_patch);
         s.h_patch = nullptr; s.h_patch_cap = 0;
@@ -341,6 +355,7 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     const size_t o_patch = take(P * P * 2);
     const size_t o_lut = take(kLutMaxWords * 4);
     const size_t o_tab = take(2 * kTabMaxBytes);
+    const size_t o_patchf = take(P * P * 4);
     const size_t shared_bytes = off;
     off = 0;
     const size_t o_lab = take(N * 4), o_labels = take(N * 2);
@@ -398,6 +413,8 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     f.patch2d = s.d_patch;
     s.d_lut = (uint32_t*)(s.arena + o_lut);
     s.d_tab = (uint16_t*)(s.arena + o_tab);
+    s.d_patchf = (float*)(s.arena + o_patchf);
+    s.pf_variant = -1;                                   // the device copy lives in the arena that was just re-carved
     s.zero_block = b + o_zero; s.zero_bytes = zero_bytes;
     CcaDev& c = s.c;
     c.frame_bytes = frame_bytes;
@@ -503,6 +520,37 @@ int prepare_lsc(Slot& s, int H, int W, int K, int S, int G, float compactness) {
     return FSLIC_OK;
 }
 
+// f32 spatial patch of the float-distance variants, expression by expression as the reference builds it:
+//   'standard' BaseContext<float>::set_spatial_patch, src/context.cpp:22-40 (the cast to DistType is a no-op for float)
+//   'l2'       ContextRealDistL2::set_spatial_patch, src/context.cpp:436-447; the reference build contracts
+//              di*di + dj*dj into fma(dj, dj, di*di) (disassembly of the reference built with its own flags), spelled out here
+int configure_patchf(Slot& s, int S, const fslic_params* p) {
+    const int color_shift = p->convert_to_lab ? 1 : 0;
+    const bool manhattan = p->manhattan_spatial_dist != 0;
+    if (s.pf_variant == p->variant && s.pf_S == S && s.pf_compactness == p->compactness && s.pf_shift == color_shift && s.pf_manhattan == manhattan)
+        return FSLIC_OK;
+    const int P = 2 * S + 1;
+    float coef = 1.0f / ((float)S / p->compactness);
+    coef *= (1 << color_shift);
+    for (int i = 0; i < P; i++)
+        for (int j = 0; j < P; j++) {
+            float v;
+            if (p->variant == FSLIC_VARIANT_REALDIST_L2) {
+                const float di = coef * (i - S), dj = coef * (j - S);
+                const float di2 = di * di;
+                v = std::fmaf(dj, dj, di2);
+            } else if (manhattan) {
+                v = (float)(coef * (std::abs(i - S) + std::abs(j - S)));
+            } else {
+                v = (float)(coef * hypotf((float)(i - S), (float)(j - S)));
+            }
+            s.h_patchf[(size_t)i * P + j] = v;
+        }
+    HIPCHK(hipMemcpyAsync(s.d_patchf, s.h_patchf, sizeof(float) * (size_t)P * P, hipMemcpyHostToDevice, s.st));
+    s.pf_variant = p->variant; s.pf_S = S; s.pf_compactness = p->compactness; s.pf_shift = color_shift; s.pf_manhattan = manhattan;
+    return FSLIC_OK;
+}
+
 int validate(const fslic_params* p, int H, int W, int K, int& S) {
     if (!p) return fail(FSLIC_E_INVALID, "params is NULL");
     if (H <= 0 || W <= 0) return fail(FSLIC_E_INVALID, "H and W must be positive");
@@ -512,7 +560,7 @@ int validate(const fslic_params* p, int H, int W, int K, int& S) {
     if (p->subsample_stride < 1 || p->subsample_stride > 255) return fail(FSLIC_E_INVALID, "subsample_stride must be in [1, 255]");
     if (p->max_iter < 0) return fail(FSLIC_E_INVALID, "max_iter must be >= 0");
     if (p->preemptive) return fail(FSLIC_E_UNSUPPORTED, "preemptive=True is not implemented on hip/gfx950");
-    if (p->variant != FSLIC_VARIANT_SLIC && p->variant != FSLIC_VARIANT_LSC) return fail(FSLIC_E_UNSUPPORTED, "unknown variant");
+    if (p->variant < FSLIC_VARIANT_SLIC || p->variant > FSLIC_VARIANT_REALDIST_L2) return fail(FSLIC_E_UNSUPPORTED, "unknown variant");
     if (!(p->compactness > 0.0f) || !std::isfinite(p->compactness)) return fail(FSLIC_E_INVALID, "compactness must be a positive finite number");
     S = (int)(int16_t)sqrt(H * W / K);   // src/context.h:60
     if (S < 1) return fail(FSLIC_E_INVALID, "num_components exceeds the number of pixels (S == 0)");
@@ -917,6 +965,21 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
         HIPCHK(hipMemset2DAsync(s.lsc_zero + (size_t)i0 * s.lsc_frame_bytes, s.lsc_frame_bytes, 0, s.lsc_zero_bytes, (size_t)n, s.st));
         launch_lsc_prepare(f, l, n, s.st);                        // before_iteration, src/lsc.cpp:12-15
     }
+    const bool rd = p->variant == FSLIC_VARIANT_REALDIST || p->variant == FSLIC_VARIANT_REALDIST_L2;
+    const bool rd_l2 = p->variant == FSLIC_VARIANT_REALDIST_L2;
+    for (int it = 0; rd && it < p->max_iter; it++) {            // src/context.cpp:158-175, BaseContext<float>
+        const bool tme = timed && s.launch_timing && it < Slot::kMaxTimedIters;
+        f.cl_yx = yx_cur; f.cl_yx_out = (yx_cur == yx_a) ? yx_b : yx_a;
+        if (tme) HIPCHK(hipEventRecord(s.ev_it[2 * it], s.st));
+        launch_rd_assign(f, s.d_patchf, rd_l2, n, rem, stride, it & 1, it & 1, true, s.st);
+        if (tme) HIPCHK(hipEventRecord(s.ev_it[2 * it + 1], s.st));
+        launch_member_sums(f, n, rem, stride, it & 1, s.st);
+        f.gen_off++;
+        pg = PassGeom{};
+        launch_bin_clusters(f, n, 1, (it + 1) & 1, it & 1, pg, s.st);
+        yx_cur = f.cl_yx_out;
+        rem = (rem + 1) % stride;
+    }
     const int dbg_mode = getenv("FSLIC_DEBUG_TIMING") ? atoi(getenv("FSLIC_DEBUG_TIMING")) : 0;
     for (int it = 0; lsc && it < p->max_iter; it++) {           // src/context.cpp:158-175 with ContextLSC's hooks
         const bool tme = timed && s.launch_timing && it < Slot::kMaxTimedIters;
@@ -931,7 +994,7 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
         yx_cur = f.cl_yx_out;
         rem = (rem + 1) % stride;
     }
-    for (int it = 0; !lsc && it < p->max_iter; it++) {          // src/context.cpp:158-175
+    for (int it = 0; !lsc && !rd && it < p->max_iter; it++) {   // src/context.cpp:158-175
         if (it == p->max_iter - 1 && dbg_mode == 2) {
             if (!s.d_dbg) HIPCHK(hipMalloc((void**)&s.d_dbg, sizeof(unsigned long long) * 8 * 65536));
             HIPCHK(hipMemsetAsync(s.d_dbg, 0, sizeof(unsigned long long) * 8 * 65536, s.st));
@@ -962,6 +1025,7 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     if (timed) HIPCHK(hipEventRecord(s.ev[2], s.st));
     // full_assign: stride 1, rem 0, no update afterwards (src/context.cpp:246-256)
     if (lsc) { f.cl_yx = yx_cur; launch_lsc_assign(f, l, n, 0, 1, p->max_iter & 1, 0, false, s.st); }
+    else if (rd) { f.cl_yx = yx_cur; launch_rd_assign(f, s.d_patchf, rd_l2, n, 0, 1, p->max_iter & 1, 0, false, s.st); }
     else if (generic) launch_assign_generic(f, n, 0, 1, p->max_iter & 1, 0, false, s.st);
     else (void)launch_assign(f, n, 0, 1, p->max_iter & 1, 0, false, s.st);
     if (timed) HIPCHK(hipEventRecord(s.ev[3], s.st));
@@ -1001,7 +1065,7 @@ int launch_group(fslic_engine* e, Slot& s, int n) {
     std::vector<unsigned char> key;
     auto put = [&](const void* p, size_t bytes) { const unsigned char* b = (const unsigned char*)p; key.insert(key.end(), b, b + bytes); };
     const int hdr[8] = {s.H, s.W, s.K, s.S, n, s.generic ? 1 : 0, 0, s.sp_patch_uploaded ? 1 : 0};
-    const void* const ptrs[8] = {s.h_cl, s.h_misc, s.h_dense_leader, s.h_dense_area, s.d_ptrs, s.h_patch, s.d_gen, s.lsc_zero};   // baked into copy nodes / arguments
+    const void* const ptrs[9] = {s.h_cl, s.h_misc, s.h_dense_leader, s.h_dense_area, s.d_ptrs, s.h_patch, s.d_gen, s.lsc_zero, s.d_patchf};   // baked into copy nodes / arguments
     put(hdr, sizeof hdr); put(ptrs, sizeof ptrs); put(&s.p, sizeof s.p); put(&s.f, sizeof s.f); put(&s.c, sizeof s.c);
     if (s.p.variant == FSLIC_VARIANT_LSC) put(&s.l, sizeof s.l);
     Slot::GraphEntry* ge = nullptr;
@@ -1058,6 +1122,10 @@ int group_begin(fslic_engine* e, Slot& s, const fslic_params* p, int H, int W, i
     if (rc) return rc;
     if (p->variant == FSLIC_VARIANT_LSC) {
         rc = prepare_lsc(s, H, W, K, S, n, p->compactness);
+        if (rc) return rc;
+    }
+    if (p->variant == FSLIC_VARIANT_REALDIST || p->variant == FSLIC_VARIANT_REALDIST_L2) {
+        rc = configure_patchf(s, S, p);
         if (rc) return rc;
     }
     rc = upload_ptrs(s, n, d_rgb, d_out);

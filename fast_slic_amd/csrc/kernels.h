@@ -198,6 +198,11 @@ void launch_lsc_prepare(const FrameDev& f, const LscDev& l, int nframes, hipStre
 void launch_lsc_assign(const FrameDev& f, const LscDev& l, int nframes, int rem, int stride, int buf, int sbuf, bool stale_sums, hipStream_t st);
 // per-cluster gather of the integer sums (into FrameDev::sums) and the weighted feature means (src/lsc.cpp:226-307)
 void launch_lsc_update(const FrameDev& f, const LscDev& l, int nframes, int rem, int stride, int sbuf, hipStream_t st);
+// Float-distance variants (realdist.hip): patchf = (2S+1)^2 f32 spatial patch; l2: squared colour / spatial terms
+void launch_rd_assign(const FrameDev& f, const float* patchf, bool l2, int nframes, int rem, int stride, int buf, int sbuf, bool stale_sums, hipStream_t st);
+// integer member sums per cluster (gather over the cluster window) into FrameDev::sums, for the variants whose assign
+// kernel does not accumulate them itself
+void launch_member_sums(const FrameDev& f, int nframes, int rem, int stride, int sbuf, hipStream_t st);
 // connectivity
 void launch_cca_phase1(const CcaDev& c, int nframes, hipStream_t st);   // local CCL, border merge, compress, collect
 // device top-K + ranking; counters[3] = status (see k_cca_select).  On status 1 the candidate arrays are left

@@ -81,6 +81,26 @@ def lsc_iterate(image, clusters, max_iter=10, compactness=10.0, min_size_factor=
     return labels, cl, pre
 
 
+REALDIST_KINDS = {"standard": 0, "l2": 1, "noq": 2}
+
+
+def realdist_iterate(image, clusters, kind="standard", max_iter=10, compactness=10.0, min_size_factor=0.25,
+                     subsample_stride=3, convert_to_lab=True, manhattan=True, num_threads=1, float_color=True):
+    """SlicRealDist / SlicRealDistL2 / SlicRealDistNoQ (fast_slic/base_slic.py:63-85) of the unmodified reference."""
+    H, W, _ = image.shape
+    image = np.ascontiguousarray(image)
+    K = clusters.shape[0]
+    cl = clusters.copy()
+    labels = np.zeros((H, W), np.uint16)
+    pre = np.zeros((H, W), np.uint16)
+    rc = lib().ref_realdist_iterate(REALDIST_KINDS[kind], H, W, K, _p(image), _p(cl), int(max_iter),
+                                    C.c_float(compactness), C.c_float(min_size_factor), int(subsample_stride),
+                                    int(bool(convert_to_lab)), int(bool(manhattan)), int(num_threads), int(bool(float_color)),
+                                    _p(labels), _p(pre))
+    assert rc == 0
+    return labels, cl, pre
+
+
 def enforce_connectivity(labels_u16, K, min_threshold, num_threads=1):
     out = np.ascontiguousarray(labels_u16, dtype=np.uint16).copy()
     H, W = out.shape

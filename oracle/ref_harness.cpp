@@ -124,6 +124,30 @@ int ref_lsc_iterate(const char* arch, int H, int W, int K, const uint8_t* rgb, C
     return 0;
 }
 
+// RealDist family: cfast_slic.pyx:198-235.  kind: 0 ContextRealDist ('standard'), 1 ContextRealDistL2 ('l2'),
+// 2 ContextRealDistNoQ ('noq', float_color as given)
+int ref_realdist_iterate(int kind, int H, int W, int K, const uint8_t* rgb, Cluster* clusters,
+                         int max_iter, float compactness, float min_size_factor, int subsample_stride,
+                         int convert_to_lab, int manhattan, int num_threads, int float_color,
+                         uint16_t* labels_out, uint16_t* prelabels_out) {
+    fslic::ContextRealDist* c = nullptr;
+    if (kind == 0) c = new fslic::ContextRealDist(H, W, K, rgb, clusters);
+    else if (kind == 1) c = new fslic::ContextRealDistL2(H, W, K, rgb, clusters);
+    else if (kind == 2) { fslic::ContextRealDistNoQ* q = new fslic::ContextRealDistNoQ(H, W, K, rgb, clusters); q->float_color = float_color != 0; c = q; }
+    else return -1;
+    configure(c, compactness, min_size_factor, subsample_stride, convert_to_lab, manhattan, num_threads);
+    c->initialize_state();
+    c->iterate(labels_out, max_iter);
+    g_timing = c->get_timing_report();
+    if (prelabels_out) {
+        for (int i = 0; i < H; i++)
+            for (int j = 0; j < W; j++)
+                prelabels_out[(size_t)i * W + j] = c->assignment.get(i, j);
+    }
+    delete c;
+    return 0;
+}
+
 const char* ref_last_timing_report() { return g_timing.c_str(); }
 
 // cfast_slic.pyx:371-396 (module-level enforce_connectivity): K = max label + 1 is computed by the caller.

@@ -100,7 +100,7 @@ def test_lsc_facade_matches_reference_surface(engine):
     assert s.slic_model.real_dist and s.slic_model.real_dist_type == "lsc"
     m = SlicModel(10)
     m.real_dist = True
-    m.real_dist_type = "l2"
+    m.real_dist_type = "noq"
     m.initialize(img)
     with pytest.raises(NotImplementedError):
         m.iterate(img, 10, 10.0, 0.25, 3)
