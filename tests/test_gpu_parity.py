@@ -382,3 +382,54 @@ def test_graph_replay_equals_direct_launches():
         assert modes[0] == 0 and 1 in modes and modes[-1] == 2, modes
     finally:
         e.close()
+
+
+def test_pipeline_of_replayed_groups_collected_in_completion_order():
+    # the bench's operating mode: several slots, every slot replaying its captured launch sequence, groups collected as
+    # they complete; different frames on every submission, every result checked against the oracle
+    import torch
+    from fast_slic_amd import Engine
+    H, W, K, n, nslots, rounds = 200, 264, 120, 4, 3, 5
+    kinds = "ABCA"
+    p = make_params(10, 10.0, 0.25, 3)
+    e = Engine(0, nslots)
+    try:
+        d_lab = [[torch.empty((H, W), dtype=torch.int16, device="cuda") for _ in range(n)] for _ in range(nslots)]
+        cls = [np.zeros((n, K), B.CLUSTER_DTYPE) for _ in range(nslots)]
+        a_lab = [e.pointer_array([t.data_ptr() for t in d_lab[s]]) for s in range(nslots)]
+        a_cls = [e.pointer_array([cls[s][i].ctypes.data for i in range(n)]) for s in range(nslots)]
+        inflight = {}                                # slot -> (expected results, device frames kept alive)
+        modes = []
+
+        def check(s):
+            e.wait_group(s)
+            modes.append(e.last_launch_mode(s))
+            exp, _keep = inflight.pop(s)
+            for i in range(n):
+                got = d_lab[s][i].cpu().numpy().view(np.uint16)
+                assert np.array_equal(got, exp[i][0]), describe_mismatch("slot %d frame %d" % (s, i), got, exp[i][0])
+                assert cls[s][i].tobytes() == exp[i][1].tobytes(), (s, i)
+
+        for g in range(rounds * nslots):
+            frames = [variant(kinds[i], H, W, seed=100 * g + i) for i in range(n)]
+            cl0 = [orc.initialize_clusters(f, K) for f in frames]
+            exp = [orc.slic_iterate(f, c) for f, c in zip(frames, cl0)]
+            s = next((t for t in range(nslots) if t not in inflight), None)
+            while s is None:
+                for t in range(nslots):
+                    if e.group_done(t):
+                        check(t)
+                        s = t
+                        break
+            for i in range(n):
+                cls[s][i] = cl0[i]
+            d_rgb = [torch.from_numpy(f).cuda() for f in frames]
+            torch.cuda.synchronize()
+            a_rgb = e.pointer_array([t.data_ptr() for t in d_rgb])
+            e.submit_group(s, a_rgb, a_cls[s], a_lab[s], n, H, W, K, p)
+            inflight[s] = (exp, (d_rgb, a_rgb))
+        for s in list(inflight):
+            check(s)
+        assert modes.count(2) >= (rounds - 2) * nslots, modes      # most groups were graph replays
+    finally:
+        e.close()
