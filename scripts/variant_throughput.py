@@ -1,5 +1,6 @@
-"""Throughput of the LSC variant (BASELINE.json configs[4]: 1280x720, K=1600) on one MI355X, next to the unmodified
-reference's LSCAvx2 + OpenMP on this box's host cores.   python scripts/lsc_throughput.py [steps] [slots]
+"""Throughput of a variant (lsc = BASELINE.json configs[4]; standard / l2 = the RealDist family) at 1280x720, K=1600 on
+one MI355X, next to the unmodified reference on this box's host cores (LSCAvx2 + OpenMP for lsc; the scalar contexts +
+OpenMP for the others, which have no SIMD specialisation).   python scripts/variant_throughput.py [lsc|standard|l2] [steps] [slots]
 Same pipeline shape as bench.py: device-resident frames, groups of 8 frames, groups collected in completion order."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,10 +11,11 @@ from fast_slic_amd import Engine, make_params, CLUSTER_DTYPE, _binding as B
 from fast_slic_amd.synth import variant
 
 H, W, K, G = 720, 1280, 1600, 8
-steps = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-nslots = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+kind = sys.argv[1] if len(sys.argv) > 1 else "lsc"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+nslots = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 eng = Engine(0, nslots)
-params = make_params(10, 10.0, 0.25, 3, variant=B.VARIANT_LSC)
+params = make_params(10, 10.0, 0.25, 3, variant={"lsc": B.VARIANT_LSC, "standard": B.VARIANT_REALDIST, "l2": B.VARIANT_REALDIST_L2}[kind])
 frames = [variant("A", H, W, seed=s) for s in range(G)]
 d_rgb = [torch.from_numpy(f).cuda() for f in frames]
 cl0 = np.zeros((G, K), CLUSTER_DTYPE)
@@ -61,7 +63,7 @@ for _ in range(steps):
 drain()
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-out = {"workload": "LSC 1280x720 K=1600, 10 iters, %d frames per group, %d slots" % (G, nslots),
+out = {"workload": "%s 1280x720 K=1600, 10 iters, %d frames per group, %d slots" % (kind, G, nslots),
        "megapixels_per_sec": round(H * W * G * steps / dt / 1e6, 1), "ms_per_group": round(dt / steps * 1e3, 4)}
 try:
     from oracle import ref
@@ -69,16 +71,20 @@ try:
         img = frames[0]
         c0 = ref.initialize_clusters(img, K)
         best = None
+        if kind == "lsc":
+            run_ref = lambda nt: ref.lsc_iterate(img, c0, num_threads=nt, arch="x64/avx2")
+        else:
+            run_ref = lambda nt: ref.realdist_iterate(img, c0, kind, num_threads=nt)
         for nt in (1, 8, 16, 32):
-            ref.lsc_iterate(img, c0, num_threads=nt, arch="x64/avx2")
+            run_ref(nt)
             ts = []
             for _ in range(3):
-                t = time.perf_counter(); ref.lsc_iterate(img, c0, num_threads=nt, arch="x64/avx2"); ts.append(time.perf_counter() - t)
+                t = time.perf_counter(); run_ref(nt); ts.append(time.perf_counter() - t)
             ms = min(ts) * 1e3
             if best is None or ms < best[1]:
                 best = (nt, ms)
-        out["cpu_reference_LSCAvx2"] = {"threads": best[0], "ms_per_frame": round(best[1], 2), "megapixels_per_sec": round(H * W / best[1] / 1e3, 1)}
+        out["cpu_reference"] = {"implementation": "LSCAvx2 + OpenMP" if kind == "lsc" else "ContextRealDist%s + OpenMP" % ("L2" if kind == "l2" else ""), "threads": best[0], "ms_per_frame": round(best[1], 2), "megapixels_per_sec": round(H * W / best[1] / 1e3, 1)}
 except Exception as e:      # the reference build is test infrastructure; absent on some boxes
-    out["cpu_reference_LSCAvx2"] = "unavailable: %s" % e
+    out["cpu_reference"] = "unavailable: %s" % e
 print(json.dumps(out))
 eng.close()
