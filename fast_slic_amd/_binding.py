@@ -298,8 +298,8 @@ def make_params(max_iter, compactness, min_size_factor, subsample_stride, conver
     return p
 
 
-VARIANT_SLIC, VARIANT_LSC, VARIANT_REALDIST, VARIANT_REALDIST_L2 = 0, 1, 2, 3     # fslic_params.variant
-_REAL_DIST_VARIANTS = {"standard": VARIANT_REALDIST, "l2": VARIANT_REALDIST_L2, "lsc": VARIANT_LSC}
+VARIANT_SLIC, VARIANT_LSC, VARIANT_REALDIST, VARIANT_REALDIST_L2, VARIANT_REALDIST_NOQ = 0, 1, 2, 3, 4     # fslic_params.variant
+_REAL_DIST_VARIANTS = {"standard": VARIANT_REALDIST, "l2": VARIANT_REALDIST_L2, "noq": VARIANT_REALDIST_NOQ, "lsc": VARIANT_LSC}
 
 
 class SlicModel(object):
@@ -404,8 +404,6 @@ class SlicModel(object):
         variant = VARIANT_SLIC
         if self.real_dist:                                                         # pyx:198-235
             if self.real_dist_type not in _REAL_DIST_VARIANTS:
-                if self.real_dist_type == "noq":
-                    raise NotImplementedError("real_dist_type 'noq' is not implemented on " + ARCH_NAME)
                 raise RuntimeError("No such real_dist_type " + repr(self.real_dist_type))      # pyx:236
             variant = _REAL_DIST_VARIANTS[self.real_dist_type]
         p = make_params(max_iter, compactness, min_size_factor, subsample_stride, self.convert_to_lab,

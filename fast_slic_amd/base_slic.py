@@ -84,6 +84,16 @@ class SlicRealDistL2Hip(SlicRealDistHip):
     real_dist_type = "l2"
 
 
+class SlicRealDistNoQHip(SlicRealDistHip):
+    """fast_slic.SlicRealDistNoQ (fast_slic/base_slic.py:77-85): float (non-quantised) centroids."""
+    real_dist_type = "noq"
+
+    def __init__(self, *args, **kwargs):
+        float_color = kwargs.pop("float_color", True)
+        super(SlicRealDistNoQHip, self).__init__(*args, **kwargs)
+        self._slic_model.float_color = float_color      # stored and unused, as in the reference (src/context.h:116)
+
+
 class LSCHip(SlicRealDistHip):
     """Drop-in for fast_slic.LSC / fast_slic.avx2.LSCAvx2 (fast_slic/base_slic.py:87-89; avx2.py:13-14)."""
     real_dist_type = "lsc"

@@ -71,7 +71,11 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg) {
         lab = f.lab[(size_t)y * f.W + x] & 0x00FFFFFFu;
         f.cl_lab[k] = lab;
         f.cl_yx_out[k] = yx;
-        shadowed = k > 0 && f.cl_yx[k - 1] == yx;
+        if (f.cl_f) {      // 'noq': the centre keeps its (clamped) float position, the colour starts as the pixel's (src/context.cpp:128-135)
+            float* c = f.cl_f + 8 * (size_t)k;
+            c[2] = (float)(lab & 255u); c[3] = (float)((lab >> 8) & 255u); c[4] = (float)((lab >> 16) & 255u);
+        }
+        shadowed = !f.cl_f && k > 0 && f.cl_yx[k - 1] == yx;
         f.cl_shadow[k] = shadowed ? 1u : 0u;
     } else {
         // a shadowed cluster is in no candidate list: it received nothing and its cpart entries are stale
@@ -99,11 +103,22 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg) {
             const int32_t L = ((int32_t)s[3] + h) / n;
             const int32_t a = ((int32_t)s[4] + h) / n;
             const int32_t b = ((int32_t)s[5] + h) / n;
+            if (f.cl_f) {
+                // centroid_quantization_enabled() == false (src/context.cpp:449-452): (float)sum / n per component
+                // (src/context.cpp:374-380); bins, phases and windows use the integer parts (src/context.cpp:214-217)
+                float* c = f.cl_f + 8 * (size_t)k;
+                const float fn = (float)n;
+                const float fy = (float)(int32_t)s[1] / fn, fx = (float)(int32_t)s[2] / fn;
+                c[0] = fy; c[1] = fx;
+                c[2] = (float)(int32_t)s[3] / fn; c[3] = (float)(int32_t)s[4] / fn; c[4] = (float)(int32_t)s[5] / fn;
+                y = min(max((int)fy, 0), f.H - 1);
+                x = min(max((int)fx, 0), f.W - 1);
+            }
             yx = ((uint32_t)y << 16) | (uint32_t)(x & 0xFFFF);
             lab = (uint32_t)(L & 255) | ((uint32_t)(a & 255) << 8) | ((uint32_t)(b & 255) << 16);
             f.cl_lab[k] = lab;
             f.cl_moved[k] = 1;
-        } else if (k > 0 && n_prev == 0u) {
+        } else if (!f.cl_f && k > 0 && n_prev == 0u) {
             shadowed = f.cl_yx[k - 1] == yx && f.cl_lab[k - 1] == lab;
         }
         f.cl_yx_out[k] = yx;

@@ -227,6 +227,9 @@ struct Slot {
         std::string err;
     };
     std::unique_ptr<Async> async;
+    float* d_clf = nullptr;          // frame 0's float centroids ('noq')
+    float* h_clf = nullptr;          // pinned, per frame K * 8 floats: upload (y, x) / download (y, x, r, g, b)
+    size_t h_clf_floats = 0;
     // float-distance variants: f32 spatial patch (shared region of the arena) and its pinned staging
     float* d_patchf = nullptr;
     float* h_patchf = nullptr;
@@ -282,6 +285,7 @@ void free_slot(Slot& s) {
     if (s.lsc_arena) hipFree(s.lsc_arena);
     if (s.h_lsc_lut) hipHostFree(s.h_lsc_lut);
     if (s.h_patchf) hipHostFree(s.h_patchf);
+    if (s.h_clf) hipHostFree(s.h_clf);
     if (s.d_dbg) hipFree(s.d_dbg);
     if (s.d_ptrs) hipFree(s.d_ptrs);
     if (s.d_gen) hipFree(s.d_gen);
@@ -338,6 +342,7 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     if (!s.h_tab) HIPCHK(hipHostMalloc((void**)&s.h_tab, 2 * kTabMaxBytes));
     if (s.h_patchf_cap < P * P) {
         if (s.h_patchf) hipHostFree(s.h_patchf);
+    if (s.h_clf) hipHostFree(s.h_clf);
         s.h_patchf = nullptr; s.h_patchf_cap = 0;
         HIPCHK(hipHostMalloc((void**)&s.h_patchf, sizeof(float) * P * P));
         s.h_patchf_cap = P * P;
@@ -360,6 +365,7 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     off = 0;
     const size_t o_lab = take(N * 4), o_labels = take(N * 2);
     const size_t o_cl = take((size_t)K * 4 * 8);                     // yx, lab, n, moved, tag, shadow, yx', yx'' (contiguous)
+    const size_t o_clf = take((size_t)K * 8 * 4);                    // float centroids of the 'noq' variant
     // partial centroid sums of the block kernel: one entry per (cluster, assign block its window can overlap);
     // blocks are 64 px wide and at least 32 visited rows (stride >= 1) tall
     const int nbx = 2 * S / 64 + 2, nby = 2 * S / 32 + 2;
@@ -398,6 +404,8 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     uint32_t* cl = (uint32_t*)(b + o_cl);
     f.cl_yx = cl; f.cl_lab = cl + K; f.cl_n = cl + 2 * (size_t)K; f.cl_moved = cl + 3 * (size_t)K; f.cl_tag = cl + 4 * (size_t)K;
     f.cl_shadow = cl + 5 * (size_t)K;
+    f.cl_f = nullptr;                                                // set per call for the 'noq' variant only
+    s.d_clf = (float*)(b + o_clf);
     s.d_yx_alt[0] = cl + 6 * (size_t)K; s.d_yx_alt[1] = cl + 7 * (size_t)K;
     f.cl_yx_out = s.d_yx_alt[0];
     f.cpart = (uint32_t*)(b + o_cpart); f.cpart_ns = nbx * nby; f.nbx = nbx;
@@ -560,7 +568,7 @@ int validate(const fslic_params* p, int H, int W, int K, int& S) {
     if (p->subsample_stride < 1 || p->subsample_stride > 255) return fail(FSLIC_E_INVALID, "subsample_stride must be in [1, 255]");
     if (p->max_iter < 0) return fail(FSLIC_E_INVALID, "max_iter must be >= 0");
     if (p->preemptive) return fail(FSLIC_E_UNSUPPORTED, "preemptive=True is not implemented on hip/gfx950");
-    if (p->variant < FSLIC_VARIANT_SLIC || p->variant > FSLIC_VARIANT_REALDIST_L2) return fail(FSLIC_E_UNSUPPORTED, "unknown variant");
+    if (p->variant < FSLIC_VARIANT_SLIC || p->variant > FSLIC_VARIANT_REALDIST_NOQ) return fail(FSLIC_E_UNSUPPORTED, "unknown variant");
     if (!(p->compactness > 0.0f) || !std::isfinite(p->compactness)) return fail(FSLIC_E_INVALID, "compactness must be a positive finite number");
     S = (int)(int16_t)sqrt(H * W / K);   // src/context.h:60
     if (S < 1) return fail(FSLIC_E_INVALID, "num_components exceeds the number of pixels (S == 0)");
@@ -906,6 +914,17 @@ void stage_group(fslic_engine* e, Slot& s, int i0, int n, bool timed) {
             h[k] = ((uint32_t)y << 16) | (uint32_t)x;
         }
     }
+    if (s.p.variant == FSLIC_VARIANT_REALDIST_NOQ) {      // assign()'s safeguard on the float position, src/context.cpp:208-211
+        for (int z = 0; z < n; z++) {
+            const fslic_cluster* cl = s.clusters[i0 + z];
+            float* h = s.h_clf + (size_t)(i0 + z) * 8 * K;
+            for (int k = 0; k < K; k++) {
+                h[8 * k + 0] = clampf(cl[k].y, 0.0f, (float)(H - 1));
+                h[8 * k + 1] = clampf(cl[k].x, 0.0f, (float)(W - 1));
+                for (int q = 2; q < 8; q++) h[8 * k + q] = 0.0f;
+            }
+        }
+    }
     if (timed) {
         s.n_timed_iters = 0; s.assign_loop_px = 0;
         const int stride = s.p.subsample_stride;
@@ -938,6 +957,12 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     // cluster centres: staged by stage_group() into the pinned block this copy reads
     HIPCHK(hipMemcpy2DAsync(f.cl_yx, fb, s.h_cl + (size_t)i0 * 4 * K, sizeof(uint32_t) * 4 * (size_t)K,
                             sizeof(uint32_t) * (size_t)K, (size_t)n, hipMemcpyHostToDevice, s.st));
+    const bool noq = p->variant == FSLIC_VARIANT_REALDIST_NOQ;
+    if (noq) {
+        f.cl_f = s.at(s.d_clf, i0);
+        HIPCHK(hipMemcpy2DAsync(f.cl_f, fb, s.h_clf + (size_t)i0 * 8 * K, sizeof(float) * 8 * (size_t)K,
+                                sizeof(float) * 8 * (size_t)K, (size_t)n, hipMemcpyHostToDevice, s.st));
+    }
     HIPCHK(hipMemset2DAsync(s.at(s.zero_block, i0), fb, 0, s.zero_bytes, (size_t)n, s.st));
     HIPCHK(hipMemset2DAsync(f.cl_n, fb, 0, sizeof(uint32_t) * 2 * (size_t)K, (size_t)n, s.st));   // cl_n, cl_moved
 
@@ -965,15 +990,19 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
         HIPCHK(hipMemset2DAsync(s.lsc_zero + (size_t)i0 * s.lsc_frame_bytes, s.lsc_frame_bytes, 0, s.lsc_zero_bytes, (size_t)n, s.st));
         launch_lsc_prepare(f, l, n, s.st);                        // before_iteration, src/lsc.cpp:12-15
     }
-    const bool rd = p->variant == FSLIC_VARIANT_REALDIST || p->variant == FSLIC_VARIANT_REALDIST_L2;
+    const bool rd = p->variant == FSLIC_VARIANT_REALDIST || p->variant == FSLIC_VARIANT_REALDIST_L2 || noq;
     const bool rd_l2 = p->variant == FSLIC_VARIANT_REALDIST_L2;
+    float noq_coef = 1.0f / ((float)S / p->compactness);        // src/context.cpp:463-464
+    noq_coef *= (1 << (p->convert_to_lab ? 1 : 0));
+    const bool noq_manhattan = p->manhattan_spatial_dist != 0;
     for (int it = 0; rd && it < p->max_iter; it++) {            // src/context.cpp:158-175, BaseContext<float>
         const bool tme = timed && s.launch_timing && it < Slot::kMaxTimedIters;
         f.cl_yx = yx_cur; f.cl_yx_out = (yx_cur == yx_a) ? yx_b : yx_a;
         if (tme) HIPCHK(hipEventRecord(s.ev_it[2 * it], s.st));
-        launch_rd_assign(f, s.d_patchf, rd_l2, n, rem, stride, it & 1, it & 1, true, s.st);
+        if (noq) launch_noq_assign(f, noq_coef, noq_manhattan, n, rem, stride, it & 1, it & 1, true, s.st);
+        else launch_rd_assign(f, s.d_patchf, rd_l2, n, rem, stride, it & 1, it & 1, true, s.st);
         if (tme) HIPCHK(hipEventRecord(s.ev_it[2 * it + 1], s.st));
-        launch_member_sums(f, n, rem, stride, it & 1, s.st);
+        launch_member_sums(f, n, rem, stride, it & 1, noq ? 1 : 0, s.st);
         f.gen_off++;
         pg = PassGeom{};
         launch_bin_clusters(f, n, 1, (it + 1) & 1, it & 1, pg, s.st);
@@ -1025,6 +1054,7 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     if (timed) HIPCHK(hipEventRecord(s.ev[2], s.st));
     // full_assign: stride 1, rem 0, no update afterwards (src/context.cpp:246-256)
     if (lsc) { f.cl_yx = yx_cur; launch_lsc_assign(f, l, n, 0, 1, p->max_iter & 1, 0, false, s.st); }
+    else if (noq) { f.cl_yx = yx_cur; launch_noq_assign(f, noq_coef, noq_manhattan, n, 0, 1, p->max_iter & 1, 0, false, s.st); }
     else if (rd) { f.cl_yx = yx_cur; launch_rd_assign(f, s.d_patchf, rd_l2, n, 0, 1, p->max_iter & 1, 0, false, s.st); }
     else if (generic) launch_assign_generic(f, n, 0, 1, p->max_iter & 1, 0, false, s.st);
     else (void)launch_assign(f, n, 0, 1, p->max_iter & 1, 0, false, s.st);
@@ -1045,6 +1075,8 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     HIPCHK(hipMemcpy2DAsync(s.h_cl + (size_t)i0 * 4 * K + K, sizeof(uint32_t) * 4 * (size_t)K, yx_up + K, fb,
                             sizeof(uint32_t) * 3 * (size_t)K, (size_t)n, hipMemcpyDeviceToHost, s.st));
     HIPCHK(hipMemcpy2DAsync(s.h_misc + 16 * (size_t)i0, 64, s.at(s.d_misc, i0), fb, 64, (size_t)n, hipMemcpyDeviceToHost, s.st));
+    if (noq) HIPCHK(hipMemcpy2DAsync(s.h_clf + (size_t)i0 * 8 * K, sizeof(float) * 8 * (size_t)K, f.cl_f, fb,
+                                     sizeof(float) * 8 * (size_t)K, (size_t)n, hipMemcpyDeviceToHost, s.st));
     return FSLIC_OK;
 }
 
@@ -1065,7 +1097,7 @@ int launch_group(fslic_engine* e, Slot& s, int n) {
     std::vector<unsigned char> key;
     auto put = [&](const void* p, size_t bytes) { const unsigned char* b = (const unsigned char*)p; key.insert(key.end(), b, b + bytes); };
     const int hdr[8] = {s.H, s.W, s.K, s.S, n, s.generic ? 1 : 0, 0, s.sp_patch_uploaded ? 1 : 0};
-    const void* const ptrs[9] = {s.h_cl, s.h_misc, s.h_dense_leader, s.h_dense_area, s.d_ptrs, s.h_patch, s.d_gen, s.lsc_zero, s.d_patchf};   // baked into copy nodes / arguments
+    const void* const ptrs[10] = {s.h_cl, s.h_misc, s.h_dense_leader, s.h_dense_area, s.d_ptrs, s.h_patch, s.d_gen, s.lsc_zero, s.d_patchf, s.h_clf};   // baked into copy nodes / arguments
     put(hdr, sizeof hdr); put(ptrs, sizeof ptrs); put(&s.p, sizeof s.p); put(&s.f, sizeof s.f); put(&s.c, sizeof s.c);
     if (s.p.variant == FSLIC_VARIANT_LSC) put(&s.l, sizeof s.l);
     Slot::GraphEntry* ge = nullptr;
@@ -1127,6 +1159,12 @@ int group_begin(fslic_engine* e, Slot& s, const fslic_params* p, int H, int W, i
     if (p->variant == FSLIC_VARIANT_REALDIST || p->variant == FSLIC_VARIANT_REALDIST_L2) {
         rc = configure_patchf(s, S, p);
         if (rc) return rc;
+    }
+    if (p->variant == FSLIC_VARIANT_REALDIST_NOQ && s.h_clf_floats < (size_t)s.cap_frames * K * 8) {
+        if (s.h_clf) hipHostFree(s.h_clf);
+        s.h_clf = nullptr; s.h_clf_floats = 0;
+        HIPCHK(hipHostMalloc((void**)&s.h_clf, sizeof(float) * 8 * (size_t)K * s.cap_frames));
+        s.h_clf_floats = (size_t)s.cap_frames * K * 8;
     }
     rc = upload_ptrs(s, n, d_rgb, d_out);
     if (rc) return rc;
@@ -1194,7 +1232,10 @@ int group_finish(fslic_engine* e, Slot& s) {
             cl[k].r = (float)(lab[k] & 255u);                 // src/context.cpp:132-134 / :370-372
             cl[k].g = (float)((lab[k] >> 8) & 255u);
             cl[k].b = (float)((lab[k] >> 16) & 255u);
-            if (moved[k]) {                                    // src/context.cpp:368-369
+            if (moved[k] && s.p.variant == FSLIC_VARIANT_REALDIST_NOQ) {      // src/context.cpp:374-380
+                const float* c = s.h_clf + ((size_t)i * K + k) * 8;
+                cl[k].y = c[0]; cl[k].x = c[1]; cl[k].r = c[2]; cl[k].g = c[3]; cl[k].b = c[4];
+            } else if (moved[k]) {                             // src/context.cpp:368-369
                 cl[k].y = (float)(yx[k] >> 16);
                 cl[k].x = (float)(yx[k] & 0xFFFFu);
             } else {                                           // assign() safeguard, src/context.cpp:208-211

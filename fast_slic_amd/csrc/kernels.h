@@ -60,6 +60,8 @@ struct FrameDev {
     uint32_t* cl_n;      // K  num_members of the last update
     uint32_t* cl_moved;  // K  1 once an update with n > 0 has moved the cluster
     uint32_t* cl_shadow; // K  1 while the cluster is kept out of the bins (identical to an earlier-ordered one)
+    float* cl_f;         // K * 8  non-quantised centroids (y, x, r, g, b, pad) of the 'noq' variant; nullptr otherwise
+                         //    (cl_yx then holds their integer parts: bins, phases and windows work on those)
     uint32_t* sums[2];   // K*6 each: count, sum y, sum x, sum L, sum a, sum b; pass `it` accumulates into [it&1]
                          // (global atomics: generic / 32-bit kernels, and stale-label pixels of the block kernel)
     uint32_t* cpart;     // K * cpart_ns * 6: per-(cluster, overlapping assign block) partial sums of the block
@@ -102,6 +104,7 @@ struct FrameDev {
         const size_t d = (size_t)z * frame_bytes;
         adv(lab, d); adv(labels, d);
         adv(cl_yx, d); adv(cl_yx_out, d); adv(cl_lab, d); adv(cl_tag, d); adv(cl_n, d); adv(cl_moved, d); adv(cl_shadow, d);
+        if (cl_f) adv(cl_f, d);
         adv(sums[0], d); adv(sums[1], d); adv(cpart, d);
         adv(cell_cnt[0], d); adv(cell_cnt[1], d); adv(cell_items[0], d); adv(cell_items[1], d);
         adv(ovf_cnt[0], d); adv(ovf_cnt[1], d); adv(ovf_items[0], d); adv(ovf_items[1], d);
@@ -202,7 +205,10 @@ void launch_lsc_update(const FrameDev& f, const LscDev& l, int nframes, int rem,
 void launch_rd_assign(const FrameDev& f, const float* patchf, bool l2, int nframes, int rem, int stride, int buf, int sbuf, bool stale_sums, hipStream_t st);
 // integer member sums per cluster (gather over the cluster window) into FrameDev::sums, for the variants whose assign
 // kernel does not accumulate them itself
-void launch_member_sums(const FrameDev& f, int nframes, int rem, int stride, int sbuf, hipStream_t st);
+// margin: the window scanned is (2(S+margin)+1)^2 (the assign kernel's out-of-window rule must use the same margin)
+void launch_member_sums(const FrameDev& f, int nframes, int rem, int stride, int sbuf, int margin, hipStream_t st);
+// 'noq' variant (ContextRealDistNoQ, src/context.cpp:449-499): distances from float centroids (FrameDev::cl_f)
+void launch_noq_assign(const FrameDev& f, float coef, bool manhattan, int nframes, int rem, int stride, int buf, int sbuf, bool stale_sums, hipStream_t st);
 // connectivity
 void launch_cca_phase1(const CcaDev& c, int nframes, hipStream_t st);   // local CCL, border merge, compress, collect
 // device top-K + ranking; counters[3] = status (see k_cca_select).  On status 1 the candidate arrays are left

@@ -134,11 +134,11 @@ __global__ __launch_bounds__(256) void k_rd_assign(FrameDev f, const float* __re
 
 // Integer member sums of every cluster over the visited rows of its window (count, y, x, L, a, b), added to what the
 // assign pass left in FrameDev::sums for out-of-window members.  One block per cluster, no atomics.
-__global__ __launch_bounds__(256) void k_member_sums(FrameDev f, int rem, int stride) {
+__global__ __launch_bounds__(256) void k_member_sums(FrameDev f, int rem, int stride, int margin) {
     f.select(blockIdx.y);
     const int k = blockIdx.x, wave = threadIdx.x >> 6, lane = LANE();
     const uint32_t yx = f.cl_yx[k];
-    const int cy = (int)(yx >> 16), cx = (int)(yx & 0xFFFFu), S = f.S, W = f.W;
+    const int cy = (int)(yx >> 16), cx = (int)(yx & 0xFFFFu), S = f.S + margin, W = f.W;
     const int y_lo = max(cy - S, 0), y_hi = min(cy + S, f.H - 1);
     const int x_lo = max(cx - S, 0), x_hi = min(cx + S, W - 1);
     const int t = y_lo - rem;
@@ -197,9 +197,144 @@ void launch_rd_assign(const FrameDev& f_, const float* patchf, bool l2, int nfra
     else hipLaunchKernelGGL(k_rd_assign<false>, grid, dim3(256), 0, st, f, patchf, rem, stride, Hv, stale_sums ? 1 : 0);
 }
 
-void launch_member_sums(const FrameDev& f_, int nframes, int rem, int stride, int sbuf, hipStream_t st) {
+void launch_member_sums(const FrameDev& f_, int nframes, int rem, int stride, int sbuf, int margin, hipStream_t st) {
     const FrameDev f = rotated(f_, 0, sbuf);
-    hipLaunchKernelGGL(k_member_sums, dim3(f.K, nframes), dim3(256), 0, st, f, rem, stride);
+    hipLaunchKernelGGL(k_member_sums, dim3(f.K, nframes), dim3(256), 0, st, f, rem, stride, margin);
+}
+
+// ---- 'noq': ContextRealDistNoQ::assign_clusters_proto (src/context.cpp:461-499) ------------------------------
+// Float centroids; per pixel-candidate the reference evaluates, in this order and with these roundings (checked against
+// the disassembly of the reference built with its own flags):
+//   manhattan:  ((|dr| + |dg|) + |db|) + |coef*(j - cx)|, then + |coef*(i - cy)|
+//   otherwise:  t = dr*dr; t = fma(dg,dg,t); t = fma(db,db,t); t = fma(dx,dx,t); t + (dy*dy)
+// and the window [ (int)(cy - S), (int)((cy + S) + 1) ) x [ (int)(cx - S), (int)((cx + S) + 1) ) clipped to the image.
+// The candidate list is gathered with one pixel of slack around the integer window (the float expression can round up
+// across an integer); the exact test decides.
+template <bool MANHATTAN>
+__global__ __launch_bounds__(256) void k_noq_assign(FrameDev f, float coef, int rem, int stride, int Hv, int stale_sums) {
+    f.select(blockIdx.z);
+    __shared__ uint32_t s_raw[192];
+    __shared__ uint32_t s_k[64];
+    __shared__ __attribute__((aligned(16))) float s_c[64 * 8];
+    __shared__ int s_cnt;
+    const int wave = (int)rfl((uint32_t)(threadIdx.x >> 6)), lane = LANE();
+    const int S = f.S, W = f.W, H = f.H;
+    const float fS = (float)S;
+    const int x0 = blockIdx.x * 64;
+    const int v0 = blockIdx.y * kRdBH;
+    if (wave == (int)((blockIdx.x + blockIdx.y) & 3u)) {
+        const int v_last = min(v0 + kRdBH, Hv) - 1;
+        TileWindow win;
+        win.wy_lo = rem + stride * v0 - S - 1; win.wy_hi = rem + stride * v_last + S + 1;
+        win.wx_lo = x0 - S - 1; win.wx_hi = min(x0 + 63, W - 1) + S + 1;
+        const int cnt = gather_candidates(f, win, s_raw, lane);
+        wave_lds_sync();
+        if (cnt <= 64) {
+            const uint32_t mytag = lane < cnt ? s_raw[128 + lane] : 0xFFFFFFFFu;
+            int rank = 0;
+            for (int j = 0; j < cnt; ++j) rank += s_raw[128 + j] < mytag ? 1 : 0;
+            if (lane < cnt) {
+                const uint32_t k = mytag & 0xFFFFu;
+                s_k[rank] = k;
+                const float4* src = reinterpret_cast<const float4*>(f.cl_f + 8 * (size_t)k);
+                float4* dst = reinterpret_cast<float4*>(s_c + rank * 8);
+                dst[0] = src[0]; dst[1] = src[1];
+            }
+        }
+        if (lane == 0) s_cnt = cnt;
+    }
+    const int x = x0 + lane;
+    const bool xok = x < W;
+    const int xc = min(x, W - 1);
+    const int vw = v0 + wave * kRdRows;
+    uint32_t pix[kRdRows];
+    int yr[kRdRows];
+#pragma unroll
+    for (int r = 0; r < kRdRows; ++r) {
+        yr[r] = rem + stride * min(vw + r, Hv - 1);
+        pix[r] = f.lab[(size_t)yr[r] * W + xc];
+    }
+    __syncthreads();
+    const int cnt = s_cnt;
+    float best[kRdRows];
+    uint32_t bk[kRdRows];
+#pragma unroll
+    for (int r = 0; r < kRdRows; ++r) { best[r] = FLT_MAX; bk[r] = 0xFFFFu; }
+    const float fx = (float)x;
+    auto consider = [&](uint32_t k, float cy, float cx, float cr, float cg, float cb) {
+        const int y_lo = max((int)(cy - fS), 0), y_hi = min((int)((cy + fS) + 1.0f), H);
+        const int x_lo = max((int)(cx - fS), 0), x_hi = min((int)((cx + fS) + 1.0f), W);
+        if (x_hi <= x0 || x_lo > x0 + 63) return;            // uniform
+        const bool inx = x >= x_lo && x < x_hi;
+        const float dx = coef * (fx - cx);
+#pragma unroll
+        for (int r = 0; r < kRdRows; ++r) {
+            if (yr[r] < y_lo || yr[r] >= y_hi) continue;       // uniform
+            const float dr = (float)(pix[r] & 255u) - cr;
+            const float dg = (float)((pix[r] >> 8) & 255u) - cg;
+            const float db = (float)((pix[r] >> 16) & 255u) - cb;
+            const float dy = coef * ((float)yr[r] - cy);
+            float d;
+            if (MANHATTAN) {
+                d = ((__builtin_fabsf(dr) + __builtin_fabsf(dg)) + __builtin_fabsf(db)) + __builtin_fabsf(dx);
+                d = d + __builtin_fabsf(dy);
+            } else {
+                float t = __fmul_rn(dr, dr);
+                t = __builtin_fmaf(dg, dg, t);
+                t = __builtin_fmaf(db, db, t);
+                t = __builtin_fmaf(dx, dx, t);
+                d = __fadd_rn(t, __fmul_rn(dy, dy));
+            }
+            if (inx && d < best[r]) { best[r] = d; bk[r] = k; }
+        }
+    };
+    if (cnt <= 64) {
+        for (int c = 0; c < cnt; ++c) {
+            const float4 a = *reinterpret_cast<const float4*>(s_c + c * 8);
+            const float cb = s_c[c * 8 + 4];
+            consider(rfl(s_k[c]), __uint_as_float(rfl(__float_as_uint(a.x))), __uint_as_float(rfl(__float_as_uint(a.y))),
+                     __uint_as_float(rfl(__float_as_uint(a.z))), __uint_as_float(rfl(__float_as_uint(a.w))), __uint_as_float(rfl(__float_as_uint(cb))));
+        }
+    } else {
+        for (uint32_t ph = 0; ph < 4; ++ph) {
+            for (int k0 = 0; k0 < f.K; k0 += 64) {
+                const int k = k0 + lane;
+                const bool live = k < f.K;
+                const uint32_t tg = live ? f.cl_tag[k] : 0xFFFFFFFFu;
+                unsigned long long m = __ballot(live && (tg >> 16) == ph);
+                while (m) {
+                    const int c = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const float* cc = f.cl_f + 8 * (size_t)(k0 + c);
+                    consider((uint32_t)(k0 + c), cc[0], cc[1], cc[2], cc[3], cc[4]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kRdRows; ++r) {
+        if (!xok || vw + r >= Hv) continue;
+        const size_t p = (size_t)yr[r] * W + x;
+        if (best[r] < FLT_MAX) {
+            st_stream(f.labels + p, (uint16_t)bk[r]);
+        } else if (stale_sums) {
+            const uint32_t old = f.labels[p];
+            if (old != 0xFFFFu) {
+                const uint32_t oyx = f.cl_yx[old];
+                if (abs(yr[r] - (int)(oyx >> 16)) > S + 1 || abs(x - (int)(oyx & 0xFFFFu)) > S + 1)      // same margin as k_member_sums
+                    global_accumulate(f.sums[0], old, (uint32_t)yr[r], (uint32_t)x, pix[r]);
+            }
+        }
+    }
+}
+
+void launch_noq_assign(const FrameDev& f_, float coef, bool manhattan, int nframes, int rem, int stride, int buf, int sbuf, bool stale_sums, hipStream_t st) {
+    const FrameDev f = rotated(f_, buf, sbuf);
+    const int Hv = (f.H - rem + stride - 1) / stride;
+    if (Hv <= 0) return;
+    const dim3 grid((f.W + 63) / 64, (Hv + kRdBH - 1) / kRdBH, nframes);
+    if (manhattan) hipLaunchKernelGGL(k_noq_assign<true>, grid, dim3(256), 0, st, f, coef, rem, stride, Hv, stale_sums ? 1 : 0);
+    else hipLaunchKernelGGL(k_noq_assign<false>, grid, dim3(256), 0, st, f, coef, rem, stride, Hv, stale_sums ? 1 : 0);
 }
 
 }  // namespace fslic

@@ -66,7 +66,8 @@ enum {
     FSLIC_VARIANT_SLIC = 0,          /* Context, uint16 distances */
     FSLIC_VARIANT_LSC = 1,           /* ContextLSC, real_dist_type 'lsc' */
     FSLIC_VARIANT_REALDIST = 2,      /* ContextRealDist, real_dist_type 'standard' (src/context.h:100-103) */
-    FSLIC_VARIANT_REALDIST_L2 = 3    /* ContextRealDistL2, real_dist_type 'l2' (src/context.h:105-111) */
+    FSLIC_VARIANT_REALDIST_L2 = 3,   /* ContextRealDistL2, real_dist_type 'l2' (src/context.h:105-111) */
+    FSLIC_VARIANT_REALDIST_NOQ = 4   /* ContextRealDistNoQ, real_dist_type 'noq' (src/context.h:113-125): float centroids */
 };
 
 typedef struct fslic_engine fslic_engine;

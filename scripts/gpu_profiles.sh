@@ -9,7 +9,7 @@ cd $R
 rocminfo 2>/dev/null | grep -E 'Marketing Name|Compute Unit|Max Clock' | head -8 > $OUT/rocminfo.txt
 nproc >> $OUT/rocminfo.txt; grep -m1 'model name' /proc/cpuinfo >> $OUT/rocminfo.txt
 timeout 600 python bench.py 2> $OUT/bench.err > $OUT/bench.json; echo "bench rc=$?"
-for v in lsc standard l2; do timeout 300 python scripts/variant_throughput.py $v 24 4 2>/dev/null | tail -1 >> $OUT/variant_throughput.json; done
+for v in lsc standard l2 noq; do timeout 300 python scripts/variant_throughput.py $v 24 4 2>/dev/null | tail -1 >> $OUT/variant_throughput.json; done
 cd /tmp && export TMPDIR=/tmp
 # 1. the bench under rocprofv3: per-kernel statistics and how the streams overlap
 rm -rf $OUT/p

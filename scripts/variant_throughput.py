@@ -1,6 +1,6 @@
 """Throughput of a variant (lsc = BASELINE.json configs[4]; standard / l2 = the RealDist family) at 1280x720, K=1600 on
 one MI355X, next to the unmodified reference on this box's host cores (LSCAvx2 + OpenMP for lsc; the scalar contexts +
-OpenMP for the others, which have no SIMD specialisation).   python scripts/variant_throughput.py [lsc|standard|l2] [steps] [slots]
+OpenMP for the others, which have no SIMD specialisation).   python scripts/variant_throughput.py [lsc|standard|l2|noq] [steps] [slots]
 Same pipeline shape as bench.py: device-resident frames, groups of 8 frames, groups collected in completion order."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,7 +15,7 @@ kind = sys.argv[1] if len(sys.argv) > 1 else "lsc"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 nslots = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 eng = Engine(0, nslots)
-params = make_params(10, 10.0, 0.25, 3, variant={"lsc": B.VARIANT_LSC, "standard": B.VARIANT_REALDIST, "l2": B.VARIANT_REALDIST_L2}[kind])
+params = make_params(10, 10.0, 0.25, 3, variant={"lsc": B.VARIANT_LSC, "standard": B.VARIANT_REALDIST, "l2": B.VARIANT_REALDIST_L2, "noq": B.VARIANT_REALDIST_NOQ}[kind])
 frames = [variant("A", H, W, seed=s) for s in range(G)]
 d_rgb = [torch.from_numpy(f).cuda() for f in frames]
 cl0 = np.zeros((G, K), CLUSTER_DTYPE)
@@ -83,7 +83,7 @@ try:
             ms = min(ts) * 1e3
             if best is None or ms < best[1]:
                 best = (nt, ms)
-        out["cpu_reference"] = {"implementation": "LSCAvx2 + OpenMP" if kind == "lsc" else "ContextRealDist%s + OpenMP" % ("L2" if kind == "l2" else ""), "threads": best[0], "ms_per_frame": round(best[1], 2), "megapixels_per_sec": round(H * W / best[1] / 1e3, 1)}
+        out["cpu_reference"] = {"implementation": "LSCAvx2 + OpenMP" if kind == "lsc" else "ContextRealDist%s + OpenMP" % {"l2": "L2", "noq": "NoQ"}.get(kind, ""), "threads": best[0], "ms_per_frame": round(best[1], 2), "megapixels_per_sec": round(H * W / best[1] / 1e3, 1)}
 except Exception as e:      # the reference build is test infrastructure; absent on some boxes
     out["cpu_reference"] = "unavailable: %s" % e
 print(json.dumps(out))

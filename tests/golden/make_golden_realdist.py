@@ -1,5 +1,5 @@
 """Generate the RealDist fixtures from the UNMODIFIED reference (oracle/_ref): SlicRealDist ('standard') and
-SlicRealDistL2 ('l2'), fast_slic/base_slic.py:63-75.
+SlicRealDistL2 ('l2') and SlicRealDistNoQ ('noq'), fast_slic/base_slic.py:63-85.
 
     make -C oracle ref && python tests/golden/make_golden_realdist.py      (build container only: needs /root/reference)
 
@@ -34,7 +34,16 @@ CASES = [
     ("l2_C_240x320_k150", "l2", "C", 240, 320, 150, {}),
     ("l2_A_97x131_k25_rgb", "l2", "A", 97, 131, 25, dict(convert_to_lab=False)),
     ("l2_A_480x640_k200", "l2", "A", 480, 640, 200, {}),
+    ("noq_A_120x160_k40", "noq", "A", 120, 160, 40, {}),
+    ("noq_B_200x150_k30_stride2_c20", "noq", "B", 200, 150, 30, dict(subsample_stride=2, compactness=20.0)),
+    ("noq_C_240x320_k150", "noq", "C", 240, 320, 150, {}),
+    ("noq_A_97x131_k25_rgb_euclid", "noq", "A", 97, 131, 25, dict(convert_to_lab=False, manhattan=False)),
+    ("noq_A_200x264_k120_euclid", "noq", "A", 200, 264, 120, dict(manhattan=False)),
+    ("noq_D_128x192_k16_iter3", "noq", "D", 128, 192, 16, dict(max_iter=3)),
+    ("noq_A_480x640_k200", "noq", "A", 480, 640, 200, {}),
+    ("noq_A_480x640_k3000_pileup", "noq", "A", 480, 640, 3000, {}),
     ("std_A_720x1280_k1600", "standard", "A", 720, 1280, 1600, {}),
+    ("noq_A_720x1280_k1600", "noq", "A", 720, 1280, 1600, {}),
     ("l2_A_720x1280_k1600", "l2", "A", 720, 1280, 1600, {}),
 ]
 

@@ -100,9 +100,9 @@ def test_lsc_facade_matches_reference_surface(engine):
     assert s.slic_model.real_dist and s.slic_model.real_dist_type == "lsc"
     m = SlicModel(10)
     m.real_dist = True
-    m.real_dist_type = "noq"
+    m.real_dist_type = "no-such-type"
     m.initialize(img)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError):
         m.iterate(img, 10, 10.0, 0.25, 3)
 
 
