@@ -878,7 +878,10 @@ __global__ __launch_bounds__(256) void k_assign_generic(FrameDev f, int rem, int
     uint32_t lbl;
     if (best != ~0ull) { lbl = (uint32_t)(best & 0xFFFFull); f.labels[p] = (uint16_t)lbl; }
     else lbl = f.labels[p];
-    if (FUSE && lbl != 0xFFFFu) global_accumulate(f.sums[0], lbl, (uint32_t)y, (uint32_t)x, pix);
+    // preemptive mode: only pixels of active (2S x 2S) cells take part in the update unless every cluster is active
+    // (src/context.cpp:304-343)
+    if (FUSE && lbl != 0xFFFFu && (!f.cell_act || f.pre_flags[0] || f.cell_act[(y / (2 * S)) * f.pre_cw + x / (2 * S)]))
+        global_accumulate(f.sums[0], lbl, (uint32_t)y, (uint32_t)x, pix);
 }
 
 void launch_assign_generic(const FrameDev& f_, int nframes, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st) {

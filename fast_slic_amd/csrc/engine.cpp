@@ -227,6 +227,9 @@ struct Slot {
         std::string err;
     };
     std::unique_ptr<Async> async;
+    uint32_t* d_pre = nullptr;       // frame 0's preemptive state: is_updatable[K], is_active[K], cells, flags
+    uint32_t* h_upd = nullptr;       // pinned: is_updatable counters back from the device, per frame K words
+    size_t h_upd_words = 0;
     float* d_clf = nullptr;          // frame 0's float centroids ('noq')
     float* h_clf = nullptr;          // pinned, per frame K * 8 floats: upload (y, x) / download (y, x, r, g, b)
     size_t h_clf_floats = 0;
@@ -286,6 +289,7 @@ void free_slot(Slot& s) {
     if (s.h_lsc_lut) hipHostFree(s.h_lsc_lut);
     if (s.h_patchf) hipHostFree(s.h_patchf);
     if (s.h_clf) hipHostFree(s.h_clf);
+    if (s.h_upd) hipHostFree(s.h_upd);
     if (s.d_dbg) hipFree(s.d_dbg);
     if (s.d_ptrs) hipFree(s.d_ptrs);
     if (s.d_gen) hipFree(s.d_gen);
@@ -343,6 +347,7 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     if (s.h_patchf_cap < P * P) {
         if (s.h_patchf) hipHostFree(s.h_patchf);
     if (s.h_clf) hipHostFree(s.h_clf);
+    if (s.h_upd) hipHostFree(s.h_upd);
         s.h_patchf = nullptr; s.h_patchf_cap = 0;
         HIPCHK(hipHostMalloc((void**)&s.h_patchf, sizeof(float) * P * P));
         s.h_patchf_cap = P * P;
@@ -366,6 +371,8 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     const size_t o_lab = take(N * 4), o_labels = take(N * 2);
     const size_t o_cl = take((size_t)K * 4 * 8);                     // yx, lab, n, moved, tag, shadow, yx', yx'' (contiguous)
     const size_t o_clf = take((size_t)K * 8 * 4);                    // float centroids of the 'noq' variant
+    const int pre_cw = (W + 2 * S - 1) / (2 * S), pre_ch = (H + 2 * S - 1) / (2 * S);      // src/preemptive.h:36-37
+    const size_t o_pre = take(((size_t)K * 2 + (size_t)pre_cw * pre_ch + 16) * 4);         // is_updatable, is_active, active cells, flags
     // partial centroid sums of the block kernel: one entry per (cluster, assign block its window can overlap);
     // blocks are 64 px wide and at least 32 visited rows (stride >= 1) tall
     const int nbx = 2 * S / 64 + 2, nby = 2 * S / 32 + 2;
@@ -405,6 +412,9 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     f.cl_yx = cl; f.cl_lab = cl + K; f.cl_n = cl + 2 * (size_t)K; f.cl_moved = cl + 3 * (size_t)K; f.cl_tag = cl + 4 * (size_t)K;
     f.cl_shadow = cl + 5 * (size_t)K;
     f.cl_f = nullptr;                                                // set per call for the 'noq' variant only
+    f.cl_upd = f.cl_act = f.cell_act = f.pre_flags = nullptr;        // set per call in preemptive mode only
+    f.pre_cw = pre_cw; f.pre_ch = pre_ch;
+    s.d_pre = (uint32_t*)(b + o_pre);
     s.d_clf = (float*)(b + o_clf);
     s.d_yx_alt[0] = cl + 6 * (size_t)K; s.d_yx_alt[1] = cl + 7 * (size_t)K;
     f.cl_yx_out = s.d_yx_alt[0];
@@ -567,7 +577,8 @@ int validate(const fslic_params* p, int H, int W, int K, int& S) {
     if (K <= 0 || K >= 65534) return fail(FSLIC_E_INVALID, "num_components must be in [1, 65533] (cfast_slic.pyx:24-27)");
     if (p->subsample_stride < 1 || p->subsample_stride > 255) return fail(FSLIC_E_INVALID, "subsample_stride must be in [1, 255]");
     if (p->max_iter < 0) return fail(FSLIC_E_INVALID, "max_iter must be >= 0");
-    if (p->preemptive) return fail(FSLIC_E_UNSUPPORTED, "preemptive=True is not implemented on hip/gfx950");
+    if (p->preemptive && p->variant != FSLIC_VARIANT_SLIC) return fail(FSLIC_E_UNSUPPORTED, "preemptive=True is implemented for the Slic variant only on hip/gfx950");
+    if (p->preemptive && !std::isfinite(p->preemptive_thres)) return fail(FSLIC_E_INVALID, "preemptive_thres must be finite");
     if (p->variant < FSLIC_VARIANT_SLIC || p->variant > FSLIC_VARIANT_REALDIST_NOQ) return fail(FSLIC_E_UNSUPPORTED, "unknown variant");
     if (!(p->compactness > 0.0f) || !std::isfinite(p->compactness)) return fail(FSLIC_E_INVALID, "compactness must be a positive finite number");
     S = (int)(int16_t)sqrt(H * W / K);   // src/context.h:60
@@ -957,6 +968,17 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     // cluster centres: staged by stage_group() into the pinned block this copy reads
     HIPCHK(hipMemcpy2DAsync(f.cl_yx, fb, s.h_cl + (size_t)i0 * 4 * K, sizeof(uint32_t) * 4 * (size_t)K,
                             sizeof(uint32_t) * (size_t)K, (size_t)n, hipMemcpyHostToDevice, s.st));
+    const bool pre = p->preemptive != 0;
+    if (pre) {
+        // PreemptiveGrid::initialize, src/preemptive.h:59-67: every counter = cooldown, everything active
+        uint32_t* base = s.at(s.d_pre, i0);
+        f.cl_upd = base; f.cl_act = base + K; f.cell_act = base + 2 * (size_t)K; f.pre_flags = f.cell_act + (size_t)f.pre_cw * f.pre_ch;
+        for (int z = 0; z < n; z++) {
+            uint32_t* bz = s.at(s.d_pre, i0 + z);
+            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)bz, 2, (size_t)K, s.st));                                   // cooldown
+            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(bz + 2 * (size_t)K + (size_t)f.pre_cw * f.pre_ch), 1, 1, s.st));   // all_active
+        }
+    }
     const bool noq = p->variant == FSLIC_VARIANT_REALDIST_NOQ;
     if (noq) {
         f.cl_f = s.at(s.d_clf, i0);
@@ -969,7 +991,7 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     if (timed) HIPCHK(hipEventRecord(s.ev[0], s.st));
     // + labels <- 0xFFFF (src/context.cpp:138-145); + a fresh range of bin generation stamps for this group's passes
     f.gen_base = s.d_gen;
-    launch_rgb_to_lab(f, n, p->convert_to_lab, e->tables, true, s.st, (uint32_t)p->max_iter + 2u);
+    launch_rgb_to_lab(f, n, p->convert_to_lab, e->tables, true, s.st, (uint32_t)p->max_iter + 3u);
     if (timed) HIPCHK(hipEventRecord(s.ev[1], s.st));
     f.gen_off = 1;
     PassGeom pg{};
@@ -1009,6 +1031,7 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
         yx_cur = f.cl_yx_out;
         rem = (rem + 1) % stride;
     }
+    const float pre_l1_thres = std::max(roundf(2 * S * p->preemptive_thres), 1.0f);      // src/preemptive.h:129
     const int dbg_mode = getenv("FSLIC_DEBUG_TIMING") ? atoi(getenv("FSLIC_DEBUG_TIMING")) : 0;
     for (int it = 0; lsc && it < p->max_iter; it++) {           // src/context.cpp:158-175 with ContextLSC's hooks
         const bool tme = timed && s.launch_timing && it < Slot::kMaxTimedIters;
@@ -1042,9 +1065,17 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
         }
         f.gen_off++;
         f.cl_yx = yx_cur; f.cl_yx_out = (yx_cur == yx_a) ? yx_b : yx_a;
-        launch_bin_clusters(f, n, 1, (it + 1) & 1, it & 1, pg, s.st);
+        if (pre) launch_preempt_update(f, n, (it + 1) & 1, it & 1, false, pre_l1_thres, s.st);     // update() + set_new_clusters()
+        else launch_bin_clusters(f, n, 1, (it + 1) & 1, it & 1, pg, s.st);
         yx_cur = f.cl_yx_out;
         rem = (rem + 1) % stride;
+    }
+    int full_buf = p->max_iter & 1;
+    if (pre) {       // PreemptiveGrid::finalize (src/preemptive.h:69-74): every cluster takes part in the full assignment
+        f.gen_off++;
+        f.cl_yx = yx_cur;
+        launch_preempt_update(f, n, (p->max_iter + 1) & 1, 0, true, pre_l1_thres, s.st);
+        full_buf = (p->max_iter + 1) & 1;
     }
     if (dbg_mode == 1) {
         if (!s.d_dbg) HIPCHK(hipMalloc((void**)&s.d_dbg, sizeof(unsigned long long) * 8 * 65536));
@@ -1056,7 +1087,7 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     if (lsc) { f.cl_yx = yx_cur; launch_lsc_assign(f, l, n, 0, 1, p->max_iter & 1, 0, false, s.st); }
     else if (noq) { f.cl_yx = yx_cur; launch_noq_assign(f, noq_coef, noq_manhattan, n, 0, 1, p->max_iter & 1, 0, false, s.st); }
     else if (rd) { f.cl_yx = yx_cur; launch_rd_assign(f, s.d_patchf, rd_l2, n, 0, 1, p->max_iter & 1, 0, false, s.st); }
-    else if (generic) launch_assign_generic(f, n, 0, 1, p->max_iter & 1, 0, false, s.st);
+    else if (generic) launch_assign_generic(f, n, 0, 1, full_buf, 0, false, s.st);
     else (void)launch_assign(f, n, 0, 1, p->max_iter & 1, 0, false, s.st);
     if (timed) HIPCHK(hipEventRecord(s.ev[3], s.st));
     if (f.dbg) {
@@ -1075,6 +1106,8 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     HIPCHK(hipMemcpy2DAsync(s.h_cl + (size_t)i0 * 4 * K + K, sizeof(uint32_t) * 4 * (size_t)K, yx_up + K, fb,
                             sizeof(uint32_t) * 3 * (size_t)K, (size_t)n, hipMemcpyDeviceToHost, s.st));
     HIPCHK(hipMemcpy2DAsync(s.h_misc + 16 * (size_t)i0, 64, s.at(s.d_misc, i0), fb, 64, (size_t)n, hipMemcpyDeviceToHost, s.st));
+    if (pre) HIPCHK(hipMemcpy2DAsync(s.h_upd + (size_t)i0 * K, sizeof(uint32_t) * (size_t)K, f.cl_upd, fb,
+                                     sizeof(uint32_t) * (size_t)K, (size_t)n, hipMemcpyDeviceToHost, s.st));
     if (noq) HIPCHK(hipMemcpy2DAsync(s.h_clf + (size_t)i0 * 8 * K, sizeof(float) * 8 * (size_t)K, f.cl_f, fb,
                                      sizeof(float) * 8 * (size_t)K, (size_t)n, hipMemcpyDeviceToHost, s.st));
     return FSLIC_OK;
@@ -1097,7 +1130,7 @@ int launch_group(fslic_engine* e, Slot& s, int n) {
     std::vector<unsigned char> key;
     auto put = [&](const void* p, size_t bytes) { const unsigned char* b = (const unsigned char*)p; key.insert(key.end(), b, b + bytes); };
     const int hdr[8] = {s.H, s.W, s.K, s.S, n, s.generic ? 1 : 0, 0, s.sp_patch_uploaded ? 1 : 0};
-    const void* const ptrs[10] = {s.h_cl, s.h_misc, s.h_dense_leader, s.h_dense_area, s.d_ptrs, s.h_patch, s.d_gen, s.lsc_zero, s.d_patchf, s.h_clf};   // baked into copy nodes / arguments
+    const void* const ptrs[11] = {s.h_cl, s.h_misc, s.h_dense_leader, s.h_dense_area, s.d_ptrs, s.h_patch, s.d_gen, s.lsc_zero, s.d_patchf, s.h_clf, s.h_upd};   // baked into copy nodes / arguments
     put(hdr, sizeof hdr); put(ptrs, sizeof ptrs); put(&s.p, sizeof s.p); put(&s.f, sizeof s.f); put(&s.c, sizeof s.c);
     if (s.p.variant == FSLIC_VARIANT_LSC) put(&s.l, sizeof s.l);
     Slot::GraphEntry* ge = nullptr;
@@ -1162,13 +1195,20 @@ int group_begin(fslic_engine* e, Slot& s, const fslic_params* p, int H, int W, i
     }
     if (p->variant == FSLIC_VARIANT_REALDIST_NOQ && s.h_clf_floats < (size_t)s.cap_frames * K * 8) {
         if (s.h_clf) hipHostFree(s.h_clf);
+    if (s.h_upd) hipHostFree(s.h_upd);
         s.h_clf = nullptr; s.h_clf_floats = 0;
         HIPCHK(hipHostMalloc((void**)&s.h_clf, sizeof(float) * 8 * (size_t)K * s.cap_frames));
         s.h_clf_floats = (size_t)s.cap_frames * K * 8;
     }
     rc = upload_ptrs(s, n, d_rgb, d_out);
     if (rc) return rc;
-    s.generic = p->variant == FSLIC_VARIANT_SLIC && (p->force_generic || !s.sp_tiled_ok);
+    s.generic = p->variant == FSLIC_VARIANT_SLIC && (p->force_generic || !s.sp_tiled_ok || p->preemptive);
+    if (p->preemptive && s.h_upd_words < (size_t)s.cap_frames * K) {
+        if (s.h_upd) hipHostFree(s.h_upd);
+        s.h_upd = nullptr; s.h_upd_words = 0;
+        HIPCHK(hipHostMalloc((void**)&s.h_upd, sizeof(uint32_t) * (size_t)K * s.cap_frames));
+        s.h_upd_words = (size_t)s.cap_frames * K;
+    }
     stage_group(e, s, 0, n, true);
     rc = launch_group(e, s, n);
     if (rc) return rc;
@@ -1243,7 +1283,7 @@ int group_finish(fslic_engine* e, Slot& s) {
                 cl[k].y = clampf(cl[k].y, 0.0f, (float)(H - 1));
             }
             if (s.p.max_iter > 0) cl[k].num_members = nm[k];  // src/context.cpp:362
-            cl[k].is_updatable = 2;                            // src/preemptive.h:59-67
+            cl[k].is_updatable = s.p.preemptive ? (uint8_t)s.h_upd[(size_t)i * K + k] : 2;   // src/preemptive.h:59-67, :131-139
             cl[k].is_active = 1;                               // src/preemptive.h:69-74
         }
     }

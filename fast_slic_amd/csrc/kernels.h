@@ -60,6 +60,12 @@ struct FrameDev {
     uint32_t* cl_n;      // K  num_members of the last update
     uint32_t* cl_moved;  // K  1 once an update with n > 0 has moved the cluster
     uint32_t* cl_shadow; // K  1 while the cluster is kept out of the bins (identical to an earlier-ordered one)
+    // preemptive mode (src/preemptive.h); cell_act == nullptr otherwise
+    uint32_t* cl_upd;    // K  is_updatable counters (cooldown 2)
+    uint32_t* cl_act;    // K  is_active
+    uint32_t* cell_act;  // pre_cw * pre_ch  active (2S x 2S) cells
+    uint32_t* pre_flags; // [0] all clusters active
+    int pre_cw, pre_ch;
     float* cl_f;         // K * 8  non-quantised centroids (y, x, r, g, b, pad) of the 'noq' variant; nullptr otherwise
                          //    (cl_yx then holds their integer parts: bins, phases and windows work on those)
     uint32_t* sums[2];   // K*6 each: count, sum y, sum x, sum L, sum a, sum b; pass `it` accumulates into [it&1]
@@ -105,6 +111,7 @@ struct FrameDev {
         adv(lab, d); adv(labels, d);
         adv(cl_yx, d); adv(cl_yx_out, d); adv(cl_lab, d); adv(cl_tag, d); adv(cl_n, d); adv(cl_moved, d); adv(cl_shadow, d);
         if (cl_f) adv(cl_f, d);
+        if (cell_act) { adv(cl_upd, d); adv(cl_act, d); adv(cell_act, d); adv(pre_flags, d); }
         adv(sums[0], d); adv(sums[1], d); adv(cpart, d);
         adv(cell_cnt[0], d); adv(cell_cnt[1], d); adv(cell_items[0], d); adv(cell_items[1], d);
         adv(ovf_cnt[0], d); adv(ovf_cnt[1], d); adv(ovf_items[0], d); adv(ovf_items[1], d);
@@ -209,6 +216,9 @@ void launch_rd_assign(const FrameDev& f, const float* patchf, bool l2, int nfram
 void launch_member_sums(const FrameDev& f, int nframes, int rem, int stride, int sbuf, int margin, hipStream_t st);
 // 'noq' variant (ContextRealDistNoQ, src/context.cpp:449-499): distances from float centroids (FrameDev::cl_f)
 void launch_noq_assign(const FrameDev& f, float coef, bool manhattan, int nframes, int rem, int stride, int buf, int sbuf, bool stale_sums, hipStream_t st);
+// preemptive mode (preempt.hip): centroid update of the updatable clusters, activity marking, bins of the active clusters;
+// rebin_all: bins of ALL clusters at their current positions (before the full assignment, src/preemptive.h:69-74)
+void launch_preempt_update(const FrameDev& f, int nframes, int buf, int sbuf, bool rebin_all, float l1_thres, hipStream_t st);
 // connectivity
 void launch_cca_phase1(const CcaDev& c, int nframes, hipStream_t st);   // local CCL, border merge, compress, collect
 // device top-K + ranking; counters[3] = status (see k_cca_select).  On status 1 the candidate arrays are left

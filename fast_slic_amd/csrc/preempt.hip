@@ -1,0 +1,101 @@
+// preempt.hip -- preemptive mode (src/preemptive.h, PreemptiveGrid): clusters that have stopped moving drop out of the
+// assignment, tiles without a moving cluster nearby drop out of the update.
+// Hand-written gfx950 kernel; see kernels.h for the launch interface and DESIGN.md for the design.
+//
+// One block per frame does what BaseContext::update (src/context.cpp:356-387) and PreemptiveGrid::set_new_clusters
+// (src/preemptive.h:114-178) do after every assignment pass, in the reference's order:
+//   A  integer centroid update of the clusters whose is_updatable counter is non-zero (the others keep position,
+//      colour AND num_members, src/context.cpp:360)
+//   B  |old.x - new.x| + |old.y - new.y| (integer abs of the truncated differences, as the reference build computes it)
+//      < l1_thres: is_updatable--, else is_updatable = cooldown (2)
+//   C  every cluster within 2S (Chebyshev) of a cluster that is still updatable becomes active, and so does the
+//      (2S x 2S) cell it lies in
+//   D  all_active = every cluster active
+//   E  the active clusters are binned for the next assignment pass
+// K^2 / 1024 neighbour tests per thread: O(10 us) for K = 1600.  The mode is an approximation meant to save CPU time;
+// here it is served for interface completeness and takes the generic (one thread per pixel) assign kernel.
+#include "device_common.h"
+
+namespace fslic {
+
+__global__ __launch_bounds__(1024) void k_preempt_update(FrameDev f, int rebin_all, float l1_thres) {
+    f.select(blockIdx.x);
+    const int tid = threadIdx.x, K = f.K, S2 = 2 * f.S;
+    for (int gi = tid; gi < f.ncell; gi += 1024) f.cell_cnt[1][gi] = 0;
+    if (tid == 0) *f.ovf_cnt[1] = 0;
+    const uint32_t* __restrict__ pos = rebin_all ? f.cl_yx : f.cl_yx_out;
+    if (!rebin_all) {
+        for (int k = tid; k < K; k += 1024) {
+            const uint32_t yx_old = f.cl_yx[k];
+            const uint32_t* s = f.sums[0] + 6 * (size_t)k;
+            uint32_t* z0 = f.sums[1] + 6 * (size_t)k;
+            uint32_t yx = yx_old;
+            uint32_t upd = f.cl_upd[k];
+            if (upd) {
+                const int32_t n = (int32_t)s[0];
+                f.cl_n[k] = (uint32_t)n;
+                if (n != 0) {
+                    const int32_t h = n / 2;
+                    const int y = min(max(((int32_t)s[1] + h) / n, 0), f.H - 1);
+                    const int x = min(max(((int32_t)s[2] + h) / n, 0), f.W - 1);
+                    const int32_t L = ((int32_t)s[3] + h) / n, a = ((int32_t)s[4] + h) / n, b = ((int32_t)s[5] + h) / n;
+                    yx = ((uint32_t)y << 16) | (uint32_t)x;
+                    f.cl_lab[k] = (uint32_t)(L & 255) | ((uint32_t)(a & 255) << 8) | ((uint32_t)(b & 255) << 16);
+                    f.cl_moved[k] = 1;
+                }
+                const int l1 = abs((int)(yx_old & 0xFFFFu) - (int)(yx & 0xFFFFu)) + abs((int)(yx_old >> 16) - (int)(yx >> 16));
+                upd = ((float)l1 < l1_thres) ? upd - 1u : 2u;
+                f.cl_upd[k] = upd;
+            }
+            f.cl_yx_out[k] = yx;
+            f.cl_act[k] = 0u;
+            z0[0] = 0; z0[1] = 0; z0[2] = 0; z0[3] = 0; z0[4] = 0; z0[5] = 0;
+        }
+        for (int c = tid; c < f.pre_cw * f.pre_ch; c += 1024) f.cell_act[c] = 0u;
+        __syncthreads();
+        for (int k = tid; k < K; k += 1024) {
+            if (!f.cl_upd[k]) continue;
+            const uint32_t yxk = f.cl_yx_out[k];
+            const int yk = (int)(yxk >> 16), xk = (int)(yxk & 0xFFFFu);
+            for (int j = 0; j < K; ++j) {
+                const uint32_t yxj = f.cl_yx_out[j];
+                const int yj = (int)(yxj >> 16), xj = (int)(yxj & 0xFFFFu);
+                if (abs(yj - yk) <= S2 && abs(xj - xk) <= S2) {
+                    f.cl_act[j] = 1u;
+                    f.cell_act[(yj / S2) * f.pre_cw + xj / S2] = 1u;
+                }
+            }
+        }
+        __syncthreads();
+        __shared__ int s_cnt;
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        int mine = 0;
+        for (int k = tid; k < K; k += 1024) mine += (int)f.cl_act[k];
+        if (mine) atomicAdd(&s_cnt, mine);
+        __syncthreads();
+        if (tid == 0) f.pre_flags[0] = s_cnt == K ? 1u : 0u;
+    }
+    const uint32_t gen = f.generation();
+    for (int k = tid; k < K; k += 1024) {
+        const uint32_t yx = pos[k];
+        const int y = (int)(yx >> 16), x = (int)(yx & 0xFFFFu);
+        const uint32_t phase = (uint32_t)(2 * ((y / f.T) & 1) + ((x / f.T) & 1));
+        ClusterRec rec;
+        rec.yx = yx; rec.lab = f.cl_lab[k]; rec.tag = (phase << 16) | (uint32_t)k; rec.pad = gen;
+        f.cl_tag[k] = rec.tag;
+        f.cl_shadow[k] = 0u;
+        if (!rebin_all && !f.cl_act[k]) continue;          // src/context.cpp:218
+        const int cell = (y >> f.cs_shift) * f.ncx + (x >> f.cs_shift);
+        const uint32_t slot = atomicAdd(&f.cell_cnt[0][cell], 1u);
+        if (slot < (uint32_t)kCellCap) f.cell_items[0][(size_t)cell * kCellCap + slot] = rec;
+        else f.ovf_items[0][atomicAdd(f.ovf_cnt[0], 1u)] = rec;
+    }
+}
+
+void launch_preempt_update(const FrameDev& f_, int nframes, int buf, int sbuf, bool rebin_all, float l1_thres, hipStream_t st) {
+    const FrameDev f = rotated(f_, buf, sbuf);
+    hipLaunchKernelGGL(k_preempt_update, dim3(nframes), dim3(1024), 0, st, f, rebin_all ? 1 : 0, l1_thres);
+}
+
+}  // namespace fslic

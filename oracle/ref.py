@@ -81,6 +81,11 @@ def lsc_iterate(image, clusters, max_iter=10, compactness=10.0, min_size_factor=
     return labels, cl, pre
 
 
+def set_preemptive(on, thres=0.05):
+    """Preemptive mode (cfast_slic.pyx:183-184) of the following *_iterate calls made from this thread."""
+    lib().ref_set_preemptive(int(bool(on)), C.c_float(thres))
+
+
 REALDIST_KINDS = {"standard": 0, "l2": 1, "noq": 2}
 
 

@@ -38,6 +38,9 @@
 #include "parallel.h"
 
 namespace {
+// preemptive mode of the next iterate calls of this thread (cfast_slic.pyx:183-184); off by default
+thread_local bool g_preemptive = false;
+thread_local float g_preemptive_thres = 0.05f;
 template <typename Ctx>
 void configure(Ctx* c, float compactness, float min_size_factor, int subsample_stride,
                int convert_to_lab, int manhattan, int num_threads) {
@@ -47,8 +50,8 @@ void configure(Ctx* c, float compactness, float min_size_factor, int subsample_s
     c->min_size_factor = min_size_factor;
     c->subsample_stride_config = (int16_t)subsample_stride;
     c->convert_to_lab = convert_to_lab != 0;
-    c->preemptive = false;
-    c->preemptive_thres = 0.05f;
+    c->preemptive = g_preemptive;
+    c->preemptive_thres = g_preemptive_thres;
     c->manhattan_spatial_dist = manhattan != 0;
     c->debug_mode = false;
 }
@@ -56,6 +59,8 @@ thread_local std::string g_timing;
 }
 
 extern "C" {
+
+void ref_set_preemptive(int on, float thres) { g_preemptive = on != 0; g_preemptive_thres = thres; }
 
 // cfast_slic.pyx:359-369
 int ref_supports_arch(const char* arch) {

@@ -215,8 +215,8 @@ def test_errors_surface_like_the_reference():
     m = SlicModel(10)
     with pytest.raises(RuntimeError):
         m.iterate(np.zeros([10, 10, 3], np.uint8), 10, 10.0, 0.25, 3)   # not initialised, pyx:151-152
-    with pytest.raises(NotImplementedError):
-        Slic(num_components=10, preemptive=True).iterate(np.zeros([64, 64, 3], np.uint8))
+    out = Slic(num_components=10, preemptive=True).iterate(np.zeros([64, 64, 3], np.uint8))      # preemptive mode exists (test_gpu_preemptive.py)
+    assert out.shape == (64, 64)
 
 
 # ---- device-resident and batched entry points ------------------------------------------------------
