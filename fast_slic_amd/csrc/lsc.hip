@@ -118,16 +118,8 @@ __global__ __launch_bounds__(256) void k_lsc_features(FrameDev f, LscDev l) {
     for (int q = 0; q < kLscFeat; ++q) st_stream(l.feat + (size_t)q * f.N + i, F[q] / w);
 }
 
-static __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
-static __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m, 64);
-    return v;
-}
+static __device__ __forceinline__ float wave_sum(float v) { return wave_reduce_add(v); }
+static __device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return wave_reduce_add(v); }
 
 // Seed centroids: unweighted mean of the features over the (2*(S/4)+1)^2 window around the centre, clipped to the
 // image (src/lsc.cpp:165-195).  One wavefront per cluster.

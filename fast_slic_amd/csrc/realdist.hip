@@ -177,9 +177,7 @@ __global__ __launch_bounds__(256) void k_member_sums(FrameDev f, int rem, int st
     }
     __shared__ uint32_t s_in[kWavesPerBlock][6];
 #pragma unroll
-    for (int q = 0; q < 6; ++q)
-#pragma unroll
-        for (int mm = 32; mm > 0; mm >>= 1) in[q] += (uint32_t)__shfl_xor((int)in[q], mm, 64);
+    for (int q = 0; q < 6; ++q) in[q] = wave_reduce_add(in[q]);
     if (lane == 0) {
 #pragma unroll
         for (int q = 0; q < 6; ++q) s_in[wave][q] = in[q];
