@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void k_cca_local(CcaDev c) {
     constexpr int T = kCcaTile;
     constexpr int TH = kCcaTileH;
     constexpr int RW = TH / 4;
-    __shared__ uint16_t s_lbl[T * TH];
+    __shared__ uint32_t s_last[4][T];       // labels of every strip's last row (all the seam merge of phase B reads)
     __shared__ uint32_t s_par[T * TH];
     __shared__ uint32_t s_area[T * TH];
     const int lane = LANE();
@@ -101,11 +101,11 @@ __global__ __launch_bounds__(256) void k_cca_local(CcaDev c) {
         const bool ok = okx && (ty0 + ly) < c.H;
         const int p = ly * T + lane;
         const uint32_t l = lbl[i];
-        const uint32_t left = __shfl_up(l, 1);
+        const uint32_t left = lane_left(l);
         const bool start = (lane == 0) || (l != left) || !ok;
         const unsigned long long m = __ballot(start);
         const uint32_t node = (uint32_t)(ly * T + (63 - __clzll(m & lowmask)));
-        s_lbl[p] = (uint16_t)l;
+        if (i == RW - 1) s_last[wave][lane] = l;
         s_area[p] = 0u;
         s_par[p] = node;
         uint32_t cur_root = node;
@@ -123,9 +123,9 @@ __global__ __launch_bounds__(256) void k_cca_local(CcaDev c) {
         const int p = ly0 * T + lane;
         const bool ok = okx && (ty0 + ly0) < c.H;
         const uint32_t l = lbl[0];
-        const uint32_t left = __shfl_up(l, 1);
-        if (ok && (uint32_t)s_lbl[p - T] == l) {
-            const bool first = (lane == 0) || (left != l) || ((uint32_t)s_lbl[p - T - 1] != l);
+        const uint32_t left = lane_left(l);
+        if (ok && s_last[wave - 1][lane] == l) {
+            const bool first = (lane == 0) || (left != l) || (s_last[wave - 1][max(lane - 1, 0)] != l);
             if (first) lds_union(s_par, (uint32_t)p, (uint32_t)(p - T));
         }
     }
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_cca_local(CcaDev c) {
         const bool ok = okx && y < c.H;
         const uint32_t r = ok ? root[i] : 0xFFFFFFFFu;
         if (ok) st_stream(c.parent + (size_t)y * c.W + x, (int32_t)((size_t)(ty0 + (int)(r / T)) * c.W + tx0 + (int)(r % T)));
-        const uint32_t rl = __shfl_up(r, 1);
+        const uint32_t rl = lane_left(r);
         const bool start = (lane == 0) || (r != rl) || !ok;
         const unsigned long long m = __ballot(start);
         if (ok && start) {
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void k_cca_local(CcaDev c) {
             const int leader = __ffsll((long long)m) - 1;
             uint32_t base = 0;
             if (lane == leader) base = atomicAdd(&s_nroots, (uint32_t)__popcll(m));
-            base = __shfl(base, leader);
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
             if (isroot) {
                 const int32_t g = (int32_t)((size_t)y * c.W + x);
                 c.area[g] = s_area[p];

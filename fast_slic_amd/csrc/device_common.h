@@ -65,6 +65,11 @@ template <class T> static __device__ __forceinline__ T wave_reduce_add(T v) {
     return (r0 + r1) + (r2 + r3);
 }
 
+// Value of the lane to the left (lane 0 keeps its own), as a DPP wavefront shift rather than ds_bpermute
+static __device__ __forceinline__ uint32_t lane_left(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+}
+
 static __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // Which assign blocks (64 px x BH visited rows) can hold pixels of a cluster centred at (cy, cx): the blocks its
