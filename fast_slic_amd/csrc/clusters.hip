@@ -24,13 +24,15 @@ static __device__ __forceinline__ void gather_sums(const FrameDev& f, const Pass
     const SlotGeom g = slot_geom((int)(yx >> 16), (int)(yx & 0xFFFFu), f.S, f.H, f.W, pg.rem, pg.stride, pg.BH, pg.Hv);
     if (!g.any) return;
     const uint32_t* cp = f.cpart + (size_t)k * f.cpart_ns * 6;
-    // entries (by, bx) in [by0, by1] x [bx0, bx1], four at a time with all their loads in flight (one memory round trip
-    // per four entries instead of one per entry: this pass is a chain of dependent loads on a handful of blocks)
+    // entries (by, bx) in [by0, by1] x [bx0, bx1], eight at a time with all their loads in flight (one memory round trip
+    // per eight entries instead of one per entry: this pass is a chain of dependent loads on a handful of blocks, and
+    // it sits on the critical path of every iteration)
     const int nx = g.bx1 - g.bx0 + 1, ne = nx * (g.by1 - g.by0 + 1);
-    for (int e0 = 0; e0 < ne; e0 += 4) {
-        uint2 v[4][3];
+    constexpr int kBatch = 8;
+    for (int e0 = 0; e0 < ne; e0 += kBatch) {
+        uint2 v[kBatch][3];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kBatch; ++u) {
             const int e = e0 + u;
             const int ey = e / nx, ex = e - ey * nx;
             v[u][0] = v[u][1] = v[u][2] = make_uint2(0u, 0u);
@@ -40,7 +42,7 @@ static __device__ __forceinline__ void gather_sums(const FrameDev& f, const Pass
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kBatch; ++u) {
             out[0] += v[u][0].x; out[1] += v[u][0].y; out[2] += v[u][1].x; out[3] += v[u][1].y; out[4] += v[u][2].x; out[5] += v[u][2].y;
         }
     }
@@ -78,6 +80,9 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg) {
         shadowed = !f.cl_f && k > 0 && f.cl_yx[k - 1] == yx;
         f.cl_shadow[k] = shadowed ? 1u : 0u;
     } else {
+        // what the tail needs, requested before the gather so that it does not cost another round trip afterwards
+        const uint32_t lab_own = live ? f.cl_lab[k] : 0u;
+        const uint32_t yx_prev = (live && k > 0) ? f.cl_yx[k - 1] : 0u, lab_prev = (live && k > 0) ? f.cl_lab[k - 1] : 0u;
         // a shadowed cluster is in no candidate list: it received nothing and its cpart entries are stale
         uint32_t s[6] = {0u, 0u, 0u, 0u, 0u, 0u};
         if (live && !(pg.use_slots && f.cl_shadow[k])) gather_sums(f, pg, k, yx, s);
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg) {
         __syncthreads();
         if (!live || threadIdx.x == 0) return;
         const uint32_t n_prev = s_n[threadIdx.x - 1];
-        lab = f.cl_lab[k];
+        lab = lab_own;
         uint32_t* z0 = f.sums[1] + 6 * (size_t)k;    // the next pass accumulates here (sums[0] is still being read by neighbours)
         const int32_t n = (int32_t)s[0];
         f.cl_n[k] = (uint32_t)n;
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg) {
             f.cl_lab[k] = lab;
             f.cl_moved[k] = 1;
         } else if (!f.cl_f && k > 0 && n_prev == 0u) {
-            shadowed = f.cl_yx[k - 1] == yx && f.cl_lab[k - 1] == lab;
+            shadowed = yx_prev == yx && lab_prev == lab;
         }
         f.cl_yx_out[k] = yx;
         f.cl_shadow[k] = shadowed ? 1u : 0u;
