@@ -346,8 +346,6 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     if (!s.h_tab) HIPCHK(hipHostMalloc((void**)&s.h_tab, 2 * kTabMaxBytes));
     if (s.h_patchf_cap < P * P) {
         if (s.h_patchf) hipHostFree(s.h_patchf);
-    if (s.h_clf) hipHostFree(s.h_clf);
-    if (s.h_upd) hipHostFree(s.h_upd);
         s.h_patchf = nullptr; s.h_patchf_cap = 0;
         HIPCHK(hipHostMalloc((void**)&s.h_patchf, sizeof(float) * P * P));
         s.h_patchf_cap = P * P;
@@ -1195,7 +1193,6 @@ int group_begin(fslic_engine* e, Slot& s, const fslic_params* p, int H, int W, i
     }
     if (p->variant == FSLIC_VARIANT_REALDIST_NOQ && s.h_clf_floats < (size_t)s.cap_frames * K * 8) {
         if (s.h_clf) hipHostFree(s.h_clf);
-    if (s.h_upd) hipHostFree(s.h_upd);
         s.h_clf = nullptr; s.h_clf_floats = 0;
         HIPCHK(hipHostMalloc((void**)&s.h_clf, sizeof(float) * 8 * (size_t)K * s.cap_frames));
         s.h_clf_floats = (size_t)s.cap_frames * K * 8;

@@ -1,0 +1,88 @@
+"""Randomized GPU parity of the variants against the UNMODIFIED reference run live (oracle/_ref, which travels to the GPU
+box as a built library; skipped when it is absent): ragged sizes, small S, every option the variants take.
+SlicRealDist / L2 / NoQ and the preemptive mode: bit for bit.  LSC: agreement metrics (f32, order-dependent sums)."""
+import numpy as np
+import pytest
+
+from fast_slic_amd import make_params
+from fast_slic_amd import _binding as B
+from fast_slic_amd.synth import variant
+from oracle import ref
+from util import describe_mismatch, cluster_fields_equal, best_overlap
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not ref.available(), reason="oracle/_ref (the reference build) is not present")]
+KIND = {"standard": B.VARIANT_REALDIST, "l2": B.VARIANT_REALDIST_L2, "noq": B.VARIANT_REALDIST_NOQ}
+
+
+def run(engine, img, cl0, variant_id, preemptive=False, thres=0.05, **kw):
+    cl = cl0.copy()
+    p = make_params(kw.get("max_iter", 10), kw.get("compactness", 10.0), kw.get("min_size_factor", 0.25),
+                    kw.get("subsample_stride", 3), kw.get("convert_to_lab", True), kw.get("manhattan", True),
+                    preemptive=preemptive, preemptive_thres=thres, variant=variant_id)
+    labels = engine.iterate(np.ascontiguousarray(img), cl, p)
+    return labels, cl, engine.last_prelabels(img.shape[0], img.shape[1])
+
+
+def random_case(rng, trial):
+    H, W = int(rng.integers(24, 220)), int(rng.integers(24, 260))
+    K = int(rng.integers(1, max(2, H * W // 60)))
+    var = "ABCD"[int(rng.integers(0, 4))]
+    kw = dict(max_iter=int(rng.integers(0, 8)), compactness=float(rng.choice([1.0, 5.0, 10.0, 30.0, 80.0])),
+              min_size_factor=float(rng.choice([0.0, 0.1, 0.25, 0.6])), subsample_stride=int(rng.integers(1, 5)),
+              convert_to_lab=bool(rng.integers(0, 2)), manhattan=bool(rng.integers(0, 3)))
+    return H, W, K, var, kw, variant(var, H, W, seed=1000 + trial)
+
+
+def test_realdist_family_random_cases_bit_equal(engine):
+    rng = np.random.default_rng(777)
+    for trial in range(36):
+        H, W, K, var, kw, img = random_case(rng, trial)
+        kind = ("standard", "l2", "noq")[trial % 3]
+        cl0 = ref.initialize_clusters(img, K)
+        r_labels, r_cl, r_pre = ref.realdist_iterate(img, cl0, kind, num_threads=1, **kw)
+        labels, cl, pre = run(engine, img, cl0, KIND[kind], **kw)
+        tag = "trial %d %s %dx%d K=%d %s %s" % (trial, kind, H, W, K, var, kw)
+        assert np.array_equal(pre, r_pre), describe_mismatch(tag + "/prelabels", pre, r_pre)
+        msgs = cluster_fields_equal(cl, r_cl)
+        assert not msgs, tag + ": " + "; ".join(msgs)
+        assert np.array_equal(labels, r_labels), describe_mismatch(tag + "/labels", labels, r_labels)
+
+
+def test_preemptive_random_cases_bit_equal(engine):
+    rng = np.random.default_rng(778)
+    for trial in range(24):
+        H, W, K, var, kw, img = random_case(rng, trial)
+        kw["max_iter"] = int(rng.integers(1, 14))
+        thres = float(rng.choice([0.0, 0.02, 0.05, 0.1, 0.3]))
+        cl0 = ref.initialize_clusters(img, K)
+        ref.set_preemptive(True, thres)
+        try:
+            r_labels, r_cl, r_lab, r_pre = ref.slic_iterate(img, cl0, stages=True, num_threads=1, arch="standard", **kw)
+        finally:
+            ref.set_preemptive(False)
+        labels, cl, pre = run(engine, img, cl0, B.VARIANT_SLIC, preemptive=True, thres=thres, **kw)
+        tag = "trial %d preemptive(%.2f) %dx%d K=%d %s %s" % (trial, thres, H, W, K, var, kw)
+        assert np.array_equal(pre, r_pre), describe_mismatch(tag + "/prelabels", pre, r_pre)
+        msgs = cluster_fields_equal(cl, r_cl)
+        assert not msgs, tag + ": " + "; ".join(msgs)
+        assert np.array_equal(labels, r_labels), describe_mismatch(tag + "/labels", labels, r_labels)
+
+
+def test_lsc_random_cases_agree(engine):
+    rng = np.random.default_rng(779)
+    worst = 1.0
+    for trial in range(16):
+        H, W, K, var, kw, img = random_case(rng, trial)
+        kw.pop("manhattan")
+        if var in "CD":          # pure noise / constant frames: the partition is decided by rounding noise alone
+            var = "A"
+            img = variant(var, H, W, seed=1000 + trial)
+        cl0 = ref.initialize_clusters(img, K)
+        r_labels, r_cl, r_pre = ref.lsc_iterate(img, cl0, num_threads=1, arch="standard", **kw)
+        labels, cl, pre = run(engine, img, cl0, B.VARIANT_LSC, **kw)
+        agree = float((pre == r_pre).mean())
+        worst = min(worst, agree)
+        assert agree >= 0.97, "trial %d %dx%d K=%d %s %s: pre-connectivity agreement %.4f" % (trial, H, W, K, var, kw, agree)
+        if K > 1 and kw["min_size_factor"] <= 0.25:
+            assert min(best_overlap(labels, r_labels), best_overlap(r_labels, labels)) >= 0.90
+    print("worst pre-connectivity agreement over the random LSC cases: %.4f" % worst)
