@@ -1211,7 +1211,7 @@ int group_begin(fslic_engine* e, Slot& s, const fslic_params* p, int H, int W, i
     if (rc) return rc;
     s.have_pre = true;
     s.last_path = s.generic ? 1 : 0;
-    if (g_host_timing) fprintf(stderr, "[fslic host] group_begin n=%d: %.1f us\n", n, now_us() - t_begin);
+    if (g_host_timing) fprintf(stderr, "[fslic host] group_begin n=%d: %.1f us | slot %d begin %.1f .. %.1f\n", n, now_us() - t_begin, (int)(&s - e->slots.data()), t_begin, now_us());
     return FSLIC_OK;
 }
 
@@ -1285,8 +1285,8 @@ int group_finish(fslic_engine* e, Slot& s) {
         }
     }
     if (g_host_timing)
-        fprintf(stderr, "[fslic host] group_finish n=%d: sync wait %.1f us, events %.1f us, host top-K (%d frames) %.1f us, write-back %.1f us (device %.1f us)\n",
-                n, t_sync - t_begin, t_ev - t_sync, n_host_topk, t_cca - t_ev, now_us() - t_cca, s.total_ms * 1e3);
+        fprintf(stderr, "[fslic host] group_finish n=%d slot %d at %.1f .. %.1f: sync wait %.1f us, events %.1f us, host top-K (%d frames) %.1f us, write-back %.1f us (device %.1f us)\n",
+                n, (int)(&s - e->slots.data()), t_begin, now_us(), t_sync - t_begin, t_ev - t_sync, n_host_topk, t_cca - t_ev, now_us() - t_cca, s.total_ms * 1e3);
     return FSLIC_OK;
 }
 
