@@ -598,8 +598,16 @@ void select_kept_sorted(const int32_t* leader, const uint32_t* area, uint32_t M,
     }
     std::vector<uint32_t> order(M);
     std::iota(order.begin(), order.end(), 0u);
-    std::partial_sort(order.begin(), order.begin() + K, order.end(),
-                      [&](uint32_t a, uint32_t b) { return area[a] > area[b]; });
+    // Which K components survive is decided by the heap-select half of std::partial_sort (src/cca.cpp:225-228 calls
+    // std::partial_sort; on an area tie at the cut the survivors depend on libstdc++'s heap mechanics).  The second half,
+    // sort_heap, only orders the survivors, and they are re-sorted by leader anyway: with libstdc++ the first half is
+    // called directly (one third less host time per tie frame), elsewhere the whole std::partial_sort.
+    auto by_area = [&](uint32_t a, uint32_t b) { return area[a] > area[b]; };
+#if defined(__GLIBCXX__)
+    std::__heap_select(order.begin(), order.begin() + K, order.end(), __gnu_cxx::__ops::__iter_comp_iter(by_area));
+#else
+    std::partial_sort(order.begin(), order.begin() + K, order.end(), by_area);
+#endif
     std::vector<uint8_t> kept(M, 0);
     for (int i = 0; i < K; i++) kept[order[i]] = 1;
     uint32_t n = 0;
