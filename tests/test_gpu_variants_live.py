@@ -86,3 +86,30 @@ def test_lsc_random_cases_agree(engine):
         if K > 1 and kw["min_size_factor"] <= 0.25:
             assert min(best_overlap(labels, r_labels), best_overlap(r_labels, labels)) >= 0.90
     print("worst pre-connectivity agreement over the random LSC cases: %.4f" % worst)
+
+
+@pytest.mark.parametrize("kind", ["standard", "noq"])
+def test_realdist_full_size_4k_bit_equal(engine, kind):
+    # BASELINE.json's large geometry (3840x2160, K=1600): the reference runs with 16 threads (its result is thread-count
+    # invariant, checked when the fixtures were generated)
+    H, W, K = 2160, 3840, 1600
+    img = variant("A", H, W)
+    cl0 = ref.initialize_clusters(img, K)
+    r_labels, r_cl, r_pre = ref.realdist_iterate(img, cl0, kind, num_threads=16)
+    labels, cl, pre = run(engine, img, cl0, KIND[kind])
+    assert np.array_equal(pre, r_pre), describe_mismatch(kind + " 4K/prelabels", pre, r_pre)
+    msgs = cluster_fields_equal(cl, r_cl)
+    assert not msgs, kind + " 4K: " + "; ".join(msgs)
+    assert np.array_equal(labels, r_labels), describe_mismatch(kind + " 4K/labels", labels, r_labels)
+
+
+def test_lsc_full_size_4k_agrees(engine):
+    H, W, K = 2160, 3840, 1600
+    img = variant("A", H, W)
+    cl0 = ref.initialize_clusters(img, K)
+    r_labels, r_cl, r_pre = ref.lsc_iterate(img, cl0, num_threads=16, arch="standard")
+    labels, cl, pre = run(engine, img, cl0, B.VARIANT_LSC)
+    agree = float((pre == r_pre).mean())
+    bo = min(best_overlap(labels, r_labels), best_overlap(r_labels, labels))
+    print("LSC 3840x2160 K=1600: pre-connectivity agreement %.4f, best-overlap %.4f" % (agree, bo))
+    assert agree >= 0.97 and bo >= 0.95
