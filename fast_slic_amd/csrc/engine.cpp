@@ -991,13 +991,13 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
         HIPCHK(hipMemcpy2DAsync(f.cl_f, fb, s.h_clf + (size_t)i0 * 8 * K, sizeof(float) * 8 * (size_t)K,
                                 sizeof(float) * 8 * (size_t)K, (size_t)n, hipMemcpyHostToDevice, s.st));
     }
-    HIPCHK(hipMemset2DAsync(s.at(s.zero_block, i0), fb, 0, s.zero_bytes, (size_t)n, s.st));
-    HIPCHK(hipMemset2DAsync(f.cl_n, fb, 0, sizeof(uint32_t) * 2 * (size_t)K, (size_t)n, s.st));   // cl_n, cl_moved
+    // sums, bin counters, flags and cl_n / cl_moved start from zero: cleared by the LAB kernel below (two memset launches less)
 
     if (timed) HIPCHK(hipEventRecord(s.ev[0], s.st));
     // + labels <- 0xFFFF (src/context.cpp:138-145); + a fresh range of bin generation stamps for this group's passes
     f.gen_base = s.d_gen;
-    launch_rgb_to_lab(f, n, p->convert_to_lab, e->tables, true, s.st, (uint32_t)p->max_iter + 3u);
+    launch_rgb_to_lab(f, n, p->convert_to_lab, e->tables, true, s.st, (uint32_t)p->max_iter + 3u,
+                      s.at(s.zero_block, i0), s.zero_bytes, f.cl_n, 2 * (size_t)K);
     if (timed) HIPCHK(hipEventRecord(s.ev[1], s.st));
     f.gen_off = 1;
     PassGeom pg{};

@@ -194,7 +194,10 @@ struct LabTables {
 // ---- launches (all asynchronous on `st`) ----------------------------------------------------
 // labels_init != nullptr: also fill the N-entry label plane with 0xFFFF (src/context.cpp:138-145)
 // gen_step != 0: first kernel of a group, advances FrameDev::gen_base by gen_step (more than the group's bin passes)
-void launch_rgb_to_lab(const FrameDev& f, int nframes, int convert, const LabTables& t, bool init_labels, hipStream_t st, uint32_t gen_step = 0);
+// zero_a / zero_b: optional per-frame regions (frame 0's address; zero_a_bytes a multiple of 16, zero_b_words dwords) the
+// kernel clears as well -- the accumulators, bin counters and flags a group starts from (no separate memset launches)
+void launch_rgb_to_lab(const FrameDev& f, int nframes, int convert, const LabTables& t, bool init_labels, hipStream_t st, uint32_t gen_step = 0,
+                       void* zero_a = nullptr, size_t zero_a_bytes = 0, uint32_t* zero_b = nullptr, size_t zero_b_words = 0);
 // mode 0: resample colours at the current centres (src/context.cpp:128-135) and bin;
 // mode 1: integer centroid update from `sums` (src/context.cpp:356-373), zero sums, and bin.
 void launch_bin_clusters(const FrameDev& f, int nframes, int mode, int buf, int sbuf, const PassGeom& pg, hipStream_t st);

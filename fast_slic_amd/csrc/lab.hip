@@ -33,12 +33,19 @@ static __device__ __forceinline__ uint32_t lab_px(uint32_t R, uint32_t G, uint32
 
 template <bool CONVERT>
 __global__ __launch_bounds__(1024) void k_rgb_to_lab(FrameDev f, const uint16_t* __restrict__ g_gamma,
-                                                     const uint16_t* __restrict__ g_labtbl, LabConst kc, int init_labels, uint32_t gen_step) {
+                                                     const uint16_t* __restrict__ g_labtbl, LabConst kc, int init_labels, uint32_t gen_step,
+                                                     char* zero_a, unsigned zero_a_quads, uint32_t* zero_b, unsigned zero_b_words) {
     __shared__ uint16_t s_gamma[256];
     __shared__ uint16_t s_lab[8194];
     // first kernel of a group: new generation of bin stamps (nothing in this kernel reads them; the stream orders the rest)
     if (gen_step && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *f.gen_base += gen_step;
     f.select(blockIdx.y);
+    {   // the group's accumulators, bin counters and flags of this frame (nothing reads them before the next kernel)
+        const size_t fo = (size_t)blockIdx.y * f.frame_bytes;
+        const unsigned t0 = blockIdx.x * blockDim.x + threadIdx.x, ts = gridDim.x * blockDim.x;
+        if (zero_a) { uint4* za = reinterpret_cast<uint4*>(zero_a + fo); for (unsigned i = t0; i < zero_a_quads; i += ts) za[i] = make_uint4(0u, 0u, 0u, 0u); }
+        if (zero_b) { uint32_t* zb = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(zero_b) + fo); for (unsigned i = t0; i < zero_b_words; i += ts) zb[i] = 0u; }
+    }
     const uint8_t* __restrict__ rgb = f.rgb;
     uint32_t* __restrict__ lab = f.lab;
     uint16_t* __restrict__ labels_init = init_labels ? f.labels : nullptr;
@@ -84,7 +91,8 @@ __global__ __launch_bounds__(1024) void k_rgb_to_lab(FrameDev f, const uint16_t*
     }
 }
 
-void launch_rgb_to_lab(const FrameDev& f, int nframes, int convert, const LabTables& t, bool init_labels, hipStream_t st, uint32_t gen_step) {
+void launch_rgb_to_lab(const FrameDev& f, int nframes, int convert, const LabTables& t, bool init_labels, hipStream_t st, uint32_t gen_step,
+                       void* zero_a, size_t zero_a_bytes, uint32_t* zero_b, size_t zero_b_words) {
     LabConst kc;
     for (int i = 0; i < 9; i++) kc.cb[i] = t.cb[i];
     int blocks = (f.N / 4 + 1023) / 1024;
@@ -92,9 +100,9 @@ void launch_rgb_to_lab(const FrameDev& f, int nframes, int convert, const LabTab
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     if (convert)
-        hipLaunchKernelGGL(k_rgb_to_lab<true>, dim3(blocks, nframes), dim3(1024), 0, st, f, t.gamma, t.labtbl, kc, init_labels ? 1 : 0, gen_step);
+        hipLaunchKernelGGL(k_rgb_to_lab<true>, dim3(blocks, nframes), dim3(1024), 0, st, f, t.gamma, t.labtbl, kc, init_labels ? 1 : 0, gen_step, (char*)zero_a, (unsigned)(zero_a_bytes / 16), zero_b, (unsigned)zero_b_words);
     else
-        hipLaunchKernelGGL(k_rgb_to_lab<false>, dim3(blocks, nframes), dim3(1024), 0, st, f, t.gamma, t.labtbl, kc, init_labels ? 1 : 0, gen_step);
+        hipLaunchKernelGGL(k_rgb_to_lab<false>, dim3(blocks, nframes), dim3(1024), 0, st, f, t.gamma, t.labtbl, kc, init_labels ? 1 : 0, gen_step, (char*)zero_a, (unsigned)(zero_a_bytes / 16), zero_b, (unsigned)zero_b_words);
 }
 
 }  // namespace fslic
