@@ -5,17 +5,20 @@ One *step* = one pass of fast_slic.Slic.iterate() (max_iter=10, defaults) over o
 frames per GPU: 8 frames of 1280x720 RGB, K=1600 (BASELINE.json configs[1]; 8 frames/GPU is the sharding of
 configs[3], so --gpus 8 is exactly the 64-frame batch).  Frames and label maps are resident in HBM when the
 timed region starts (torch tensors; the C ABI gets raw device pointers).  The 8 frames of a step form ONE launch
-group (every kernel covers all 8 frames); consecutive steps alternate between the engine's slots (streams)
-through the asynchronous submit/wait entry points, so the host side of a step (cluster upload and write-back,
-std::partial_sort on a top-K tie) overlaps the kernels of the next one.  Every step starts cold from the grid
-seeding and is complete (labels in HBM, clusters written back on the host) before the timed region ends.
+group (every kernel covers all 8 frames); a step goes to whichever of the engine's slots (stream + host thread) is
+free, through the asynchronous submit / done / wait entry points, so several groups are in flight and the host side
+of one (cluster upload and write-back, the heap-select on a top-K tie) overlaps the kernels of the others; groups are
+collected in completion order.  Every step starts cold from the grid seeding and is complete (labels in HBM,
+clusters written back on the host) before the timed region ends.
 One process per GPU, frames are independent so there is no data-path collective; torch.distributed (RCCL)
 carries only the barrier and the max-over-ranks of the elapsed time.
 
-Prints ONE JSON line on rank 0.  Extra keys: "roofline" (dominant kernel = the full-assign launch, HIP-event
-timed on its own stream inside the engine), "cpu_baseline" (the unmodified reference, SlicAvx2 + OpenMP, on
-this host's cores; the plain-C port if oracle/_ref is absent), "roofline_4k" (the north-star kernel:
-full-assign at 3840x2160, K=1600, measured after the timed region, not part of `value`).
+Prints ONE JSON line on rank 0.  Extra keys: "roofline" (dominant kernel = k_assign_blk, the 11 assign launches of a
+group, HIP-event timed on their own stream inside the engine on the groups of slot 0 during the timed region; its
+"alone_on_the_gpu" sub-object repeats the measurement with nothing else in flight), "cpu_baseline" (the unmodified
+reference, SlicAvx2 + OpenMP, on this host's cores; the plain-C port if oracle/_ref is absent), "roofline_4k" (the
+north-star kernel: full-assign at 3840x2160, K=1600, four frames and one frame per launch, measured after the timed
+region, not part of `value`).
 """
 import argparse
 import json

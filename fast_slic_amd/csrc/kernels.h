@@ -1,5 +1,6 @@
 // kernels.h -- launch interface between the host engine (engine.cpp) and the gfx950 kernels
-// (kernels.hip).  Internal to the library; the public boundary is include/fslic_hip.h.
+// (lab / clusters / assign / cca / lsc / realdist / preempt .hip).  Internal to the library; the public boundary is
+// include/fslic_hip.h.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
