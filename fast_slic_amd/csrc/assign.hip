@@ -699,6 +699,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
         }
         uint16_t* rowp = f.labels + (size_t)yw_lo * W;
         const uint32_t xo = (uint32_t)x;
+        // Interior wavefront with every pixel assigned (the rule, by far): straight-line stores under one column mask.
+        // Otherwise (bottom rows missing, or a pixel no window reached: it keeps its label and still takes part in the
+        // update) row by row with the full rules.
+        us2 worst = best[0];
+#pragma unroll
+        for (int q = 1; q < R / 2; ++q) worst = __builtin_elementwise_max(worst, best[q]);
+        const bool all_found = __ballot(worst.x == 0xFFFF || worst.y == 0xFFFF) == 0ull;
+        if (all_found && nrows == R) {
+            if (okx) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) st_stream(rowp + (size_t)r * STRIDE * W + xo, (uint16_t)kk[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t key = (r & 1) ? (uint32_t)best[r / 2].y : (uint32_t)best[r / 2].x;
+                slot[r] = (FUSE && okx) ? (key & 63u) : kNoSlot;
+            }
+        } else {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const bool ok = okx && r < nrows;
@@ -715,6 +733,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
             }
             rowp += (size_t)STRIDE * W;
         }
+    }
     }
     FSLIC_STAMP(4);
     if (FUSE) {
