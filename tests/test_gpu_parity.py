@@ -433,3 +433,14 @@ def test_pipeline_of_replayed_groups_collected_in_completion_order():
         assert modes.count(2) >= (rounds - 2) * nslots, modes      # most groups were graph replays
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("H,W,K", [(1080, 1920, 60000), (300, 400, 30000)])
+def test_huge_cluster_counts(engine, H, W, K):
+    # S < 8: the generic kernel; more top-K candidates than the device sorts: the host sorts (select status 2)
+    img = variant("A", H, W)
+    cl0 = orc.initialize_clusters(img, K)
+    labels, cl, pre, path = run_hip(engine, img, cl0)
+    o_labels, o_cl, o_lab, o_pre = orc.slic_iterate(img, cl0, stages=True)
+    assert path == 1
+    assert_same("%dx%d K=%d" % (H, W, K), (labels, cl, pre), (o_labels, o_cl, o_pre))
