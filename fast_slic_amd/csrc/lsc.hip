@@ -314,7 +314,8 @@ __global__ __launch_bounds__(256) void k_lsc_assign(FrameDev f, LscDev l, int re
 __global__ __launch_bounds__(256) void k_lsc_update(FrameDev f, LscDev l, int rem, int stride) {
     f.select(blockIdx.y);
     l.select(blockIdx.y);
-    const int k = blockIdx.x, wave = threadIdx.x >> 6, lane = LANE();
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = LANE();      // one wavefront per cluster, four clusters per block
+    if (k >= f.K) return;
     const uint32_t yx = f.cl_yx[k];
     const int cy = (int)(yx >> 16), cx = (int)(yx & 0xFFFFu), S = f.S, W = f.W;
     const size_t N = (size_t)f.N;
@@ -323,28 +324,26 @@ __global__ __launch_bounds__(256) void k_lsc_update(FrameDev f, LscDev l, int re
     const int t = y_lo - rem;
     const int v_first = t <= 0 ? 0 : (t + stride - 1) / stride;
     // the stale-pixel contributions of the assign pass, fetched now so that the tail does not wait for them
-    const int tq = threadIdx.x;
     uint32_t pre_sum = 0;
     long long pre_ex = 0;
-    if (tq < 6) pre_sum = f.sums[0][6 * (size_t)k + tq];
-    if (tq >= 64 && tq < 64 + kLscFeat + 1) pre_ex = l.extra[(size_t)k * kLscExPitch + (tq - 64)];
+    if (lane < 6) pre_sum = f.sums[0][6 * (size_t)k + lane];
+    if (lane <= kLscFeat) pre_ex = l.extra[(size_t)k * kLscExPitch + lane];
     uint32_t in[6] = {0u, 0u, 0u, 0u, 0u, 0u};
     float acc[kLscFeat + 1];
 #pragma unroll
     for (int q = 0; q <= kLscFeat; ++q) acc[q] = 0.0f;
-    // Wavefront w takes window rows w, w+4, ... (visited rows only), kUpdRows of them per trip, lanes over the columns.
-    // Two memory round trips per trip: the labels of all rows, then the features of the matching pixels -- the loads
-    // of a non-matching lane are redirected to the window's first pixel (one cached line for all of them) so that they
-    // can be issued unconditionally and all at once.
-    constexpr int kUpdRows = 5;
+    // kUpdRows visited rows of the window per trip, lanes over the columns.  Two memory round trips per trip: the labels
+    // of all rows, then the features of the matching pixels -- the loads of a non-matching lane are redirected to the
+    // window's first pixel (one cached line for all of them) so that they can be issued unconditionally and all at once.
+    constexpr int kUpdRows = 4;
     const size_t p_first = (size_t)min(rem + stride * v_first, f.H - 1) * W + x_lo;
-    for (int y0 = rem + stride * (v_first + wave); y0 <= y_hi; y0 += kUpdRows * kWavesPerBlock * stride) {
+    for (int y0 = rem + stride * v_first; y0 <= y_hi; y0 += kUpdRows * stride) {
         for (int x = x_lo + lane; x - lane <= x_hi; x += 64) {
             size_t p[kUpdRows];
             uint32_t lb[kUpdRows];
 #pragma unroll
             for (int u = 0; u < kUpdRows; ++u) {
-                const int y = y0 + u * kWavesPerBlock * stride;
+                const int y = y0 + u * stride;
                 p[u] = (y <= y_hi && x <= x_hi) ? (size_t)y * W + x : p_first;
                 lb[u] = f.labels[p[u]];
             }
@@ -353,7 +352,7 @@ __global__ __launch_bounds__(256) void k_lsc_update(FrameDev f, LscDev l, int re
             bool m[kUpdRows];
 #pragma unroll
             for (int u = 0; u < kUpdRows; ++u) {
-                const int y = y0 + u * kWavesPerBlock * stride;
+                const int y = y0 + u * stride;
                 m[u] = y <= y_hi && x <= x_hi && lb[u] == (uint32_t)k;
                 const size_t pp = m[u] ? p[u] : p_first;
                 pix[u] = f.lab[pp];
@@ -364,7 +363,7 @@ __global__ __launch_bounds__(256) void k_lsc_update(FrameDev f, LscDev l, int re
 #pragma unroll
             for (int u = 0; u < kUpdRows; ++u) {
                 if (!m[u]) continue;
-                const int y = y0 + u * kWavesPerBlock * stride;
+                const int y = y0 + u * stride;
                 in[0] += 1u; in[1] += (uint32_t)y; in[2] += (uint32_t)x;
                 in[3] += pix[u] & 255u; in[4] += (pix[u] >> 8) & 255u; in[5] += (pix[u] >> 16) & 255u;
 #pragma unroll
@@ -373,33 +372,24 @@ __global__ __launch_bounds__(256) void k_lsc_update(FrameDev f, LscDev l, int re
             }
         }
     }
-    __shared__ uint32_t s_in[kWavesPerBlock][6];
-    __shared__ float s_acc[kWavesPerBlock][kLscFeat + 1];
+    // fixed reduction order (DPP tree, then the four 16-lane rows): run-to-run identical
 #pragma unroll
     for (int q = 0; q < 6; ++q) in[q] = wave_sum(in[q]);
 #pragma unroll
     for (int q = 0; q <= kLscFeat; ++q) acc[q] = wave_sum(acc[q]);
-    if (lane == 0) {
+    uint32_t my_in = in[0];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) s_in[wave][q] = in[q];
+    for (int q = 1; q < 6; ++q) my_in = lane == q ? in[q] : my_in;
+    if (lane < 6) f.sums[0][6 * (size_t)k + lane] = pre_sum + my_in;
+    float my_acc = acc[0];
 #pragma unroll
-        for (int q = 0; q <= kLscFeat; ++q) s_acc[wave][q] = acc[q];
+    for (int q = 1; q <= kLscFeat; ++q) my_acc = lane == q ? acc[q] : my_acc;
+    if (lane <= kLscFeat && pre_ex != 0) {
+        my_acc += (float)((double)pre_ex / (double)kLscFixScale);
+        l.extra[(size_t)k * kLscExPitch + lane] = 0;
     }
-    __syncthreads();
-    const int q = threadIdx.x;
-    if (q < 6) {
-        f.sums[0][6 * (size_t)k + q] = pre_sum + (((s_in[0][q] + s_in[1][q]) + s_in[2][q]) + s_in[3][q]);
-    }
-    __shared__ float s_tot[kLscFeat + 1];
-    if (q >= 64 && q < 64 + kLscFeat + 1) {
-        const int j = q - 64;
-        long long* e = l.extra + (size_t)k * kLscExPitch + j;
-        float v = ((s_acc[0][j] + s_acc[1][j]) + s_acc[2][j]) + s_acc[3][j];
-        if (pre_ex != 0) { v += (float)((double)pre_ex / (double)kLscFixScale); *e = 0; }
-        s_tot[j] = v;
-    }
-    __syncthreads();
-    if (q < kLscFeat) l.cfeat[(size_t)k * kLscCfPitch + q] = s_tot[q] / s_tot[kLscFeat];
+    const float tot_w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_acc), kLscFeat));
+    if (lane < kLscFeat) l.cfeat[(size_t)k * kLscCfPitch + lane] = my_acc / tot_w;
 }
 
 // ---- launches -------------------------------------------------------------------------------

@@ -133,29 +133,30 @@ __global__ __launch_bounds__(256) void k_rd_assign(FrameDev f, const float* __re
 }
 
 // Integer member sums of every cluster over the visited rows of its window (count, y, x, L, a, b), added to what the
-// assign pass left in FrameDev::sums for out-of-window members.  One block per cluster, no atomics.
+// assign pass left in FrameDev::sums for out-of-window members.  One wavefront per cluster (four clusters per block),
+// no atomics, no LDS: lanes over the window's columns, kRows rows in flight per trip.
 __global__ __launch_bounds__(256) void k_member_sums(FrameDev f, int rem, int stride, int margin) {
     f.select(blockIdx.y);
-    const int k = blockIdx.x, wave = threadIdx.x >> 6, lane = LANE();
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = LANE();
+    if (k >= f.K) return;
     const uint32_t yx = f.cl_yx[k];
     const int cy = (int)(yx >> 16), cx = (int)(yx & 0xFFFFu), S = f.S + margin, W = f.W;
     const int y_lo = max(cy - S, 0), y_hi = min(cy + S, f.H - 1);
     const int x_lo = max(cx - S, 0), x_hi = min(cx + S, W - 1);
     const int t = y_lo - rem;
     const int v_first = t <= 0 ? 0 : (t + stride - 1) / stride;
-    const int tq = threadIdx.x;
     uint32_t pre_sum = 0;
-    if (tq < 6) pre_sum = f.sums[0][6 * (size_t)k + tq];
+    if (lane < 6) pre_sum = f.sums[0][6 * (size_t)k + lane];
     uint32_t in[6] = {0u, 0u, 0u, 0u, 0u, 0u};
-    constexpr int kRows = 5;
+    constexpr int kRows = 6;
     const size_t p_first = (size_t)min(rem + stride * v_first, f.H - 1) * W + x_lo;
-    for (int y0 = rem + stride * (v_first + wave); y0 <= y_hi; y0 += kRows * kWavesPerBlock * stride) {
+    for (int y0 = rem + stride * v_first; y0 <= y_hi; y0 += kRows * stride) {
         for (int x = x_lo + lane; x - lane <= x_hi; x += 64) {
             size_t p[kRows];
             uint32_t lb[kRows];
 #pragma unroll
             for (int u = 0; u < kRows; ++u) {
-                const int y = y0 + u * kWavesPerBlock * stride;
+                const int y = y0 + u * stride;
                 p[u] = (y <= y_hi && x <= x_hi) ? (size_t)y * W + x : p_first;
                 lb[u] = f.labels[p[u]];
             }
@@ -163,27 +164,24 @@ __global__ __launch_bounds__(256) void k_member_sums(FrameDev f, int rem, int st
             bool m[kRows];
 #pragma unroll
             for (int u = 0; u < kRows; ++u) {
-                const int y = y0 + u * kWavesPerBlock * stride;
+                const int y = y0 + u * stride;
                 m[u] = y <= y_hi && x <= x_hi && lb[u] == (uint32_t)k;
                 pix[u] = f.lab[m[u] ? p[u] : p_first];
             }
 #pragma unroll
             for (int u = 0; u < kRows; ++u) {
                 if (!m[u]) continue;
-                in[0] += 1u; in[1] += (uint32_t)(y0 + u * kWavesPerBlock * stride); in[2] += (uint32_t)x;
+                in[0] += 1u; in[1] += (uint32_t)(y0 + u * stride); in[2] += (uint32_t)x;
                 in[3] += pix[u] & 255u; in[4] += (pix[u] >> 8) & 255u; in[5] += (pix[u] >> 16) & 255u;
             }
         }
     }
-    __shared__ uint32_t s_in[kWavesPerBlock][6];
 #pragma unroll
     for (int q = 0; q < 6; ++q) in[q] = wave_reduce_add(in[q]);
-    if (lane == 0) {
+    uint32_t mine = in[0];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) s_in[wave][q] = in[q];
-    }
-    __syncthreads();
-    if (tq < 6) f.sums[0][6 * (size_t)k + tq] = pre_sum + (((s_in[0][tq] + s_in[1][tq]) + s_in[2][tq]) + s_in[3][tq]);
+    for (int q = 1; q < 6; ++q) mine = lane == q ? in[q] : mine;
+    if (lane < 6) f.sums[0][6 * (size_t)k + lane] = pre_sum + mine;
 }
 
 void launch_rd_assign(const FrameDev& f_, const float* patchf, bool l2, int nframes, int rem, int stride, int buf, int sbuf, bool stale_sums, hipStream_t st) {
@@ -197,7 +195,7 @@ void launch_rd_assign(const FrameDev& f_, const float* patchf, bool l2, int nfra
 
 void launch_member_sums(const FrameDev& f_, int nframes, int rem, int stride, int sbuf, int margin, hipStream_t st) {
     const FrameDev f = rotated(f_, 0, sbuf);
-    hipLaunchKernelGGL(k_member_sums, dim3(f.K, nframes), dim3(256), 0, st, f, rem, stride, margin);
+    hipLaunchKernelGGL(k_member_sums, dim3((f.K + 3) / 4, nframes), dim3(256), 0, st, f, rem, stride, margin);
 }
 
 // ---- 'noq': ContextRealDistNoQ::assign_clusters_proto (src/context.cpp:461-499) ------------------------------
