@@ -349,12 +349,11 @@ typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 // One block = 64 columns x (4 wavefronts x R) visited rows.  The key of a pixel-candidate is 16 bits,
 // (distance << 6) | idx, idx = rank of the candidate in (phase, k) order within the block's list (<= 64 entries),
 // distance < 1024; two rows share one VALU instruction:
-//     s   = v_sad_u8 (pix[r],   clab, 0)
-//     s   = v_sad_hi_u8(pix[r+1], clab, s)           two colour distances packed
-//     t   = v_lshl_add_u32(s, 6, idx|idx<<16)
-//     key = v_pk_add_u16(t, spatial pair) clamp      0xffff outside the window: saturates, never wins
+//     s   = v_sad_u8   (pix[r],   clab, spatial pair)   the table's (row r, row r+1) word is the accumulator: + colour of row r
+//     s   = v_sad_hi_u8(pix[r+1], clab, s)              + colour of row r+1 in the high half: two distances packed
+//     key = v_pk_mad_u16(s, 64, idx|idx<<16) clamp      outside the window the table holds kTabOut: saturates to 0xffff, never wins
 //     best= v_pk_min_u16(best, key)
-// i.e. 2.5 VALU + one aligned LDS read per pixel-candidate pair.  The spatial pair comes from an LDS copy of the
+// i.e. 2 VALU per pixel-candidate + one aligned LDS read per pair (or per 8 rows).  The spatial pair comes from an LDS copy of the
 // reference's patch (src/context.cpp:22-40) laid out so that the rows of a wavefront are immediate offsets from one
 // per-lane address (two layouts, see VT below).  The prologue is paid once per BLOCK and costs one memory round trip:
 //   wavefront 0   fetches every bin slot the block's pixels can see (all loads in flight at once), compacts the
@@ -372,6 +371,15 @@ typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 // Algorithmic traffic: 4 B read + 2 B written per visited pixel.
 // =============================================================================================
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+
+// key pair = min(dist * 64 + idx, 0xffff) for two rows at once: v_pk_mad_u16 with the clamp bit saturates the full-width
+// result, so a distance carrying the out-of-window marker (kTabOut, >= 1024) or an idx operand of 0xffff gives 0xffff
+static __device__ __forceinline__ us2 key_pair(uint32_t dist01, uint32_t idx01) {
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, 64, %2 op_sel_hi:[1,0,1] clamp" : "=v"(r) : "v"(dist01), "s"(idx01));
+    return __builtin_bit_cast(us2, r);
+}
+
 
 // s_bitreplicate_b64_b32: every bit of the source twice, in order (bit i -> bits 2i, 2i+1)
 static __device__ __forceinline__ unsigned long long sbitrep(uint32_t v) {
@@ -400,13 +408,13 @@ static __device__ __forceinline__ void row_masks(uint32_t inv, uint32_t (&m)[R /
 }
 
 // VT (Manhattan patch only): the spatial term is a function of d = |dx| + |dy| alone, so the LDS table derives from the
-// one-dimensional, V-shaped  V[t] = patch(|t - Cc|) << 6  (0xffff beyond 2S) instead of the (S+2) x (2S+2pad+1)
+// one-dimensional, V-shaped  V[t] = patch(|t - Cc|)  (kTabOut beyond 2S) instead of the (S+2) x (2S+2pad+1)
 // column-major patch copy (26 KB at S = 72, re-read by every block).  Row r of a candidate reads V[Cc + dy_r + ux]
 // when dy_r >= 0 and V[Cc + dy_r - ux] when dy_r < 0: either way the index advances with the row, so the rows are
 // still fixed offsets from ONE per-lane base as long as they lie on one side of the centre; a candidate whose centre
 // row lies inside the wavefront's rows is walked twice (rows above, rows below).  Lanes outside the x window use
 // ux = 2S+1, which lands beyond 2S for every row; rows outside the y window are switched off by a per-pair scalar
-// mask OR-ed in together with idx (v_lshl_or_b32: no extra VALU).
+// mask OR-ed into the idx operand on the scalar unit (0xffff + anything saturates: no extra VALU).
 template <int R, bool FUSE, int STRIDE, bool VT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_assign_blk(FrameDev f, int rem, int Hv) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];   // spatial table (u16), f.tab_words dwords; 16-byte aligned: the row-vector reads are ds_read_b128
@@ -612,30 +620,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
                     spw[R / 2 - 4] = e1.x; spw[R / 2 - 3] = e1.y; spw[R / 2 - 2] = e1.z; spw[R / 2 - 1] = e1.w;
                 }
             }
-#if FSLIC_EXP == 4
-#pragma unroll
-            for (int q = 0; q < R / 2; ++q) {
-                const uint32_t s0 = __builtin_amdgcn_sad_u8(pix[2 * q], clab, 0u);
-                const uint32_t s01 = __builtin_amdgcn_sad_hi_u8(pix[2 * q + 1], clab, s0);
-                const uint32_t t = (s01 << 6) | (mq ? (mq[q] | idx01) : idx01);
-                best[q] = __builtin_elementwise_min(best[q], __builtin_elementwise_add_sat(__builtin_bit_cast(us2, t), __builtin_bit_cast(us2, spw[q])));
-            }
-#else
-            // three sweeps over the row pairs instead of one chain per pair: a packed op that consumes the result of the
+            // sweeps over the row pairs instead of one chain per pair: a packed op that consumes the result of the
             // packed op issued just before it costs a wait state (s_nop) on this target
             uint32_t t[R / 2];
 #pragma unroll
             for (int q = 0; q < R / 2; ++q) {
-                const uint32_t s0 = __builtin_amdgcn_sad_u8(pix[2 * q], clab, 0u);
-                const uint32_t s01 = __builtin_amdgcn_sad_hi_u8(pix[2 * q + 1], clab, s0);
-                t[q] = (s01 << 6) | (mq ? (mq[q] | idx01) : idx01);                            // v_lshl_or_b32, scalar 3rd operand
+                const uint32_t s0 = __builtin_amdgcn_sad_u8(pix[2 * q], clab, spw[q]);          // spatial pair + colour distance of row 2q
+                t[q] = __builtin_amdgcn_sad_hi_u8(pix[2 * q + 1], clab, s0);                     // + colour distance of row 2q+1 in the high half
             }
             us2 key[R / 2];
 #pragma unroll
-            for (int q = 0; q < R / 2; ++q) key[q] = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, t[q]), __builtin_bit_cast(us2, spw[q]));
+            for (int q = 0; q < R / 2; ++q) key[q] = key_pair(t[q], mq ? (mq[q] | idx01) : idx01);
 #pragma unroll
             for (int q = 0; q < R / 2; ++q) best[q] = __builtin_elementwise_min(best[q], key[q]);
-#endif
         };
 #pragma unroll 1
         while (todo) {
@@ -673,12 +670,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
         const uint32_t idx01 = (uint32_t)c | ((uint32_t)c << 16);
 #pragma unroll
         for (int q = 0; q < R / 2; ++q) {
-            const us2 sp = __builtin_bit_cast(us2, s_dyn[a0 + (2 * q) * STRIDE]);            // one aligned ds_read_b32 per row pair
-            const uint32_t s0 = __builtin_amdgcn_sad_u8(pix[2 * q], clab, 0u);
+            const uint32_t sp = s_dyn[a0 + (2 * q) * STRIDE];                                 // one aligned ds_read_b32 per row pair
+            const uint32_t s0 = __builtin_amdgcn_sad_u8(pix[2 * q], clab, sp);
             const uint32_t s01 = __builtin_amdgcn_sad_hi_u8(pix[2 * q + 1], clab, s0);
-            const uint32_t t = (s01 << 6) + idx01;
-            const us2 key = __builtin_elementwise_add_sat(__builtin_bit_cast(us2, t), sp);
-            best[q] = __builtin_elementwise_min(best[q], key);
+            best[q] = __builtin_elementwise_min(best[q], key_pair(s01, idx01));
         }
     }
     }

@@ -789,7 +789,7 @@ int print_phase_stamps(Slot& s, const char* what) {
 // Spatial-distance configuration of a frame: the reference's patch (src/context.cpp:22-40) and the three device
 // encodings of it.  Cached per slot: a video stream calls iterate() with the same (S, compactness, options)
 // for every frame, so the tables are built and uploaded once.
-//   packed kernel : column-major u16 table tab[ux'][dy + dyoff] of (patch << 6), 0xffff outside the window
+//   packed kernel : u16 tables of the patch values (V-shaped row vectors or pair-packed columns), kTabOut outside the window
 //   32-bit kernel : exact fixed-point multiplier (M, C), or an LDS table when none exists / non-Manhattan
 //   generic kernel: the patch itself
 int configure_spatial(Slot& s, int S, const fslic_params* p) {
@@ -854,9 +854,9 @@ int configure_spatial(Slot& s, int S, const fslic_params* p) {
             if ((size_t)tlen * 16 > kTabMaxBytes) return false;
             auto V = [&](int t) -> uint16_t {
                 const int d = std::abs(t - Cc);
-                if (d > 2 * S) return 0xFFFFu;
+                if (d > 2 * S) return kTabOut;
                 const int di = std::min(d, S), dj = d - di;
-                return (uint16_t)(patch[(size_t)(S - di) * Pp + (S + dj)] << 6);
+                return patch[(size_t)(S - di) * Pp + (S + dj)];
             };
             for (int t = 0; t < tlen; t++)
                 for (int k = 0; k < 8; k++) dst[(size_t)t * 8 + k] = V(t + k * stride);
@@ -872,8 +872,8 @@ int configure_spatial(Slot& s, int S, const fslic_params* p) {
         }
     }
     if (!f.tab_vmode && S >= 8 && max_sp + 765u < 1024u) {
-        // Pair-packed column-major copy of the patch: dword [ux][j] = (e(j), e(j + stride)), e(j) = patch[dy = j - dyoff][ux] << 6
-        // or 0xffff outside the window.  A pair of rows is then ONE 4-byte-aligned ds_read_b32 with an immediate offset
+        // Pair-packed column-major copy of the patch: dword [ux][j] = (e(j), e(j + stride)), e(j) = patch[dy = j - dyoff][ux]
+        // or kTabOut outside the window.  A pair of rows is then ONE 4-byte-aligned ds_read_b32 with an immediate offset
         // (the u16 layout needed either a v_perm per pair or, at stride 1, 2-byte-aligned b128 reads, which cost 64 clk of
         // the CU's LDS pipe each).  One table per stride: `tab` for the full pass, `tabs` for the subsampled passes.
         auto build2d = [&](int stride, int rows, uint32_t* dst, int& words, int& nrpad_out, int& dyoff_out) -> bool {
@@ -884,12 +884,12 @@ int configure_spatial(Slot& s, int S, const fslic_params* p) {
             if (bytes > kTabMaxBytes) return false;
             auto e = [&](int ux, int j) -> uint32_t {
                 const int dy = j - dyoff;
-                if (j < 0 || j >= NR || dy < -S || dy > S || ux > S) return 0xFFFFu;
-                return (uint32_t)(uint16_t)(patch[(size_t)(S + dy) * Pp + (S + ux)] << 6);
+                if (j < 0 || j >= NR || dy < -S || dy > S || ux > S) return kTabOut;
+                return (uint32_t)patch[(size_t)(S + dy) * Pp + (S + ux)];
             };
             for (int ux = 0; ux <= S + 1; ux++)
                 for (int j = 0; j < nrpad; j++) dst[(size_t)ux * nrpad + j] = e(ux, j) | (e(ux, j + stride) << 16);
-            for (size_t i = (size_t)(S + 2) * nrpad; i < bytes / 4; i++) dst[i] = 0xFFFFFFFFu;
+            for (size_t i = (size_t)(S + 2) * nrpad; i < bytes / 4; i++) dst[i] = kTabOut | ((uint32_t)kTabOut << 16);
             words = (int)(bytes / 4); nrpad_out = nrpad; dyoff_out = dyoff;
             return true;
         };

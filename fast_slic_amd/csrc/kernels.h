@@ -33,6 +33,10 @@ struct ClusterRec {
 // a per-frame sub-arena of identical layout; the pointers below are those of the group's first frame and
 // select(z) advances them to frame z (z = the launch's last grid dimension).  Input frames and output label
 // maps are the caller's buffers and come as per-frame pointers.
+// Out-of-window marker of the packed kernel's spatial tables: any value v with 1024 <= v and v + 765 < 65536; the key
+// (v + colour) * 64 + idx then saturates to 0xffff = never wins.
+constexpr uint16_t kTabOut = 0x4000;
+
 struct FrameDev {
     size_t frame_bytes;  // distance between the sub-arenas of consecutive frames
     const uint8_t* const* rgbs;       // DEVICE array: the group's input frames (N*3 bytes each), caller's buffers
@@ -85,15 +89,15 @@ struct FrameDev {
     // LDS spatial table of the tiled kernel (lut_words == 0: fixed-point mode, no table)
     const uint32_t* lut;       // lut_words entries: patch value << 16, or kHuge for out-of-window indices
     int lut_words, lut_row, lut_oow;   // index = ux' + uy' * lut_row, ux'/uy' = |d| if <= S else lut_oow
-    // packed 16-bit kernel: column-major spatial table tab[ux'][dy + tab_dyoff], (patch << 6) or 0xffff
+    // packed 16-bit kernel: spatial table of patch values, kTabOut outside the window (two layouts, see tab_vmode)
     const uint16_t* tab;       // tab_words * 2 entries (tab_words == 0: packed kernel not applicable)
     int tab_words, tab_nrpad, tab_dyoff;
-    int tab_vmode, tab_xout;   // tab_vmode: `tab` is the row-vector form of the V-shaped 1-D table V[t] = patch(|t - tab_dyoff|) << 6
+    int tab_vmode, tab_xout;   // tab_vmode: `tab` is the row-vector form of the V-shaped 1-D table V[t] = patch(|t - tab_dyoff|) (kTabOut beyond 2S)
                                // (Manhattan patch): 16-byte entry t = V[t + k*stride], k = 0..7; lanes outside the x window use
                                // |dx| = tab_xout.  `tab` serves the full (stride 1) pass, `tabs` the subsampled passes
     const uint16_t* tabs;
     int tabs_words, tabs_dyoff, tabs_nrpad;
-    // tab_vmode == 0: pair-packed column-major patch copy, dword [ux'][j] = (e(j), e(j+stride)) with e = patch << 6 or 0xffff
+    // tab_vmode == 0: pair-packed column-major patch copy, dword [ux'][j] = (e(j), e(j+stride)) with e = patch or kTabOut
     // outside the window, row pitch tab_nrpad dwords, j = dy + tab_dyoff
     // generic-path tables
     const uint16_t* patch2d;   // (2S+1)^2, src/context.cpp:22-40
