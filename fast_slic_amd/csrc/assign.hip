@@ -389,6 +389,14 @@ static __device__ __forceinline__ unsigned long long sbitrep(uint32_t v) {
 }
 // One 32-bit word per pair of rows: 0xffff in the half of every row whose bit is set in `inv` (R bits), each bit
 // replicated 16 times by four rounds of s_bitreplicate (scalar unit only).
+// best = min(best, key) IN PLACE: with the plain builtin the compiler keeps the loop-carried minima and the pass's
+// results in two register sets and copies one into the other (8-16 v_mov per candidate, a fifth of the pass)
+static __device__ __forceinline__ void min_in_place(us2& best, us2 key) {
+    uint32_t b = __builtin_bit_cast(uint32_t, best);
+    asm("v_pk_min_u16 %0, %0, %1" : "+v"(b) : "v"(__builtin_bit_cast(uint32_t, key)));
+    best = __builtin_bit_cast(us2, b);
+}
+
 template <int R>
 static __device__ __forceinline__ void row_masks(uint32_t inv, uint32_t (&m)[R / 2]) {
     static_assert(R == 8 || R == 16, "row masks are built for 8 or 16 rows");
@@ -632,29 +640,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
 #pragma unroll
             for (int q = 0; q < R / 2; ++q) key[q] = key_pair(t[q], mq ? (mq[q] | idx01) : idx01);
 #pragma unroll
-            for (int q = 0; q < R / 2; ++q) best[q] = __builtin_elementwise_min(best[q], key[q]);
+            for (int q = 0; q < R / 2; ++q) min_in_place(best[q], key[q]);
         };
-#pragma unroll 1
-        while (todo) {
-            const int c = __builtin_ctzll(todo);
-            todo &= todo - 1ull;
+        // Three loops, each with ONE straight-line form of the pass (the order of the candidates is irrelevant: the key
+        // carries idx).  With the forms as branches of one loop body the compiler linearised them into guarded blocks,
+        // kept the running minima in two register sets and copied between them: 8-16 v_mov per candidate.
+        //   whole : every row inside the window and on one side of the centre (index = k0 -/+ |dx|): no masks
+        //   above : some rows above the centre, masked          below : some rows at/below the centre, masked
+        // (a candidate whose centre row lies inside this wavefront's rows is in both masked loops)
+        const bool mine_todo = (todo >> lane) & 1ull;
+        const uint32_t va_j = vab_j & 0xFFFFu, vb_j = vab_j >> 16;
+        unsigned long long todo_whole = __ballot(mine_todo && (va_j == full || vb_j == full));
+        unsigned long long todo_above = __ballot(mine_todo && va_j != 0u && va_j != full);
+        unsigned long long todo_below = __ballot(mine_todo && vb_j != 0u && vb_j != full);
+        auto fetch = [&](int c, uint32_t& clab, uint32_t& uxc, uint32_t& k0, uint32_t& idx01) {
             const uint32_t cyx = __builtin_amdgcn_readlane(yx_j, c);
-            const uint32_t clab = __builtin_amdgcn_readlane(lab_j, c);
-            const uint32_t vab = __builtin_amdgcn_readlane(vab_j, c);
+            clab = __builtin_amdgcn_readlane(lab_j, c);
             const int cy = (int)(cyx >> 16), cx = (int)(cyx & 0xFFFFu);
             const uint32_t ux = __builtin_amdgcn_sad_u16((uint32_t)x, (uint32_t)cx, 0u);      // |x - cx|
-            const uint32_t uxc = ux <= (uint32_t)S ? ux : xout;
-            const uint32_t k0 = (uint32_t)(Cc + yw_lo - cy);                                   // wave-uniform
-            const uint32_t idx01 = (uint32_t)c | ((uint32_t)c << 16);
-            if (vab == (full << 16) || vab == full) {     // every row inside the window and on one side of the centre:
-                const int sgn = vab == full ? -1 : 1;     // at/below (+) or above (-); one code path for both
-                pass(clab, k0 + (uint32_t)__mul24((int)uxc, sgn), idx01, nullptr);
-            } else {                                      // window edge and / or centre row inside this wavefront's rows
-                const uint32_t va = vab & 0xFFFFu, vb = vab >> 16;
-                uint32_t mq[R / 2];
-                if (va) { row_masks<R>(~va & full, mq); pass(clab, k0 - uxc, idx01, mq); }
-                if (vb) { row_masks<R>(~vb & full, mq); pass(clab, k0 + uxc, idx01, mq); }
-            }
+            uxc = ux <= (uint32_t)S ? ux : xout;
+            k0 = (uint32_t)(Cc + yw_lo - cy);                                                  // wave-uniform
+            idx01 = (uint32_t)c | ((uint32_t)c << 16);
+        };
+#pragma unroll 1
+        while (todo_whole) {
+            const int c = __builtin_ctzll(todo_whole);
+            todo_whole &= todo_whole - 1ull;
+            uint32_t clab, uxc, k0, idx01;
+            fetch(c, clab, uxc, k0, idx01);
+            const bool above = __builtin_amdgcn_readlane(va_j, c) != 0u;
+            pass(clab, k0 + (uint32_t)__mul24((int)uxc, above ? -1 : 1), idx01, nullptr);
+        }
+#pragma unroll 1
+        while (todo_above) {
+            const int c = __builtin_ctzll(todo_above);
+            todo_above &= todo_above - 1ull;
+            uint32_t clab, uxc, k0, idx01, mq[R / 2];
+            fetch(c, clab, uxc, k0, idx01);
+            row_masks<R>(~__builtin_amdgcn_readlane(va_j, c) & full, mq);
+            pass(clab, k0 - uxc, idx01, mq);
+        }
+#pragma unroll 1
+        while (todo_below) {
+            const int c = __builtin_ctzll(todo_below);
+            todo_below &= todo_below - 1ull;
+            uint32_t clab, uxc, k0, idx01, mq[R / 2];
+            fetch(c, clab, uxc, k0, idx01);
+            row_masks<R>(~__builtin_amdgcn_readlane(vb_j, c) & full, mq);
+            pass(clab, k0 + uxc, idx01, mq);
         }
     } else {
 #pragma unroll 1
@@ -673,7 +706,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
             const uint32_t sp = s_dyn[a0 + (2 * q) * STRIDE];                                 // one aligned ds_read_b32 per row pair
             const uint32_t s0 = __builtin_amdgcn_sad_u8(pix[2 * q], clab, sp);
             const uint32_t s01 = __builtin_amdgcn_sad_hi_u8(pix[2 * q + 1], clab, s0);
-            best[q] = __builtin_elementwise_min(best[q], key_pair(s01, idx01));
+            min_in_place(best[q], key_pair(s01, idx01));
         }
     }
     }
