@@ -459,21 +459,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
     FSLIC_STAMP(0);
     const unsigned long long wc0 = f.dbg ? wall_clock64() : 0ull;
 
-    // 1. pixel loads first; nothing below depends on them until the argmin
+    // 1. pixel loads: nothing depends on them until the argmin, but they are issued AFTER the loads the prologue waits
+    // for (bins, table).  Every wavefront of the chip starts at the same time; with the pixel loads first the few bytes on the
+    // critical path queued behind the whole frame's pixel traffic (prologue 4 us of a wavefront life of 8 us at 4K).
     // Out-of-image lanes and rows re-read the last valid column / row instead of being masked off: no exec juggling
     // around the loads (their results are never stored and never reach the centroid sums).
     uint32_t pix[R];
-    if (nrows > 0) {
+    auto load_pixels = [&]() {
         const uint32_t xc = (uint32_t)min(x, W - 1);
+        const int nr1 = max(nrows, 1) - 1;             // a wavefront without rows (bottom edge) re-reads the image's last visited row
+        const int ybase = nrows > 0 ? yw_lo : rem + (Hv - 1) * STRIDE;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const uint32_t* rowp = f.lab + (size_t)(yw_lo + min(r, nrows - 1) * STRIDE) * W;   // wave-uniform base
+            const uint32_t* rowp = f.lab + (size_t)(ybase + min(r, nr1) * STRIDE) * W;   // wave-uniform base
             pix[r] = rowp[xc];
         }
-    } else {
-#pragma unroll
-        for (int r = 0; r < R; ++r) pix[r] = 0u;
-    }
+    };
 
     // The list is built by ONE wavefront while the other three stage the table.  A block's wavefront i runs on SIMD i, so
     // with a fixed choice the list builders of all resident blocks of a CU would share one SIMD (measured: their ~800
@@ -500,24 +501,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
             if (keep && pos < 64) { s_braw[pos] = rec.yx; s_braw[64 + pos] = rec.lab; s_braw[128 + pos] = rec.tag; }
             cnt += __popcll(m);
         };
-        // lane -> (cell column, slot); a cell row of up to 8 cells is one 16-byte load per lane, six cell rows in flight
-        for (int cx0 = 0; cx0 < ncxr; cx0 += 8) {
+        // lane -> (cell column, slot); a cell row of up to 8 cells is one 16-byte load per lane, six cell rows in flight.
+        // The first trip (the only one unless the block sees more than 8 x 6 cells) is issued ahead of the pixel loads.
+        auto issue = [&](int cx0, int cy0, ClusterRec (&rr)[6], bool (&okr)[6]) {
             const int cxi = cx0 + (lane >> 3);
             const bool colok = cxi < ncxr;
-            const ClusterRec* base = citems + ((size_t)cya * f.ncx + cxa + min(cxi, ncxr - 1)) * kCellCap + (lane & 7);
-            for (int cy0 = cya; cy0 <= cyb; cy0 += 6) {
+            const ClusterRec* base = citems + ((size_t)cy0 * f.ncx + cxa + min(cxi, ncxr - 1)) * kCellCap + (lane & 7);
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {      // unconditional loads (rows past the range re-read the last one)
+                okr[u] = colok && (cy0 + u) <= cyb;
+                rr[u] = base[(size_t)min(u, cyb - cy0) * f.ncx * kCellCap];
+            }
+        };
+        auto consume = [&](const ClusterRec (&rr)[6], const bool (&okr)[6]) {
+#pragma unroll
+            for (int u = 0; u < 6; ++u) visit(rr[u], okr[u] && rr[u].pad == gen && in_window(rr[u], win));
+        };
+        {
+            ClusterRec rr[6];
+            bool okr[6];
+            issue(0, cya, rr, okr);
+            load_pixels();
+            consume(rr, okr);
+        }
+        for (int cx0 = 0; cx0 < ncxr; cx0 += 8)
+            for (int cy0 = cx0 == 0 ? cya + 6 : cya; cy0 <= cyb; cy0 += 6) {
                 ClusterRec rr[6];
                 bool okr[6];
-#pragma unroll
-                for (int u = 0; u < 6; ++u) {      // unconditional loads (rows past the range re-read the last one)
-                    okr[u] = colok && (cy0 + u) <= cyb;
-                    rr[u] = base[(size_t)min(u, cyb - cy0) * f.ncx * kCellCap];
-                }
-                base += 6 * (size_t)f.ncx * kCellCap;
-#pragma unroll
-                for (int u = 0; u < 6; ++u) visit(rr[u], okr[u] && rr[u].pad == gen && in_window(rr[u], win));
+                issue(cx0, cy0, rr, okr);
+                consume(rr, okr);
             }
-        }
         for (uint32_t i0 = 0; i0 < novf; i0 += 64) {
             const uint32_t i = i0 + lane;
             ClusterRec rec;
@@ -552,10 +565,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
         uint4* dst = reinterpret_cast<uint4*>(s_dyn);
         const int nq = f.tab_words >> 2;
         const int t = ((wave - gwave - 1) & 3) * 64 + lane;      // 0..191 over the three staging wavefronts
-#if FSLIC_EXP == 3
-        if (false)
-#endif
-        for (int b0 = 0; b0 < nq; b0 += 4 * 192) {     // indices past the end are clamped: the last quad is rewritten, no masking
+        {                                              // first trip (the whole table unless it exceeds 12 KB), ahead of the pixel loads
+            uint4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = src[min(u * 192 + t, nq - 1)];
+            load_pixels();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dst[min(u * 192 + t, nq - 1)] = q[u];
+        }
+        for (int b0 = 4 * 192; b0 < nq; b0 += 4 * 192) {     // indices past the end are clamped: the last quad is rewritten, no masking
             uint4 q[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) q[u] = src[min(b0 + u * 192 + t, nq - 1)];
