@@ -426,7 +426,7 @@ static __device__ __forceinline__ void row_masks(uint32_t inv, uint32_t (&m)[R /
 template <int R, bool FUSE, int STRIDE, bool VT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_assign_blk(FrameDev f, int rem, int Hv) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];   // spatial table (u16), f.tab_words dwords; 16-byte aligned: the row-vector reads are ds_read_b128
-    __shared__ uint32_t s_braw[3 * 64];
+    __shared__ uint32_t s_braw[3 * 128];                 // compaction buffer: entries 0..63 kept records, 64..127 scratch
     __shared__ uint4 s_list[64];                         // {yx, lab, k, cpart entry | kNoSlot}
     __shared__ uint32_t s_bn;
     // centroid accumulators: per (candidate, copy) two 64-bit words of three 20-bit-spaced fields each,
@@ -458,6 +458,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
     } while (0)
     FSLIC_STAMP(0);
     const unsigned long long wc0 = f.dbg ? wall_clock64() : 0ull;
+    // sub-phases of the list-building wavefront: records 32768.. of the stamp buffer, one per block
+#define FSLIC_GSTAMP(slot_)                                                                             \
+    do {                                                                                                 \
+        if (f.dbg && lane == 0)                                                                          \
+            f.dbg[((size_t)32768 + (blockIdx.y * gridDim.x + blockIdx.x)) * 8 + (slot_)] = __builtin_readcyclecounter(); \
+    } while (0)
 
     // 1. pixel loads: nothing depends on them until the argmin, but they are issued AFTER the loads the prologue waits
     // for (bins, table).  Every wavefront of the chip starts at the same time; with the pixel loads first the few bytes on the
@@ -469,11 +475,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
         const uint32_t xc = (uint32_t)min(x, W - 1);
         const int nr1 = max(nrows, 1) - 1;             // a wavefront without rows (bottom edge) re-reads the image's last visited row
         const int ybase = nrows > 0 ? yw_lo : rem + (Hv - 1) * STRIDE;
+        // one 64-bit row address per wavefront, then 32-bit byte offsets (R * STRIDE * W * 4 < 2^32): a 64-bit product per
+        // row was 6 scalar instructions per load on the list builder's critical path
+        const char* base = reinterpret_cast<const char*>(f.lab + (size_t)ybase * W);
+        const uint32_t pitch = (uint32_t)(STRIDE * W) * 4u, vo = xc * 4u;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t* rowp = f.lab + (size_t)(ybase + min(r, nr1) * STRIDE) * W;   // wave-uniform base
-            pix[r] = rowp[xc];
-        }
+        for (int r = 0; r < R; ++r) pix[r] = *reinterpret_cast<const uint32_t*>(base + (vo + (uint32_t)min(r, nr1) * pitch));
     };
 
     // The list is built by ONE wavefront while the other three stage the table.  A block's wavefront i runs on SIMD i, so
@@ -482,6 +489,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
     const int gwave = (int)((blockIdx.x + blockIdx.y + blockIdx.z) & 3u);
     if (wave == gwave) {
         // 2a. the block's candidate list
+        FSLIC_GSTAMP(0);
         const uint32_t novf = *f.ovf_cnt[0];
         const int sh = f.cs_shift;
         const ClusterRec* __restrict__ citems = f.cell_items[0];
@@ -495,41 +503,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
         const int cya = max(win.wy_lo, 0) >> sh, cyb = min(win.wy_hi, f.H - 1) >> sh;
         const int ncxr = cxb - cxa + 1;
         int cnt = 0;
+        // branch-free: a record that is not kept goes to a scratch entry (64 + lane), one past 64 kept to entry 63 (the block
+        // then bails out anyway)
         auto visit = [&](const ClusterRec& rec, bool keep) {
             const unsigned long long m = __ballot(keep);
-            const int pos = cnt + __popcll(m & lowmask);
-            if (keep && pos < 64) { s_braw[pos] = rec.yx; s_braw[64 + pos] = rec.lab; s_braw[128 + pos] = rec.tag; }
+            const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)cnt));
+            const int idx = keep ? min(pos, 63) : 64 + lane;
+            s_braw[idx] = rec.yx; s_braw[128 + idx] = rec.lab; s_braw[256 + idx] = rec.tag;
             cnt += __popcll(m);
         };
         // lane -> (cell column, slot); a cell row of up to 8 cells is one 16-byte load per lane, six cell rows in flight.
         // The first trip (the only one unless the block sees more than 8 x 6 cells) is issued ahead of the pixel loads.
+        const char* const cbase = reinterpret_cast<const char*>(citems);
+        const uint32_t cpitch = (uint32_t)f.ncx * (uint32_t)(kCellCap * sizeof(ClusterRec));      // bytes per cell row (32-bit byte offsets)
         auto issue = [&](int cx0, int cy0, ClusterRec (&rr)[6], bool (&okr)[6]) {
             const int cxi = cx0 + (lane >> 3);
             const bool colok = cxi < ncxr;
-            const ClusterRec* base = citems + ((size_t)cy0 * f.ncx + cxa + min(cxi, ncxr - 1)) * kCellCap + (lane & 7);
+            const uint32_t vo = ((uint32_t)(cxa + min(cxi, ncxr - 1)) * kCellCap + (uint32_t)(lane & 7)) * (uint32_t)sizeof(ClusterRec) + (uint32_t)cy0 * cpitch;
 #pragma unroll
             for (int u = 0; u < 6; ++u) {      // unconditional loads (rows past the range re-read the last one)
                 okr[u] = colok && (cy0 + u) <= cyb;
-                rr[u] = base[(size_t)min(u, cyb - cy0) * f.ncx * kCellCap];
+                rr[u] = *reinterpret_cast<const ClusterRec*>(cbase + (vo + (uint32_t)min(u, cyb - cy0) * cpitch));
             }
         };
-        auto consume = [&](const ClusterRec (&rr)[6], const bool (&okr)[6]) {
+        auto consume = [&](int cy0, const ClusterRec (&rr)[6], const bool (&okr)[6]) {
 #pragma unroll
-            for (int u = 0; u < 6; ++u) visit(rr[u], okr[u] && rr[u].pad == gen && in_window(rr[u], win));
+            for (int u = 0; u < 6; ++u)
+                if (cy0 + u <= cyb) visit(rr[u], okr[u] && rr[u].pad == gen && in_window(rr[u], win));     // uniform
         };
         {
             ClusterRec rr[6];
             bool okr[6];
             issue(0, cya, rr, okr);
             load_pixels();
-            consume(rr, okr);
+            FSLIC_GSTAMP(1);
+            if (f.dbg) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(R) : "memory");
+            FSLIC_GSTAMP(2);
+            consume(cya, rr, okr);
         }
+        FSLIC_GSTAMP(3);
         for (int cx0 = 0; cx0 < ncxr; cx0 += 8)
             for (int cy0 = cx0 == 0 ? cya + 6 : cya; cy0 <= cyb; cy0 += 6) {
                 ClusterRec rr[6];
                 bool okr[6];
                 issue(cx0, cy0, rr, okr);
-                consume(rr, okr);
+                consume(cy0, rr, okr);
             }
         for (uint32_t i0 = 0; i0 < novf; i0 += 64) {
             const uint32_t i = i0 + lane;
@@ -539,15 +557,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
             visit(rec, i < novf && in_window(rec, win));
         }
         __builtin_amdgcn_wave_barrier();
+        FSLIC_GSTAMP(4);
         // rank by (phase, k): list order == visit order of the reference's scatter (src/context.cpp:214-242)
         const int bn = cnt;
         if (bn <= 64) {
             const bool act = lane < bn;
             const uint32_t yx_j = act ? s_braw[lane] : 0u;
-            const uint32_t lab_j = act ? s_braw[64 + lane] : 0u;
-            const uint32_t tag_j = act ? s_braw[128 + lane] : 0xFFFFFFFFu;
-            int rank = 0;
-            for (int i = 0; i < bn; ++i) rank += (int)(__builtin_amdgcn_readlane(tag_j, i) < tag_j);
+            const uint32_t lab_j = act ? s_braw[128 + lane] : 0u;
+            const uint32_t tag_j = act ? s_braw[256 + lane] : 0xFFFFFFFFu;
+            int rank = 0;             // four at a time (independent readlanes); lanes >= bn hold 0xffffffff, which is never smaller
+            for (int i = 0; i < bn; i += 4)
+                rank += (int)(__builtin_amdgcn_readlane(tag_j, i) < tag_j) + (int)(__builtin_amdgcn_readlane(tag_j, i + 1) < tag_j) +
+                        (int)(__builtin_amdgcn_readlane(tag_j, i + 2) < tag_j) + (int)(__builtin_amdgcn_readlane(tag_j, i + 3) < tag_j);
             uint32_t entry = kNoSlot;
             if (FUSE) {
                 const uint32_t k = tag_j & 0xFFFFu;
@@ -559,6 +580,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
             if (act) s_list[rank] = make_uint4(yx_j, lab_j, tag_j & 0xFFFFu, entry);
         }
         if (lane == 0) s_bn = (uint32_t)bn;
+        FSLIC_GSTAMP(5);
     } else {
         // 2b. spatial table -> LDS, four 16-byte loads in flight per thread; centroid accumulators <- 0
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(f.tab);
@@ -842,6 +864,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
         f.dbg[o + 7] = wall_clock64() - wc0;          // 100 MHz reference clock over the wavefront's life
     }
 #undef FSLIC_STAMP
+#undef FSLIC_GSTAMP
 }
 
 template <int R, bool FUSE, int STRIDE>

@@ -760,7 +760,7 @@ int print_phase_stamps(Slot& s, const char* what) {
     HIPCHK(hipMemcpy(h.data(), s.d_dbg, h.size() * 8, hipMemcpyDeviceToHost));
     double ph[5] = {0, 0, 0, 0, 0}, nr = 0, nn = 0;
     int cnt = 0;
-    for (int b = 0; b < nw; b++) {
+    for (int b = 0; b < 32768; b++) {
         if (h[(size_t)b * 8] == 0 || h[(size_t)b * 8 + 5] == 0) continue;
         cnt++;
         for (int q = 0; q < 5; q++) ph[q] += (double)(h[(size_t)b * 8 + q + 1] - h[(size_t)b * 8 + q]);
@@ -768,7 +768,7 @@ int print_phase_stamps(Slot& s, const char* what) {
     }
     {
         std::vector<double> life, pro;
-        for (int b = 0; b < nw; b++) {
+        for (int b = 0; b < 32768; b++) {
             if (h[(size_t)b * 8] == 0 || h[(size_t)b * 8 + 5] == 0) continue;
             life.push_back((double)(h[(size_t)b * 8 + 5] - h[(size_t)b * 8]));
             pro.push_back((double)(h[(size_t)b * 8 + 1] - h[(size_t)b * 8]));
@@ -779,6 +779,18 @@ int print_phase_stamps(Slot& s, const char* what) {
             fprintf(stderr, "[fslic dbg]   wavefront life (cycles): min %.0f p10 %.0f p50 %.0f p90 %.0f max %.0f | prologue: min %.0f p10 %.0f p50 %.0f p90 %.0f max %.0f\n",
                     q(life, 0), q(life, 0.1), q(life, 0.5), q(life, 0.9), q(life, 1), q(pro, 0), q(pro, 0.1), q(pro, 0.5), q(pro, 0.9), q(pro, 1));
         }
+    }
+    {   // sub-phases of the list-building wavefronts (block kernel): records 32768.. of the buffer
+        double g[5] = {0, 0, 0, 0, 0};
+        int gc = 0;
+        for (int b = 32768; b < nw; b++) {
+            if (h[(size_t)b * 8] == 0 || h[(size_t)b * 8 + 5] == 0) continue;
+            gc++;
+            for (int q = 0; q < 5; q++) g[q] += (double)(h[(size_t)b * 8 + q + 1] - h[(size_t)b * 8 + q]);
+        }
+        if (gc > 0)
+            fprintf(stderr, "[fslic dbg]   list builder (%d blocks) avg ticks: address+issue %.0f  bins arrive %.0f  compact %.0f  overflow list %.0f  rank+entries %.0f\n",
+                    gc, g[0] / gc, g[1] / gc, g[2] / gc, g[3] / gc, g[4] / gc);
     }
     if (cnt == 0) cnt = 1;
     const double tot = ph[0] + ph[1] + ph[2] + ph[3] + ph[4];
