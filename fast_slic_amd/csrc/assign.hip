@@ -682,15 +682,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
 #pragma unroll
             for (int q = 0; q < R / 2; ++q) min_in_place(best[q], key[q]);
         };
-        // Three loops, each with ONE straight-line form of the pass (the order of the candidates is irrelevant: the key
+        // Four loops, each with ONE straight-line form of the pass (the order of the candidates is irrelevant: the key
         // carries idx).  With the forms as branches of one loop body the compiler linearised them into guarded blocks,
         // kept the running minima in two register sets and copied between them: 8-16 v_mov per candidate.
-        //   whole : every row inside the window and on one side of the centre (index = k0 -/+ |dx|): no masks
+        //   whole : every row inside the window and on one side of the centre (above: index k0 - |dx|, below: k0 + |dx|): no masks
         //   above : some rows above the centre, masked          below : some rows at/below the centre, masked
         // (a candidate whose centre row lies inside this wavefront's rows is in both masked loops)
         const bool mine_todo = (todo >> lane) & 1ull;
         const uint32_t va_j = vab_j & 0xFFFFu, vb_j = vab_j >> 16;
-        unsigned long long todo_whole = __ballot(mine_todo && (va_j == full || vb_j == full));
+        unsigned long long todo_wa = __ballot(mine_todo && va_j == full);      // whole, above the centre
+        unsigned long long todo_wb = __ballot(mine_todo && vb_j == full);      // whole, at/below
         unsigned long long todo_above = __ballot(mine_todo && va_j != 0u && va_j != full);
         unsigned long long todo_below = __ballot(mine_todo && vb_j != 0u && vb_j != full);
         auto fetch = [&](int c, uint32_t& clab, uint32_t& uxc, uint32_t& k0, uint32_t& idx01) {
@@ -703,13 +704,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
             idx01 = (uint32_t)c | ((uint32_t)c << 16);
         };
 #pragma unroll 1
-        while (todo_whole) {
-            const int c = __builtin_ctzll(todo_whole);
-            todo_whole &= todo_whole - 1ull;
+        while (todo_wa) {
+            const int c = __builtin_ctzll(todo_wa);
+            todo_wa &= todo_wa - 1ull;
             uint32_t clab, uxc, k0, idx01;
             fetch(c, clab, uxc, k0, idx01);
-            const bool above = __builtin_amdgcn_readlane(va_j, c) != 0u;
-            pass(clab, k0 + (uint32_t)__mul24((int)uxc, above ? -1 : 1), idx01, nullptr);
+            pass(clab, k0 - uxc, idx01, nullptr);
+        }
+#pragma unroll 1
+        while (todo_wb) {
+            const int c = __builtin_ctzll(todo_wb);
+            todo_wb &= todo_wb - 1ull;
+            uint32_t clab, uxc, k0, idx01;
+            fetch(c, clab, uxc, k0, idx01);
+            pass(clab, k0 + uxc, idx01, nullptr);
         }
 #pragma unroll 1
         while (todo_above) {
