@@ -371,6 +371,8 @@ typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 // Algorithmic traffic: 4 B read + 2 B written per visited pixel.
 // =============================================================================================
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+constexpr int kRawBuffer = 0x00020000;     // 4th dword of a raw (stride 0) buffer descriptor on gfx9-family targets: DATA_FORMAT = 32
+constexpr int kAuxSc1 = 16;                // cache policy bit of the buffer builtins: sc1 (write through at agent scope)
 
 // key pair = min(dist * 64 + idx, 0xffff) for two rows at once: v_pk_mad_u16 with the clamp bit saturates the full-width
 // result, so a distance carrying the out-of-window marker (kTabOut, >= 1024) or an idx operand of 0xffff gives 0xffff
@@ -473,14 +475,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
     uint32_t pix[R];
     auto load_pixels = [&]() {
         const uint32_t xc = (uint32_t)min(x, W - 1);
-        const int nr1 = max(nrows, 1) - 1;             // a wavefront without rows (bottom edge) re-reads the image's last visited row
-        const int ybase = nrows > 0 ? yw_lo : rem + (Hv - 1) * STRIDE;
-        // one 64-bit row address per wavefront, then 32-bit byte offsets (R * STRIDE * W * 4 < 2^32): a 64-bit product per
-        // row was 6 scalar instructions per load on the list builder's critical path
-        const char* base = reinterpret_cast<const char*>(f.lab + (size_t)ybase * W);
-        const uint32_t pitch = (uint32_t)(STRIDE * W) * 4u, vo = xc * 4u;
+        const int nr1 = (int)rfl((uint32_t)(max(nrows, 1) - 1));      // a wavefront without rows (bottom edge) re-reads the image's last visited row
+        const int ybase = (int)rfl((uint32_t)(nrows > 0 ? yw_lo : rem + (Hv - 1) * STRIDE));   // (both wave-uniform: stated, the scalar offsets below must be SGPRs)
+        // buffer loads: the row goes into the instruction's scalar offset, the column into ONE shared vector offset, so a
+        // row costs no vector instruction beyond the load itself (a 64-bit address per row was 6 scalar + 1 vector)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(f.lab), 0, (int)((uint32_t)f.N * 4u), kRawBuffer);
+        const uint32_t pitch = (uint32_t)(STRIDE * W) * 4u, soff0 = (uint32_t)ybase * (uint32_t)W * 4u;
+        const int vo = (int)(xc * 4u);
 #pragma unroll
-        for (int r = 0; r < R; ++r) pix[r] = *reinterpret_cast<const uint32_t*>(base + (vo + (uint32_t)min(r, nr1) * pitch));
+        for (int r = 0; r < R; ++r) pix[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (int)(soff0 + (uint32_t)min(r, nr1) * pitch), 0);
     };
 
     // The list is built by ONE wavefront while the other three stage the table.  A block's wavefront i runs on SIMD i, so
@@ -783,9 +786,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
         for (int q = 1; q < R / 2; ++q) worst = __builtin_elementwise_max(worst, best[q]);
         const bool all_found = __ballot(worst.x == 0xFFFF || worst.y == 0xFFFF) == 0ull;
         if (all_found && nrows == R) {
-            if (okx) {
+            if (okx) {      // written through (sc1, see st_stream), row in the scalar offset, column in one shared vector offset
+                const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(f.labels, 0, (int)((uint32_t)f.N * 2u), kRawBuffer);
+                const uint32_t so0 = (uint32_t)yw_lo * (uint32_t)W * 2u, pitch2 = (uint32_t)(STRIDE * W) * 2u;
 #pragma unroll
-                for (int r = 0; r < R; ++r) st_stream(rowp + (size_t)r * STRIDE * W + xo, (uint16_t)kk[r]);
+                for (int r = 0; r < R; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b16((uint16_t)kk[r], ws, (int)(xo * 2u), (int)(so0 + (uint32_t)r * pitch2), kAuxSc1);
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -913,7 +919,7 @@ PassGeom launch_assign(const FrameDev& f_, int nframes, int rem, int stride, int
     pg.rem = rem; pg.stride = stride; pg.Hv = Hv; pg.BH = kWavesPerBlock * 8; pg.use_slots = 0;
     if (Hv <= 0) return pg;
     static const int which = getenv("FSLIC_ASSIGN") ? atoi(getenv("FSLIC_ASSIGN")) : 0;   // 32: force the 32-bit kernel (A/B timing)
-    if (f.tab_words > 0 && stride >= 1 && stride <= 3 && which == 0) {       // block-level packed kernel
+    if (f.tab_words > 0 && stride >= 1 && stride <= 3 && which == 0 && (unsigned long long)f.N * 4ull < 0xFFFFFFFFull) {       // block-level packed kernel (its buffer loads address a plane with 32-bit byte offsets)
         if (!fuse_update && stride == 1) {
             if (assign_rows_per_wave(f, nframes, Hv, false) == 16) launch_assign_blk_t<16, false, 1>(f, nframes, rem, Hv, st);
             else launch_assign_blk_t<8, false, 1>(f, nframes, rem, Hv, st);

@@ -20,7 +20,7 @@ python $R/scripts/rocpd_stats.py overlap $DB 0.4 > $OUT/bench_stream_overlap.txt
 python $R/scripts/rocpd_stats.py window $DB 5000 700 > $OUT/bench_all_streams_window.txt
 rm -rf $OUT/p
 # 2. single-stream timelines
-for cfg in "720 1280 1600 4 slic 8" "2160 3840 1600 4 slic 1" "2160 3840 1600 4 slic 4" "2160 3840 6000 4 slic 1" "720 1280 1600 4 lsc 8"; do
+for cfg in "720 1280 1600 4 slic 8" "2160 3840 1600 4 slic 1" "2160 3840 1600 4 slic 4" "2160 3840 1600 4 slic 8" "2160 3840 6000 4 slic 1" "720 1280 1600 4 lsc 8"; do
   set -- $cfg
   tag=${2}x${1}_k${3}_${5}_x${6}
   rm -rf $OUT/p
@@ -47,7 +47,7 @@ cd $R
 GRAFT_REPO_ROOT=$R PMC_G=8 bash scripts/gpu_pmc_cycles.sh > $OUT/pmc_cycles_4k_x8.txt 2>&1
 GRAFT_REPO_ROOT=$R PMC_H=720 PMC_W=1280 PMC_G=8 bash scripts/gpu_pmc_cycles.sh > $OUT/pmc_cycles_720p_x8.txt 2>&1
 # 5. microbenchmarks
-for m in kernel_boundary graph_launch lds_unaligned dispatch_rate valu_rate; do
+for m in ${MICROBENCH:-kernel_boundary graph_launch lds_unaligned dispatch_rate valu_rate pk_mad_clamp}; do
   [ -x scripts/microbench/$m.out ] && timeout 200 scripts/microbench/$m.out > $OUT/microbench_$m.txt 2>&1
 done
 ls $OUT
