@@ -820,34 +820,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
     FSLIC_STAMP(4);
     if (FUSE) {
         {
-            bool uni = slot[0] != kNoSlot;
-#pragma unroll
-            for (int r = 1; r < R; ++r) uni = uni && (slot[r] == slot[0]);
+            // A column's rows fall into one or two runs of equal slot (a superpixel is taller than a wavefront's rows), so the
+            // sums are kept in registers per run and flushed when the slot changes: 2 LDS atomics per run instead of 2 per
+            // pixel (the 64-bit words as two 32-bit halves: no field carries across bit 32, see s_acc).
             const uint32_t copy = (uint32_t)lane & (kBlkCopies - 1);
             const uint32_t dyw = (uint32_t)(wave * R * STRIDE);            // first row of this wavefront relative to the block's
-            if (uni) {   // whole column in one superpixel: one pair of LDS atomics for R pixels
-                uint32_t sL = 0, sa = 0, sb = 0;
-#pragma unroll
-                for (int r = 0; r < R; ++r) { sL += pix[r] & 255u; sa += (pix[r] >> 8) & 255u; sb += (pix[r] >> 16) & 255u; }
-                unsigned long long* a = s_acc + (slot[0] * kBlkCopies + copy) * 2;
-                const unsigned long long A = (unsigned long long)(sL | (sa << 20)) | ((unsigned long long)(sb << 8) << 32);
-                const uint32_t sdy = (uint32_t)R * dyw + (uint32_t)(STRIDE * (R * (R - 1) / 2));
-                const unsigned long long B = (unsigned long long)((uint32_t)R * (uint32_t)lane | (sdy << 20)) | ((unsigned long long)((uint32_t)R << 8) << 32);
-                atomicAdd(a, A);
-                atomicAdd(a + 1, B);
-            } else {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    if (slot[r] != kNoSlot) {
-                        unsigned long long* a = s_acc + (slot[r] * kBlkCopies + copy) * 2;
-                        const uint32_t p = pix[r];
-                        const unsigned long long A = (unsigned long long)((p & 255u) | ((p & 0xFF00u) << 12)) | ((unsigned long long)((p >> 8) & 0xFF00u) << 32);
-                        const unsigned long long B = (unsigned long long)((uint32_t)lane | ((dyw + (uint32_t)(r * STRIDE)) << 20)) | (256ull << 32);
-                        atomicAdd(a, A);
-                        atomicAdd(a + 1, B);
-                    }
+            uint32_t cur = slot[0], a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0;
+            auto flush = [&]() {
+                if (cur != kNoSlot) {
+                    unsigned long long* a = s_acc + (cur * kBlkCopies + copy) * 2;
+                    atomicAdd(a, (unsigned long long)a_lo | ((unsigned long long)a_hi << 32));
+                    atomicAdd(a + 1, (unsigned long long)b_lo | ((unsigned long long)b_hi << 32));
                 }
+            };
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (r > 0 && slot[r] != cur) {
+                    flush();
+                    cur = slot[r]; a_lo = 0; a_hi = 0; b_lo = 0; b_hi = 0;
+                }
+                const uint32_t p = pix[r];
+                a_lo += (p & 255u) | ((p & 0xFF00u) << 12);                // sum L | sum a << 20
+                a_hi += (p >> 8) & 0xFF00u;                               // sum b << 40
+                b_lo += (uint32_t)lane | ((dyw + (uint32_t)(r * STRIDE)) << 20);   // sum (x - x0) | sum (y - y0) << 20
+                b_hi += 256u;                                             // count << 40
             }
+            flush();
         }
         __syncthreads();
         // one plain store per (candidate, quantity): entry reserved for (cluster, this block), zeros included
