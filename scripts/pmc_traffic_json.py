@@ -1,0 +1,34 @@
+"""profiles/rNN_pmc_fetch_write_*.csv (scripts/gpu_profiles.sh, step 3) -> profiles/rNN_pmc_assign_traffic.json, the per-launch
+HBM traffic of the assign kernels that bench.py reports as roofline.traffic.
+   python scripts/pmc_traffic_json.py [profiles/r01]"""
+import csv, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+prefix = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r01")
+SETS = {"720p_x8": ("1280x720_x8", 1280 * 720 * 8, 3), "4k_k1600": ("3840x2160_x1", 3840 * 2160, 3)}   # tag, pixels per launch, subsample stride
+
+
+def read(path):
+    d = {}
+    for r in csv.reader(open(path)):
+        if len(r) < 4 or r[0] == "kernel":
+            continue
+        d[(r[0], r[1])] = float(r[2])
+    return d
+
+
+out = {"note": "bytes per launch = FETCH_SIZE*1024*2 + WRITE_SIZE*1024 (gfx950 correction on the read side only); mean over the "
+               "dispatches of separate rocprofv3 --pmc passes (profiles/r01_pmc_fetch_write_*.csv)"}
+for key, (tag, px, stride) in SETS.items():
+    d = read("%s_pmc_fetch_write_%s.csv" % (prefix, tag))
+    ent = {}
+    for name, fused in (("full_assign", False), ("fused_assign_update", True)):
+        sel = [k for k in d if "k_assign_blk" in k[0] and (", true," in k[0]) == fused]
+        f = [d[k] for k in sel if k[1] == "FETCH_SIZE"]
+        w = [d[k] for k in sel if k[1] == "WRITE_SIZE"]
+        if not f or not w:
+            continue
+        ent[name] = {"fetch_kib": round(f[0], 1), "write_kib": round(w[0], 1), "bytes": round(f[0] * 1024 * 2 + w[0] * 1024, 1),
+                     "algorithmic_bytes": 6 * px // (stride if fused else 1)}
+    out[key] = ent
+json.dump(out, open(prefix + "_pmc_assign_traffic.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
