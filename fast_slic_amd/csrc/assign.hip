@@ -2,6 +2,7 @@
 // Hand-written gfx950 (CDNA4, wave64) kernels of the SLIC hot path; see kernels.h for the launch interface and
 // DESIGN.md for the design.  All arithmetic on this path is integer, so results are bit-identical to the reference.
 #include "device_common.h"
+#include <type_traits>
 #ifndef FSLIC_EXP
 #define FSLIC_EXP 0      // timing experiments (scripts/gpu_exp.sh): results are wrong when != 0
 #endif
@@ -430,6 +431,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];   // spatial table (u16), f.tab_words dwords; 16-byte aligned: the row-vector reads are ds_read_b128
     __shared__ uint32_t s_braw[3 * 128];                 // compaction buffer: entries 0..63 kept records, 64..127 scratch
     __shared__ uint4 s_list[64];                         // {yx, lab, k, cpart entry | kNoSlot}
+    __shared__ uint16_t s_k16[256];                      // cluster number by the low BYTE of a key: entry e = k of candidate e & 63 (four replicas), so
+                                                         // the epilogue's address is one SDWA shift of the key instead of mask + shift
     __shared__ uint32_t s_bn;
     // centroid accumulators: per (candidate, copy) two 64-bit words of three 20-bit-spaced fields each,
     //   A = sum L | sum a << 20 | sum b << 40        B = sum (x - x0) | sum (y - y0) << 20 | count << 40
@@ -580,7 +583,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
                 if (g.any && by >= g.by0 && by <= g.by1)
                     entry = (k * (uint32_t)f.cpart_ns + (uint32_t)((by - g.by0) * f.nbx + (bx - g.bx0))) * 6u;
             }
-            if (act) s_list[rank] = make_uint4(yx_j, lab_j, tag_j & 0xFFFFu, entry);
+            if (act) {
+                s_list[rank] = make_uint4(yx_j, lab_j, tag_j & 0xFFFFu, entry);
+                const uint16_t k16 = (uint16_t)(tag_j & 0xFFFFu);
+                s_k16[rank] = k16; s_k16[64 + rank] = k16; s_k16[128 + rank] = k16; s_k16[192 + rank] = k16;
+            }
         }
         if (lane == 0) s_bn = (uint32_t)bn;
         FSLIC_GSTAMP(5);
@@ -697,12 +704,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
         unsigned long long todo_wb = __ballot(mine_todo && vb_j == full);      // whole, at/below
         unsigned long long todo_above = __ballot(mine_todo && va_j != 0u && va_j != full);
         unsigned long long todo_below = __ballot(mine_todo && vb_j != 0u && vb_j != full);
-        auto fetch = [&](int c, uint32_t& clab, uint32_t& uxc, uint32_t& k0, uint32_t& idx01) {
+        // CLAMP: lanes outside the x window get |dx| = xout (every row then reads the marker); !CLAMP: the caller runs the pass
+        // under `if (uxc <= S)` instead, i.e. with those lanes switched off (one vector instruction less per candidate)
+        auto fetch = [&](int c, uint32_t& clab, uint32_t& uxc, uint32_t& k0, uint32_t& idx01, auto clamp_tag) {
+            constexpr bool CLAMP = decltype(clamp_tag)::value;
             const uint32_t cyx = __builtin_amdgcn_readlane(yx_j, c);
             clab = __builtin_amdgcn_readlane(lab_j, c);
             const int cy = (int)(cyx >> 16), cx = (int)(cyx & 0xFFFFu);
             const uint32_t ux = __builtin_amdgcn_sad_u16((uint32_t)x, (uint32_t)cx, 0u);      // |x - cx|
-            uxc = ux <= (uint32_t)S ? ux : xout;
+            uxc = CLAMP ? (ux <= (uint32_t)S ? ux : xout) : ux;
             k0 = (uint32_t)(Cc + yw_lo - cy);                                                  // wave-uniform
             idx01 = (uint32_t)c | ((uint32_t)c << 16);
         };
@@ -711,23 +721,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
             const int c = __builtin_ctzll(todo_wa);
             todo_wa &= todo_wa - 1ull;
             uint32_t clab, uxc, k0, idx01;
-            fetch(c, clab, uxc, k0, idx01);
-            pass(clab, k0 - uxc, idx01, nullptr);
+            fetch(c, clab, uxc, k0, idx01, std::false_type{});
+            if (uxc <= (uint32_t)S) pass(clab, k0 - uxc, idx01, nullptr);
         }
 #pragma unroll 1
         while (todo_wb) {
             const int c = __builtin_ctzll(todo_wb);
             todo_wb &= todo_wb - 1ull;
             uint32_t clab, uxc, k0, idx01;
-            fetch(c, clab, uxc, k0, idx01);
-            pass(clab, k0 + uxc, idx01, nullptr);
+            fetch(c, clab, uxc, k0, idx01, std::false_type{});
+            if (uxc <= (uint32_t)S) pass(clab, k0 + uxc, idx01, nullptr);
         }
 #pragma unroll 1
         while (todo_above) {
             const int c = __builtin_ctzll(todo_above);
             todo_above &= todo_above - 1ull;
             uint32_t clab, uxc, k0, idx01, mq[R / 2];
-            fetch(c, clab, uxc, k0, idx01);
+            fetch(c, clab, uxc, k0, idx01, std::true_type{});
             row_masks<R>(~__builtin_amdgcn_readlane(va_j, c) & full, mq);
             pass(clab, k0 - uxc, idx01, mq);
         }
@@ -736,7 +746,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
             const int c = __builtin_ctzll(todo_below);
             todo_below &= todo_below - 1ull;
             uint32_t clab, uxc, k0, idx01, mq[R / 2];
-            fetch(c, clab, uxc, k0, idx01);
+            fetch(c, clab, uxc, k0, idx01, std::true_type{});
             row_masks<R>(~__builtin_amdgcn_readlane(vb_j, c) & full, mq);
             pass(clab, k0 + uxc, idx01, mq);
         }
@@ -773,7 +783,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
 #if FSLIC_EXP == 2
             kk[r] = key & 63u;
 #else
-            kk[r] = s_list[key & 63u].z;                            // idx 63 when not found: read, never used
+            kk[r] = s_k16[key & 255u];                              // entry 255 when not found: read, never used
 #endif
         }
         uint16_t* rowp = f.labels + (size_t)yw_lo * W;
