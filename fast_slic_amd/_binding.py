@@ -42,6 +42,7 @@ EXPORTS = [
     "fslic_hip_wait_group", "fslic_hip_rgb_to_lab",
     "fslic_hip_enforce_connectivity", "fslic_hip_last_prelabels", "fslic_hip_last_timing_report",
     "fslic_hip_last_device_times", "fslic_hip_set_launch_timing", "fslic_hip_last_assign_loop", "fslic_hip_last_group_frames", "fslic_hip_last_path", "fslic_hip_last_launch_mode", "fslic_hip_group_done", "fslic_hip_last_error", "fslic_hip_version",
+    "fslic_hip_get_connectivity", "fslic_hip_knn_connectivity", "fslic_hip_get_mask_density", "fslic_hip_cluster_density_to_mask",
 ]
 
 _lib = None
@@ -119,6 +120,11 @@ def load_library():
             lib.fslic_hip_last_launch_mode.argtypes = [vp, i32]
         lib.fslic_hip_last_error.restype = C.c_char_p
         lib.fslic_hip_version.restype = C.c_char_p
+        if hasattr(lib, "fslic_hip_get_connectivity"):
+            lib.fslic_hip_get_connectivity.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+            lib.fslic_hip_knn_connectivity.argtypes = [i32, i32, i32, vp, C.c_size_t, vp, vp]
+            lib.fslic_hip_get_mask_density.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
+            lib.fslic_hip_cluster_density_to_mask.argtypes = [vp, i32, i32, i32, vp, vp, vp]
         _lib = lib
         return lib
 
@@ -174,6 +180,41 @@ class Engine(object):
         H, W = out.shape
         _check(load_library().fslic_hip_enforce_connectivity(self._h, out.ctypes.data, H, W, int(K), int(min_threshold)))
         return out
+
+    # ---- superpixel-graph utilities (src/fast-slic.cpp); labels / mask / result: numpy arrays or raw device pointers (int) ----
+    @staticmethod
+    def _plane(a, dtype):
+        """(pointer, keep-alive) of a host array or of device memory given as an integer address."""
+        if isinstance(a, (int, np.integer)):
+            return C.c_void_p(int(a)), None
+        arr = np.ascontiguousarray(a, dtype=dtype)
+        return C.c_void_p(arr.ctypes.data), arr
+
+    def get_connectivity(self, labels, H, W, K):
+        ptr, keep = self._plane(labels, np.uint16)
+        num = np.zeros(K, np.int32)
+        nb = np.zeros((K, 12), np.uint32)
+        _check(load_library().fslic_hip_get_connectivity(self._h, H, W, int(K), ptr, num.ctypes.data, nb.ctypes.data))
+        return num, nb
+
+    def get_mask_density(self, clusters, labels, mask, H, W):
+        lp, k1 = self._plane(labels, np.uint16)
+        mp, k2 = self._plane(mask, np.uint8)
+        cl = np.ascontiguousarray(clusters)
+        dens = np.zeros(cl.shape[0], np.uint8)
+        _check(load_library().fslic_hip_get_mask_density(self._h, H, W, cl.shape[0], cl.ctypes.data, lp, mp, dens.ctypes.data))
+        return dens
+
+    def cluster_density_to_mask(self, labels, densities, H, W, out=None):
+        lp, k1 = self._plane(labels, np.uint16)
+        d = np.ascontiguousarray(densities, dtype=np.uint8)
+        if out is None:
+            res = np.empty((H, W), np.uint8)
+            op = C.c_void_p(res.ctypes.data)
+        else:
+            res, op = out, C.c_void_p(int(out))
+        _check(load_library().fslic_hip_cluster_density_to_mask(self._h, H, W, d.shape[0], lp, d.ctypes.data, op))
+        return res
 
     def iterate(self, image, clusters, params):
         """Host numpy in, host numpy out (uint16 labels); clusters (CLUSTER_DTYPE[K]) updated in place."""
@@ -397,6 +438,45 @@ class SlicModel(object):
                                                             self._clusters.ctypes.data))
         self.initialized = True
 
+    @staticmethod
+    def _check_assignments(assignments):
+        a = np.asarray(assignments)
+        if a.dtype != np.int16 or a.ndim != 2 or not a.flags["C_CONTIGUOUS"]:
+            raise ValueError("assignments must be a C-contiguous int16 array of shape [H, W]")
+        return a
+
+    def get_connectivity(self, assignments):                                       # pyx:262-273
+        a = self._check_assignments(assignments)
+        H, W = a.shape
+        num, nb = self._engine.get_connectivity(a.view(np.uint16), H, W, self.num_components)
+        return NodeConnectivity(num, nb)
+
+    def get_knn_connectivity(self, assignments, num_neighbors):                    # pyx:275-282
+        a = self._check_assignments(assignments)
+        H, W = a.shape
+        num, nb = knn_connectivity(H, W, self._clusters, num_neighbors)
+        return NodeConnectivity(num, nb)
+
+    def get_mask_density(self, mask, assignments):                                 # pyx:284-304
+        a = self._check_assignments(assignments)
+        m = np.asarray(mask)
+        if m.dtype != np.uint8 or m.ndim != 2 or not m.flags["C_CONTIGUOUS"]:
+            raise ValueError("mask must be a C-contiguous uint8 array of shape [H, W]")
+        H, W = a.shape
+        if m.shape[0] != H or m.shape[1] != W:
+            raise ValueError("The shape of mask does not match the one of assignments")          # pyx:290-291
+        return self._engine.get_mask_density(self._clusters, a.view(np.uint16), m, H, W)
+
+    def broadcast_density_to_mask(self, densities, assignments):                   # pyx:306-324
+        a = self._check_assignments(assignments)
+        d = np.asarray(densities)
+        if d.dtype != np.uint8 or d.ndim != 1:
+            raise ValueError("densities must be a uint8 array of shape [K]")
+        if d.shape[0] != self.num_components:
+            raise ValueError("The shape of densities should match the number of clusters")       # pyx:310-311
+        H, W = a.shape
+        return self._engine.cluster_density_to_mask(a.view(np.uint16), d, H, W)
+
     def iterate(self, image, max_iter, compactness, min_size_factor, subsample_stride):   # pyx:150-260
         if not self.initialized:
             raise RuntimeError("Slic model is not initialized")                    # pyx:151-152
@@ -414,6 +494,30 @@ class SlicModel(object):
         result = labels.astype(np.int16)                                           # pyx:258-260
         result[labels == 0xFFFF] = -1
         return result
+
+
+class NodeConnectivity(object):
+    """cfast_slic.NodeConnectivity (cfast_slic.pyx:330-351): per-cluster neighbour lists."""
+
+    def __init__(self, num_neighbors, neighbors):
+        self.num_neighbors = num_neighbors
+        self.neighbors = neighbors
+
+    def tolist(self):                                                              # pyx:337-347
+        return [[int(v) for v in self.neighbors[k, :self.num_neighbors[k]]] for k in range(self.num_neighbors.shape[0])]
+
+
+def knn_connectivity(H, W, clusters, num_neighbors):
+    """fast_slic_knn_connectivity (src/fast-slic.cpp:80-130): host only, no engine needed."""
+    cl = np.ascontiguousarray(clusters)
+    K = cl.shape[0]
+    n = int(num_neighbors)
+    if n < 0:
+        raise OverflowError("num_neighbors must be non-negative")
+    num = np.zeros(K, np.int32)
+    nb = np.zeros((K, max(n, 1)), np.uint32)
+    _check(load_library().fslic_hip_knn_connectivity(int(H), int(W), K, cl.ctypes.data, n, num.ctypes.data, nb.ctypes.data))
+    return num, nb[:, :n]
 
 
 def enforce_connectivity(assignments, min_threshold, device=0):

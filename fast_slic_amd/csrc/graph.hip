@@ -1,0 +1,118 @@
+// graph.hip -- superpixel-graph utilities on a finished label map (src/fast-slic.cpp), gfx950.
+//   k_mask_sums        : per-cluster sums of a mask plane            (fast_slic_get_mask_density, src/fast-slic.cpp:141-150)
+//   k_density_to_mask  : per-pixel broadcast of a per-cluster value  (fast_slic_cluster_density_to_mask, :156-168)
+//   k_adjacent_pairs   : the distinct adjacent label pairs of the map with the raster position of their FIRST
+//                        occurrence in the reference's scan (fast_slic_get_connectivity, :16-78); the host orders them
+//                        and applies the sequential 12-neighbour cap (engine.cpp)
+// All integer work; HBM-bound (2-3 B per pixel), no reshaping.
+#include "device_common.h"
+#include <algorithm>
+
+namespace fslic {
+
+// ---- mask density -----------------------------------------------------------------------------
+// One wavefront per 64 consecutive pixels.  The labels of a run of pixels repeat, so the wavefront adds up the mask
+// values of every distinct label it holds (DPP reduction) and issues ONE global atomic per (wavefront, label) instead
+// of one per pixel.  Kt = (uint16_t)K as in the reference's comparison (src/fast-slic.cpp:147).
+__global__ __launch_bounds__(256) void k_mask_sums(const uint16_t* __restrict__ labels, const uint8_t* __restrict__ mask,
+                                                   uint32_t* __restrict__ sums, unsigned long long N, uint32_t Kt) {
+    const int lane = LANE();
+    const unsigned long long nwaves = (unsigned long long)gridDim.x * 4ull;
+    const uint32_t wave = rfl(threadIdx.x >> 6);
+    for (unsigned long long base = ((unsigned long long)blockIdx.x * 4ull + wave) * 64ull; base < N; base += nwaves * 64ull) {
+        const unsigned long long p = base + (unsigned long long)lane;
+        const bool ok = p < N;
+        const uint32_t lab = ok ? (uint32_t)labels[p] : 0xFFFFFFFFu;
+        const uint32_t m = ok ? (uint32_t)mask[p] : 0u;
+        const bool live = ok && lab < Kt;
+        unsigned long long todo = __ballot(live);
+        while (todo) {                                              // wave-uniform: every lane takes part in the reduction
+            const int l = __builtin_ctzll(todo);
+            const uint32_t cur = __builtin_amdgcn_readlane(lab, l);
+            const bool mine = live && lab == cur;
+            const unsigned long long same = __ballot(mine);
+            const uint32_t s = wave_reduce_add<uint32_t>(mine ? m : 0u);
+            if (lane == l && s != 0u) atomicAdd(&sums[cur], s);
+            todo &= ~same;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_density_to_mask(const uint16_t* __restrict__ labels, const uint8_t* __restrict__ dens,
+                                                         uint8_t* __restrict__ out, unsigned long long N, uint32_t Kt) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256ull;
+    for (unsigned long long p = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; p < N; p += stride) {
+        const uint32_t lab = labels[p];
+        out[p] = lab < Kt ? dens[lab] : (uint8_t)0;
+    }
+}
+
+// ---- adjacency --------------------------------------------------------------------------------
+// The reference scans the pixels (i < H-1, j < W-1) in raster order and looks right, down and down-right
+// (src/fast-slic.cpp:69-71).  Event key of an occurrence = pixel index * 4 + direction: ascending key == scan order.
+// Open-addressing table keyed by the unordered pair (lo << 16 | hi); the value is the minimum event key.
+// Plain pre-reads only ever see values that are not newer than the truth (keys only decrease, a filled slot never
+// changes), so skipping on them is safe; the atomics decide.
+constexpr uint32_t kPairEmpty = 0xFFFFFFFFu;
+static __device__ __forceinline__ uint32_t pair_hash(uint32_t v) {
+    v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16;
+    return v;
+}
+__global__ __launch_bounds__(256) void k_adjacent_pairs(const uint16_t* __restrict__ labels, int H, int W, uint32_t K,
+                                                        uint32_t* __restrict__ tab_pair, unsigned long long* __restrict__ tab_key,
+                                                        uint32_t cap_mask, uint32_t* __restrict__ counters) {
+    const unsigned long long npx = (unsigned long long)(H - 1) * (unsigned long long)(W - 1);
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256ull;
+    for (unsigned long long q = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; q < npx; q += stride) {
+        const unsigned long long i = q / (unsigned long long)(W - 1), j = q - i * (unsigned long long)(W - 1);
+        const unsigned long long p = i * (unsigned long long)W + j;
+        const uint32_t s = labels[p];
+        if (s >= K) continue;
+        const uint32_t t3[3] = {labels[p + 1], labels[p + (unsigned long long)W], labels[p + (unsigned long long)W + 1]};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const uint32_t t = t3[d];
+            if (t >= K || t == s) continue;
+            if (d == 1 && t == t3[0]) continue;                     // same pair as a smaller key of this very pixel
+            if (d == 2 && (t == t3[0] || t == t3[1])) continue;
+            const uint32_t pair = (min(s, t) << 16) | max(s, t);
+            const unsigned long long key = p * 4ull + (unsigned long long)d;
+            uint32_t h = pair_hash(pair) & cap_mask;
+            bool done = false;
+            for (uint32_t probe = 0; probe <= cap_mask; ++probe) {
+                uint32_t cur = tab_pair[h];
+                if (cur == kPairEmpty) {
+                    cur = atomicCAS(&tab_pair[h], kPairEmpty, pair);
+                    if (cur == kPairEmpty) { atomicAdd(&counters[0], 1u); cur = pair; }      // counters[0]: distinct pairs stored
+                }
+                if (cur == pair) {
+                    if (tab_key[h] > key) atomicMin(&tab_key[h], key);
+                    done = true;
+                    break;
+                }
+                h = (h + 1u) & cap_mask;
+            }
+            if (!done) atomicExch(&counters[1], 1u);                // counters[1]: table full
+        }
+    }
+}
+
+// ---- launches ---------------------------------------------------------------------------------
+static inline int grid_for(unsigned long long items, unsigned long long per_block) {
+    const unsigned long long want = (items + per_block - 1) / per_block;
+    return (int)std::max<unsigned long long>(1ull, std::min<unsigned long long>(want, 256ull * 32ull));   // grid-stride beyond 32 blocks per CU
+}
+void launch_mask_sums(const uint16_t* labels, const uint8_t* mask, uint32_t* sums, size_t N, int K, hipStream_t st) {
+    hipLaunchKernelGGL(k_mask_sums, dim3(grid_for(N, 256)), dim3(256), 0, st, labels, mask, sums, (unsigned long long)N, (uint32_t)(uint16_t)K);
+}
+void launch_density_to_mask(const uint16_t* labels, const uint8_t* dens, uint8_t* out, size_t N, int K, hipStream_t st) {
+    hipLaunchKernelGGL(k_density_to_mask, dim3(grid_for(N, 256)), dim3(256), 0, st, labels, dens, out, (unsigned long long)N, (uint32_t)(uint16_t)K);
+}
+void launch_adjacent_pairs(const uint16_t* labels, int H, int W, int K, uint32_t* tab_pair, unsigned long long* tab_key,
+                           uint32_t cap, uint32_t* counters, hipStream_t st) {
+    if (H < 2 || W < 2) return;
+    const unsigned long long npx = (unsigned long long)(H - 1) * (unsigned long long)(W - 1);
+    hipLaunchKernelGGL(k_adjacent_pairs, dim3(grid_for(npx, 256)), dim3(256), 0, st, labels, H, W, (uint32_t)K, tab_pair, tab_key, cap - 1u, counters);
+}
+
+}  // namespace fslic

@@ -135,6 +135,34 @@ int fslic_hip_rgb_to_lab(fslic_engine* e, int H, int W, const uint8_t* rgb, int 
  * exposed by cfast_slic.enforce_connectivity (cfast_slic.pyx:371-396).  In place, host pointer. */
 int fslic_hip_enforce_connectivity(fslic_engine* e, uint16_t* labels, int H, int W, int K, int min_threshold);
 
+/* ---- Superpixel-graph utilities on a finished label map (src/fast-slic.h:13-17, src/fast-slic.cpp; reached from
+ * SlicModel.get_connectivity / get_knn_connectivity / get_mask_density / broadcast_density_to_mask,
+ * cfast_slic.pyx:262-324).  `labels` (H*W uint16), `mask` (H*W uint8) and `result` (H*W uint8) may be host pointers or
+ * device pointers (a label map left in HBM by fslic_hip_iterate_device needs no copy); the per-cluster arrays are host
+ * arrays.  The reference returns a heap-allocated Connectivity (src/fast-slic-common.h:25-29); here the same content is
+ * written into caller arrays: num_neighbors[K] and neighbors[K][stride] (unused entries 0). */
+
+/* fast_slic_get_connectivity(H, W, K, assignment), src/fast-slic.cpp:16-78: for every cluster its adjacent clusters
+ * (right / down / down-right scan) in the order the raster scan meets them, at most 12 per cluster with the
+ * reference's order-dependent cut-off.  stride = 12. */
+int fslic_hip_get_connectivity(fslic_engine* e, int H, int W, int K, const uint16_t* labels,
+                               int* num_neighbors, uint32_t* neighbors);
+
+/* fast_slic_knn_connectivity(H, W, K, clusters, num_neighbors), src/fast-slic.cpp:80-130.  Host only (O(K)); the
+ * neighbour order is the reference's heap order.  stride = n_neighbors. */
+int fslic_hip_knn_connectivity(int H, int W, int K, const fslic_cluster* clusters, size_t n_neighbors,
+                               int* num_neighbors, uint32_t* neighbors);
+
+/* fast_slic_get_mask_density(H, W, K, clusters, assignment, mask, cluster_densities), src/fast-slic.cpp:141-154:
+ * densities[k] = min(255, sum of mask over the pixels labelled k / max(num_members[k], 1)). */
+int fslic_hip_get_mask_density(fslic_engine* e, int H, int W, int K, const fslic_cluster* clusters,
+                               const uint16_t* labels, const uint8_t* mask, uint8_t* densities);
+
+/* fast_slic_cluster_density_to_mask(H, W, K, clusters, assignment, cluster_densities, result), src/fast-slic.cpp:156-168
+ * (the reference's `clusters` argument is unused and not taken): result[p] = densities[labels[p]], 0 for labels >= K. */
+int fslic_hip_cluster_density_to_mask(fslic_engine* e, int H, int W, int K, const uint16_t* labels,
+                                      const uint8_t* densities, uint8_t* result);
+
 /* Labels after full_assign and before the connectivity pass (BaseContext::assignment,
  * src/context.cpp:182-190) of the last fslic_hip_iterate*() call on `slot`; host pointer, H*W. */
 int fslic_hip_last_prelabels(fslic_engine* e, int slot, uint16_t* prelabels);

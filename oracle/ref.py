@@ -113,6 +113,48 @@ def enforce_connectivity(labels_u16, K, min_threshold, num_threads=1):
     return out
 
 
+def get_connectivity(labels_u16, K):
+    """fast_slic_get_connectivity (src/fast-slic.cpp:16-78) -> (num[K] int32, neighbors[K,12] uint32)"""
+    a = np.ascontiguousarray(labels_u16, dtype=np.uint16)
+    H, W = a.shape
+    num = np.zeros(K, np.int32)
+    nb = np.zeros((K, 12), np.uint32)
+    assert lib().ref_get_connectivity(H, W, int(K), _p(a), _p(num), _p(nb)) == 0
+    return num, nb
+
+
+def knn_connectivity(H, W, clusters, num_neighbors, num_threads=1):
+    """fast_slic_knn_connectivity (src/fast-slic.cpp:80-130) -> (num[K] int32, neighbors[K,n] uint32)"""
+    cl = np.ascontiguousarray(clusters)
+    K = cl.shape[0]
+    num = np.zeros(K, np.int32)
+    nb = np.zeros((K, max(int(num_neighbors), 1)), np.uint32)
+    assert lib().ref_knn_connectivity(int(H), int(W), K, _p(cl), int(num_neighbors), int(num_threads), _p(num), _p(nb)) == 0
+    return num, nb[:, :int(num_neighbors)]
+
+
+def get_mask_density(clusters, labels_u16, mask):
+    """fast_slic_get_mask_density (src/fast-slic.cpp:141-154)"""
+    a = np.ascontiguousarray(labels_u16, dtype=np.uint16)
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    cl = np.ascontiguousarray(clusters)
+    H, W = a.shape
+    d = np.zeros(cl.shape[0], np.uint8)
+    assert lib().ref_get_mask_density(H, W, cl.shape[0], _p(cl), _p(a), _p(m), _p(d)) == 0
+    return d
+
+
+def cluster_density_to_mask(clusters, labels_u16, densities):
+    """fast_slic_cluster_density_to_mask (src/fast-slic.cpp:156-168)"""
+    a = np.ascontiguousarray(labels_u16, dtype=np.uint16)
+    d = np.ascontiguousarray(densities, dtype=np.uint8)
+    cl = np.ascontiguousarray(clusters)
+    H, W = a.shape
+    out = np.zeros((H, W), np.uint8)
+    assert lib().ref_cluster_density_to_mask(H, W, cl.shape[0], _p(cl), _p(a), _p(d), _p(out)) == 0
+    return out
+
+
 def lab_tables():
     g = np.zeros(256, np.int32)
     t = np.zeros(8193, np.int32)

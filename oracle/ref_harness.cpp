@@ -36,6 +36,7 @@
 #undef protected
 #undef private
 #include "parallel.h"
+#include "fast-slic.h"
 
 namespace {
 // preemptive mode of the next iterate calls of this thread (cfast_slic.pyx:183-184); off by default
@@ -160,6 +161,36 @@ int ref_enforce_connectivity(uint16_t* labels, int H, int W, int K, int min_thre
     fsparallel::Scope scope(num_threads);
     cca::ConnectivityEnforcer ce(labels, H, W, K, min_threshold);
     ce.execute(labels);
+    return 0;
+}
+
+// ---- superpixel-graph utilities on a finished label map (src/fast-slic.cpp) ----
+// The reference returns a heap-allocated Connectivity; flattened here to num[K] + neighbors[K][stride].
+static void flatten_connectivity(Connectivity* conn, int K, int stride, int* num_out, uint32_t* nb_out) {
+    for (int k = 0; k < K; k++) {
+        num_out[k] = conn->num_neighbors[k];
+        for (int j = 0; j < stride; j++) nb_out[(size_t)k * stride + j] = j < conn->num_neighbors[k] ? conn->neighbors[k][j] : 0u;
+    }
+    fast_slic_free_connectivity(conn);
+}
+// fast_slic_get_connectivity (src/fast-slic.cpp:16-78); stride is its max_conn = 12
+int ref_get_connectivity(int H, int W, int K, const uint16_t* labels, int* num_out, uint32_t* nb_out) {
+    flatten_connectivity(fast_slic_get_connectivity(H, W, K, labels), K, 12, num_out, nb_out);
+    return 0;
+}
+// fast_slic_knn_connectivity (src/fast-slic.cpp:80-130); stride = num_neighbors
+int ref_knn_connectivity(int H, int W, int K, const Cluster* clusters, int num_neighbors, int num_threads, int* num_out, uint32_t* nb_out) {
+    fsparallel::Scope scope(num_threads);
+    flatten_connectivity(fast_slic_knn_connectivity(H, W, K, clusters, (size_t)num_neighbors), K, num_neighbors, num_out, nb_out);
+    return 0;
+}
+// fast_slic_get_mask_density / fast_slic_cluster_density_to_mask (src/fast-slic.cpp:141-168)
+int ref_get_mask_density(int H, int W, int K, const Cluster* clusters, const uint16_t* labels, const uint8_t* mask, uint8_t* densities) {
+    fast_slic_get_mask_density(H, W, K, clusters, labels, mask, densities);
+    return 0;
+}
+int ref_cluster_density_to_mask(int H, int W, int K, const Cluster* clusters, const uint16_t* labels, const uint8_t* densities, uint8_t* result) {
+    fast_slic_cluster_density_to_mask(H, W, K, clusters, labels, densities, result);
     return 0;
 }
 
