@@ -1703,7 +1703,7 @@ int fslic_hip_get_mask_density(fslic_engine* e, int H, int W, int K, const fslic
     Staged d_lab, d_mask, d_sums;
     if ((rc = stage_in(labels, N * 2, st, d_lab)) || (rc = stage_in(mask, N, st, d_mask)) || (rc = device_scratch((size_t)K * 4, d_sums))) return rc;
     HIPCHK(hipMemsetAsync(d_sums.p, 0, (size_t)K * 4, st));
-    launch_mask_sums((const uint16_t*)d_lab.p, (const uint8_t*)d_mask.p, (uint32_t*)d_sums.p, N, K, st);
+    launch_mask_sums((const uint16_t*)d_lab.p, (const uint8_t*)d_mask.p, (uint32_t*)d_sums.p, H, W, K, st);
     std::vector<uint32_t> sums((size_t)K);
     HIPCHK(hipMemcpyAsync(sums.data(), d_sums.p, (size_t)K * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));

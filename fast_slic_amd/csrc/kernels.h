@@ -237,7 +237,7 @@ void launch_cca_phase2(const CcaDev& c, int nframes, hipStream_t st);   // chain
 void launch_cca_set_kept(const CcaDev& c, const int32_t* d_leaders, const uint16_t* d_labels, int n, hipStream_t st);
 
 // superpixel-graph utilities on a finished label map (graph.hip; src/fast-slic.cpp)
-void launch_mask_sums(const uint16_t* labels, const uint8_t* mask, uint32_t* sums, size_t N, int K, hipStream_t st);
+void launch_mask_sums(const uint16_t* labels, const uint8_t* mask, uint32_t* sums, int H, int W, int K, hipStream_t st);
 void launch_density_to_mask(const uint16_t* labels, const uint8_t* dens, uint8_t* out, size_t N, int K, hipStream_t st);
 // tab_pair / tab_key: `cap` (a power of two) entries, all bytes 0xFF; counters: 2 words, zero ([0] pairs stored, [1] table full)
 void launch_adjacent_pairs(const uint16_t* labels, int H, int W, int K, uint32_t* tab_pair, unsigned long long* tab_key,
