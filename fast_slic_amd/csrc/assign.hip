@@ -500,7 +500,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
         const int sh = f.cs_shift;
         const ClusterRec* __restrict__ citems = f.cell_items[0];
         const ClusterRec* __restrict__ oitems = f.ovf_items[0];
-        const unsigned long long lowmask = (1ull << lane) - 1ull;
         TileWindow win;
         const int vlast = min(vrow_b0 + BH - 1, Hv - 1);
         win.wy_lo = rem + vrow_b0 * STRIDE - S; win.wy_hi = rem + vlast * STRIDE + S;
