@@ -926,7 +926,7 @@ PassGeom launch_assign(const FrameDev& f_, int nframes, int rem, int stride, int
     pg.rem = rem; pg.stride = stride; pg.Hv = Hv; pg.BH = kWavesPerBlock * 8; pg.use_slots = 0;
     if (Hv <= 0) return pg;
     static const int which = getenv("FSLIC_ASSIGN") ? atoi(getenv("FSLIC_ASSIGN")) : 0;   // 32: force the 32-bit kernel (A/B timing)
-    if (f.tab_words > 0 && stride >= 1 && stride <= 3 && which == 0 && (unsigned long long)f.N * 4ull < 0xFFFFFFFFull) {       // block-level packed kernel (its buffer loads address a plane with 32-bit byte offsets)
+    if (f.tab_words > 0 && stride >= 1 && stride <= 3 && which == 0 && (unsigned long long)f.N * 4ull < 0x7FFFFFFFull) {       // block-level packed kernel (its buffer loads address a plane with 31-bit byte offsets; larger planes take the 32-bit kernel)
         if (!fuse_update && stride == 1) {
             if (assign_rows_per_wave(f, nframes, Hv, false) == 16) launch_assign_blk_t<16, false, 1>(f, nframes, rem, Hv, st);
             else launch_assign_blk_t<8, false, 1>(f, nframes, rem, Hv, st);
