@@ -43,6 +43,7 @@ EXPORTS = [
     "fslic_hip_enforce_connectivity", "fslic_hip_last_prelabels", "fslic_hip_last_timing_report",
     "fslic_hip_last_device_times", "fslic_hip_set_launch_timing", "fslic_hip_last_assign_loop", "fslic_hip_last_group_frames", "fslic_hip_last_path", "fslic_hip_last_launch_mode", "fslic_hip_group_done", "fslic_hip_last_error", "fslic_hip_version",
     "fslic_hip_get_connectivity", "fslic_hip_knn_connectivity", "fslic_hip_get_mask_density", "fslic_hip_cluster_density_to_mask",
+    "fslic_hip_pipeline_submit", "fslic_hip_pipeline_drain", "fslic_hip_last_host_topk_frames",
 ]
 
 _lib = None
@@ -104,6 +105,9 @@ def load_library():
         lib.fslic_hip_iterate_batch.argtypes = [vp, C.POINTER(Params), i32, i32, i32, i32, vp, vp, vp, i32]
         lib.fslic_hip_submit_group.argtypes = [vp, i32, C.POINTER(Params), i32, i32, i32, i32, vp, vp, vp]
         lib.fslic_hip_wait_group.argtypes = [vp, i32]
+        lib.fslic_hip_pipeline_submit.argtypes = [vp, C.POINTER(Params), i32, i32, i32, i32, vp, vp, vp]
+        lib.fslic_hip_pipeline_drain.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+        lib.fslic_hip_last_host_topk_frames.argtypes = [vp, i32]
         if hasattr(lib, "fslic_hip_group_done"):
             lib.fslic_hip_group_done.argtypes = [vp, i32]
         lib.fslic_hip_rgb_to_lab.argtypes = [vp, i32, i32, vp, i32, vp]
@@ -256,6 +260,21 @@ class Engine(object):
     def wait_group(self, slot):
         _check(load_library().fslic_hip_wait_group(self._h, int(slot)))
 
+    def pipeline_submit(self, a_rgb, a_clusters, a_labels, n, H, W, K, params):
+        """Hand one group of n device-resident frames to whichever slot is free (blocks only while all are occupied)."""
+        _check(load_library().fslic_hip_pipeline_submit(self._h, C.byref(params), H, W, K, n,
+                                                        C.cast(a_rgb, C.c_void_p), C.cast(a_clusters, C.c_void_p),
+                                                        C.cast(a_labels, C.c_void_p)))
+
+    def pipeline_drain(self):
+        """Wait for every submitted group; dict of the totals since the previous drain."""
+        ms, g, f, h = C.c_double(), C.c_longlong(), C.c_longlong(), C.c_longlong()
+        _check(load_library().fslic_hip_pipeline_drain(self._h, C.byref(ms), C.byref(g), C.byref(f), C.byref(h)))
+        return {"device_ms": ms.value, "groups": g.value, "frames": f.value, "host_topk_frames": h.value}
+
+    def last_host_topk_frames(self, slot=0):
+        return int(load_library().fslic_hip_last_host_topk_frames(self._h, int(slot)))
+
     def group_done(self, slot):
         """True when wait_group(slot) would not block."""
         return load_library().fslic_hip_group_done(self._h, int(slot)) != 0
@@ -297,11 +316,16 @@ _default_engines = {}
 _engine_lock = threading.Lock()
 
 
+DEFAULT_ENGINE_SLOTS = 4      # concurrent iterate() calls (different SlicModels, different threads) per GPU before they queue
+
+
 def default_engine(device=0):
+    """The process-wide engine of a GPU, shared by every SlicModel on it.  Its entry points are thread-safe: a call takes
+    one of the engine's slots for its duration (cfast_slic.pyx:188-193 runs iterate() without the GIL, and so does ctypes)."""
     with _engine_lock:
         e = _default_engines.get(device)
         if e is None:
-            e = Engine(device, 1)
+            e = Engine(device, DEFAULT_ENGINE_SLOTS)
             _default_engines[device] = e
         return e
 

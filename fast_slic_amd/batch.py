@@ -62,3 +62,87 @@ def sum_over_ranks(value, dist, device="cpu"):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+# ---- launching one process per GPU ----------------------------------------------------------------------------------
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(world, argv, extra_env=None):
+    """Run `argv` (a python command line) as `world` processes, rank r with RANK = LOCAL_RANK = r, WORLD_SIZE = world and a
+    rendezvous on 127.0.0.1 -- what `python -m torch.distributed.run --nproc-per-node world` would set up.  Rank 0 inherits
+    stdout (it prints the result line); the call returns the largest exit code."""
+    import subprocess
+    import sys
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    return max(p.wait() for p in procs)
+
+
+def gpu_numa_cpus(local_rank):
+    """CPUs of the NUMA node the rank's GPU hangs off (sysfs: the PCI device's numa_node and that node's cpulist), or
+    None when the topology cannot be read (containers without sysfs, CPU-only test runs)."""
+    bdf = None
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(local_rank)
+        if hasattr(pr, "pci_bus_id"):
+            bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, getattr(pr, "pci_device_id", 0))
+    except Exception:       # noqa: BLE001 - no GPU / no torch: no pinning
+        bdf = None
+    try:
+        if bdf is None:
+            import glob
+            cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/numa_node"))
+            path = cards[local_rank] if local_rank < len(cards) else None
+        else:
+            path = "/sys/bus/pci/devices/%s/numa_node" % str(bdf).lower()
+        if not path or not os.path.exists(path):
+            return None
+        node = int(open(path).read().strip())
+        if node < 0:
+            return None
+        cpus = []
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.extend(range(int(a), int(b or a) + 1))
+        return cpus or None
+    except (OSError, ValueError, IndexError):
+        return None
+
+
+def pin_to_gpu_numa_node(local_rank, world):
+    """Keep this rank's host threads (slot threads, staging, write-back) on the NUMA node of its GPU; when the node is
+    unknown, on an equal share of the visible CPUs.  Returns the CPU set chosen (for the bench line)."""
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return None
+    cpus = gpu_numa_cpus(local_rank)
+    if cpus:
+        cpus = [c for c in cpus if c in set(avail)]
+    if not cpus and world > 1:
+        per = max(1, len(avail) // world)
+        cpus = avail[local_rank * per:(local_rank + 1) * per]
+    if not cpus:
+        return None
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        return None
+    return cpus

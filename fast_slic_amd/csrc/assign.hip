@@ -3,9 +3,6 @@
 // DESIGN.md for the design.  All arithmetic on this path is integer, so results are bit-identical to the reference.
 #include "device_common.h"
 #include <type_traits>
-#ifndef FSLIC_EXP
-#define FSLIC_EXP 0      // timing experiments (scripts/gpu_exp.sh): results are wrong when != 0
-#endif
 
 namespace fslic {
 
@@ -64,17 +61,11 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
     const int x = x0 + lane;
     const int vrow_w0 = (blockIdx.y * kWavesPerBlock + wave) * R;
     const bool okx = x < W;
-#define FSLIC_STAMP(slot_)                                                                              \
-    do {                                                                                                 \
-        if (f.dbg && lane == 0)                                                                          \
-            f.dbg[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kWavesPerBlock + wave) * 8 + (slot_)] = __builtin_readcyclecounter(); \
-    } while (0)
     if (LUT) {
         for (int i = tid; i < f.lut_words; i += 256) s_lut[i] = f.lut[i];
         __syncthreads();                     // the only barrier of the kernel
     }
     if (vrow_w0 >= Hv) return;               // wave-uniform
-    FSLIC_STAMP(0);
     const int yw_lo = rem + vrow_w0 * stride;
     const int nrows = min(R, Hv - vrow_w0);
     const uint32_t novf = *f.ovf_cnt[0];   // issued early, consumed after the cell gather
@@ -143,7 +134,6 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
         nraw += __popcll(m);
     }
     __builtin_amdgcn_wave_barrier();   // staging writes above, cross-lane reads below: keep program order
-    FSLIC_STAMP(1);
 
     const uint32_t M = f.M, Coff = f.C;
     uint32_t hi16;   // 0xffff0000 in a VGPR so that (w & hi16) | c is one v_and_or_b32 with c in an SGPR
@@ -243,7 +233,6 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
         n = nraw - __popcll(dupmask);
     }
     __builtin_amdgcn_wave_barrier();
-    FSLIC_STAMP(2);
 
     // 4. the argmin over the sorted list
     uint32_t best[R];
@@ -264,7 +253,6 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
             best[r] = min(best[r], LUT ? (w | (uint32_t)c) : ((w & hi16) | (uint32_t)c));
         }
     }
-    FSLIC_STAMP(3);
 
     // 5. write labels (+ fused centroid sums)
     uint32_t slot[R];
@@ -290,7 +278,6 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
             }
         }
     }
-    FSLIC_STAMP(4);
     if (FUSE) {
         bool uni = slot[0] != 0xFFFFFFFFu;
 #pragma unroll
@@ -334,13 +321,6 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
             }
         }
     }
-    FSLIC_STAMP(5);
-    if (f.dbg && lane == 0) {
-        const size_t o = ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kWavesPerBlock + wave) * 8;
-        f.dbg[o + 6] = (unsigned long long)nraw;
-        f.dbg[o + 7] = (unsigned long long)n;
-    }
-#undef FSLIC_STAMP
 }
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -456,19 +436,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
     const bool okx = x < W;
     const int nrows = max(0, min(R, Hv - vrow_w0));      // 0: this wavefront has no rows (bottom edge)
     const int yw_lo = rem + vrow_w0 * STRIDE;
-#define FSLIC_STAMP(slot_)                                                                              \
-    do {                                                                                                 \
-        if (f.dbg && lane == 0)                                                                          \
-            f.dbg[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kWavesPerBlock + wave) * 8 + (slot_)] = __builtin_readcyclecounter(); \
-    } while (0)
-    FSLIC_STAMP(0);
-    const unsigned long long wc0 = f.dbg ? wall_clock64() : 0ull;
-    // sub-phases of the list-building wavefront: records 32768.. of the stamp buffer, one per block
-#define FSLIC_GSTAMP(slot_)                                                                             \
-    do {                                                                                                 \
-        if (f.dbg && lane == 0)                                                                          \
-            f.dbg[((size_t)32768 + (blockIdx.y * gridDim.x + blockIdx.x)) * 8 + (slot_)] = __builtin_readcyclecounter(); \
-    } while (0)
 
     // 1. pixel loads: nothing depends on them until the argmin, but they are issued AFTER the loads the prologue waits
     // for (bins, table).  Every wavefront of the chip starts at the same time; with the pixel loads first the few bytes on the
@@ -495,7 +462,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
     const int gwave = (int)((blockIdx.x + blockIdx.y + blockIdx.z) & 3u);
     if (wave == gwave) {
         // 2a. the block's candidate list
-        FSLIC_GSTAMP(0);
         const uint32_t novf = *f.ovf_cnt[0];
         const int sh = f.cs_shift;
         const ClusterRec* __restrict__ citems = f.cell_items[0];
@@ -541,12 +507,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
             bool okr[6];
             issue(0, cya, rr, okr);
             load_pixels();
-            FSLIC_GSTAMP(1);
-            if (f.dbg) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(R) : "memory");
-            FSLIC_GSTAMP(2);
             consume(cya, rr, okr);
         }
-        FSLIC_GSTAMP(3);
         for (int cx0 = 0; cx0 < ncxr; cx0 += 8)
             for (int cy0 = cx0 == 0 ? cya + 6 : cya; cy0 <= cyb; cy0 += 6) {
                 ClusterRec rr[6];
@@ -562,7 +524,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
             visit(rec, i < novf && in_window(rec, win));
         }
         __builtin_amdgcn_wave_barrier();
-        FSLIC_GSTAMP(4);
         // rank by (phase, k): list order == visit order of the reference's scatter (src/context.cpp:214-242)
         const int bn = cnt;
         if (bn <= 64) {
@@ -589,7 +550,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
             }
         }
         if (lane == 0) s_bn = (uint32_t)bn;
-        FSLIC_GSTAMP(5);
     } else {
         // 2b. spatial table -> LDS, four 16-byte loads in flight per thread; centroid accumulators <- 0
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(f.tab);
@@ -617,7 +577,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
         }
     }
     __syncthreads();
-    FSLIC_STAMP(1);
     const int bn = (int)rfl(s_bn);
     if (bn > 64) {                            // more live candidates than idx bits: the host redoes the frame generically
         if (tid == 0) *f.err_flag = 1u;
@@ -633,7 +592,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
         const int cyj = (int)(yx_j >> 16);
         todo = __ballot(lane < bn && nrows > 0 && cyj + S >= yw_lo && cyj - S <= yw_hi);
     }
-    FSLIC_STAMP(2);
 
     // 4. the argmin, two rows per instruction
     us2 best[R / 2];
@@ -665,10 +623,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
         const uint4* const s_rv = reinterpret_cast<const uint4*>(s_dyn);
         auto pass = [&](uint32_t clab, uint32_t base, uint32_t idx01, const uint32_t* mq) {
             uint32_t spw[R / 2];
-#if FSLIC_EXP == 1
-            for (int q = 0; q < R / 2; ++q) spw[q] = base;
-            if (false)
-#endif
             {
                 const uint4 e0 = s_rv[base];
                 spw[0] = e0.x; spw[1] = e0.y; spw[2] = e0.z; spw[3] = e0.w;
@@ -770,7 +724,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
         }
     }
     }
-    FSLIC_STAMP(3);
 
     // 5. write labels (+ fused centroid sums)
     uint32_t slot[R];
@@ -779,11 +732,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint32_t key = (r & 1) ? (uint32_t)best[r / 2].y : (uint32_t)best[r / 2].x;
-#if FSLIC_EXP == 2
-            kk[r] = key & 63u;
-#else
             kk[r] = s_k16[key & 255u];                              // entry 255 when not found: read, never used
-#endif
         }
         uint16_t* rowp = f.labels + (size_t)yw_lo * W;
         const uint32_t xo = (uint32_t)x;
@@ -826,7 +775,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
         }
     }
     }
-    FSLIC_STAMP(4);
     if (FUSE) {
         {
             // A column's rows fall into one or two runs of equal slot (a superpixel is taller than a wavefront's rows), so the
@@ -878,14 +826,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
             }
         }
     }
-    FSLIC_STAMP(5);
-    if (f.dbg && lane == 0) {
-        const size_t o = ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kWavesPerBlock + wave) * 8;
-        f.dbg[o + 6] = (unsigned long long)bn;
-        f.dbg[o + 7] = wall_clock64() - wc0;          // 100 MHz reference clock over the wavefront's life
-    }
-#undef FSLIC_STAMP
-#undef FSLIC_GSTAMP
 }
 
 template <int R, bool FUSE, int STRIDE>
@@ -899,8 +839,6 @@ static void launch_assign_blk_t(const FrameDev& f_, int nframes, int rem, int Hv
 }
 
 static int assign_rows_per_wave(const FrameDev& f, int nframes, int Hv, bool fuse_update) {
-    const char* e = getenv("FSLIC_ASSIGN_R");
-    if (e && (atoi(e) == 8 || atoi(e) == 16)) return atoi(e);
     const int tiles_x = (f.W + kTileW - 1) / kTileW;
     const int blocks8 = nframes * tiles_x * ((Hv + kWavesPerBlock * 8 - 1) / (kWavesPerBlock * 8));
     return (!fuse_update && blocks8 > 3072) ? 16 : 8;
@@ -925,8 +863,7 @@ PassGeom launch_assign(const FrameDev& f_, int nframes, int rem, int stride, int
     PassGeom pg;
     pg.rem = rem; pg.stride = stride; pg.Hv = Hv; pg.BH = kWavesPerBlock * 8; pg.use_slots = 0;
     if (Hv <= 0) return pg;
-    static const int which = getenv("FSLIC_ASSIGN") ? atoi(getenv("FSLIC_ASSIGN")) : 0;   // 32: force the 32-bit kernel (A/B timing)
-    if (f.tab_words > 0 && stride >= 1 && stride <= 3 && which == 0 && (unsigned long long)f.N * 4ull < 0x7FFFFFFFull) {       // block-level packed kernel (its buffer loads address a plane with 31-bit byte offsets; larger planes take the 32-bit kernel)
+    if (f.tab_words > 0 && stride >= 1 && stride <= 3 && (unsigned long long)f.N * 4ull < 0x7FFFFFFFull) {       // block-level packed kernel (its buffer loads address a plane with 31-bit byte offsets; larger planes take the 32-bit kernel)
         if (!fuse_update && stride == 1) {
             if (assign_rows_per_wave(f, nframes, Hv, false) == 16) launch_assign_blk_t<16, false, 1>(f, nframes, rem, Hv, st);
             else launch_assign_blk_t<8, false, 1>(f, nframes, rem, Hv, st);

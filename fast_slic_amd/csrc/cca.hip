@@ -14,7 +14,7 @@ namespace fslic {
 //   k_cca_border   unions across tile borders (global atomicMin)
 //   k_cca_compress tile-local roots -> global roots, areas summed into the global root
 //   k_cca_collect  global roots with area >= threshold -> candidate list for the top-K step
-//   (host)         std::partial_sort / ranking of <= few thousand (leader, area) pairs
+//   k_cca_select   top-K by area and ranking by leader in one block, including the area tie at the cut
 //   k_cca_chain    every other component takes the final label of the component left of (or
 //                  above) its leader, src/cca.cpp:240-254, resolved by chasing toward smaller leaders
 //   k_cca_relabel  out[p] = final[root(p)]
@@ -381,9 +381,170 @@ static __device__ __forceinline__ void select_pass(const uint32_t* s_area, uint3
     __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int cap, unsigned long long* dbg) {
-#define SEL_STAMP(i_) do { if (dbg && threadIdx.x == 0 && blockIdx.x == 0) dbg[i_] = __builtin_amdgcn_s_memrealtime(); } while (0)   // 100 MHz
-    SEL_STAMP(0);
+// ---------------------------------------------------------------------------------------------
+// The tie at the top-K cut, on the device.  libstdc++'s std::partial_sort = __heap_select + __sort_heap; only the first
+// decides WHICH K components survive (the survivors are re-sorted by leader anyway, src/cca.cpp:229), and it is a
+// deterministic sequence of heap operations on the candidates in ascending-leader order with comp(l, r) = area[l] > area[r]
+// (src/cca.cpp:180-186): bits/stl_heap.h __make_heap / __adjust_heap / __push_heap, bits/stl_algo.h __heap_select (GCC 11;
+// the tests pin the same restatement against the live library).
+//   1. rank every candidate by leader (bucket ranking), permute (leader, area) into that order
+//   2. __make_heap over the first K: level by level from the deepest parents up.  __adjust_heap(p) touches only p's
+//      subtree and the sequential loop visits parents in descending index order, i.e. deeper levels first; parents of one
+//      level have disjoint subtrees, so a level can run in parallel (one thread per parent) with identical results
+//   3. the __heap_select loop over candidates K..M-1 is sequential: one wavefront scans 64 candidates at a time for
+//      area > area[top] (the top's area never decreases, so a candidate rejected once stays rejected) and replays
+//      __pop_heap for the survivors in index order (all lanes walk the same path, lane 0 stores)
+//   4. the heap's K entries are the kept set: label = rank among the kept in leader order (src/cca.cpp:229-237)
+// The heap is two arrays moved in tandem (candidate index, its area): one LDS round trip per level instead of two.
+// ---------------------------------------------------------------------------------------------
+static __device__ __forceinline__ void tie_adjust_heap(uint32_t* hi, uint32_t* ha, int hole, int len, uint32_t vi, uint32_t va, bool writer) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        const uint32_t a1 = lds_ld(ha + child), a0 = lds_ld(ha + child - 1);
+        uint32_t am = a1;
+        if (a1 > a0) { child--; am = a0; }                   // comp(first[child], first[child - 1])
+        const uint32_t im = lds_ld(hi + child);
+        if (writer) { lds_st(hi + hole, im); lds_st(ha + hole, am); }
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        const uint32_t im = lds_ld(hi + child - 1), am = lds_ld(ha + child - 1);
+        if (writer) { lds_st(hi + hole, im); lds_st(ha + hole, am); }
+        hole = child - 1;
+    }
+    // __push_heap(first, hole, top, value)
+    int parent = (hole - 1) / 2;
+    while (hole > top) {
+        const uint32_t ap = lds_ld(ha + parent);
+        if (!(ap > va)) break;                                // comp(first[parent], value)
+        const uint32_t ip = lds_ld(hi + parent);
+        if (writer) { lds_st(hi + hole, ip); lds_st(ha + hole, ap); }
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    if (writer) { lds_st(hi + hole, vi); lds_st(ha + hole, va); }
+}
+
+static __device__ __forceinline__ void tie_heap_select(const CcaDev& c, uint32_t M, uint32_t K, uint32_t* s_area, uint32_t* s_lead, uint32_t* s_key,
+                                                       uint32_t* s_bcnt, uint32_t* s_bstart, uint32_t* s_bfill, uint32_t* s_w) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    constexpr int PER = kSelSortCap / 1024;                   // candidates per thread
+    // 1. leader order
+    int bsh = 0;
+    while ((((uint32_t)c.N - 1u) >> bsh) >= (uint32_t)kSelBuckets) bsh++;
+    for (int i = tid; i < 3 * kSelBuckets; i += 1024) s_bcnt[i] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < M; i += 1024) atomicAdd(&s_bcnt[s_lead[i] >> bsh], 1u);
+    __syncthreads();
+    {
+        const uint32_t a = s_bcnt[2 * tid], b = s_bcnt[2 * tid + 1];
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan_1024(a + b, s_w, tot);
+        s_bstart[2 * tid] = ex;
+        s_bstart[2 * tid + 1] = ex + a;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < M; i += 1024) {
+        const uint32_t b = s_lead[i] >> bsh;
+        s_key[s_bstart[b] + atomicAdd(&s_bfill[b], 1u)] = s_lead[i];
+    }
+    __syncthreads();
+    uint32_t my_lead[PER], my_area[PER], my_rank[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)q * 1024u;
+        my_lead[q] = 0; my_area[q] = 0; my_rank[q] = 0xFFFFFFFFu;
+        if (i < M) {
+            const uint32_t me = s_lead[i];
+            const uint32_t b = me >> bsh;
+            const uint32_t lo = s_bstart[b], hi = lo + s_bcnt[b];
+            uint32_t r = lo;
+            for (uint32_t j = lo; j < hi; ++j) r += (uint32_t)(s_key[j] < me);
+            my_lead[q] = me; my_area[q] = s_area[i]; my_rank[q] = r;
+        }
+    }
+    __syncthreads();
+    // leaders in order -> global (read back in step 4), areas in order -> s_area; s_key <- heap indices, s_lead <- heap areas
+    uint32_t* const hi_ = s_key;
+    uint32_t* const ha_ = s_lead;
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+        if (my_rank[q] != 0xFFFFFFFFu) {
+            const uint32_t r = my_rank[q];
+            c.cand_leader[r] = (int32_t)my_lead[q];
+            s_area[r] = my_area[q];
+            if (r < K) { hi_[r] = r; ha_[r] = my_area[q]; }
+        }
+    __syncthreads();
+    // 2. __make_heap(first, first + K)
+    const int len = (int)K;
+    if (len >= 2) {
+        const int last_parent = (len - 2) / 2;
+        int d = 0;
+        while (((2 << d) - 1) <= last_parent) d++;           // depth of the deepest parent
+        for (; d >= 0; --d) {
+            const int lo = (1 << d) - 1, hi = min((2 << d) - 2, last_parent);
+            for (int p = lo + tid; p <= hi; p += 1024)
+                tie_adjust_heap(hi_, ha_, p, len, lds_ld(hi_ + p), lds_ld(ha_ + p), true);
+            __syncthreads();
+        }
+    }
+    // 3. for (i = K; i < M; ++i) if (comp(*i, *first)) __pop_heap(first, middle, i)
+    if (tid < 64) {
+        uint32_t top_area = lds_ld(ha_);
+        for (uint32_t base = K; base < M; base += 64) {
+            const uint32_t i = base + (uint32_t)lane;
+            const uint32_t a = i < M ? s_area[i] : 0u;
+            unsigned long long m = __ballot(i < M && a > top_area);
+            while (m) {
+                const int j = __builtin_ctzll(m);
+                m &= m - 1ull;
+                const uint32_t aj = (uint32_t)__builtin_amdgcn_readlane((int)a, j);
+                if (aj > top_area) {
+                    tie_adjust_heap(hi_, ha_, 0, len, base + (uint32_t)j, aj, lane == 0);
+                    top_area = lds_ld(ha_);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // 4. kept set = the heap's K entries; label = rank among the kept in leader order
+    // flags live in ha_ (the heap areas are dead once the indices are read): read all indices first
+    uint32_t kept_idx[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const uint32_t t = (uint32_t)tid + (uint32_t)q * 1024u;
+        kept_idx[q] = t < K ? hi_[t] : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < M; i += 1024) ha_[i] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+        if (kept_idx[q] != 0xFFFFFFFFu) ha_[kept_idx[q]] = 1u;
+    __syncthreads();
+    // exclusive scan of the flags: thread t owns candidates [PER * t, PER * t + PER)
+    uint32_t fl[PER], cnt = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const uint32_t i = (uint32_t)tid * PER + (uint32_t)q;
+        fl[q] = i < M ? ha_[i] : 0u;
+        cnt += fl[q];
+    }
+    uint32_t total;
+    uint32_t run = block_excl_scan_1024(cnt, s_w, total);
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const uint32_t i = (uint32_t)tid * PER + (uint32_t)q;
+        if (fl[q]) c.final_lab[c.cand_leader[i]] = (uint16_t)run;
+        run += fl[q];
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int cap) {
     c.select(blockIdx.x);
     extern __shared__ uint32_t s_dyn[];
     uint32_t* const s_area = s_dyn;
@@ -420,7 +581,6 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int cap, unsigned
         if (lane == 0 && amax) atomicMax(&s_v[0], amax);
         __syncthreads();
     }
-    SEL_STAMP(1);
     // 2. K-th largest area: 12 bits per pass, starting just above the top bit of the largest area
     uint32_t astar = 0;           // keep iff area >= astar
     if (M > (uint32_t)K) {
@@ -445,47 +605,18 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int cap, unsigned
         if (lane == 0 && eq) atomicAdd(&s_v[4], eq);
         __syncthreads();
         if (s_v[4] != kk) {
-            // tie at the cut: hand the host the candidates in ascending-leader order.  Same bucket ranking as step 3
-            // below, applied to every candidate: rank = position in the leader-sorted list (a bitonic sort of the
-            // pairs took 30 us here).
+            // Area tie at the cut: which of the tied components std::partial_sort (src/cca.cpp:225-228) keeps depends on
+            // libstdc++'s heap mechanics, so its __heap_select is replayed here, operation by operation, on the candidates
+            // in ascending-leader order (the order the reference feeds it).  See tie_heap_select below.
             if (M > (uint32_t)kSelSortCap) {
                 if (tid == 0) c.counters[3] = 2u;
                 return;
             }
-            int bsh = 0;
-            while ((((uint32_t)c.N - 1u) >> bsh) >= (uint32_t)kSelBuckets) bsh++;
-            for (int i = tid; i < 3 * kSelBuckets; i += 1024) s_bcnt[i] = 0;
-            __syncthreads();
-            for (uint32_t i = tid; i < M; i += 1024) atomicAdd(&s_bcnt[s_lead[i] >> bsh], 1u);
-            __syncthreads();
-            {
-                const uint32_t a = s_bcnt[2 * tid], b = s_bcnt[2 * tid + 1];
-                uint32_t tot;
-                const uint32_t ex = block_excl_scan_1024(a + b, s_w, tot);
-                s_bstart[2 * tid] = ex;
-                s_bstart[2 * tid + 1] = ex + a;
-            }
-            __syncthreads();
-            for (uint32_t i = tid; i < M; i += 1024) {
-                const uint32_t b = s_lead[i] >> bsh;
-                s_key[s_bstart[b] + atomicAdd(&s_bfill[b], 1u)] = s_lead[i];
-            }
-            __syncthreads();
-            for (uint32_t i = tid; i < M; i += 1024) {
-                const uint32_t me = s_lead[i];
-                const uint32_t b = me >> bsh;
-                const uint32_t lo = s_bstart[b], hi = lo + s_bcnt[b];
-                uint32_t r = lo;
-                for (uint32_t j = lo; j < hi; ++j) r += (uint32_t)(s_key[j] < me);
-                c.cand_leader[r] = (int32_t)me;
-                c.cand_area[r] = s_area[i];
-                if (c.host_leader) { c.host_leader[r] = (int32_t)me; c.host_area[r] = s_area[i]; }
-            }
-            if (tid == 0) c.counters[3] = 1u;
+            tie_heap_select(c, M, (uint32_t)K, s_area, s_lead, s_key, s_bcnt, s_bstart, s_bfill, s_w);
+            if (tid == 0) c.counters[3] = 0u;
             return;
         }
     }
-    SEL_STAMP(2);
     // 3. rank of every kept leader among the kept leaders (labels 0,1,2.. in raster order of the first pixel,
     //    src/cca.cpp:229-237): bucket by raster-index range, exclusive scan of the bucket sizes, rank inside the bucket
     int bsh = 0;
@@ -503,14 +634,12 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int cap, unsigned
         s_bstart[2 * tid + 1] = ex + a;
     }
     __syncthreads();
-    SEL_STAMP(3);
     for (uint32_t i = tid; i < M; i += 1024)
         if (s_area[i] >= astar) {
             const uint32_t b = s_lead[i] >> bsh;
             s_key[s_bstart[b] + atomicAdd(&s_bfill[b], 1u)] = s_lead[i];
         }
     __syncthreads();
-    SEL_STAMP(4);
     for (uint32_t i = tid; i < M; i += 1024)
         if (s_area[i] >= astar) {
             const uint32_t me = s_lead[i];
@@ -521,8 +650,6 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int cap, unsigned
             c.final_lab[me] = (uint16_t)r;
         }
     if (tid == 0) c.counters[3] = 0u;
-    SEL_STAMP(5);
-#undef SEL_STAMP
 }
 
 void launch_cca_phase1(const CcaDev& c, int nframes, hipStream_t st) {
@@ -536,7 +663,7 @@ void launch_cca_phase1(const CcaDev& c, int nframes, hipStream_t st) {
     hipLaunchKernelGGL(k_cca_collect, dim3(tx * ty, nframes), dim3(256), 0, st, c);
 }
 
-void launch_cca_select(const CcaDev& c, int nframes, hipStream_t st, unsigned long long* dbg) {
+void launch_cca_select(const CcaDev& c, int nframes, hipStream_t st) {
     // LDS capacity: no frame has more candidates than N / max(threshold, 1)
     long long need = (long long)c.N / (c.min_threshold > 1 ? c.min_threshold : 1) + 1;
     int cap = 1024;
@@ -547,7 +674,7 @@ void launch_cca_select(const CcaDev& c, int nframes, hipStream_t st, unsigned lo
     static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(k_cca_select), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                            (int)((3 * (size_t)kSelCap + 3 * (size_t)kSelBuckets) * sizeof(uint32_t)));
     (void)attr_once;
-    hipLaunchKernelGGL(k_cca_select, dim3(nframes), dim3(1024), lds, st, c, cap, dbg);
+    hipLaunchKernelGGL(k_cca_select, dim3(nframes), dim3(1024), lds, st, c, cap);
 }
 
 // Host path only: forget what the device select / chain wrote, then set the host's choice.

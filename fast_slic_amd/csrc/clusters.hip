@@ -49,8 +49,10 @@ static __device__ __forceinline__ void gather_sums(const FrameDev& f, const Pass
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg) {
+__global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg, const uint32_t* __restrict__ src_yx, size_t src_stride) {
     f.select(blockIdx.y);
+    // mode 0: the centres of a group start are read where the host staged them (pinned memory), no upload command
+    const uint32_t* __restrict__ yx_in = (MODE == 0 && src_yx) ? src_yx + (size_t)blockIdx.y * src_stride : f.cl_yx;
     // mode 1: consecutive blocks overlap by one cluster: thread 0 of a block only computes the member count of the
     // cluster before the block's first one (the shadow test below needs the predecessor's count)
     const int gi = blockIdx.x * blockDim.x + threadIdx.x;
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg) {
     if (gi == 0) *f.ovf_cnt[1] = 0;
     const int k = MODE == 0 ? gi : (int)(blockIdx.x * (blockDim.x - 1) + threadIdx.x) - 1;
     const bool live = k >= 0 && k < f.K;
-    uint32_t yx = live ? f.cl_yx[k] : 0u;
+    uint32_t yx = live ? yx_in[k] : 0u;
     int y = (int)(yx >> 16), x = (int)(yx & 0xFFFF);
     uint32_t lab;
     // A cluster whose integer state (y, x, L, a, b) equals that of cluster k-1 has the same distance to every
@@ -73,16 +75,17 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg) {
         lab = f.lab[(size_t)y * f.W + x] & 0x00FFFFFFu;
         f.cl_lab[k] = lab;
         f.cl_yx_out[k] = yx;
+        if (src_yx) f.cl_yx[k] = yx;      // device copy of the staged centres (the LSC seeding reads it)
         if (f.cl_f) {      // 'noq': the centre keeps its (clamped) float position, the colour starts as the pixel's (src/context.cpp:128-135)
             float* c = f.cl_f + 8 * (size_t)k;
             c[2] = (float)(lab & 255u); c[3] = (float)((lab >> 8) & 255u); c[4] = (float)((lab >> 16) & 255u);
         }
-        shadowed = !f.cl_f && k > 0 && f.cl_yx[k - 1] == yx;
+        shadowed = !f.cl_f && k > 0 && yx_in[k - 1] == yx;
         f.cl_shadow[k] = shadowed ? 1u : 0u;
     } else {
         // what the tail needs, requested before the gather so that it does not cost another round trip afterwards
         const uint32_t lab_own = live ? f.cl_lab[k] : 0u;
-        const uint32_t yx_prev = (live && k > 0) ? f.cl_yx[k - 1] : 0u, lab_prev = (live && k > 0) ? f.cl_lab[k - 1] : 0u;
+        const uint32_t yx_prev = (live && k > 0) ? yx_in[k - 1] : 0u, lab_prev = (live && k > 0) ? f.cl_lab[k - 1] : 0u;
         // a shadowed cluster is in no candidate list: it received nothing and its cpart entries are stale
         uint32_t s[6] = {0u, 0u, 0u, 0u, 0u, 0u};
         if (live && !(pg.use_slots && f.cl_shadow[k])) gather_sums(f, pg, k, yx, s);
@@ -146,15 +149,38 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg) {
     }
 }
 
-void launch_bin_clusters(const FrameDev& f_, int nframes, int mode, int buf, int sbuf, const PassGeom& pg, hipStream_t st) {
+void launch_bin_clusters(const FrameDev& f_, int nframes, int mode, int buf, int sbuf, const PassGeom& pg, hipStream_t st,
+                         const uint32_t* src_yx, size_t src_stride) {
     const FrameDev f = rotated(f_, buf, sbuf);
     if (mode == 0) {
         const int n = f.K > f.ncell ? f.K : f.ncell;
-        hipLaunchKernelGGL(k_bin_clusters<0>, dim3((n + 255) / 256, nframes), dim3(256), 0, st, f, pg);
+        hipLaunchKernelGGL(k_bin_clusters<0>, dim3((n + 255) / 256, nframes), dim3(256), 0, st, f, pg, src_yx, src_stride);
     } else {
         const int bk = (f.K + 254) / 255, bc = (f.ncell + 255) / 256;    // 255 clusters per block (see the kernel)
-        hipLaunchKernelGGL(k_bin_clusters<1>, dim3(bk > bc ? bk : bc, nframes), dim3(256), 0, st, f, pg);
+        hipLaunchKernelGGL(k_bin_clusters<1>, dim3(bk > bc ? bk : bc, nframes), dim3(256), 0, st, f, pg, nullptr, (size_t)0);
     }
+}
+
+// Results of a group -> the engine's pinned host blocks (device-accessible), written in place by the kernel: no copy
+// command in the launch sequence.  Visible to the host once the stream has been synchronised.
+__global__ __launch_bounds__(256) void k_export_state(FrameDev f, const uint32_t* yx_cur, uint32_t* h_cl, size_t h_stride, const uint32_t* misc0, uint32_t* h_misc) {
+    const int z = blockIdx.y;
+    const size_t d = (size_t)z * f.frame_bytes;
+    FrameDev::adv(yx_cur, d); FrameDev::adv(misc0, d);
+    f.select(z);
+    uint32_t* out = h_cl + (size_t)z * h_stride;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int K = f.K;
+    if (i < K) out[i] = yx_cur[i];
+    else if (i < 4 * K) out[i] = f.cl_lab[i - K];          // cl_lab, cl_n, cl_moved are contiguous (K words each)
+    if (blockIdx.x == 0 && threadIdx.x < 16) h_misc[16 * (size_t)z + threadIdx.x] = misc0[threadIdx.x];
+}
+
+void launch_export_state(const FrameDev& f, int nframes, const uint32_t* yx_cur, uint32_t* h_cl, size_t h_stride,
+                         const uint32_t* misc0, uint32_t* h_misc, hipStream_t st) {
+    FrameDev g = f;
+    g.rgbs = nullptr;                         // select() must not touch the caller's pointer table here
+    hipLaunchKernelGGL(k_export_state, dim3((4 * f.K + 255) / 256, nframes), dim3(256), 0, st, g, yx_cur, h_cl, h_stride, misc0, h_misc);
 }
 
 }  // namespace fslic

@@ -84,7 +84,6 @@ struct FrameDev {
     ClusterRec* cell_items[2]; // ncell * kCellCap
     uint32_t* ovf_cnt[2];      // 1
     ClusterRec* ovf_items[2];  // K
-    unsigned long long* dbg;   // optional per-block phase stamps of k_assign (FSLIC_DEBUG_TIMING=1), else nullptr
     uint32_t* err_flag;        // != 0: a block overflowed its LDS candidate list -> host reruns generic
     // LDS spatial table of the tiled kernel (lut_words == 0: fixed-point mode, no table)
     const uint32_t* lut;       // lut_words entries: patch value << 16, or kHuge for out-of-window indices
@@ -121,7 +120,6 @@ struct FrameDev {
         adv(cell_cnt[0], d); adv(cell_cnt[1], d); adv(cell_items[0], d); adv(cell_items[1], d);
         adv(ovf_cnt[0], d); adv(ovf_cnt[1], d); adv(ovf_items[0], d); adv(ovf_items[1], d);
         adv(err_flag, d);
-        if (z != 0) dbg = nullptr;   // phase stamps (bring-up aid) cover the group's first frame only
     }
 };
 
@@ -148,12 +146,6 @@ struct CcaDev {
     uint32_t* counters;   // [1] M = number of candidates (append cursor of k_cca_collect), [2] M again, [3] select status
     int32_t* cand_leader; // dense candidate list (global roots with area >= threshold): leaders,
     uint32_t* cand_area;  //   and areas; capacity ntiles * kCcaTilePx >= N.  Unordered unless the select status is 1
-    // pinned HOST memory (device-accessible), host_stride entries per frame: on a tie at the top-K cut the select kernel
-    // leaves the leader-sorted candidates here as well, so the host sort needs no copy command and no second wait
-    int32_t* host_leader;
-    uint32_t* host_area;
-    size_t host_stride;
-
     __host__ __device__ __forceinline__ void select(int z) {
         out = outs[z];
         FrameDev::adv(in, (size_t)z * in_stride);
@@ -161,7 +153,6 @@ struct CcaDev {
         FrameDev::adv(parent, d); FrameDev::adv(area, d); FrameDev::adv(final_lab, d); FrameDev::adv(roots, d);
         FrameDev::adv(tile_cnt, d); FrameDev::adv(counters, d);
         FrameDev::adv(cand_leader, d); FrameDev::adv(cand_area, d);
-        host_leader += (size_t)z * host_stride; host_area += (size_t)z * host_stride;
     }
 };
 
@@ -205,7 +196,15 @@ void launch_rgb_to_lab(const FrameDev& f, int nframes, int convert, const LabTab
                        void* zero_a = nullptr, size_t zero_a_bytes = 0, uint32_t* zero_b = nullptr, size_t zero_b_words = 0);
 // mode 0: resample colours at the current centres (src/context.cpp:128-135) and bin;
 // mode 1: integer centroid update from `sums` (src/context.cpp:356-373), zero sums, and bin.
-void launch_bin_clusters(const FrameDev& f, int nframes, int mode, int buf, int sbuf, const PassGeom& pg, hipStream_t st);
+// mode 0 with src_yx != nullptr: the centres come from there (the engine's pinned staging block, read in place; frame z at
+// src_yx + z * src_stride words) instead of FrameDev::cl_yx.
+void launch_bin_clusters(const FrameDev& f, int nframes, int mode, int buf, int sbuf, const PassGeom& pg, hipStream_t st,
+                         const uint32_t* src_yx = nullptr, size_t src_stride = 0);
+// End of a group: positions (yx_cur: frame 0's current position buffer), colour / member count / moved flag (the 3K words
+// after FrameDev::cl_lab) and the frame's 16 status words (misc0: frame 0's) -> the engine's pinned blocks, frame z at
+// h_cl + z * h_stride words: [0,K) yx, [K,4K) lab, n, moved; h_misc + 16 z.
+void launch_export_state(const FrameDev& f, int nframes, const uint32_t* yx_cur, uint32_t* h_cl, size_t h_stride,
+                         const uint32_t* misc0, uint32_t* h_misc, hipStream_t st);
 // One assign pass over rows == rem (mod stride); fuse_update also accumulates the centroid sums
 // of src/context.cpp:301-354 for the same rows.  Returns the geometry the following cluster pass needs.
 PassGeom launch_assign(const FrameDev& f, int nframes, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st);
@@ -229,9 +228,8 @@ void launch_noq_assign(const FrameDev& f, float coef, bool manhattan, int nframe
 void launch_preempt_update(const FrameDev& f, int nframes, int buf, int sbuf, bool rebin_all, float l1_thres, hipStream_t st);
 // connectivity
 void launch_cca_phase1(const CcaDev& c, int nframes, hipStream_t st);   // local CCL, border merge, compress, collect
-// device top-K + ranking; counters[3] = status (see k_cca_select).  On status 1 the candidate arrays are left
-// sorted by leader for the host.  dbg: 6 cycle stamps of block 0 (bring-up aid)
-void launch_cca_select(const CcaDev& c, int nframes, hipStream_t st, unsigned long long* dbg = nullptr);
+// device top-K + ranking, including the area tie at the cut; counters[3] = status (see k_cca_select)
+void launch_cca_select(const CcaDev& c, int nframes, hipStream_t st);
 void launch_cca_phase2(const CcaDev& c, int nframes, hipStream_t st);   // chain resolution + relabel
 // host top-K path, one frame at a time (the CcaDev passed in is already advanced to that frame)
 void launch_cca_set_kept(const CcaDev& c, const int32_t* d_leaders, const uint16_t* d_labels, int n, hipStream_t st);

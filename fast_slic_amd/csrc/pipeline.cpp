@@ -1,0 +1,271 @@
+// pipeline.cpp -- who may use a slot, and the asynchronous forms of a group.  Part of the host engine, see
+// engine_internal.h.
+//
+// The reference runs iterate() `with nogil` on a per-call Context (cfast_slic.pyx:188-193; thread count and timer are
+// thread_local, src/parallel.cpp:14, src/timer.cpp:45), so concurrent calls on different models are legal.  Here every
+// call needs one of the engine's slots (stream + arena): synchronous entry points take a free slot for their duration
+// and wait while all are taken, so threads sharing one engine run concurrently up to n_slots and are serialised beyond.
+// Asynchronous groups (fslic_hip_submit_group / fslic_hip_pipeline_submit) run on the slot's own host thread.
+#include "engine_internal.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+namespace fslic {
+
+namespace {
+thread_local std::string g_err;
+}
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+const std::string& last_error() { return g_err; }
+void set_last_error(const std::string& msg) { g_err = msg; }
+
+namespace {
+Knobs read_knobs() {
+    Knobs k;
+    const char* g = getenv("FSLIC_GROUP");
+    k.group_size = g ? std::min(std::max(atoi(g), 1), (int)kMaxGroup) : 8;
+    const char* gr = getenv("FSLIC_GRAPH");
+    k.use_graphs = !(gr && atoi(gr) == 0);
+    k.poison = getenv("FSLIC_POISON") != nullptr;
+    k.host_timing = getenv("FSLIC_HOST_TIMING") != nullptr;
+    return k;
+}
+const Knobs g_knobs = read_knobs();      // once, when the library is loaded
+}  // namespace
+const Knobs& knobs() { return g_knobs; }
+
+// ---- slot ownership ------------------------------------------------------------------------------------------------
+int acquire_slot(fslic_engine* e, int want, int& slot) {
+    std::unique_lock<std::mutex> lk(e->mu);
+    const int ns = (int)e->slots.size();
+    if (want >= ns) return fail(FSLIC_E_INVALID, "slot out of range");
+    for (;;) {
+        if (want >= 0) {
+            Slot& s = e->slots[want];
+            if (s.pending) return fail(FSLIC_E_INVALID, "the slot still owns an unfinished group (call fslic_hip_wait_group first)");
+            if (!s.busy) { s.busy = true; slot = want; return FSLIC_OK; }
+        } else {
+            bool any_usable = false;
+            for (int i = 0; i < ns; i++) {
+                Slot& s = e->slots[i];
+                if (s.pending) continue;
+                any_usable = true;
+                if (!s.busy) { s.busy = true; slot = i; return FSLIC_OK; }
+            }
+            if (!any_usable) return fail(FSLIC_E_INVALID, "every slot owns an unfinished asynchronous group");
+        }
+        e->cv.wait(lk);
+    }
+}
+
+int acquire_all_slots(fslic_engine* e) {
+    std::unique_lock<std::mutex> lk(e->mu);
+    for (;;) {
+        bool free_all = true;
+        for (const Slot& s : e->slots) {
+            if (s.pending) return fail(FSLIC_E_INVALID, "a slot still owns an unfinished group");
+            free_all = free_all && !s.busy;
+        }
+        if (free_all) break;
+        e->cv.wait(lk);
+    }
+    for (Slot& s : e->slots) s.busy = true;
+    return FSLIC_OK;
+}
+
+void release_slot(fslic_engine* e, int slot) {
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        e->slots[slot].busy = false;
+    }
+    e->cv.notify_all();
+}
+
+void release_all_slots(fslic_engine* e) {
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        for (Slot& s : e->slots) s.busy = false;
+    }
+    e->cv.notify_all();
+}
+
+// ---- the slot's host thread: one group at a time, begin + finish ---------------------------------------------------
+namespace {
+
+void slot_worker(fslic_engine* e, Slot* s) {
+    Slot::Async& a = *s->async;
+    (void)hipSetDevice(e->device);
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(e->mu);
+            e->cv.wait(lk, [&] { return a.has_job || a.quit; });
+            if (a.quit) return;
+        }
+        int rc = group_begin(e, *s, &a.p, a.H, a.W, a.K, a.n, a.d_rgb, a.clusters, a.d_out);
+        if (rc == FSLIC_OK) rc = group_finish(e, *s);
+        {
+            std::lock_guard<std::mutex> lk(e->mu);
+            a.rc = rc;
+            a.err = rc ? last_error() : std::string();
+            a.has_job = false;
+            a.done = true;
+        }
+        e->cv.notify_all();
+    }
+}
+
+// caller holds e->mu; the slot is neither busy nor pending
+void hand_over(fslic_engine* e, Slot& s, const fslic_params* p, int H, int W, int K, int n,
+               const uint8_t* const* d_rgb, fslic_cluster* const* clusters, uint16_t* const* d_labels) {
+    if (!s.async) {
+        s.async.reset(new Slot::Async());
+        s.async->worker = std::thread(slot_worker, e, &s);
+    }
+    Slot::Async& a = *s.async;
+    a.p = *p; a.H = H; a.W = W; a.K = K; a.n = n;
+    s.launch_timing = e->launch_timing;      // sampled on the caller's thread: the worker may start later
+    for (int i = 0; i < n; i++) { a.d_rgb[i] = d_rgb[i]; a.clusters[i] = clusters[i]; a.d_out[i] = d_labels[i]; }
+    a.done = false;
+    a.has_job = true;
+    s.pending = true;
+}
+
+int check_group_args(fslic_engine* e, const fslic_params* p, int H, int W, int K, int n_frames,
+                     const uint8_t* const* d_rgb, fslic_cluster* const* clusters, uint16_t* const* d_labels) {
+    if (!e) return fail(FSLIC_E_INVALID, "engine is NULL");
+    if (n_frames < 1 || n_frames > (int)kMaxGroup || !d_rgb || !clusters || !d_labels) return fail(FSLIC_E_INVALID, "bad group arguments");
+    int S = 0;
+    const int rc = validate(p, H, W, K, S);          // argument errors surface on the caller's thread
+    if (rc) return rc;
+    for (int i = 0; i < n_frames; i++)
+        if (!clusters[i] || !d_rgb[i] || !d_labels[i]) return fail(FSLIC_E_INVALID, "NULL pointer argument");
+    return FSLIC_OK;
+}
+
+// caller holds e->mu: fold a completed pipeline group into the engine's totals and free its slot
+void pipeline_collect(fslic_engine* e, Slot& s) {
+    Slot::Async& a = *s.async;
+    if (a.rc != FSLIC_OK && e->pipe_rc == FSLIC_OK) { e->pipe_rc = a.rc; e->pipe_err = a.err; }
+    e->pipe_device_ms += s.total_ms;
+    e->pipe_groups += 1;
+    e->pipe_frames += s.nframes;
+    e->pipe_host_topk += s.n_host_topk;
+    s.pending = false;
+}
+
+}  // namespace
+
+void stop_slot_thread(fslic_engine* e, Slot& s) {
+    if (!s.async) return;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        s.async->quit = true;
+    }
+    e->cv.notify_all();
+    if (s.async->worker.joinable()) s.async->worker.join();
+    s.async.reset();
+}
+
+}  // namespace fslic
+
+using namespace fslic;
+
+extern "C" {
+
+int fslic_hip_submit_group(fslic_engine* e, int slot, const fslic_params* p, int H, int W, int K, int n_frames,
+                           const uint8_t* const* d_rgb, fslic_cluster* const* clusters, uint16_t* const* d_labels) {
+    int rc = check_group_args(e, p, H, W, K, n_frames, d_rgb, clusters, d_labels);
+    if (rc) return rc;
+    if (slot < 0 || slot >= (int)e->slots.size()) return fail(FSLIC_E_INVALID, "slot out of range");
+    {
+        std::unique_lock<std::mutex> lk(e->mu);
+        Slot& s = e->slots[slot];
+        if (s.pending) return fail(FSLIC_E_INVALID, "the slot still owns an unfinished group (call fslic_hip_wait_group first)");
+        e->cv.wait(lk, [&] { return !s.busy; });             // a synchronous call of another thread is using the slot
+        hand_over(e, s, p, H, W, K, n_frames, d_rgb, clusters, d_labels);
+    }
+    e->cv.notify_all();
+    return FSLIC_OK;
+}
+
+int fslic_hip_wait_group(fslic_engine* e, int slot) {
+    if (!e) return fail(FSLIC_E_INVALID, "engine is NULL");
+    if (slot < 0 || slot >= (int)e->slots.size()) return fail(FSLIC_E_INVALID, "slot out of range");
+    Slot& s = e->slots[slot];
+    int rc;
+    {
+        std::unique_lock<std::mutex> lk(e->mu);
+        if (!s.pending) return FSLIC_OK;
+        Slot::Async& a = *s.async;
+        e->cv.wait(lk, [&] { return a.done; });
+        rc = a.rc;
+        if (rc) set_last_error(a.err);
+        s.pending = false;
+        if (rc == FSLIC_OK) set_thread_timing_report(make_timing_report(s));
+    }
+    e->cv.notify_all();
+    return rc;
+}
+
+int fslic_hip_group_done(fslic_engine* e, int slot) {
+    if (!e || slot < 0 || slot >= (int)e->slots.size()) return -1;
+    std::lock_guard<std::mutex> lk(e->mu);
+    Slot& s = e->slots[slot];
+    if (!s.pending) return 1;
+    return s.async->done ? 1 : 0;
+}
+
+// The submit / drain pipeline: the engine picks the slot.  submit returns as soon as the group has been handed to a
+// slot thread; it blocks only while every slot is occupied, and collects completed groups itself.
+int fslic_hip_pipeline_submit(fslic_engine* e, const fslic_params* p, int H, int W, int K, int n_frames,
+                              const uint8_t* const* d_rgb, fslic_cluster* const* clusters, uint16_t* const* d_labels) {
+    int rc = check_group_args(e, p, H, W, K, n_frames, d_rgb, clusters, d_labels);
+    if (rc) return rc;
+    {
+        std::unique_lock<std::mutex> lk(e->mu);
+        Slot* pick = nullptr;
+        for (;;) {
+            for (Slot& s : e->slots)                          // completed groups first: their slots become free
+                if (s.pending && s.async && s.async->done) pipeline_collect(e, s);
+            if (e->pipe_rc != FSLIC_OK) { set_last_error(e->pipe_err); return e->pipe_rc; }   // reported once more by drain
+            for (Slot& s : e->slots)
+                if (!s.pending && !s.busy) { pick = &s; break; }
+            if (pick) break;
+            e->cv.wait(lk);
+        }
+        hand_over(e, *pick, p, H, W, K, n_frames, d_rgb, clusters, d_labels);
+    }
+    e->cv.notify_all();
+    return FSLIC_OK;
+}
+
+int fslic_hip_pipeline_drain(fslic_engine* e, double* device_ms, long long* groups, long long* frames, long long* host_topk_frames) {
+    if (!e) return fail(FSLIC_E_INVALID, "engine is NULL");
+    int rc;
+    {
+        std::unique_lock<std::mutex> lk(e->mu);
+        for (Slot& s : e->slots) {
+            if (!s.pending) continue;
+            Slot::Async& a = *s.async;
+            e->cv.wait(lk, [&] { return a.done; });
+            pipeline_collect(e, s);
+        }
+        rc = e->pipe_rc;
+        if (rc) set_last_error(e->pipe_err);
+        if (device_ms) *device_ms = e->pipe_device_ms;
+        if (groups) *groups = e->pipe_groups;
+        if (frames) *frames = e->pipe_frames;
+        if (host_topk_frames) *host_topk_frames = e->pipe_host_topk;
+        e->pipe_rc = FSLIC_OK; e->pipe_err.clear();
+        e->pipe_device_ms = 0; e->pipe_groups = 0; e->pipe_frames = 0; e->pipe_host_topk = 0;
+    }
+    e->cv.notify_all();
+    return rc;
+}
+
+}  // extern "C"

@@ -5,9 +5,13 @@
  * Every entry point names the reference interface it replaces; paths are relative to the
  * reference repository root.  Plain C types only: no C++ or torch types cross this boundary.
  *
- * Threading (cfast_slic.pyx:188-193 releases the GIL around the calls replaced here): calls on one
- * engine handle are serialised by the caller; different handles (one per GPU) may be driven from
- * different threads.  The library never calls into Python.
+ * Threading (cfast_slic.pyx:188-193 releases the GIL around the calls replaced here, and the reference's
+ * per-call Context makes concurrent iterate() calls on different models legal): every entry point may be
+ * called from any thread at any time.  A call needs one of the engine's n_slots slots (a HIP stream and
+ * its buffers); synchronous calls take a free slot for their duration and wait while all are taken, so
+ * up to n_slots calls run concurrently on one engine and further ones queue.  A slot that owns a group
+ * submitted with fslic_hip_submit_group is handed to nobody until fslic_hip_wait_group has collected it.
+ * The timing report and the error message are per calling thread.  The library never calls into Python.
  *
  * All functions returning int return 0 on success and a non-zero FSLIC_E_* code on failure;
  * fslic_hip_last_error() then returns a thread-local human-readable message.  No exception
@@ -116,7 +120,7 @@ int fslic_hip_iterate_batch(fslic_engine* e, const fslic_params* p, int H, int W
  * (1..16) device-resident frames on `slot` and returns without waiting; wait blocks until that group is complete,
  * serves its host-side steps and writes the clusters back.  The pointer arrays are copied; clusters[i] and the
  * device buffers must stay valid until the wait.  With two slots the host work of one group (cluster upload and
- * write-back, std::partial_sort on a top-K tie) overlaps the kernels of the other. */
+ * write-back) overlaps the kernels of the other. */
 int fslic_hip_submit_group(fslic_engine* e, int slot, const fslic_params* p, int H, int W, int K, int n_frames,
                            const uint8_t* const* d_rgb, fslic_cluster* const* clusters, uint16_t* const* d_labels);
 int fslic_hip_wait_group(fslic_engine* e, int slot);
@@ -124,6 +128,17 @@ int fslic_hip_wait_group(fslic_engine* e, int slot);
  * idle, 0 while it is in flight, -1 on a bad argument.  Lets a caller with several slots collect groups in completion
  * order instead of submission order (groups with a top-K tie take longer than the others). */
 int fslic_hip_group_done(fslic_engine* e, int slot);
+
+/* The same, with the engine choosing the slot (NEW surface): submit hands one group of n_frames (1..16)
+ * device-resident frames to whichever slot is free and returns; it blocks only while every slot is occupied and
+ * collects completed groups itself (their clusters are written back by then).  drain waits for everything submitted
+ * so far and returns the first error of any group since the previous drain; the optional outputs receive the totals
+ * over those groups: device time (ms, HIP events per group), groups, frames, and the number of frames whose top-K
+ * step fell back to the host.  A video pipeline calls submit once per group of frames and drain at the end. */
+int fslic_hip_pipeline_submit(fslic_engine* e, const fslic_params* p, int H, int W, int K, int n_frames,
+                              const uint8_t* const* d_rgb, fslic_cluster* const* clusters, uint16_t* const* d_labels);
+int fslic_hip_pipeline_drain(fslic_engine* e, double* device_ms, long long* groups, long long* frames,
+                             long long* host_topk_frames);
 
 /* Stage entry points (used by the parity tests; each mirrors one stage of iterate()). */
 
@@ -168,8 +183,9 @@ int fslic_hip_cluster_density_to_mask(fslic_engine* e, int H, int W, int K, cons
 int fslic_hip_last_prelabels(fslic_engine* e, int slot, uint16_t* prelabels);
 
 /* Replaces BaseContext::get_timing_report (src/context.h:74): JSON with the fstimer schema
- * {"name","duration"(us),"children"} (src/timer.cpp:4-18), durations from HIP events of the last
- * call on slot 0.  Pointer valid until the next call on the engine. */
+ * {"name","duration"(us),"children"} (src/timer.cpp:4-18), durations from HIP events of the CALLING THREAD's last
+ * fslic_hip_iterate* / fslic_hip_wait_group (thread-local like the reference's timer, src/timer.cpp:45).  Pointer
+ * valid until that thread's next call. */
 const char* fslic_hip_last_timing_report(fslic_engine* e);
 
 /* Device time (ms, HIP events on the slot's stream) of the last frame GROUP on `slot`: whole pipeline, and
@@ -188,11 +204,16 @@ int fslic_hip_last_group_frames(fslic_engine* e, int slot);
 
 /* How the last group on `slot` reached the GPU: 0 = operations enqueued one by one, 1 = captured into a hipGraph during
  * this call and launched, 2 = replay of a captured graph.  (The engine captures a launch sequence the second time it
- * sees the same geometry / options / group size; FSLIC_GRAPH=0 disables that.)  Testing / diagnostics aid. */
+ * sees the same geometry / options / group size; the environment variable FSLIC_GRAPH=0, read when the library is
+ * loaded, disables that.)  Testing / diagnostics aid. */
 int fslic_hip_last_launch_mode(fslic_engine* e, int slot);
 
 /* Which kernel family served the last call on `slot`: 0 = tiled (LDS candidate lists), 1 = generic. */
 int fslic_hip_last_path(fslic_engine* e, int slot);
+
+/* Frames of the last group on `slot` whose top-K step of the connectivity pass ran on the host (more candidate
+ * components than the device sorts in one block; an area tie at the cut is resolved on the device). */
+int fslic_hip_last_host_topk_frames(fslic_engine* e, int slot);
 
 const char* fslic_hip_last_error(void);
 const char* fslic_hip_version(void);

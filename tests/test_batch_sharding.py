@@ -57,3 +57,34 @@ def test_two_rank_gloo_reduction_and_cover():
         assert total == 1300.0                            # sum over ranks
         assert [f for s in objs for f in s] == list(range(13))
         assert set(objs[0]).isdisjoint(objs[1])
+
+
+def test_bench_launches_its_own_ranks_bare():
+    """`python bench.py --gpus 2` as the driver types it (no torch.distributed.run around it): the script spawns the two
+    ranks, they rendezvous on 127.0.0.1 over gloo, the timed region is bracketed by barriers, rank 0 prints ONE line with
+    the max-over-ranks time.  --dry-run replaces the GPU work by sleeps (rank 1 is the slow one), nothing else."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "2", "--dry-run"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["units_all_ranks"] == 40.0
+    assert out["ms_per_step"] >= 2.0                      # rank 1 sleeps 2 ms per step: the slowest rank decides
+
+
+def test_torchrun_environment_is_respected():
+    import json
+    import subprocess
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(batch.free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--dry-run"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert json.loads(r.stdout.decode().strip().splitlines()[-1])["n_gpus"] == 1
+    env["WORLD_SIZE"] = "2"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--dry-run"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode != 0                               # --gpus must agree with the launcher's WORLD_SIZE

@@ -1,0 +1,227 @@
+"""GPU parity at the benchmark's own operating point, the device-side top-K tie, and concurrent callers (-m gpu).
+
+* the submit / drain pipeline exactly as bench.py drives it: 8 x 1280x720 K=1600 per group (seeds 0..7), 6 slots,
+  hipGraph replay, several rounds, EVERY label map and EVERY Cluster byte against the oracle; then the 64 frames of
+  BASELINE.json configs[3] (seeds 0..63) and one group of eight 3840x2160 frames
+* area ties at the top-K cut (src/cca.cpp:225-228) are resolved on the device by replaying libstdc++'s
+  __heap_select; label maps built to tie massively are checked against the oracle (whose heap restatement
+  tests/test_oracle.py pins against the live std::partial_sort) and against the live reference when present
+* four Python threads drive four models through the process-wide engine at once (the reference allows that:
+  cfast_slic.pyx:188-193 releases the GIL, per-call Context) and every result is bit-equal to the oracle
+"""
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from oracle import ref
+from fast_slic_amd import _binding as B
+from fast_slic_amd import Engine, Slic, make_params
+from fast_slic_amd.synth import variant
+from util import describe_mismatch, cluster_fields_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _expected(frames, K):
+    out = []
+    for f in frames:
+        labels, cl = orc.slic_iterate(f, orc.initialize_clusters(f, K))
+        out.append((labels, cl))
+    return out
+
+
+def _run_pipeline(H, W, K, seeds, group, nslots, rounds, expect_replay=True):
+    """Submit `rounds` times the groups cut from `seeds` through fslic_hip_pipeline_submit on `nslots` slots; every
+    submission owns its label maps and cluster blocks, all of them are compared with the oracle after the drain."""
+    import torch
+    p = make_params(10, 10.0, 0.25, 3)
+    frames = [variant("A", H, W, seed=s) for s in seeds]
+    exp = _expected(frames, K)
+    cl0 = np.zeros((len(frames), K), B.CLUSTER_DTYPE)
+    lib = B.load_library()
+    for i, f in enumerate(frames):
+        lib.fslic_hip_initialize_clusters(H, W, K, f.ctypes.data, cl0[i].ctypes.data)
+    e = Engine(0, nslots)
+    try:
+        d_rgb = [torch.from_numpy(f).cuda() for f in frames]
+        torch.cuda.synchronize()
+        subs = []
+        for r in range(rounds):
+            for g0 in range(0, len(frames), group):
+                idx = list(range(g0, min(g0 + group, len(frames))))
+                d_lab = [torch.full((H, W), -7, dtype=torch.int16, device="cuda") for _ in idx]
+                cls = cl0[idx].copy()
+                a_rgb = e.pointer_array([d_rgb[i].data_ptr() for i in idx])
+                a_lab = e.pointer_array([t.data_ptr() for t in d_lab])
+                a_cls = e.pointer_array([cls[j].ctypes.data for j in range(len(idx))])
+                torch.cuda.synchronize()
+                e.pipeline_submit(a_rgb, a_cls, a_lab, len(idx), H, W, K, p)
+                subs.append((r, idx, d_lab, cls, (a_rgb, a_lab, a_cls)))
+        tot = e.pipeline_drain()
+        assert tot["groups"] == len(subs) and tot["frames"] == rounds * len(frames)
+        assert tot["host_topk_frames"] == 0, tot            # ties are resolved on the device
+        assert tot["device_ms"] > 0.0
+        for r, idx, d_lab, cls, _keep in subs:
+            for j, i in enumerate(idx):
+                got = d_lab[j].cpu().numpy().view(np.uint16)
+                assert np.array_equal(got, exp[i][0]), describe_mismatch("round %d seed %d" % (r, seeds[i]), got, exp[i][0])
+                assert cls[j].tobytes() == exp[i][1].tobytes(), "round %d seed %d: %s" % (r, seeds[i], "; ".join(cluster_fields_equal(cls[j], exp[i][1])))
+        if expect_replay:
+            modes = [e.last_launch_mode(s) for s in range(nslots)]
+            assert 2 in modes, modes                        # slots that served more than two groups replay their graph
+    finally:
+        e.close()
+
+
+def test_bench_operating_point_8x720p_six_slots_three_rounds():
+    # exactly bench.py's timed loop: one group = seeds 0..7 at 1280x720 K=1600; 6 slots; 18 groups so that every slot goes
+    # direct -> capture -> replay; seeds 2 and 4 carry an area tie at the top-K cut
+    _run_pipeline(720, 1280, 1600, list(range(8)), 8, 6, 18)
+
+
+def test_config4_all_64_frames():
+    # BASELINE.json configs[3]: 64 frames (seeds 0..63) of 1280x720 K=1600, 8 per group
+    _run_pipeline(720, 1280, 1600, list(range(64)), 8, 6, 1)
+
+
+def test_one_group_of_eight_4k_frames():
+    _run_pipeline(2160, 3840, 1600, list(range(8)), 8, 2, 5)
+
+
+# ---- the area tie at the top-K cut, on the device ---------------------------------------------------------------
+def _tie_maps():
+    rng = np.random.RandomState(5)
+    maps = []
+    # (a) a chequerboard of 8x8 cells with random labels: hundreds of components of area 64 (and multiples where equal
+    #     neighbours merge): almost every cut falls inside a tie
+    for (H, W, cell, nlab) in [(256, 256, 8, 40), (200, 328, 4, 7), (300, 300, 10, 500)]:
+        gy, gx = (H + cell - 1) // cell, (W + cell - 1) // cell
+        lab = rng.randint(0, nlab, (gy, gx)).astype(np.uint16)
+        maps.append(np.repeat(np.repeat(lab, cell, 0), cell, 1)[:H, :W].copy())
+    # (b) horizontal stripes of equal length
+    m = np.zeros((128, 512), np.uint16)
+    m[:] = (np.arange(512) // 16)[None, :] + 32 * (np.arange(128) % 2)[:, None]
+    maps.append(m)
+    # (c) noise: thousands of tiny components, threshold 1 keeps all of them as candidates
+    maps.append(rng.randint(0, 3, (96, 160)).astype(np.uint16))
+    return maps
+
+
+@pytest.mark.parametrize("mi", range(5))
+def test_device_resolves_area_ties_like_partial_sort(engine, mi):
+    m = _tie_maps()[mi]
+    ncomp_hint = [1, 2, 5, 17, 64, 200, 333, 700, 1500, 4000]
+    for thr in (0, 1, 16, 64):
+        for K in ncomp_hint:
+            exp = orc.enforce_connectivity(m, K, thr)
+            got = engine.enforce_connectivity(m, K, thr)
+            assert np.array_equal(got, exp), describe_mismatch("map %d K=%d thr=%d" % (mi, K, thr), got, exp)
+            if ref.available() and hasattr(ref, "enforce_connectivity"):
+                live = ref.enforce_connectivity(m, K, thr)
+                assert np.array_equal(got, live), describe_mismatch("map %d K=%d thr=%d vs the live reference" % (mi, K, thr), got, live)
+
+
+# ---- concurrent callers ------------------------------------------------------------------------------------------
+def test_four_threads_four_models_concurrently():
+    shapes = [(240, 320, 150), (300, 400, 200), (480, 640, 200), (200, 264, 120)]
+    imgs = [[variant("AB"[r % 2], H, W, seed=10 * t + r) for r in range(6)] for t, (H, W, K) in enumerate(shapes)]
+    exp = []
+    for t, (H, W, K) in enumerate(shapes):
+        cl = None
+        per = []
+        for img in imgs[t]:                                  # warm start chain, like a video stream (clusters carry over)
+            cl = orc.initialize_clusters(img, K) if cl is None else cl
+            labels, cl = orc.slic_iterate(img, cl)
+            per.append((orc.to_int16(labels), cl.copy()))
+        exp.append(per)
+    errors = []
+    start = threading.Barrier(len(shapes))
+
+    def work(t):
+        try:
+            H, W, K = shapes[t]
+            s = Slic(num_components=K, compactness=10)
+            start.wait()
+            for r, img in enumerate(imgs[t]):
+                got = s.iterate(img)
+                if not np.array_equal(got, exp[t][r][0]):
+                    errors.append("thread %d frame %d: labels differ" % (t, r))
+                if s.slic_model.cluster_array.tobytes() != exp[t][r][1].tobytes():
+                    errors.append("thread %d frame %d: clusters differ" % (t, r))
+                if '"iterate"' not in s.slic_model.last_timing_report:
+                    errors.append("thread %d frame %d: no timing report" % (t, r))
+        except Exception as ex:                              # noqa: BLE001 - reported below
+            errors.append("thread %d: %r" % (t, ex))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(len(shapes))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, "\n".join(errors)
+
+
+def test_more_threads_than_slots_queue_up():
+    # 8 threads on an engine with 2 slots: calls beyond the slot count wait for a slot instead of racing
+    H, W, K = 160, 200, 60
+    imgs = [variant("A", H, W, seed=s) for s in range(8)]
+    exp = [orc.slic_iterate(im, orc.initialize_clusters(im, K)) for im in imgs]
+    e = Engine(0, 2)
+    p = make_params(10, 10.0, 0.25, 3)
+    errors = []
+
+    def work(t):
+        try:
+            for _ in range(3):
+                cl = orc.initialize_clusters(imgs[t], K).view(B.CLUSTER_DTYPE).copy()
+                labels = e.iterate(imgs[t], cl, p)
+                if not np.array_equal(labels, exp[t][0]) or cl.tobytes() != exp[t][1].tobytes():
+                    errors.append("thread %d differs" % t)
+        except Exception as ex:                              # noqa: BLE001
+            errors.append("thread %d: %r" % (t, ex))
+
+    try:
+        threads = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+    finally:
+        e.close()
+    assert not errors, "\n".join(errors)
+
+
+def test_stage_entry_points_refuse_a_slot_with_a_group_in_flight():
+    import torch
+    H, W, K = 120, 160, 40
+    img = variant("A", H, W)
+    e = Engine(0, 1)
+    try:
+        p = make_params(10, 10.0, 0.25, 3)
+        d = torch.from_numpy(img).cuda()
+        out = torch.empty((H, W), dtype=torch.int16, device="cuda")
+        cl = orc.initialize_clusters(img, K).view(B.CLUSTER_DTYPE).copy()
+        torch.cuda.synchronize()
+        a_rgb, a_lab, a_cl = e.pointer_array([d.data_ptr()]), e.pointer_array([out.data_ptr()]), e.pointer_array([cl.ctypes.data])
+        e.submit_group(0, a_rgb, a_cl, a_lab, 1, H, W, K, p)
+        with pytest.raises(ValueError):                      # the only slot owns an uncollected group
+            e.enforce_connectivity(np.zeros((8, 8), np.uint16), 4, 0)
+        with pytest.raises(ValueError):
+            e.rgb_to_lab(img)
+        e.wait_group(0)
+        exp = orc.slic_iterate(img, orc.initialize_clusters(img, K))
+        assert np.array_equal(out.cpu().numpy().view(np.uint16), exp[0]) and cl.tobytes() == exp[1].tobytes()
+        assert e.enforce_connectivity(np.zeros((8, 8), np.uint16), 4, 0).shape == (8, 8)
+    finally:
+        e.close()
+
+
+def test_enforce_connectivity_rejects_more_labels_than_uint16():
+    e = Engine(0, 1)
+    try:
+        with pytest.raises(ValueError):
+            e.enforce_connectivity(np.zeros((8, 8), np.uint16), 65537, 0)
+    finally:
+        e.close()
