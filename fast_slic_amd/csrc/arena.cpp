@@ -104,7 +104,6 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     const size_t TT = (size_t)kCcaTilePx;
     const size_t o_parent = take(N * 4), o_area = take(N * 4), o_final = take(N * 2), o_roots = take(ntiles * TT * 4);
     const size_t o_candl = take(ntiles * TT * 4), o_canda = take(ntiles * TT * 4);
-    const size_t o_tcnt = take(ntiles * 4);
     const size_t o_keepl = take((size_t)K * 4), o_keepb = take((size_t)K * 2);
     const size_t o_rgb = take(N * 3), o_out = take(N * 2);
     const size_t frame_bytes = off;
@@ -157,7 +156,6 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     c.counters = misc + 4;
     c.cand_leader = (int32_t*)(b + o_candl); c.cand_area = (uint32_t*)(b + o_canda);
     s.cand_capacity = ntiles * TT;
-    c.tile_cnt = (uint32_t*)(b + o_tcnt);
     s.d_keep_leader = (int32_t*)(b + o_keepl); s.d_keep_label = (uint16_t*)(b + o_keepb);
     s.d_rgb_stage = (uint8_t*)(b + o_rgb); s.d_out_stage = (uint16_t*)(b + o_out);
     s.keyH = H; s.keyW = W; s.keyK = K;

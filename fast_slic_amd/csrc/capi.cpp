@@ -263,4 +263,13 @@ int fslic_hip_last_host_topk_frames(fslic_engine* e, int slot) {
     return e->slots[slot].n_host_topk;
 }
 
+#ifdef FSLIC_LAB
+// lab build only: the 16 status words of frame `frame` of the last group on `slot` as the export left them in pinned memory
+int fslic_hip_debug_status_words(fslic_engine* e, int slot, int frame, uint32_t* out16) {
+    if (!e || slot < 0 || slot >= (int)e->slots.size() || frame < 0 || frame >= (int)kMaxGroup || !out16) return FSLIC_E_INVALID;
+    std::memcpy(out16, e->slots[slot].h_misc + 16 * (size_t)frame, 64);
+    return FSLIC_OK;
+}
+#endif
+
 }  // extern "C"

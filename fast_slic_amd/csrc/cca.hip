@@ -8,16 +8,16 @@ namespace fslic {
 // =============================================================================================
 // Connectivity / min-size pass (src/cca.cpp).  GPU union-find whose roots are the minimum raster
 // index of each component, exactly the "leader" the reference ends up with (src/cca.h:36-57).
-//   k_cca_local    64x64 tiles resolved entirely in LDS (row runs by ballot, vertical unions by LDS
+//   k_cca_local    64x32 tiles resolved entirely in LDS (row runs by ballot, vertical unions by LDS
 //                  atomicMin), writes parent[p] = global index of the tile-local root, tile-local
-//                  areas, and appends tile-local roots to a list
+//                  areas, and appends the tile-local roots to the frame's dense root list
 //   k_cca_border   unions across tile borders (global atomicMin)
-//   k_cca_compress tile-local roots -> global roots, areas summed into the global root
-//   k_cca_collect  global roots with area >= threshold -> candidate list for the top-K step
+//   k_cca_compress tile-local roots -> global roots, areas summed into the global root; the components whose
+//                  area reaches the threshold are appended to the candidate list as they cross it
 //   k_cca_select   top-K by area and ranking by leader in one block, including the area tie at the cut
 //   k_cca_chain    every other component takes the final label of the component left of (or
 //                  above) its leader, src/cca.cpp:240-254, resolved by chasing toward smaller leaders
-//   k_cca_relabel  out[p] = final[root(p)]
+//   k_cca_relabel  out[p] = final[root(p)] (and the group's results to the host)
 // =============================================================================================
 // LDS accessors.  They are relaxed workgroup-scope atomics rather than `volatile` accesses on purpose:
 // volatile blocks the address-space inference and the accesses become FLAT instructions, which reach the LDS
@@ -68,8 +68,16 @@ static __device__ __forceinline__ uint32_t lds_find_ro(uint32_t* par, uint32_t x
 //  C  flatten: every pixel -> tile-local root (min raster index), parent plane written, run lengths added
 //     to the root's area
 //  D  tile-local roots appended to the root list (one global atomic per wavefront row)
+#if defined(FSLIC_LAB) && FSLIC_LAB == 2      // lab build 2: per-phase time of the tile kernel, summed over the blocks into status words 8..13 (100 MHz ticks)
+#define LOC_STAMP(i_) do { __syncthreads(); if (threadIdx.x == 0) { const uint32_t t_ = (uint32_t)__builtin_amdgcn_s_memrealtime(); atomicAdd(&c.counters[4 + (i_)], t_ - loc_t); loc_t = t_; } } while (0)
+#else
+#define LOC_STAMP(i_) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void k_cca_local(CcaDev c) {
     c.select(blockIdx.z);
+#if defined(FSLIC_LAB) && FSLIC_LAB == 2
+    uint32_t loc_t = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
     constexpr int T = kCcaTile;
     constexpr int TH = kCcaTileH;
     constexpr int RW = TH / 4;
@@ -90,6 +98,7 @@ __global__ __launch_bounds__(256) void k_cca_local(CcaDev c) {
         const int y = ty0 + ly0 + i;
         lbl[i] = (okx && y < c.H) ? (uint32_t)c.in[(size_t)y * c.W + x] : 0x10000u;
     }
+    LOC_STAMP(0);
     // ---- A ----
     // Per row: every pixel whose upper neighbour has the same label folds the (possibly stale) root carried in
     // its VGPR into its run's node with a non-returning ds_min; one dependent ds_read then yields the run's
@@ -118,6 +127,7 @@ __global__ __launch_bounds__(256) void k_cca_local(CcaDev c) {
         up_root = cur_root;
     }
     __syncthreads();
+    LOC_STAMP(1);
     // ---- B ----
     if (wave > 0) {
         const int p = ly0 * T + lane;
@@ -130,6 +140,7 @@ __global__ __launch_bounds__(256) void k_cca_local(CcaDev c) {
         }
     }
     __syncthreads();
+    LOC_STAMP(2);
     // ---- C ----
     uint32_t root[RW];
 #pragma unroll
@@ -155,15 +166,16 @@ __global__ __launch_bounds__(256) void k_cca_local(CcaDev c) {
         }
     }
     __syncthreads();
-    // ---- D ---- tile-local roots -> this tile's slice of the root list.  No global atomic: a single
-    // returning atomic word saturates near 88 ops/us on this chip, which at one append per wavefront-row
-    // (130k at 4K) cost 1.2 ms in the first version of this kernel.
-    __shared__ uint32_t s_nroots;
+    LOC_STAMP(3);
+    // ---- D ---- tile-local roots -> the frame's dense root list: positions inside the tile first (LDS counter), then ONE
+    // returning global atomic per tile reserves the tile's range (a returning atomic per wavefront row saturated a single
+    // word near 88 ops/us: 1.2 ms at 4K in the first version of this kernel).  A dense list lets the passes over the roots
+    // (compress, collect, chain) run as flat, evenly loaded grids instead of one mostly idle block per tile.
+    __shared__ uint32_t s_nroots, s_base;
     if (threadIdx.x == 0) s_nroots = 0;
     __syncthreads();
-    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
-    int32_t* const my_roots = c.roots + (size_t)tile * (T * TH);
-#pragma unroll 4
+    uint32_t pos[RW];
+#pragma unroll
     for (int i = 0; i < RW; ++i) {
         const int ly = ly0 + i;
         const int y = ty0 + ly;
@@ -171,20 +183,30 @@ __global__ __launch_bounds__(256) void k_cca_local(CcaDev c) {
         const int p = ly * T + lane;
         const bool isroot = ok && root[i] == (uint32_t)p;
         const unsigned long long m = __ballot(isroot);
+        pos[i] = 0xFFFFFFFFu;
         if (m) {
             const int leader = __ffsll((long long)m) - 1;
             uint32_t base = 0;
             if (lane == leader) base = atomicAdd(&s_nroots, (uint32_t)__popcll(m));
             base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-            if (isroot) {
-                const int32_t g = (int32_t)((size_t)y * c.W + x);
-                c.area[g] = s_area[p];
-                my_roots[base + __popcll(m & ((1ull << lane) - 1ull))] = g;
-            }
+            if (isroot) pos[i] = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) c.tile_cnt[tile] = s_nroots;
+    if (threadIdx.x == 0) s_base = s_nroots ? atomicAdd(&c.counters[0], s_nroots) : 0u;
+    __syncthreads();
+    const uint32_t gbase = s_base;
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+        if (pos[i] != 0xFFFFFFFFu) {
+            const int ly = ly0 + i;
+            const int32_t g = (int32_t)((size_t)(ty0 + ly) * c.W + x);
+            const uint32_t a = s_area[ly * T + lane];
+            c.area[g] = a;
+            c.roots[gbase + pos[i]] = g;
+            c.cand_area[gbase + pos[i]] = a;      // the root's own (tile-local) area, dense: what k_cca_compress adds to the global root
+        }
+    LOC_STAMP(4);
 }
 
 static __device__ __forceinline__ int32_t g_load(int32_t* p) {
@@ -238,15 +260,25 @@ __global__ __launch_bounds__(256) void k_cca_border(CcaDev c, int nh, int nv) {
     }
 }
 
-// One block per tile for the passes over tile-local roots.
+// Pass over the frame's tile-local roots (counters[0] of them, dense): flat grid, one root per thread.
+//   * tile-local root -> global root (read-only walk), parent flattened, its tile-local area added to the global root's
+//   * global roots get their final label reset
+//   * candidates (components with area >= threshold, src/cca.cpp:213-217) are found HERE, without a second pass over
+//     complete areas: a component's area only grows, so it crosses the threshold exactly once -- either it starts at or
+//     above it (the root's own tile-local area: its owner appends it) or exactly one addition takes it across (old <
+//     threshold <= old + a: that thread appends it).  Leaders only; the select kernel reads the final areas.
 __global__ __launch_bounds__(256) void k_cca_compress(CcaDev c) {
     c.select(blockIdx.y);
-    constexpr int TT = kCcaTilePx;
-    const int tile = blockIdx.x;
-    const uint32_t n = c.tile_cnt[tile];
-    const int32_t* __restrict__ my_roots = c.roots + (size_t)tile * TT;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const int32_t r = my_roots[i];
+    const uint32_t n = c.counters[0];
+    const int lane = LANE();
+    const uint32_t gstride = gridDim.x * blockDim.x;
+    const int64_t thr = (int64_t)c.min_threshold;
+    // a wavefront's trips are uniform (the ballot below needs every lane)
+    for (uint32_t w0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); w0 < n; w0 += gstride) {
+        const uint32_t i = w0 + (uint32_t)lane;
+        const bool live = i < n;
+        const int32_t r = c.roots[min(i, n - 1)];
+        const uint32_t a = c.cand_area[min(i, n - 1)];
         // READ-ONLY walk: a path-halving store of another thread (parent[r] = some ancestor) could land after this
         // thread's parent[r] = g and leave r one level short of flat, and chain / relabel rely on parent[parent[p]]
         // being the global root (an intermittent wrong label at 4K, about one run in six, was exactly that)
@@ -256,55 +288,25 @@ __global__ __launch_bounds__(256) void k_cca_compress(CcaDev c) {
             if (p == g) break;
             g = p;
         }
-        if (g != r) {
-            __hip_atomic_store(c.parent + r, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            atomicAdd(&c.area[g], c.area[r]);
-        }
-    }
-}
-
-// Global roots: reset their final label; those with area >= threshold (src/cca.cpp:213-217) become candidates,
-// appended to the frame's dense candidate arrays (one returning atomic per tile on counters[1], which ends up as M).
-__global__ __launch_bounds__(256) void k_cca_collect(CcaDev c) {
-    c.select(blockIdx.y);
-    constexpr int TT = kCcaTilePx;
-    __shared__ uint32_t s_n, s_base;
-    __shared__ int32_t s_cl[256];
-    __shared__ uint32_t s_ca[256];
-    const int tile = blockIdx.x;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    const uint32_t n = c.tile_cnt[tile];
-    const int32_t* __restrict__ my_roots = c.roots + (size_t)tile * TT;
-    for (uint32_t i0 = 0; i0 < n; i0 += blockDim.x) {
-        const uint32_t i = i0 + threadIdx.x;
         bool cand = false;
-        int32_t r = 0;
-        uint32_t a = 0;
-        if (i < n) {
-            r = my_roots[i];
-            if (c.parent[r] == r) {
+        int32_t leader = g;
+        if (live) {
+            if (g == r) {
                 c.final_lab[r] = 0xFFFFu;
-                a = c.area[r];
-                cand = (int64_t)a >= (int64_t)c.min_threshold;
+                cand = (int64_t)a >= thr;
+            } else {
+                __hip_atomic_store(c.parent + r, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t old = atomicAdd(&c.area[g], a);
+                cand = (int64_t)old < thr && (int64_t)old + (int64_t)a >= thr;
             }
         }
-        if (cand) {
-            const uint32_t pos = atomicAdd(&s_n, 1u);
-            s_cl[pos] = r; s_ca[pos] = a;
-        }
-        __syncthreads();
-        const uint32_t m = s_n;
+        const unsigned long long m = __ballot(cand);
         if (m) {
-            if (threadIdx.x == 0) s_base = atomicAdd(&c.counters[1], m);
-            __syncthreads();
-            if (threadIdx.x < m) {
-                c.cand_leader[s_base + threadIdx.x] = s_cl[threadIdx.x];
-                c.cand_area[s_base + threadIdx.x] = s_ca[threadIdx.x];
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) s_n = 0;
-            __syncthreads();
+            const int first = __ffsll((long long)m) - 1;
+            uint32_t base = 0;
+            if (lane == first) base = atomicAdd(&c.counters[1], (uint32_t)__popcll(m));
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+            if (cand) c.cand_leader[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = leader;
         }
     }
 }
@@ -397,40 +399,98 @@ static __device__ __forceinline__ void select_pass(const uint32_t* s_area, uint3
 //   4. the heap's K entries are the kept set: label = rank among the kept in leader order (src/cca.cpp:229-237)
 // The heap is two arrays moved in tandem (candidate index, its area): one LDS round trip per level instead of two.
 // ---------------------------------------------------------------------------------------------
-static __device__ __forceinline__ void tie_adjust_heap(uint32_t* hi, uint32_t* ha, int hole, int len, uint32_t vi, uint32_t va, bool writer) {
-    const int top = hole;
-    int child = hole;
-    while (child < (len - 1) / 2) {
-        child = 2 * (child + 1);
-        const uint32_t a1 = lds_ld(ha + child), a0 = lds_ld(ha + child - 1);
-        uint32_t am = a1;
-        if (a1 > a0) { child--; am = a0; }                   // comp(first[child], first[child - 1])
-        const uint32_t im = lds_ld(hi + child);
-        if (writer) { lds_st(hi + hole, im); lds_st(ha + hole, am); }
-        hole = child;
+typedef unsigned long long heap_t;      // area << 32 | candidate index: one LDS access moves an entry, comp looks at the high half
+static __device__ __forceinline__ heap_t hp_ld(heap_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+static __device__ __forceinline__ void hp_st(heap_t* p, heap_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+static __device__ __forceinline__ uint32_t hp_area(heap_t e) { return (uint32_t)(e >> 32); }
+
+// Net effect of bits/stl_heap.h __adjust_heap(first, hole, len, value, comp) (which ends in __push_heap), comp(l, r) =
+// area[l] > area[r], on a range whose part below `hole` is a valid heap.  libstdc++ walks the hole down to a leaf along the
+// preferred children (the child with the smaller area, the right one on a tie; the walk does not look at `value`), then
+// pushes `value` back up along the same path while the parent's area is larger.  Areas never decrease along that path, so
+// everything below the first entry whose area exceeds value's returns to where it was: the result is the entries e_1 .. e_h
+// of the path moved up one place and `value` stored at position h, h = the last path index whose area is <= value's.  That
+// is a top-down sift that stops at the first larger child -- identical results, a handful of levels instead of the whole
+// depth twice (pinned against the library's own heap calls in the tests, like the rest of the tie path).
+static __device__ __forceinline__ void tie_adjust_heap(heap_t* h, int hole, int len, heap_t value, bool writer) {
+    int cur = hole;
+    for (;;) {
+        int child;
+        heap_t em;
+        if (cur < (len - 1) / 2) {
+            child = 2 * (cur + 1);
+            const heap_t e1 = hp_ld(h + child), e0 = hp_ld(h + child - 1);     // both children in one LDS round trip
+            em = e1;
+            if (hp_area(e1) > hp_area(e0)) { child--; em = e0; }              // comp(first[child], first[child - 1])
+        } else if ((len & 1) == 0 && cur == (len - 2) / 2) {                   // the one node with a single (left) child
+            child = 2 * cur + 1;
+            em = hp_ld(h + child);
+        } else {
+            break;
+        }
+        if (hp_area(em) > hp_area(value)) break;                              // __push_heap would bring it back here
+        if (writer) hp_st(h + cur, em);
+        cur = child;
     }
-    if ((len & 1) == 0 && child == (len - 2) / 2) {
-        child = 2 * (child + 1);
-        const uint32_t im = lds_ld(hi + child - 1), am = lds_ld(ha + child - 1);
-        if (writer) { lds_st(hi + hole, im); lds_st(ha + hole, am); }
-        hole = child - 1;
-    }
-    // __push_heap(first, hole, top, value)
-    int parent = (hole - 1) / 2;
-    while (hole > top) {
-        const uint32_t ap = lds_ld(ha + parent);
-        if (!(ap > va)) break;                                // comp(first[parent], value)
-        const uint32_t ip = lds_ld(hi + parent);
-        if (writer) { lds_st(hi + hole, ip); lds_st(ha + hole, ap); }
-        hole = parent;
-        parent = (hole - 1) / 2;
-    }
-    if (writer) { lds_st(hi + hole, vi); lds_st(ha + hole, va); }
+    if (writer) hp_st(h + cur, value);
 }
 
+// __pop_heap(first, middle, i) of the __heap_select loop = the sift above started at the root, executed by ONE wavefront.
+// The walk's choices do not depend on the new value, only on the heap, and a dependent LDS read per level is what a
+// sequential walk costs (most of the 11 levels at K = 1600: the candidates past the K-th leader are ordinary, large
+// components that sink to the leaves).  Here the wavefront fetches a whole sub-tree at once -- lane j (1..63) reads the node
+// with heap number j relative to the current node: five levels below it in ONE LDS round trip -- and resolves those
+// five levels with cross-lane reads (v_readlane, scalar compares); lane 0 stores the moves.  Nodes past the heap's end read as
+// area 0xffffffff, which reproduces the walk's rules for the node with one child and for leaves.  All lanes of the
+// wavefront must be active; control flow is uniform.
+static __device__ __forceinline__ void tie_replace_root(heap_t* h, int len, heap_t value, int lane) {
+    constexpr uint32_t kInf = 0xFFFFFFFFu;
+    const uint32_t va = hp_area(value);
+    const int t = 31 - __clz(lane | 1);                       // depth of relative node `lane` (lane 0: unused)
+    const int off = lane - (1 << t);
+    int cur = 0;                                               // absolute index of the node the value may still end up at
+    for (;;) {
+        const long long idx = (((long long)(cur + 1)) << t) + off - 1;
+        const bool ok = lane >= 1 && idx < (long long)len;
+        const heap_t e = ok ? hp_ld(h + idx) : ((heap_t)kInf << 32);
+        const uint32_t e_hi = (uint32_t)(e >> 32), e_lo = (uint32_t)e;
+        // five levels, straight-line (a taken scalar branch costs more than a level's arithmetic): lane s keeps step s's
+        // move (the node it fills and the child entry that moves up), lanes 0..5 the node reached before step s
+        int j = 1, node = cur;
+        uint32_t stops = 0;
+        int w_pos = 0;
+        uint32_t w_hi = 0, w_lo = 0;
+#pragma unroll
+        for (int s5 = 0; s5 < 5; ++s5) {
+            const int jl = (2 * j) & 63, jr = (2 * j + 1) & 63;
+            const uint32_t al = (uint32_t)__builtin_amdgcn_readlane((int)e_hi, jl), ar = (uint32_t)__builtin_amdgcn_readlane((int)e_hi, jr);
+            const bool left = ar > al;                         // comp(first[right], first[left]): the smaller area, the right child on a tie
+            const int jc = left ? jl : jr;
+            const uint32_t ac = left ? al : ar;
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)e_lo, jc);
+            stops |= (uint32_t)(ac == kInf || ac > va) << s5;  // leaf, or __push_heap would bring the value back up to here
+            if (lane == s5) { w_pos = node; w_hi = ac; w_lo = lo; }
+            node = 2 * node + (left ? 1 : 2);
+            j = jc;
+        }
+        if (lane == 5) w_pos = node;
+        const int nmove = stops ? __builtin_ctz(stops) : 5;    // moves of this round that really happen
+        if (lane < nmove) hp_st(h + w_pos, ((heap_t)w_hi << 32) | w_lo);
+        cur = __builtin_amdgcn_readlane(w_pos, nmove);
+        if (stops) break;
+    }
+    if (lane == 0) hp_st(h + cur, value);
+}
+
+#if defined(FSLIC_LAB) && FSLIC_LAB == 1      // lab build only (make LAB=1): 100 MHz time stamps of the select kernel in the unused status words 8..15
+#define SEL_STAMP(i_) do { if (threadIdx.x == 0) c.counters[4 + (i_)] = (uint32_t)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SEL_STAMP(i_) do { } while (0)
+#endif
 static __device__ __forceinline__ void tie_heap_select(const CcaDev& c, uint32_t M, uint32_t K, uint32_t* s_area, uint32_t* s_lead, uint32_t* s_key,
                                                        uint32_t* s_bcnt, uint32_t* s_bstart, uint32_t* s_bfill, uint32_t* s_w) {
     const int tid = threadIdx.x, lane = tid & 63;
+    SEL_STAMP(2);
     constexpr int PER = kSelSortCap / 1024;                   // candidates per thread
     // 1. leader order
     int bsh = 0;
@@ -467,18 +527,19 @@ static __device__ __forceinline__ void tie_heap_select(const CcaDev& c, uint32_t
         }
     }
     __syncthreads();
-    // leaders in order -> global (read back in step 4), areas in order -> s_area; s_key <- heap indices, s_lead <- heap areas
-    uint32_t* const hi_ = s_key;
-    uint32_t* const ha_ = s_lead;
+    // leaders in order -> global (read back in step 4), areas in order -> s_area; the heap (K 64-bit entries) takes over
+    // s_lead and s_key, which are adjacent and dead from here on (2 * cap words >= 2 K)
+    heap_t* const heap = reinterpret_cast<heap_t*>(s_lead);
 #pragma unroll
     for (int q = 0; q < PER; ++q)
         if (my_rank[q] != 0xFFFFFFFFu) {
             const uint32_t r = my_rank[q];
             c.cand_leader[r] = (int32_t)my_lead[q];
             s_area[r] = my_area[q];
-            if (r < K) { hi_[r] = r; ha_[r] = my_area[q]; }
+            if (r < K) heap[r] = ((heap_t)my_area[q] << 32) | r;
         }
     __syncthreads();
+    SEL_STAMP(3);
     // 2. __make_heap(first, first + K)
     const int len = (int)K;
     if (len >= 2) {
@@ -488,13 +549,14 @@ static __device__ __forceinline__ void tie_heap_select(const CcaDev& c, uint32_t
         for (; d >= 0; --d) {
             const int lo = (1 << d) - 1, hi = min((2 << d) - 2, last_parent);
             for (int p = lo + tid; p <= hi; p += 1024)
-                tie_adjust_heap(hi_, ha_, p, len, lds_ld(hi_ + p), lds_ld(ha_ + p), true);
+                tie_adjust_heap(heap, p, len, hp_ld(heap + p), true);
             __syncthreads();
         }
     }
+    SEL_STAMP(4);
     // 3. for (i = K; i < M; ++i) if (comp(*i, *first)) __pop_heap(first, middle, i)
     if (tid < 64) {
-        uint32_t top_area = lds_ld(ha_);
+        uint32_t top_area = hp_area(hp_ld(heap));
         for (uint32_t base = K; base < M; base += 64) {
             const uint32_t i = base + (uint32_t)lane;
             const uint32_t a = i < M ? s_area[i] : 0u;
@@ -504,22 +566,24 @@ static __device__ __forceinline__ void tie_heap_select(const CcaDev& c, uint32_t
                 m &= m - 1ull;
                 const uint32_t aj = (uint32_t)__builtin_amdgcn_readlane((int)a, j);
                 if (aj > top_area) {
-                    tie_adjust_heap(hi_, ha_, 0, len, base + (uint32_t)j, aj, lane == 0);
-                    top_area = lds_ld(ha_);
+                    tie_replace_root(heap, len, ((heap_t)aj << 32) | (heap_t)(base + (uint32_t)j), lane);
+                    top_area = hp_area(hp_ld(heap));
                 }
             }
         }
     }
     __syncthreads();
+    SEL_STAMP(5);
     // 4. kept set = the heap's K entries; label = rank among the kept in leader order
-    // flags live in ha_ (the heap areas are dead once the indices are read): read all indices first
+    // the kept flags reuse the heap's words (dead once its indices have been read): read all indices first
     uint32_t kept_idx[PER];
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         const uint32_t t = (uint32_t)tid + (uint32_t)q * 1024u;
-        kept_idx[q] = t < K ? hi_[t] : 0xFFFFFFFFu;
+        kept_idx[q] = t < K ? (uint32_t)heap[t] : 0xFFFFFFFFu;
     }
     __syncthreads();
+    uint32_t* const ha_ = s_lead;
     for (uint32_t i = tid; i < M; i += 1024) ha_[i] = 0u;
     __syncthreads();
 #pragma unroll
@@ -542,11 +606,13 @@ static __device__ __forceinline__ void tie_heap_select(const CcaDev& c, uint32_t
         if (fl[q]) c.final_lab[c.cand_leader[i]] = (uint16_t)run;
         run += fl[q];
     }
+    SEL_STAMP(6);
 }
 
 __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int cap) {
     c.select(blockIdx.x);
-    extern __shared__ uint32_t s_dyn[];
+    SEL_STAMP(0);
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];     // the tie path overlays 64-bit heap entries
     uint32_t* const s_area = s_dyn;
     uint32_t* const s_lead = s_dyn + cap;
     uint32_t* const s_key = s_dyn + 2 * cap;
@@ -569,9 +635,10 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int cap) {
     }
     uint32_t amax = 0;
     for (uint32_t i = tid; i < M; i += 1024) {
-        const uint32_t a = c.cand_area[i];
+        const uint32_t l = (uint32_t)c.cand_leader[i];
+        const uint32_t a = c.area[l];
         s_area[i] = a;
-        s_lead[i] = (uint32_t)c.cand_leader[i];
+        s_lead[i] = l;
         amax = max(amax, a);
     }
     __syncthreads();
@@ -604,6 +671,7 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int cap) {
         for (int off = 32; off > 0; off >>= 1) eq += (uint32_t)__shfl_xor(eq, off);
         if (lane == 0 && eq) atomicAdd(&s_v[4], eq);
         __syncthreads();
+        SEL_STAMP(1);
         if (s_v[4] != kk) {
             // Area tie at the cut: which of the tied components std::partial_sort (src/cca.cpp:225-228) keeps depends on
             // libstdc++'s heap mechanics, so its __heap_select is replayed here, operation by operation, on the candidates
@@ -652,6 +720,13 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int cap) {
     if (tid == 0) c.counters[3] = 0u;
 }
 
+// Grid of a pass over the roots: one root per thread for up to N / 12 roots (a structured frame has fewer: 57 k of 922 k
+// pixels at 1280x720), more trips for noise; at least one block.
+static int root_pass_blocks(const CcaDev& c) {
+    const int b = (c.N / 12 + 255) / 256;
+    return b < 1 ? 1 : b;
+}
+
 void launch_cca_phase1(const CcaDev& c, int nframes, hipStream_t st) {
     constexpr int T = kCcaTile;
     const int tx = (c.W + T - 1) / T, ty = (c.H + kCcaTileH - 1) / kCcaTileH;
@@ -659,8 +734,7 @@ void launch_cca_phase1(const CcaDev& c, int nframes, hipStream_t st) {
     const int nh = (ty - 1) * c.W, nv = (tx - 1) * c.H;
     if (nh + nv > 0)
         hipLaunchKernelGGL(k_cca_border, dim3((nh + nv + 255) / 256, nframes), dim3(256), 0, st, c, nh, nv);
-    hipLaunchKernelGGL(k_cca_compress, dim3(tx * ty, nframes), dim3(256), 0, st, c);
-    hipLaunchKernelGGL(k_cca_collect, dim3(tx * ty, nframes), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_cca_compress, dim3(root_pass_blocks(c), nframes), dim3(256), 0, st, c);
 }
 
 void launch_cca_select(const CcaDev& c, int nframes, hipStream_t st) {
@@ -679,12 +753,9 @@ void launch_cca_select(const CcaDev& c, int nframes, hipStream_t st) {
 
 // Host path only: forget what the device select / chain wrote, then set the host's choice.
 __global__ __launch_bounds__(256) void k_cca_reset_final(CcaDev c) {
-    constexpr int TT = kCcaTilePx;
-    const int tile = blockIdx.x;
-    const uint32_t n = c.tile_cnt[tile];
-    const int32_t* __restrict__ my_roots = c.roots + (size_t)tile * TT;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const int32_t r = my_roots[i];
+    const uint32_t n = c.counters[0];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int32_t r = c.roots[i];
         if (c.parent[r] == r) c.final_lab[r] = 0xFFFFu;
     }
 }
@@ -692,44 +763,68 @@ __global__ void k_cca_set_kept(CcaDev c, const int32_t* __restrict__ leaders, co
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) c.final_lab[leaders[i]] = labels[i];
 }
+// Host top-K path: areas of the candidates, dense next to their leaders (the device path reads them in place).
+__global__ void k_cca_gather_area(CcaDev c) {
+    const uint32_t M = c.counters[1];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) c.cand_area[i] = c.area[c.cand_leader[i]];
+}
+void launch_cca_gather_area(const CcaDev& c, hipStream_t st) {
+    hipLaunchKernelGGL(k_cca_gather_area, dim3(64), dim3(256), 0, st, c);
+}
+
 void launch_cca_set_kept(const CcaDev& c, const int32_t* d_leaders, const uint16_t* d_labels, int n, hipStream_t st) {
-    constexpr int T = kCcaTile;
-    const int ntiles = ((c.W + T - 1) / T) * ((c.H + kCcaTileH - 1) / kCcaTileH);
-    hipLaunchKernelGGL(k_cca_reset_final, dim3(ntiles), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_cca_reset_final, dim3(root_pass_blocks(c)), dim3(256), 0, st, c);
     if (n <= 0) return;
     hipLaunchKernelGGL(k_cca_set_kept, dim3((n + 255) / 256), dim3(256), 0, st, c, d_leaders, d_labels, n);
 }
 
 // Every component that was not kept takes the final label of the component left of (or, in column 0,
 // above) its leader (src/cca.cpp:240-254).  Leaders strictly decrease along the chase, so it terminates.
-__global__ __launch_bounds__(256) void k_cca_chain(CcaDev c) {
-    c.select(blockIdx.y);
-    constexpr int TT = kCcaTilePx;
-    const int tile = blockIdx.x;
-    const uint32_t n = c.tile_cnt[tile];
-    const int32_t* __restrict__ my_roots = c.roots + (size_t)tile * TT;
+// Final label of a component that was not kept (src/cca.cpp:240-254): that of the component left of (in column 0: above) its
+// leader, followed along the chain until a component with a final label or pixel 0 is reached.  Leaders strictly decrease
+// along the chain, so it terminates.  (Evaluating this per pixel inside the relabel pass instead of once per root was
+// measured: 59 us instead of 18 + 20 for eight 1280x720 frames -- a wavefront waits for its longest chain.)
+static __device__ __forceinline__ uint32_t chase_final(const CcaDev& c, int32_t cur) {
     const int W = c.W;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const int32_t r = my_roots[i];
-        if (c.parent[r] != r) continue;
-        if (__hip_atomic_load(c.final_lab + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0xFFFFu) continue;   // kept
-        int32_t cur = r;
-        uint32_t f;
-        for (;;) {
-            if (cur == 0) { f = 0; break; }        // src/cca.cpp:238
-            const int32_t t = (cur % W > 0) ? cur - 1 : cur - W;   // src/cca.cpp:243-248
-            const int32_t g = c.parent[c.parent[t]];
-            f = __hip_atomic_load(c.final_lab + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (f != 0xFFFFu) break;
-            cur = g;
-        }
-        __hip_atomic_store(c.final_lab + r, (uint16_t)f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        if (cur == 0) return 0u;                        // src/cca.cpp:238
+        const int32_t t = (cur % W > 0) ? cur - 1 : cur - W;   // src/cca.cpp:243-248
+        const int32_t g = c.parent[c.parent[t]];
+        const uint32_t f = __hip_atomic_load(c.final_lab + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f != 0xFFFFu) return f;
+        cur = g;
     }
 }
 
-__global__ __launch_bounds__(256) void k_cca_relabel(CcaDev c) {
+__global__ __launch_bounds__(256) void k_cca_chain(CcaDev c) {
     c.select(blockIdx.y);
-    const int gstride = gridDim.x * blockDim.x;
+    const uint32_t n = c.counters[0];
+    const uint32_t gstride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gstride) {
+        const int32_t r = c.roots[i];
+        if (c.parent[r] != r) continue;
+        if (__hip_atomic_load(c.final_lab + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0xFFFFu) continue;   // kept
+        __hip_atomic_store(c.final_lab + r, (uint16_t)chase_final(c, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// The last kernel of a group also carries the group's results to the host: blocks past the relabel grid copy the
+// cluster state and the frame's status words into the engine's pinned blocks (ExportDev; K == 0: nothing to export).
+__global__ __launch_bounds__(256) void k_cca_relabel(CcaDev c, ExportDev ex, int relabel_blocks) {
+    const int z = blockIdx.y;
+    if ((int)blockIdx.x >= relabel_blocks) {
+        const size_t d = (size_t)z * ex.frame_bytes;
+        const uint32_t* yx = ex.yx_cur; const uint32_t* rest = ex.lab_n_moved; const uint32_t* misc = ex.misc0;
+        FrameDev::adv(yx, d); FrameDev::adv(rest, d); FrameDev::adv(misc, d);
+        uint32_t* out = ex.h_cl + (size_t)z * ex.h_stride;
+        const int K = ex.K;
+        for (int i = ((int)blockIdx.x - relabel_blocks) * blockDim.x + threadIdx.x; i < 4 * K; i += ((int)gridDim.x - relabel_blocks) * blockDim.x)
+            out[i] = i < K ? yx[i] : rest[i - K];              // [0,K) positions, [K,4K) colour, member count, moved flag
+        if ((int)blockIdx.x == relabel_blocks && threadIdx.x < 16) ex.h_misc[16 * (size_t)z + threadIdx.x] = misc[threadIdx.x];
+        return;
+    }
+    c.select(z);
+    const int gstride = relabel_blocks * blockDim.x;
     const int nquad = c.N >> 2;
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += gstride) {
         const int4 lr = reinterpret_cast<const int4*>(c.parent)[q];
@@ -744,15 +839,16 @@ __global__ __launch_bounds__(256) void k_cca_relabel(CcaDev c) {
         st_stream(c.out + p, c.final_lab[c.parent[c.parent[p]]]);
 }
 
-void launch_cca_phase2(const CcaDev& c, int nframes, hipStream_t st) {
-    constexpr int T = kCcaTile;
-    const int ntiles = ((c.W + T - 1) / T) * ((c.H + kCcaTileH - 1) / kCcaTileH);
-    hipLaunchKernelGGL(k_cca_chain, dim3(ntiles, nframes), dim3(256), 0, st, c);
+void launch_cca_phase2(const CcaDev& c, int nframes, hipStream_t st, const ExportDev* ex_) {
+    hipLaunchKernelGGL(k_cca_chain, dim3(root_pass_blocks(c), nframes), dim3(256), 0, st, c);
     int blocks = (c.N / 4 + 255) / 256;
     const int cap = (4096 + nframes - 1) / nframes;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_cca_relabel, dim3(blocks, nframes), dim3(256), 0, st, c);
+    ExportDev ex{};
+    if (ex_) ex = *ex_;
+    const int eb = ex.K > 0 ? (4 * ex.K + 1023) / 1024 : 0;          // a few blocks: 4K words per frame
+    hipLaunchKernelGGL(k_cca_relabel, dim3(blocks + eb, nframes), dim3(256), 0, st, c, ex, blocks);
 }
 
 }  // namespace fslic

@@ -161,26 +161,4 @@ void launch_bin_clusters(const FrameDev& f_, int nframes, int mode, int buf, int
     }
 }
 
-// Results of a group -> the engine's pinned host blocks (device-accessible), written in place by the kernel: no copy
-// command in the launch sequence.  Visible to the host once the stream has been synchronised.
-__global__ __launch_bounds__(256) void k_export_state(FrameDev f, const uint32_t* yx_cur, uint32_t* h_cl, size_t h_stride, const uint32_t* misc0, uint32_t* h_misc) {
-    const int z = blockIdx.y;
-    const size_t d = (size_t)z * f.frame_bytes;
-    FrameDev::adv(yx_cur, d); FrameDev::adv(misc0, d);
-    f.select(z);
-    uint32_t* out = h_cl + (size_t)z * h_stride;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int K = f.K;
-    if (i < K) out[i] = yx_cur[i];
-    else if (i < 4 * K) out[i] = f.cl_lab[i - K];          // cl_lab, cl_n, cl_moved are contiguous (K words each)
-    if (blockIdx.x == 0 && threadIdx.x < 16) h_misc[16 * (size_t)z + threadIdx.x] = misc0[threadIdx.x];
-}
-
-void launch_export_state(const FrameDev& f, int nframes, const uint32_t* yx_cur, uint32_t* h_cl, size_t h_stride,
-                         const uint32_t* misc0, uint32_t* h_misc, hipStream_t st) {
-    FrameDev g = f;
-    g.rgbs = nullptr;                         // select() must not touch the caller's pointer table here
-    hipLaunchKernelGGL(k_export_state, dim3((4 * f.K + 255) / 256, nframes), dim3(256), 0, st, g, yx_cur, h_cl, h_stride, misc0, h_misc);
-}
-
 }  // namespace fslic

@@ -229,7 +229,7 @@ int ensure_cand_capacity(Slot& s, size_t M);
 int validate(const fslic_params* p, int H, int W, int K, int& S);
 int upload_ptrs(Slot& s, int n, const uint8_t* const* d_rgb, uint16_t* const* d_out);
 CcaDev cca_view(const Slot& s, int i0, const uint16_t* d_in0, size_t in_stride, int K, int min_threshold);
-void cca_enqueue(Slot& s, const CcaDev& c, int i0, int n);
+void cca_enqueue(Slot& s, const CcaDev& c, int i0, int n, const ExportDev* ex = nullptr);
 int cca_finish_group(Slot& s, int first, int n, const uint16_t* d_in0, size_t in_stride, int K, int thres);
 int group_begin(fslic_engine* e, Slot& s, const fslic_params* p, int H, int W, int K, int n,
                 const uint8_t* const* d_rgb, fslic_cluster* const* clusters, uint16_t* const* d_out);

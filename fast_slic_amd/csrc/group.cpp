@@ -71,7 +71,7 @@ CcaDev cca_view(const Slot& s, int i0, const uint16_t* d_in0, size_t in_stride, 
     FrameDev::adv(c.in, (size_t)i0 * in_stride);
     const size_t d = (size_t)i0 * c.frame_bytes;
     FrameDev::adv(c.parent, d); FrameDev::adv(c.area, d); FrameDev::adv(c.final_lab, d); FrameDev::adv(c.roots, d);
-    FrameDev::adv(c.tile_cnt, d); FrameDev::adv(c.counters, d);
+    FrameDev::adv(c.counters, d);
     FrameDev::adv(c.cand_leader, d); FrameDev::adv(c.cand_area, d);
     c.outs = reinterpret_cast<uint16_t* const*>(s.d_ptrs + kMaxGroup + i0);
     return c;
@@ -90,11 +90,11 @@ int upload_ptrs(Slot& s, int n, const uint8_t* const* d_rgb, uint16_t* const* d_
 // Connectivity pass, fully asynchronous on the slot's stream: tile CCL, seams, compress, collect, device
 // top-K + ranking, chain, relabel, for frames [i0, i0+n) (c = cca_view(s, i0, ...)).  The select status of every
 // frame ends up in its misc words; cca_finish_group() serves the frames whose status is not 0.
-void cca_enqueue(Slot& s, const CcaDev& c, int i0, int n) {
+void cca_enqueue(Slot& s, const CcaDev& c, int i0, int n, const ExportDev* ex) {
     (void)i0;
     launch_cca_phase1(c, n, s.st);
     launch_cca_select(c, n, s.st);
-    launch_cca_phase2(c, n, s.st);
+    launch_cca_phase2(c, n, s.st, ex);
 }
 
 // After the stream has been synchronised and h_misc refreshed.  The select kernel resolves the top-K step on the
@@ -113,6 +113,7 @@ int cca_finish_group(Slot& s, int first, int n, const uint16_t* d_in0, size_t in
         const uint32_t M = hm[4 + 1];
         int rc = ensure_cand_capacity(s, std::max<size_t>(M, 1) * 2);
         if (rc) return rc;
+        launch_cca_gather_area(c1, s.st);
         HIPCHK(hipMemcpyAsync(s.h_cand_leader, d_dl, sizeof(int32_t) * M, hipMemcpyDeviceToHost, s.st));
         HIPCHK(hipMemcpyAsync(s.h_cand_area, d_da, sizeof(uint32_t) * M, hipMemcpyDeviceToHost, s.st));
         HIPCHK(hipStreamSynchronize(s.st));
@@ -227,11 +228,11 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     uint32_t* const yx_a = yx_up + 6 * (size_t)K;       // this frame's d_yx_alt[0]
     uint32_t* const yx_b = yx_up + 7 * (size_t)K;       // this frame's d_yx_alt[1]
     f.cl_yx = yx_up; f.cl_yx_out = yx_a;
+    const int stride = p->subsample_stride;
+    const bool lsc = p->variant == FSLIC_VARIANT_LSC;
     launch_bin_clusters(f, n, 0, 0, 0, pg, s.st, s.h_cl + (size_t)i0 * 4 * K, 4 * (size_t)K);
     uint32_t* yx_cur = yx_a;
-    const int stride = p->subsample_stride;
     int rem = 0;
-    const bool lsc = p->variant == FSLIC_VARIANT_LSC;
     LscDev l = s.l;
     if (lsc) {
         l.select(i0);
@@ -303,11 +304,14 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     // enforce_connectivity, src/context.cpp:14-20
     const int thres = (int)round((double)(S * S) * (double)p->min_size_factor);
     const CcaDev c = cca_view(s, i0, s.f.labels, fb, K, thres);
-    cca_enqueue(s, c, i0, n);
+    // cluster state, overflow flag and connectivity status back to the host: the last kernel of the connectivity pass
+    // writes them into the slot's pinned blocks (three 2-D copy commands per group before: blit kernels with their own
+    // barriers).  The status words are final once the select kernel has run, the cluster state since the loop ended.
+    ExportDev ex{};
+    ex.frame_bytes = fb; ex.K = K; ex.yx_cur = yx_cur; ex.lab_n_moved = yx_up + K; ex.misc0 = s.at(s.d_misc, i0);
+    ex.h_cl = s.h_cl + (size_t)i0 * 4 * K; ex.h_stride = 4 * (size_t)K; ex.h_misc = s.h_misc + 16 * (size_t)i0;
+    cca_enqueue(s, c, i0, n, &ex);
     if (timed) HIPCHK(hipEventRecord(s.ev[4], s.st));
-    // cluster state, overflow flag and connectivity status back to the host: one small kernel writes them into the
-    // slot's pinned blocks (three 2-D copy commands per group before; each was a blit kernel plus its own barriers)
-    launch_export_state(f, n, yx_cur, s.h_cl + (size_t)i0 * 4 * K, 4 * (size_t)K, s.at(s.d_misc, i0), s.h_misc + 16 * (size_t)i0, s.st);
     if (pre) HIPCHK(hipMemcpy2DAsync(s.h_upd + (size_t)i0 * K, sizeof(uint32_t) * (size_t)K, f.cl_upd, fb,
                                      sizeof(uint32_t) * (size_t)K, (size_t)n, hipMemcpyDeviceToHost, s.st));
     if (noq) HIPCHK(hipMemcpy2DAsync(s.h_clf + (size_t)i0 * 8 * K, sizeof(float) * 8 * (size_t)K, f.cl_f, fb,

@@ -141,17 +141,17 @@ struct CcaDev {
     int32_t* parent;      // N
     uint32_t* area;       // N (sparse: valid at tile-local roots)
     uint16_t* final_lab;  // N (sparse: valid at global roots)
-    int32_t* roots;       // ntiles * kCcaTilePx: tile t's tile-local roots at [t*kCcaTilePx, +tile_cnt[t])
-    uint32_t* tile_cnt;   // ntiles
-    uint32_t* counters;   // [1] M = number of candidates (append cursor of k_cca_collect), [2] M again, [3] select status
+    int32_t* roots;       // the frame's tile-local roots, dense: counters[0] of them (capacity N)
+    uint32_t* counters;   // [0] number of tile-local roots (append cursor of k_cca_local), [1] M = number of candidates (append cursor of k_cca_collect), [2] M again, [3] select status
     int32_t* cand_leader; // dense candidate list (global roots with area >= threshold): leaders,
-    uint32_t* cand_area;  //   and areas; capacity ntiles * kCcaTilePx >= N.  Unordered unless the select status is 1
+    uint32_t* cand_area;  //   same capacity (>= N): the tile-local areas next to `roots` until k_cca_compress has run, then free
+                          //   (the host top-K path gathers the candidates' areas into it)
     __host__ __device__ __forceinline__ void select(int z) {
         out = outs[z];
         FrameDev::adv(in, (size_t)z * in_stride);
         const size_t d = (size_t)z * frame_bytes;
         FrameDev::adv(parent, d); FrameDev::adv(area, d); FrameDev::adv(final_lab, d); FrameDev::adv(roots, d);
-        FrameDev::adv(tile_cnt, d); FrameDev::adv(counters, d);
+        FrameDev::adv(counters, d);
         FrameDev::adv(cand_leader, d); FrameDev::adv(cand_area, d);
     }
 };
@@ -200,11 +200,7 @@ void launch_rgb_to_lab(const FrameDev& f, int nframes, int convert, const LabTab
 // src_yx + z * src_stride words) instead of FrameDev::cl_yx.
 void launch_bin_clusters(const FrameDev& f, int nframes, int mode, int buf, int sbuf, const PassGeom& pg, hipStream_t st,
                          const uint32_t* src_yx = nullptr, size_t src_stride = 0);
-// End of a group: positions (yx_cur: frame 0's current position buffer), colour / member count / moved flag (the 3K words
-// after FrameDev::cl_lab) and the frame's 16 status words (misc0: frame 0's) -> the engine's pinned blocks, frame z at
-// h_cl + z * h_stride words: [0,K) yx, [K,4K) lab, n, moved; h_misc + 16 z.
-void launch_export_state(const FrameDev& f, int nframes, const uint32_t* yx_cur, uint32_t* h_cl, size_t h_stride,
-                         const uint32_t* misc0, uint32_t* h_misc, hipStream_t st);
+
 // One assign pass over rows == rem (mod stride); fuse_update also accumulates the centroid sums
 // of src/context.cpp:301-354 for the same rows.  Returns the geometry the following cluster pass needs.
 PassGeom launch_assign(const FrameDev& f, int nframes, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st);
@@ -230,8 +226,22 @@ void launch_preempt_update(const FrameDev& f, int nframes, int buf, int sbuf, bo
 void launch_cca_phase1(const CcaDev& c, int nframes, hipStream_t st);   // local CCL, border merge, compress, collect
 // device top-K + ranking, including the area tie at the cut; counters[3] = status (see k_cca_select)
 void launch_cca_select(const CcaDev& c, int nframes, hipStream_t st);
-void launch_cca_phase2(const CcaDev& c, int nframes, hipStream_t st);   // chain resolution + relabel
+// End of a group: what the last kernel also writes into the engine's pinned host blocks (device-accessible), so that a
+// group's launch sequence holds no copy command.  Pointers are frame 0's (frame z: + z * frame_bytes); frame z lands at
+// h_cl + z * h_stride words: [0,K) positions, [K,4K) colour / member count / moved flag; h_misc + 16 z: the status words.
+struct ExportDev {
+    size_t frame_bytes;
+    int K;                          // 0: nothing to export
+    const uint32_t* yx_cur;         // the current position buffer
+    const uint32_t* lab_n_moved;    // FrameDev::cl_lab (cl_n and cl_moved follow it, K words each)
+    const uint32_t* misc0;          // the frame's 16 status words
+    uint32_t* h_cl;
+    size_t h_stride;
+    uint32_t* h_misc;
+};
+void launch_cca_phase2(const CcaDev& c, int nframes, hipStream_t st, const ExportDev* ex = nullptr);   // chain resolution + relabel (+ export)
 // host top-K path, one frame at a time (the CcaDev passed in is already advanced to that frame)
+void launch_cca_gather_area(const CcaDev& c, hipStream_t st);   // cand_area[i] = area of candidate i (c already advanced to the frame)
 void launch_cca_set_kept(const CcaDev& c, const int32_t* d_leaders, const uint16_t* d_labels, int n, hipStream_t st);
 
 // superpixel-graph utilities on a finished label map (graph.hip; src/fast-slic.cpp)

@@ -338,6 +338,8 @@ static void assign(Ctx* c) {
 }
 
 /* src/context.cpp:301-387 update() (preemptive off, centroid quantisation on) */
+static long g_stale_pixels;   /* diagnostics: visited pixels that kept a label although no window covered them in the last assign */
+long orc_last_stale_pixels(void) { return g_stale_pixels; }
 static void update(Ctx* c) {
     int H = c->H, W = c->W, K = c->K;
     int32_t* n = (int32_t*)calloc(K, sizeof(int32_t));
@@ -346,6 +348,7 @@ static void update(Ctx* c) {
         for (int j = 0; j < W; j++) {
             uint16_t k = c->assignment[i * W + j];
             if (k == 0xFFFF) continue;
+            if (c->min_dists[i * W + j] == 0xFFFF) g_stale_pixels++;
             const uint8_t* px = &c->lab[4 * (i * W + j)];
             n[k]++;
             acc[5 * k + 0] = (int32_t)((uint32_t)acc[5 * k + 0] + (uint32_t)i);
@@ -401,6 +404,7 @@ int orc_slic_iterate(int H, int W, int K, const uint8_t* rgb, OrcCluster* cluste
     for (int p = 0; p < N; p++) c.assignment[p] = 0xFFFF; /* :138-145, once per call */
     set_spatial_patch(&c, compactness, color_shift, manhattan);
     c.rem = 0; c.stride = subsample_stride;              /* :149-150 */
+    g_stale_pixels = 0;
     for (int k = 0; k < K; k++) clusters[k].is_updatable = 2;  /* src/preemptive.h:59-67 */
     for (int it = 0; it < max_iter; it++) {              /* :158-175 */
         assign(&c);

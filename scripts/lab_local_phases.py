@@ -1,0 +1,27 @@
+"""Lab build 2 (FSLIC_LIB=fast_slic_amd/libfslic_hip_lab2.so): per-phase time of k_cca_local, averaged over the blocks of a frame."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from fast_slic_amd import Engine, make_params, CLUSTER_DTYPE, _binding as B
+from fast_slic_amd.synth import variant
+H, W, K, G = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+e = Engine(0, 1)
+imgs = [variant("A", H, W, seed=g) for g in range(G)]
+d = [torch.from_numpy(im).cuda() for im in imgs]
+l = [torch.empty((H, W), dtype=torch.int16, device="cuda") for _ in imgs]
+cl0 = []
+for im in imgs:
+    cl = np.zeros(K, CLUSTER_DTYPE); B.load_library().fslic_hip_initialize_clusters(H, W, K, im.ctypes.data, cl.ctypes.data); cl0.append(cl)
+torch.cuda.synchronize()
+p = make_params(10, 10.0, 0.25, 3)
+lib = B.load_library()
+lib.fslic_hip_debug_status_words.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+for i in range(3):
+    e.iterate_batch([t.data_ptr() for t in d], [c.copy() for c in cl0], [t.data_ptr() for t in l], H, W, p, True)
+nblk = ((W + 63) // 64) * ((H + 31) // 32)
+names = ["loads", "A rows", "B seams", "C flatten+areas", "D roots+stores"]
+for f in range(min(G, 3)):
+    w = np.zeros(16, np.uint32)
+    lib.fslic_hip_debug_status_words(e._h, 0, f, w.ctypes.data)
+    print("frame %d (%d blocks, %d roots): " % (f, nblk, w[4]) + "  ".join("%s %.2fus" % (names[i], w[8 + i] / 100.0 / nblk) for i in range(5)))

@@ -86,6 +86,57 @@ def test_heap_select_keeps_the_k_largest_and_matches_reference_on_ties(golden_sm
         assert (np.sort(area[kept])[::-1] == np.sort(area)[::-1][:K]).all()
 
 
+def _topdown_sift(h, area, hole, ln, value):
+    """The form of libstdc++'s __adjust_heap the device replays (fast_slic_amd/csrc/cca.hip, tie_adjust_heap): walk down the
+    preferred children (smaller area, right child on a tie) and stop at the first child whose area exceeds the value's."""
+    cur, va = hole, area[value]
+    while True:
+        if cur < (ln - 1) // 2:
+            r = 2 * (cur + 1)
+            child = r - 1 if area[h[r]] > area[h[r - 1]] else r
+        elif (ln & 1) == 0 and cur == (ln - 2) // 2:
+            child = 2 * cur + 1
+        else:
+            break
+        if area[h[child]] > va:
+            break
+        h[cur] = h[child]
+        cur = child
+    h[cur] = value
+
+
+def _topdown_heap_select(M, K, area):
+    h = list(range(K))
+    for p in range((K - 2) // 2, -1, -1) if K >= 2 else []:
+        _topdown_sift(h, area, p, K, h[p])
+    for i in range(K, M):
+        if area[i] > area[h[0]]:
+            _topdown_sift(h, area, 0, K, i)
+    return sorted(h)
+
+
+def test_topdown_sift_keeps_exactly_what_libstdcxx_heap_select_keeps():
+    # The device resolves an area tie at the top-K cut with a top-down sift that stops early instead of libstdc++'s
+    # walk-to-the-leaf-and-push-back; both must keep the same components on every input, ties included.
+    rng = np.random.RandomState(1)
+    for trial in range(1500):
+        M = int(rng.randint(2, 400))
+        K = int(rng.randint(1, M))
+        style = trial % 4
+        if style == 0:
+            area = rng.randint(1, 6, M)
+        elif style == 1:
+            area = rng.randint(1, 50, M)
+        elif style == 2:
+            area = np.sort(rng.randint(1, 20, M))
+        else:
+            area = np.sort(rng.randint(1, 20, M))[::-1].copy()
+        area = area.astype(np.int32)
+        got = _topdown_heap_select(M, K, area)
+        exp = sorted(orc.heap_select(np.arange(M, dtype=np.int32), K, area)[:K].tolist())
+        assert got == exp, (trial, M, K)
+
+
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built (no /root/reference here)")
 def test_oracle_equals_live_reference():
     rng = np.random.default_rng(3)
