@@ -275,6 +275,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-4k", action="store_true", help="skip the 4K, K=6000, LSC and end-to-end sub-objects")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--timed-only", action="store_true", help="the timed region and nothing else (profiling runs: no roofline / parity / baseline legs)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / timing reduction only (no GPU work): CPU test of the N>1 path")
     args = ap.parse_args()
 
@@ -361,6 +362,11 @@ def main():
             "device_ms_per_frame": round(totals["device_ms"] / max(totals["frames"], 1), 4),
             "host_topk_frames": totals["host_topk_frames"],
         }
+        if args.timed_only:
+            print(json.dumps(out))
+            sys.stdout.flush()
+            eng.close()
+            return
         if not args.no_parity:
             bad = parity_of(wl, first + args.steps - 1)
             out["parity"] = not bad

@@ -270,6 +270,14 @@ int fslic_hip_debug_status_words(fslic_engine* e, int slot, int frame, uint32_t*
     std::memcpy(out16, e->slots[slot].h_misc + 16 * (size_t)frame, 64);
     return FSLIC_OK;
 }
+// lab build only: the last `nwords` words of frame `frame`'s candidate-leader array (where lab build 2 leaves the tile
+// kernel's time stamps)
+int fslic_hip_debug_cand_tail(fslic_engine* e, int slot, int frame, int nwords, int32_t* out) {
+    if (!e || slot < 0 || slot >= (int)e->slots.size() || !out) return FSLIC_E_INVALID;
+    Slot& s = e->slots[slot];
+    const int32_t* base = s.at(s.c.cand_leader, frame) + (size_t)s.c.N - nwords;
+    return hipMemcpy(out, base, sizeof(int32_t) * (size_t)nwords, hipMemcpyDeviceToHost) == hipSuccess ? FSLIC_OK : FSLIC_E_HIP;
+}
 #endif
 
 }  // extern "C"

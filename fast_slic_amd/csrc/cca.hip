@@ -68,8 +68,8 @@ static __device__ __forceinline__ uint32_t lds_find_ro(uint32_t* par, uint32_t x
 //  C  flatten: every pixel -> tile-local root (min raster index), parent plane written, run lengths added
 //     to the root's area
 //  D  tile-local roots appended to the root list (one global atomic per wavefront row)
-#if defined(FSLIC_LAB) && FSLIC_LAB == 2      // lab build 2: per-phase time of the tile kernel, summed over the blocks into status words 8..13 (100 MHz ticks)
-#define LOC_STAMP(i_) do { __syncthreads(); if (threadIdx.x == 0) { const uint32_t t_ = (uint32_t)__builtin_amdgcn_s_memrealtime(); atomicAdd(&c.counters[4 + (i_)], t_ - loc_t); loc_t = t_; } } while (0)
+#if defined(FSLIC_LAB) && FSLIC_LAB == 2      // lab build 2: time stamps of the tile kernel (100 MHz ticks since the block's start), 8 words per block at the end of the (idle) candidate array
+#define LOC_STAMP(i_) do { __syncthreads(); if (threadIdx.x == 0) c.cand_leader[(size_t)c.N - 8 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x + 1) + (i_)] = (int32_t)((uint32_t)__builtin_amdgcn_s_memrealtime() - loc_t); } while (0)
 #else
 #define LOC_STAMP(i_) do { } while (0)
 #endif
@@ -84,6 +84,8 @@ __global__ __launch_bounds__(256) void k_cca_local(CcaDev c) {
     __shared__ uint32_t s_last[4][T];       // labels of every strip's last row (all the seam merge of phase B reads)
     __shared__ uint32_t s_par[T * TH];
     __shared__ uint32_t s_area[T * TH];
+    __shared__ uint32_t s_nroots, s_base;
+    if (threadIdx.x == 0) s_nroots = 0;        // (three barriers lie between this and its first use)
     const int lane = LANE();
     const int wave = (int)rfl((uint32_t)(threadIdx.x >> 6));
     const int tx0 = blockIdx.x * T, ty0 = blockIdx.y * TH;
@@ -120,9 +122,16 @@ __global__ __launch_bounds__(256) void k_cca_local(CcaDev c) {
         uint32_t cur_root = node;
         if (i > 0) {
             const bool up_same = ok && (lbl[i - 1] == l);
-            if (up_same) __hip_atomic_fetch_min(s_par + node, up_root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // one lane speaks for its neighbours: consecutive pixels of a run that carry the same root above would all hit
+            // the same LDS word (same-address atomics of a wavefront are served one lane after the other: a 40-pixel run was
+            // 40 serial operations on the CU's one LDS pipe, which every resident block shares)
+            // (the lane shifts are evaluated by every lane, outside the short-circuit expression: a DPP shift returns the
+            // lane's own value when its source lane is masked off)
+            const uint32_t left_root = lane_left(up_root), left_same = lane_left((uint32_t)up_same);
+            const bool rep = up_same && (start || left_root != up_root || left_same == 0u);
+            if (rep) __hip_atomic_fetch_min(s_par + node, up_root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (ok) cur_root = lds_ld(s_par + node);
-            if (up_same && up_root != cur_root) lds_union(s_par, up_root, cur_root);
+            if (rep && up_root != cur_root) lds_union(s_par, up_root, cur_root);
         }
         up_root = cur_root;
     }
@@ -149,13 +158,16 @@ __global__ __launch_bounds__(256) void k_cca_local(CcaDev c) {
     for (int i = 0; i < RW; ++i) root[i] = s_par[root[i]];
 #pragma unroll
     for (int i = 0; i < RW; ++i) root[i] = lds_find_ro(s_par, root[i]);
+    // run lengths -> the root's area; and, in the same sweep, this wavefront's tile-local roots: their positions inside the
+    // wavefront's share of the root list come from ballots alone (running count in a scalar register)
+    uint32_t pos[RW];
+    uint32_t wcount = 0;
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
         const int ly = ly0 + i;
         const int y = ty0 + ly;
         const bool ok = okx && y < c.H;
         const uint32_t r = ok ? root[i] : 0xFFFFFFFFu;
-        if (ok) st_stream(c.parent + (size_t)y * c.W + x, (int32_t)((size_t)(ty0 + (int)(r / T)) * c.W + tx0 + (int)(r % T)));
         const uint32_t rl = lane_left(r);
         const bool start = (lane == 0) || (r != rl) || !ok;
         const unsigned long long m = __ballot(start);
@@ -164,49 +176,44 @@ __global__ __launch_bounds__(256) void k_cca_local(CcaDev c) {
             const int len = higher ? __ffsll((long long)higher) : (64 - lane);
             atomicAdd(&s_area[r], (uint32_t)len);
         }
+        const bool isroot = ok && root[i] == (uint32_t)(ly * T + lane);
+        const unsigned long long mr = __ballot(isroot);
+        pos[i] = isroot ? wcount + (uint32_t)__popcll(mr & ((1ull << lane) - 1ull)) : 0xFFFFFFFFu;
+        wcount += (uint32_t)__popcll(mr);
     }
-    __syncthreads();
     LOC_STAMP(3);
-    // ---- D ---- tile-local roots -> the frame's dense root list: positions inside the tile first (LDS counter), then ONE
-    // returning global atomic per tile reserves the tile's range (a returning atomic per wavefront row saturated a single
-    // word near 88 ops/us: 1.2 ms at 4K in the first version of this kernel).  A dense list lets the passes over the roots
-    // (compress, collect, chain) run as flat, evenly loaded grids instead of one mostly idle block per tile.
-    __shared__ uint32_t s_nroots, s_base;
-    if (threadIdx.x == 0) s_nroots = 0;
+    // ---- D ---- tile-local roots -> the frame's dense root list.  One LDS atomic per wavefront places its roots inside
+    // the tile's range, ONE returning global atomic per tile reserves that range (a returning atomic per wavefront row
+    // saturated a single word near 88 ops/us: 1.2 ms at 4K in the first version of this kernel).  The global stores of the
+    // kernel come AFTER it: a wavefront waiting for the atomic's result would also wait for every store it has in flight
+    // (the parent plane is written through), and the other three wait for it at the barrier -- that wait was 8 - 14 us of a
+    // 25 us block life.  A dense list lets the passes over the roots run as flat, evenly loaded grids.
+    uint32_t wbase = 0;
+    if (lane == 0 && wcount) wbase = atomicAdd(&s_nroots, wcount);
+    wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+    __syncthreads();                              // every wavefront's share of s_nroots and every run's area are in
+    LOC_STAMP(4);
+    if (threadIdx.x == 0) s_base = s_nroots ? atomicAdd(&c.counters[0], s_nroots) : 0u;
     __syncthreads();
-    uint32_t pos[RW];
+    LOC_STAMP(5);
+    const uint32_t gbase = s_base + wbase;
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
         const int ly = ly0 + i;
         const int y = ty0 + ly;
-        const bool ok = okx && y < c.H;
-        const int p = ly * T + lane;
-        const bool isroot = ok && root[i] == (uint32_t)p;
-        const unsigned long long m = __ballot(isroot);
-        pos[i] = 0xFFFFFFFFu;
-        if (m) {
-            const int leader = __ffsll((long long)m) - 1;
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(&s_nroots, (uint32_t)__popcll(m));
-            base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-            if (isroot) pos[i] = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (okx && y < c.H) {
+            const uint32_t r = root[i];
+            st_stream(c.parent + (size_t)y * c.W + x, (int32_t)((size_t)(ty0 + (int)(r / T)) * c.W + tx0 + (int)(r % T)));
         }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) s_base = s_nroots ? atomicAdd(&c.counters[0], s_nroots) : 0u;
-    __syncthreads();
-    const uint32_t gbase = s_base;
-#pragma unroll
-    for (int i = 0; i < RW; ++i)
         if (pos[i] != 0xFFFFFFFFu) {
-            const int ly = ly0 + i;
-            const int32_t g = (int32_t)((size_t)(ty0 + ly) * c.W + x);
+            const int32_t g = (int32_t)((size_t)y * c.W + x);
             const uint32_t a = s_area[ly * T + lane];
             c.area[g] = a;
             c.roots[gbase + pos[i]] = g;
             c.cand_area[gbase + pos[i]] = a;      // the root's own (tile-local) area, dense: what k_cca_compress adds to the global root
         }
-    LOC_STAMP(4);
+    }
+    LOC_STAMP(6);
 }
 
 static __device__ __forceinline__ int32_t g_load(int32_t* p) {
@@ -826,14 +833,23 @@ __global__ __launch_bounds__(256) void k_cca_relabel(CcaDev c, ExportDev ex, int
     c.select(z);
     const int gstride = relabel_blocks * blockDim.x;
     const int nquad = c.N >> 2;
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += gstride) {
-        const int4 lr = reinterpret_cast<const int4*>(c.parent)[q];
+    // the next quad's parents are requested before this quad's labels are stored: a load issued after a written-through
+    // store cannot be waited for without waiting for the store's acknowledgement as well
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    int4 lr = make_int4(0, 0, 0, 0);
+    if (q < nquad) lr = reinterpret_cast<const int4*>(c.parent)[q];
+    while (q < nquad) {
+        const int qn = q + gstride;
+        int4 lrn = make_int4(0, 0, 0, 0);
+        if (qn < nquad) lrn = reinterpret_cast<const int4*>(c.parent)[qn];
         const uint32_t a = c.final_lab[c.parent[lr.x]], b = c.final_lab[c.parent[lr.y]];
         const uint32_t d = c.final_lab[c.parent[lr.z]], e = c.final_lab[c.parent[lr.w]];
         uint2 o;
         o.x = a | (b << 16);
         o.y = d | (e << 16);
         st_stream(reinterpret_cast<uint2*>(c.out) + q, o);
+        lr = lrn;
+        q = qn;
     }
     for (int p = (nquad << 2) + blockIdx.x * blockDim.x + threadIdx.x; p < c.N; p += gstride)
         st_stream(c.out + p, c.final_lab[c.parent[c.parent[p]]]);

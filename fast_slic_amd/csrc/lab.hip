@@ -60,9 +60,22 @@ __global__ __launch_bounds__(1024) void k_rgb_to_lab(FrameDev f, const uint16_t*
     }
     const int nquad = aligned4 ? (N >> 2) : 0;
     const int gstride = gridDim.x * blockDim.x;
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += gstride) {
+    // Software-pipelined over the thread's quads: the next quad's loads are issued BEFORE this quad's stores, so that
+    // waiting for them does not also wait for the acknowledgement of the written-through stores (one vector-memory
+    // counter covers both; a load issued after a store cannot be waited for without the store).
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t w0 = 0, w1 = 0, w2 = 0;
+    if (q < nquad) {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(rgb) + 3 * (size_t)q;
-        const uint32_t w0 = src[0], w1 = src[1], w2 = src[2];
+        w0 = src[0]; w1 = src[1]; w2 = src[2];
+    }
+    while (q < nquad) {
+        const int qn = q + gstride;
+        uint32_t n0 = 0, n1 = 0, n2 = 0;
+        if (qn < nquad) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(rgb) + 3 * (size_t)qn;
+            n0 = src[0]; n1 = src[1]; n2 = src[2];
+        }
         uint32_t r0 = w0 & 255, g0 = (w0 >> 8) & 255, b0 = (w0 >> 16) & 255;
         uint32_t r1 = w0 >> 24, g1 = w1 & 255, b1 = (w1 >> 8) & 255;
         uint32_t r2 = (w1 >> 16) & 255, g2 = w1 >> 24, b2 = w2 & 255;
@@ -82,6 +95,8 @@ __global__ __launch_bounds__(1024) void k_rgb_to_lab(FrameDev f, const uint16_t*
         st_stream(reinterpret_cast<uint4*>(lab) + q, o);
         // assignment plane <- 0xFFFF once per call (src/context.cpp:138-145)
         if (labels_init) st_stream(reinterpret_cast<uint2*>(labels_init) + q, make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu));
+        w0 = n0; w1 = n1; w2 = n2;
+        q = qn;
     }
     // tail (and the whole image when the source pointer is not 4-byte aligned)
     for (int p = (nquad << 2) + blockIdx.x * blockDim.x + threadIdx.x; p < N; p += gstride) {

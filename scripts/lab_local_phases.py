@@ -20,8 +20,12 @@ lib.fslic_hip_debug_status_words.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_v
 for i in range(3):
     e.iterate_batch([t.data_ptr() for t in d], [c.copy() for c in cl0], [t.data_ptr() for t in l], H, W, p, True)
 nblk = ((W + 63) // 64) * ((H + 31) // 32)
-names = ["loads", "A rows", "B seams", "C flatten+areas", "D roots+stores"]
+lib.fslic_hip_debug_cand_tail.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+names = ["loads", "A rows", "B seams", "C flatten+areas", "D count", "D global atomic", "D stores issued"]
 for f in range(min(G, 3)):
-    w = np.zeros(16, np.uint32)
-    lib.fslic_hip_debug_status_words(e._h, 0, f, w.ctypes.data)
-    print("frame %d (%d blocks, %d roots): " % (f, nblk, w[4]) + "  ".join("%s %.2fus" % (names[i], w[8 + i] / 100.0 / nblk) for i in range(5)))
+    w = np.zeros(8 * nblk, np.int32)
+    lib.fslic_hip_debug_cand_tail(e._h, 0, f, 8 * nblk, w.ctypes.data)
+    st = w.reshape(nblk, 8)[:, :7].astype(np.float64) / 100.0          # us since the block's start
+    d = np.diff(np.concatenate([np.zeros((nblk, 1)), st], 1), axis=1)
+    print("frame %d (%d blocks): block life mean %.2f us (p10 %.2f, p90 %.2f); phases: " % (f, nblk, st[:, 6].mean(), np.percentile(st[:, 6], 10), np.percentile(st[:, 6], 90))
+          + "  ".join("%s %.2f" % (names[i], d[:, i].mean()) for i in range(7)))
