@@ -407,7 +407,7 @@ static __device__ __forceinline__ void row_masks(uint32_t inv, uint32_t (&m)[R /
 // ux = 2S+1, which lands beyond 2S for every row; rows outside the y window are switched off by a per-pair scalar
 // mask OR-ed into the idx operand on the scalar unit (0xffff + anything saturates: no extra VALU).
 template <int R, bool FUSE, int STRIDE, bool VT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_assign_blk(FrameDev f, int rem, int Hv) {
+static __device__ __forceinline__ void assign_blk_body(FrameDev& f, int rem, int Hv) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];   // spatial table (u16), f.tab_words dwords; 16-byte aligned: the row-vector reads are ds_read_b128
     __shared__ uint32_t s_braw[3 * 128];                 // compaction buffer: entries 0..63 kept records, 64..127 scratch
     __shared__ uint4 s_list[64];                         // {yx, lab, k, cpart entry | kNoSlot}
@@ -828,14 +828,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_as
     }
 }
 
+// The kernels proper.  Register budgets are part of the design: left to itself the compiler schedules these bodies into
+// 82 - 90 VGPRs (5 - 6 wavefronts per SIMD); what it needs without spilling is 52 (16 rows per wavefront, no centroid sums:
+// 8 wavefronts per SIMD) and 66 - 68 (8 rows: 7 per SIMD).  At 3840x2160 the difference is 51 vs 60 us per fused launch
+// of eight frames and 69 vs 81 us for the full assignment (the round-1 kernels happened to get the small allocation because
+// their debug stamps cut the body into pieces; removing the stamps lost it until the budgets were stated).
+template <int R, bool FUSE, int STRIDE, bool VT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(7, 8))) void k_assign_blk(FrameDev f, int rem, int Hv) {
+    assign_blk_body<R, FUSE, STRIDE, VT>(f, rem, Hv);
+}
+template <int R, bool FUSE, int STRIDE, bool VT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void k_assign_blk_w8(FrameDev f, int rem, int Hv) {
+    assign_blk_body<R, FUSE, STRIDE, VT>(f, rem, Hv);
+}
+
 template <int R, bool FUSE, int STRIDE>
 static void launch_assign_blk_t(const FrameDev& f_, int nframes, int rem, int Hv, hipStream_t st) {
     FrameDev f = f_;
     if (FUSE) { f.tab = f.tabs; f.tab_words = f.tabs_words; f.tab_dyoff = f.tabs_dyoff; f.tab_nrpad = f.tabs_nrpad; }   // table of the subsampled stride
     dim3 grid((f.W + kTileW - 1) / kTileW, (Hv + kWavesPerBlock * R - 1) / (kWavesPerBlock * R), nframes);
     const size_t lds = (size_t)f.tab_words * sizeof(uint32_t);
-    if (f.tab_vmode) hipLaunchKernelGGL((k_assign_blk<R, FUSE, STRIDE, true>), grid, dim3(256), lds, st, f, rem, Hv);
-    else hipLaunchKernelGGL((k_assign_blk<R, FUSE, STRIDE, false>), grid, dim3(256), lds, st, f, rem, Hv);
+    if constexpr (R == 16 && !FUSE) {
+        if (f.tab_vmode) hipLaunchKernelGGL((k_assign_blk_w8<R, FUSE, STRIDE, true>), grid, dim3(256), lds, st, f, rem, Hv);
+        else hipLaunchKernelGGL((k_assign_blk_w8<R, FUSE, STRIDE, false>), grid, dim3(256), lds, st, f, rem, Hv);
+    } else {
+        if (f.tab_vmode) hipLaunchKernelGGL((k_assign_blk<R, FUSE, STRIDE, true>), grid, dim3(256), lds, st, f, rem, Hv);
+        else hipLaunchKernelGGL((k_assign_blk<R, FUSE, STRIDE, false>), grid, dim3(256), lds, st, f, rem, Hv);
+    }
 }
 
 static int assign_rows_per_wave(const FrameDev& f, int nframes, int Hv, bool fuse_update) {

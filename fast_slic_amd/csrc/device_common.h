@@ -35,6 +35,9 @@ static __device__ __forceinline__ void wave_lds_sync() {
 // end-of-kernel release otherwise writes all dirty lines back in one burst that nothing overlaps -- measured
 // (scripts/microbench/kernel_boundary.hip): a kernel storing 16 MB takes 8.9 us with plain stores and 3.5 us with
 // sc1 stores (64 MB: 24.9 -> ~10 us).
+#if defined(FSLIC_LAB) && FSLIC_LAB == 3      // lab build 3: plain (write-back) stores instead, to measure what the write-through costs / saves
+template <class T> static __device__ __forceinline__ void st_stream(T* p, T v) { *p = v; }
+#else
 static __device__ __forceinline__ void st_stream(uint16_t* p, uint16_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 static __device__ __forceinline__ void st_stream(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 static __device__ __forceinline__ void st_stream(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -47,6 +50,7 @@ static __device__ __forceinline__ void st_stream(uint4* p, uint4 v) {
     const u4 q = {v.x, v.y, v.z, v.w};
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(q) : "memory");
 }
+#endif
 
 // Sum over the 64 lanes of a wavefront without the LDS crossbar: __shfl_xor is ds_bpermute, which occupies the CU's LDS
 // pipe (measured: 56 % LDS-busy in a kernel that reduces 17 values per wavefront with it).  Four DPP steps leave every

@@ -1,5 +1,5 @@
 """Profiling workload: n single-stream steps of G frames of H x W, K clusters, device-resident, through the C ABI.
-   python scripts/frames.py H W K [n] [slic|lsc] [G]    (FSLIC_DEBUG_TIMING=1|2 prints per-phase cycle stamps of the assign kernel)"""
+   python scripts/frames.py H W K [n] [slic|lsc] [G]    """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -22,10 +22,17 @@ for i in range(3):
 nblk = ((W + 63) // 64) * ((H + 31) // 32)
 lib.fslic_hip_debug_cand_tail.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
 names = ["loads", "A rows", "B seams", "C flatten+areas", "D count", "D global atomic", "D stores issued"]
-for f in range(min(G, 3)):
+g0 = None
+for f in range(G):
     w = np.zeros(8 * nblk, np.int32)
     lib.fslic_hip_debug_cand_tail(e._h, 0, f, 8 * nblk, w.ctypes.data)
     st = w.reshape(nblk, 8)[:, :7].astype(np.float64) / 100.0          # us since the block's start
     d = np.diff(np.concatenate([np.zeros((nblk, 1)), st], 1), axis=1)
+    t0 = w.reshape(nblk, 8)[:, 7].astype(np.uint32).astype(np.int64)
+    g0 = t0.min() if g0 is None else g0
+    print("frame %d: first block starts %.1f us after the kernel's first, last block ends at %.1f us" % (f, (t0.min() - g0) / 100.0, ((t0 - g0) / 100.0 + w.reshape(nblk, 8)[:, 6] / 100.0).max()))
+    rel = np.sort((t0 - t0.min()) / 100.0)
+    alive = [(int(((t0 - t0.min()) / 100.0 <= t).sum() - ((t0 - t0.min()) / 100.0 + st[:, 6] <= t).sum())) for t in (1, 3, 6, 10, 15, 20, 30)]
+    print("frame %d: block starts (us after the first): p10 %.1f p50 %.1f p90 %.1f max %.1f; blocks of this frame alive at t=1,3,6,10,15,20,30 us: %s" % (f, rel[nblk // 10], rel[nblk // 2], rel[nblk * 9 // 10], rel[-1], alive))
     print("frame %d (%d blocks): block life mean %.2f us (p10 %.2f, p90 %.2f); phases: " % (f, nblk, st[:, 6].mean(), np.percentile(st[:, 6], 10), np.percentile(st[:, 6], 90))
           + "  ".join("%s %.2f" % (names[i], d[:, i].mean()) for i in range(7)))
