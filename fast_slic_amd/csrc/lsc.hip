@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void k_lsc_seed(FrameDev f, LscDev l) {
 // A pixel takes cluster k iff it lies in k's window and dist < best so far (strict, src/lsc.cpp:217; a NaN
 // centroid therefore never wins and +inf never beats the initial FLT_MAX).  More than 64 candidates (piled-up
 // clusters): the block walks all K clusters in visit order instead.
-__global__ __launch_bounds__(256) void k_lsc_assign(FrameDev f, LscDev l, int rem, int stride, int Hv, int stale_sums) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_lsc_assign(FrameDev f, LscDev l, int rem, int stride, int Hv, int stale_sums) {
     f.select(blockIdx.z);
     l.select(blockIdx.z);
     __shared__ uint32_t s_raw[192];
