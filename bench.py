@@ -63,6 +63,19 @@ def pmc_traffic(key):
     return None, None
 
 
+def rocprof_avg_us(csv_name, needle):
+    """Average duration (us) of the first kernel whose name contains `needle` in a committed rocprofv3 summary
+    (profiles/<round>_kernel_stats_*.csv, written by scripts/gpu_profiles.sh from a --kernel-trace run); None when absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "%s_%s" % (PROFILE_TAG, csv_name))) as f:
+            for line in f:
+                if needle in line:
+                    return float(line.rsplit('",', 1)[1].split(",")[2])
+    except (OSError, ValueError, IndexError):
+        pass
+    return None
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(H, W, K, budget_s=8.0):
     """Reference timed on this host: iterate(img, 10) only, fresh clusters per frame (the reference re-allocates its
@@ -386,6 +399,14 @@ def main():
             "full_assign": alone["full_assign"], "all_assign_launches": alone["all_assign_launches"],
             "device_ms_per_frame": alone["device_ms_per_frame"],
         }
+        # the same launch by rocprofv3's kernel duration (committed summary of `scripts/frames.py 720 1280 1600 6 slic 8` under
+        # --kernel-trace): events on the stream also see the launch gap of the directly enqueued (timed) group
+        rp = rocprof_avg_us("kernel_stats_1280x720_k1600_slic_x8.csv", "k_assign_blk<8, true, 3") if (args.workload == "720p" and fpg == 8) else None
+        if rp:
+            out["roofline"]["by_rocprofv3_kernel_duration"] = {
+                "avg_launch_us": rp, "achieved": round(gbs(fu["bytes_per_launch"], rp * 1e-3), 2),
+                "frac": round(gbs(fu["bytes_per_launch"], rp * 1e-3) / HBM_PEAK_GBS, 4),
+                "source": "profiles/%s_kernel_stats_1280x720_k1600_slic_x8.csv" % PROFILE_TAG}
         # contended: slot 0's groups carry per-launch events while the other slots keep the GPU busy
         base = len(wl.sets)
         wl.buffers(6 * nslots)

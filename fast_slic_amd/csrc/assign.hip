@@ -830,7 +830,7 @@ static __device__ __forceinline__ void assign_blk_body(FrameDev& f, int rem, int
 
 // The kernels proper.  Register budgets are part of the design: left to itself the compiler schedules these bodies into
 // 82 - 90 VGPRs (5 - 6 wavefronts per SIMD); what it needs without spilling is 52 (16 rows per wavefront, no centroid sums:
-// 8 wavefronts per SIMD) and 66 - 68 (8 rows: 7 per SIMD).  At 3840x2160 the difference is 51 vs 60 us per fused launch
+// 8 wavefronts per SIMD), 66 - 68 (8 rows: 7 per SIMD) and 74 - 80 (16 rows with centroid sums: 6 per SIMD).  At 3840x2160 the difference is 51 vs 60 us per fused launch
 // of eight frames and 69 vs 81 us for the full assignment (the round-1 kernels happened to get the small allocation because
 // their debug stamps cut the body into pieces; removing the stamps lost it until the budgets were stated).
 template <int R, bool FUSE, int STRIDE, bool VT>
@@ -839,6 +839,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_wav
 }
 template <int R, bool FUSE, int STRIDE, bool VT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void k_assign_blk_w8(FrameDev f, int rem, int Hv) {
+    assign_blk_body<R, FUSE, STRIDE, VT>(f, rem, Hv);
+}
+
+template <int R, bool FUSE, int STRIDE, bool VT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(6, 8))) void k_assign_blk_w6(FrameDev f, int rem, int Hv) {
     assign_blk_body<R, FUSE, STRIDE, VT>(f, rem, Hv);
 }
 
@@ -851,6 +856,8 @@ static void launch_assign_blk_t(const FrameDev& f_, int nframes, int rem, int Hv
     if constexpr (R == 16 && !FUSE) {
         if (f.tab_vmode) hipLaunchKernelGGL((k_assign_blk_w8<R, FUSE, STRIDE, true>), grid, dim3(256), lds, st, f, rem, Hv);
         else hipLaunchKernelGGL((k_assign_blk_w8<R, FUSE, STRIDE, false>), grid, dim3(256), lds, st, f, rem, Hv);
+    } else if constexpr (R == 16 && FUSE) {          // only launched with the row-vector table (launch_assign)
+        hipLaunchKernelGGL((k_assign_blk_w6<R, FUSE, STRIDE, true>), grid, dim3(256), lds, st, f, rem, Hv);
     } else {
         if (f.tab_vmode) hipLaunchKernelGGL((k_assign_blk<R, FUSE, STRIDE, true>), grid, dim3(256), lds, st, f, rem, Hv);
         else hipLaunchKernelGGL((k_assign_blk<R, FUSE, STRIDE, false>), grid, dim3(256), lds, st, f, rem, Hv);
@@ -890,6 +897,19 @@ PassGeom launch_assign(const FrameDev& f_, int nframes, int rem, int stride, int
         }
         if (fuse_update) {
             pg.use_slots = 1;
+            // Launches of many blocks (3840x2160 frames in groups) with the row-vector table: 16 rows per wavefront, i.e. 64
+            // visited rows per block -- the block prologue (candidate list, table) is paid once per 4096 pixels instead of
+            // 2048.  Small launches keep 8 rows (more, shorter-lived blocks fill the chip better); so does the 2-D table,
+            // whose LDS footprint grows with the rows a wavefront spans.
+            const int tiles_x = (f.W + kTileW - 1) / kTileW;
+            const bool r16 = f.tab_vmode && nframes * tiles_x * ((Hv + kWavesPerBlock * 8 - 1) / (kWavesPerBlock * 8)) > 3072;
+            if (r16) {
+                pg.BH = kWavesPerBlock * 16;
+                if (stride == 1) launch_assign_blk_t<16, true, 1>(f, nframes, rem, Hv, st);
+                else if (stride == 2) launch_assign_blk_t<16, true, 2>(f, nframes, rem, Hv, st);
+                else launch_assign_blk_t<16, true, 3>(f, nframes, rem, Hv, st);
+                return pg;
+            }
             if (stride == 1) launch_assign_blk_t<8, true, 1>(f, nframes, rem, Hv, st);
             else if (stride == 2) launch_assign_blk_t<8, true, 2>(f, nframes, rem, Hv, st);
             else launch_assign_blk_t<8, true, 3>(f, nframes, rem, Hv, st);

@@ -69,17 +69,21 @@ static __device__ __forceinline__ uint32_t lds_find_ro(uint32_t* par, uint32_t x
 //     to the root's area
 //  D  tile-local roots appended to the root list (one global atomic per wavefront row)
 #if defined(FSLIC_LAB) && FSLIC_LAB == 2      // lab build 2: time stamps of the tile kernel (100 MHz ticks since the block's start), 8 words per block at the end of the (idle) candidate array
-#define LOC_STAMP(i_) do { __syncthreads(); if (threadIdx.x == 0) c.cand_leader[(size_t)c.N - 8 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x + 1) + (i_)] = (int32_t)((uint32_t)__builtin_amdgcn_s_memrealtime() - loc_t); } while (0)
+#define LOC_STAMP(i_) do { __syncthreads(); if (threadIdx.x == 0) c.cand_leader[(size_t)c.N - 8 * (size_t)(blockIdx.y * (gridDim.x / nframes) + tile_x + 1) + (i_)] = (int32_t)((uint32_t)__builtin_amdgcn_s_memrealtime() - loc_t); } while (0)
 #else
 #define LOC_STAMP(i_) do { } while (0)
 #endif
 // (at most 80 SGPRs: with the ~105 the compiler takes by itself only six wavefronts fit a SIMD's scalar register file
 // instead of eight -- measured with per-block time stamps: 1500 blocks resident instead of 2048, 39 us instead of 2 rounds)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cca_local(CcaDev c) {
-    c.select(blockIdx.z);
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cca_local(CcaDev c, int nframes) {
+    // The frame is the FASTEST-varying part of the block index: blocks that start together then reserve their root ranges on
+    // different frames' counters (with the frame slowest, the first 1800 blocks of a 4K group all hit frame 0's counter at
+    // once: 7 us instead of 0.8 us per block for that atomic, profiles/r02_lab_tile_ccl_phases_4k.txt)
+    const int frame = (int)(blockIdx.x % (unsigned)nframes), tile_x = (int)(blockIdx.x / (unsigned)nframes);
+    c.select(frame);
 #if defined(FSLIC_LAB) && FSLIC_LAB == 2
     const uint32_t loc_t = (uint32_t)__builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0) c.cand_leader[(size_t)c.N - 8 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x + 1) + 7] = (int32_t)loc_t;      // absolute start
+    if (threadIdx.x == 0) c.cand_leader[(size_t)c.N - 8 * (size_t)(blockIdx.y * (gridDim.x / nframes) + tile_x + 1) + 7] = (int32_t)loc_t;      // absolute start
 #endif
     constexpr int T = kCcaTile;
     constexpr int TH = kCcaTileH;
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cc
     if (threadIdx.x == 0) s_nroots = 0;        // (three barriers lie between this and its first use)
     const int lane = LANE();
     const int wave = (int)rfl((uint32_t)(threadIdx.x >> 6));
-    const int tx0 = blockIdx.x * T, ty0 = blockIdx.y * TH;
+    const int tx0 = tile_x * T, ty0 = blockIdx.y * TH;
     const int x = tx0 + lane;
     const bool okx = x < c.W;
     const int ly0 = wave * RW;
@@ -277,14 +281,17 @@ __global__ __launch_bounds__(256) void k_cca_border(CcaDev c, int nh, int nv) {
 //     complete areas: a component's area only grows, so it crosses the threshold exactly once -- either it starts at or
 //     above it (the root's own tile-local area: its owner appends it) or exactly one addition takes it across (old <
 //     threshold <= old + a: that thread appends it).  Leaders only; the select kernel reads the final areas.
-__global__ __launch_bounds__(256) void k_cca_compress(CcaDev c) {
-    c.select(blockIdx.y);
+__global__ __launch_bounds__(256) void k_cca_compress(CcaDev c, int nframes) {
+    // frame = fastest-varying part of the block index, as in k_cca_local: the candidate appends of blocks that run together
+    // go to different frames' counters
+    const uint32_t bx = blockIdx.x / (unsigned)nframes, nbx = gridDim.x / (unsigned)nframes;
+    c.select((int)(blockIdx.x % (unsigned)nframes));
     const uint32_t n = c.counters[0];
     const int lane = LANE();
-    const uint32_t gstride = gridDim.x * blockDim.x;
+    const uint32_t gstride = nbx * blockDim.x;
     const int64_t thr = (int64_t)c.min_threshold;
     // a wavefront's trips are uniform (the ballot below needs every lane)
-    for (uint32_t w0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); w0 < n; w0 += gstride) {
+    for (uint32_t w0 = bx * blockDim.x + (threadIdx.x & ~63u); w0 < n; w0 += gstride) {
         const uint32_t i = w0 + (uint32_t)lane;
         const bool live = i < n;
         const int32_t r = c.roots[min(i, n - 1)];
@@ -740,11 +747,11 @@ static int root_pass_blocks(const CcaDev& c) {
 void launch_cca_phase1(const CcaDev& c, int nframes, hipStream_t st) {
     constexpr int T = kCcaTile;
     const int tx = (c.W + T - 1) / T, ty = (c.H + kCcaTileH - 1) / kCcaTileH;
-    hipLaunchKernelGGL(k_cca_local, dim3(tx, ty, nframes), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_cca_local, dim3(tx * nframes, ty), dim3(256), 0, st, c, nframes);
     const int nh = (ty - 1) * c.W, nv = (tx - 1) * c.H;
     if (nh + nv > 0)
         hipLaunchKernelGGL(k_cca_border, dim3((nh + nv + 255) / 256, nframes), dim3(256), 0, st, c, nh, nv);
-    hipLaunchKernelGGL(k_cca_compress, dim3(root_pass_blocks(c), nframes), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_cca_compress, dim3(root_pass_blocks(c) * nframes), dim3(256), 0, st, c, nframes);
 }
 
 void launch_cca_select(const CcaDev& c, int nframes, hipStream_t st) {

@@ -74,7 +74,16 @@ def test_lsc_random_cases_agree(engine):
     for trial in range(16):
         H, W, K, var, kw, img = random_case(rng, trial)
         kw.pop("manhattan")
-        if var in "CD":          # pure noise / constant frames: the partition is decided by rounding noise alone
+        if var in "CD":
+            # Pure noise / constant frames: which of several equidistant centroids a pixel takes is decided by the last bit
+            # of an f32 sum, so agreement with the reference (whose own sums depend on its thread schedule) has no stable
+            # floor.  What is required instead: the engine's result is DETERMINISTIC (two runs, bit-equal label maps and
+            # clusters: fixed reduction trees, fixed-point side sums, no float atomics) and well-formed.  The agreement
+            # floors below are then checked on a structured frame of the same geometry.
+            la, ca, pa = run(engine, img, ref.initialize_clusters(img, K), B.VARIANT_LSC, **kw)
+            lb, cb, pb = run(engine, img, ref.initialize_clusters(img, K), B.VARIANT_LSC, **kw)
+            assert np.array_equal(la, lb) and np.array_equal(pa, pb) and ca.tobytes() == cb.tobytes(), "trial %d %s: LSC is not run-to-run identical" % (trial, var)
+            assert int(pa[pa != 0xFFFF].max()) < K
             var = "A"
             img = variant(var, H, W, seed=1000 + trial)
         cl0 = ref.initialize_clusters(img, K)
