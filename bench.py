@@ -452,7 +452,8 @@ def main():
             wlsc = Workload(eng, 720, 1280, 1600, list(range(8)), variant_id=1)
             tl = wlsc.timed_groups(4, bytes_per_px=LSC_ASSIGN_BYTES_PER_PX)
             out["lsc_c5"] = {"workload": "1280x720 LSC variant, K=1600, 8 frames/GPU (configs[4])", "megapixels_per_sec": wlsc.throughput(12)[0],
-                             "dominant_kernel": "k_lsc_assign (10-D distance, 46 B per visited pixel)", "assign": tl["fused_assign_update"],
+                             "dominant_kernel": "k_lsc_assign_sums (10-D distance + the fused update sums; priced at 46 B per visited pixel, it also reads the 4 B LAB word)",
+                             "fused_assign_update": tl["fused_assign_update"],
                              "full_assign": tl["full_assign"], "device_ms_per_frame": tl["device_ms_per_frame"]}
             del wlsc
             out["end_to_end"] = end_to_end(H, W, K)

@@ -84,9 +84,6 @@ struct FrameDev {
     ClusterRec* cell_items[2]; // ncell * kCellCap
     uint32_t* ovf_cnt[2];      // 1
     ClusterRec* ovf_items[2];  // K
-#if defined(FSLIC_LAB) && FSLIC_LAB == 4
-    unsigned long long* dbg;   // lab build 4 only: the round-1 assign kernels with their phase stamps (always nullptr)
-#endif
     uint32_t* err_flag;        // != 0: a block overflowed its LDS candidate list -> host reruns generic
     // LDS spatial table of the tiled kernel (lut_words == 0: fixed-point mode, no table)
     const uint32_t* lut;       // lut_words entries: patch value << 16, or kHuge for out-of-window indices

@@ -120,6 +120,9 @@ __global__ __launch_bounds__(256) void k_lsc_features(FrameDev f, LscDev l) {
 
 static __device__ __forceinline__ float wave_sum(float v) { return wave_reduce_add(v); }
 static __device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return wave_reduce_add(v); }
+// fixed point of the fused update's accumulators: a wavefront's partial sum (256 pixels) of w*F stays below 256 * 51 and
+// one of w below 256 * 23000, so these scales keep the rounded partials inside 32 bits; the accumulators themselves are 64-bit
+constexpr float kLscFixF = 65536.0f, kLscFixW = 128.0f;
 
 // Seed centroids: unweighted mean of the features over the (2*(S/4)+1)^2 window around the centre, clipped to the
 // image (src/lsc.cpp:165-195).  One wavefront per cluster.
@@ -164,6 +167,62 @@ __global__ __launch_bounds__(256) void k_lsc_seed(FrameDev f, LscDev l) {
     }
 }
 
+// ---- cross-lane fold of the fused update ----------------------------------------------------
+// A halving butterfly: at each level two values are folded across one lane bit into ONE register, the lanes with the bit
+// clear keeping the first value's partial sum and the lanes with the bit set the second's (v_permlane32_swap / v_permlane16_swap
+// across the halves and the 16-lane rows, DPP moves under bank masks below that).  The order of the additions is fixed.
+typedef unsigned int lsc_u2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ float lsc_add(float a, float b) { return a + b; }
+static __device__ __forceinline__ uint32_t lsc_add(uint32_t a, uint32_t b) { return a + b; }
+static __device__ __forceinline__ uint32_t lsc_bits(float a) { return __float_as_uint(a); }
+static __device__ __forceinline__ uint32_t lsc_bits(uint32_t a) { return a; }
+template <typename T> static __device__ __forceinline__ T lsc_from(uint32_t a);
+template <> __device__ __forceinline__ float lsc_from<float>(uint32_t a) { return __uint_as_float(a); }
+template <> __device__ __forceinline__ uint32_t lsc_from<uint32_t>(uint32_t a) { return a; }
+template <typename T> static __device__ __forceinline__ T fold32(T a, T b) {     // lanes 0..31: a[l] + a[l+32]; lanes 32..63: b[l-32] + b[l]
+    const lsc_u2 r = __builtin_amdgcn_permlane32_swap(lsc_bits(a), lsc_bits(b), false, false);
+    return lsc_add(lsc_from<T>(r[0]), lsc_from<T>(r[1]));
+}
+template <typename T> static __device__ __forceinline__ T fold16(T a, T b) {     // even rows: a[row] + a[row+1]; odd rows: b[row-1] + b[row]
+    const lsc_u2 r = __builtin_amdgcn_permlane16_swap(lsc_bits(a), lsc_bits(b), false, false);
+    return lsc_add(lsc_from<T>(r[0]), lsc_from<T>(r[1]));
+}
+template <int CTRL, int BANKS_A, typename T> static __device__ __forceinline__ T fold_dpp(T a, T b) {   // banks A: a + a', the others: b + b'
+    const uint32_t m1 = __builtin_amdgcn_update_dpp(lsc_bits(b), lsc_bits(a), CTRL, 0xF, BANKS_A, false);
+    const uint32_t m2 = __builtin_amdgcn_update_dpp(lsc_bits(a), lsc_bits(b), CTRL, 0xF, 0xF ^ BANKS_A, false);
+    return lsc_add(lsc_from<T>(m1), lsc_from<T>(m2));
+}
+template <int CTRL, typename T> static __device__ __forceinline__ T sum_dpp(T a) {
+    return lsc_add(a, lsc_from<T>(__builtin_amdgcn_update_dpp(0u, lsc_bits(a), CTRL, 0xF, 0xF, true)));
+}
+constexpr int kDppRor8 = 0x128, kDppHalfMirror = 0x141, kDppQuadSwap1 = 0xB1, kDppQuadSwap2 = 0x4E;
+// 12 floats -> the total of v[q] in every lane of the quads with slot_f == q (see the slot arithmetic in the assign kernel)
+static __device__ __forceinline__ float lsc_fold12(const float* v) {
+    float g[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) g[i] = fold32(v[2 * i], v[2 * i + 1]);
+    float h[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) h[i] = fold16(g[2 * i], g[2 * i + 1]);
+    const float m0 = fold_dpp<kDppRor8, 0x3>(h[0], h[1]);
+    const float m1 = sum_dpp<kDppRor8>(h[2]);
+    float t = fold_dpp<kDppHalfMirror, 0x5>(m0, m1);
+    t = sum_dpp<kDppQuadSwap1>(t);
+    return sum_dpp<kDppQuadSwap2>(t);
+}
+// 6 integers -> the total of v[q] in every lane of the octets with slot_u == q
+static __device__ __forceinline__ uint32_t lsc_fold6(const uint32_t* v) {
+    uint32_t g[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g[i] = fold32(v[2 * i], v[2 * i + 1]);
+    const uint32_t h0 = fold16(g[0], g[1]);
+    const uint32_t h1 = fold16(g[2], 0u);
+    uint32_t t = fold_dpp<kDppRor8, 0x3>(h0, h1);
+    t = sum_dpp<kDppHalfMirror>(t);
+    t = sum_dpp<kDppQuadSwap1>(t);
+    return sum_dpp<kDppQuadSwap2>(t);
+}
+
 // ---- assignment -----------------------------------------------------------------------------
 // Block = 64 columns x (4 wavefronts x kLscRows visited rows).  Wavefront 0 collects the clusters whose window can
 // reach the block from the coarse bins, orders them by the reference's visit order (phase, k) and stages their
@@ -171,18 +230,25 @@ __global__ __launch_bounds__(256) void k_lsc_seed(FrameDev f, LscDev l) {
 // A pixel takes cluster k iff it lies in k's window and dist < best so far (strict, src/lsc.cpp:217; a NaN
 // centroid therefore never wins and +inf never beats the initial FLT_MAX).  More than 64 candidates (piled-up
 // clusters): the block walks all K clusters in visit order instead.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_lsc_assign(FrameDev f, LscDev l, int rem, int stride, int Hv, int stale_sums) {
+template <bool stale_sums>
+static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, int rem, int stride, int Hv) {
     f.select(blockIdx.z);
     l.select(blockIdx.z);
     __shared__ uint32_t s_raw[192];
     __shared__ uint32_t s_yx[64], s_k[64];
     __shared__ __attribute__((aligned(16))) float s_cf[64 * 12];
     __shared__ int s_cnt;
+    // block-level accumulators of the fused update: per candidate of the block's list 11 feature sums (2^-20 fixed point)
+    // and 6 integer sums, 64-bit words (LDS atomics; flushed with ONE set of global atomics per (block, cluster))
+    constexpr int kAccW = kLscFeat + 1 + 6;
+    __shared__ unsigned long long s_accx[64 * kAccW];
     const int wave = threadIdx.x >> 6, lane = LANE();
     const int S = f.S, W = f.W;
     const size_t N = (size_t)f.N;
     const int x0 = blockIdx.x * 64;
     const int v0 = blockIdx.y * kLscBH;
+    if (stale_sums)
+        for (int i = threadIdx.x; i < 64 * kAccW; i += 256) s_accx[i] = 0ull;
     if (wave == 0) {
         const int v_last = min(v0 + kLscBH, Hv) - 1;
         TileWindow win;
@@ -279,117 +345,139 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
             }
         }
     }
+    // labels out; with an update following (stale_sums), also the label each visited pixel carries into update(): the new one,
+    // or the one it keeps when nothing accepted it (src/lsc.cpp:217-220 never touches such a pixel; 0xFFFF: none yet)
+    uint32_t lbl[kLscRows];
 #pragma unroll
     for (int r = 0; r < kLscRows; ++r) {
+        lbl[r] = 0xFFFFu;
         if (!xok || vw + r >= Hv) continue;
         const size_t p = (size_t)yr[r] * W + x;
         if (best[r >> 1][r & 1] < FLT_MAX) {
             st_stream(f.labels + p, (uint16_t)bk[r]);
+            lbl[r] = bk[r];
         } else if (stale_sums) {
-            // Nothing accepted this pixel: it keeps its label (src/lsc.cpp:217-220 never touches it) and the update sums
-            // it under that label (src/context.cpp:301-354, src/lsc.cpp:256-269).  The update kernel gathers over
-            // cluster windows, so a pixel outside the window of its own (stale) cluster is added here instead.
-            const uint32_t old = f.labels[p];
-            if (old != 0xFFFFu) {
-                const uint32_t oyx = f.cl_yx[old];
-                if (abs(yr[r] - (int)(oyx >> 16)) > S || abs(x - (int)(oyx & 0xFFFFu)) > S) {
-                    global_accumulate(f.sums[0], old, (uint32_t)yr[r], (uint32_t)x, f.lab[p]);
-                    const float w = l.weight[p];
-                    unsigned long long* e = reinterpret_cast<unsigned long long*>(l.extra + (size_t)old * kLscExPitch);
+            lbl[r] = f.labels[p];
+        }
+    }
+    if (!stale_sums) return;
+    // ---- update(), fused: the sums of src/context.cpp:301-354 (count, y, x, L, a, b) and of src/lsc.cpp:256-269 (sum w*F per
+    // feature, sum w) over this wavefront's pixels.  Two levels: every lane first folds the rows that carry ITS pending label
+    // (f32 FMA chain like the reference build; labels run in vertical stretches, so one or two rounds cover the lane); the
+    // labels present among the lanes are then served one by one: lanes of another label contribute zeros, a halving butterfly
+    // (lsc_fold: 43 cross-lane operations for the 17 values, against 102 for 17 full wave sums) leaves value q's total in the
+    // lanes of slot q, and ONE 64-bit LDS atomic instruction adds all 17 to the block's accumulators (the float sums in fixed
+    // point, so the totals do not depend on the order in which wavefronts arrive: run-to-run identical).  This replaces a
+    // kernel that re-scanned every cluster's window for its members (64 of 100 us per iteration at 8 x 1280x720).
+    float wgt[kLscRows];
+    uint32_t pix[kLscRows];
 #pragma unroll
-                    for (int q = 0; q < kLscFeat; ++q)
-                        atomicAdd(e + q, (unsigned long long)(long long)__builtin_rintf(w * F[r >> 1][q][r & 1] * kLscFixScale));
-                    atomicAdd(e + kLscFeat, (unsigned long long)(long long)__builtin_rintf(w * kLscFixScale));
+    for (int r = 0; r < kLscRows; ++r) {
+        const size_t p = (size_t)yr[r] * W + xc;
+        wgt[r] = l.weight[p];
+        pix[r] = f.lab[p];
+    }
+    uint32_t todo_rows = 0;                       // bit r: row r still has to be summed
+#pragma unroll
+    for (int r = 0; r < kLscRows; ++r) todo_rows |= (lbl[r] != 0xFFFFu ? 1u : 0u) << r;
+    const uint32_t my_k = lane < min(cnt, 64) && cnt <= 64 ? s_k[lane] : 0xFFFFFFFFu;      // the block's list: lane c = candidate c
+    // slot of this lane after the fold: the float sums end in the quads (lane bit 2 clear: slots 0..7, set: 8..10), the
+    // integer sums in the octets; one lane of each adds
+    const int b5 = (lane >> 5) & 1, b4 = (lane >> 4) & 1, b3 = (lane >> 3) & 1, b2 = (lane >> 2) & 1;
+    const int slot_f = b2 ? 8 + 2 * b4 + b5 : 4 * b3 + 2 * b4 + b5;
+    const int slot_u = b3 ? 4 + b5 : 2 * b4 + b5;
+    const bool adds_f = (lane & 3) == 0 && !(b2 && b3) && slot_f <= kLscFeat;
+    const bool adds_u = (lane & 7) == 1 && !(b3 && b4);
+    const int slot = adds_f ? slot_f : kLscFeat + 1 + slot_u;
+    const float fix = slot_f == kLscFeat ? kLscFixW : kLscFixF;
+    for (;;) {
+        uint32_t mine = 0xFFFFFFFFu;
+#pragma unroll
+        for (int r = 0; r < kLscRows; ++r) mine = ((todo_rows >> r) & 1u) ? lbl[r] : mine;
+        if (!__ballot(mine != 0xFFFFFFFFu)) break;
+        uint32_t in[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+        float acc[kLscFeat + 1];
+#pragma unroll
+        for (int q = 0; q <= kLscFeat; ++q) acc[q] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < kLscRows; ++r) {
+            const bool m = ((todo_rows >> r) & 1u) && lbl[r] == mine;
+            if (m) {
+                in[0] += 1u; in[1] += (uint32_t)yr[r]; in[2] += (uint32_t)x;
+                in[3] += pix[r] & 255u; in[4] += (pix[r] >> 8) & 255u; in[5] += (pix[r] >> 16) & 255u;
+#pragma unroll
+                for (int q = 0; q < kLscFeat; ++q) acc[q] = __builtin_fmaf(wgt[r], F[r >> 1][q][r & 1], acc[q]);
+                acc[kLscFeat] += wgt[r];
+                todo_rows &= ~(1u << r);
+            }
+        }
+        for (;;) {
+            const unsigned long long pend = __ballot(mine != 0xFFFFFFFFu);
+            if (!pend) break;
+            const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)mine, __builtin_ctzll(pend));
+            const bool sel = mine == k0;
+            mine = sel ? 0xFFFFFFFFu : mine;
+            float fv[kLscFeat + 2];
+            uint32_t uv[6];
+#pragma unroll
+            for (int q = 0; q <= kLscFeat; ++q) fv[q] = sel ? acc[q] : 0.0f;
+            fv[kLscFeat + 1] = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) uv[q] = sel ? in[q] : 0u;
+            const float tf = lsc_fold12(fv);
+            const uint32_t tu = lsc_fold6(uv);
+            const unsigned long long v = adds_f ? (unsigned long long)(long long)(int)__builtin_rintf(tf * fix) : (unsigned long long)tu;
+            const unsigned long long hit = __ballot(my_k == k0);
+            if (adds_f || adds_u) {
+                if (hit) {                            // a candidate of the block's list: into the block's accumulators
+                    atomicAdd(&s_accx[__builtin_ctzll(hit) * kAccW + slot], v);
+                } else if (adds_f) {                  // a label kept from an earlier pass whose cluster is not in the list, or no list (pile-up): directly
+                    atomicAdd(reinterpret_cast<unsigned long long*>(l.extra + (size_t)k0 * kLscExPitch) + slot_f, v);
+                } else {
+                    atomicAdd(f.sums[0] + 6 * (size_t)k0 + slot_u, tu);
                 }
             }
         }
     }
+    __syncthreads();
+    // one set of global atomics per (block, cluster that received pixels here)
+    for (int i = threadIdx.x; i < min(cnt, 64) * kAccW && cnt <= 64; i += 256) {
+        const int c = i / kAccW, q = i - c * kAccW;
+        if (s_accx[c * kAccW + kLscFeat + 1] == 0ull) continue;          // count == 0: nothing for this cluster
+        const unsigned long long v = s_accx[i];
+        const uint32_t k = s_k[c];
+        if (q <= kLscFeat) atomicAdd(reinterpret_cast<unsigned long long*>(l.extra + (size_t)k * kLscExPitch) + q, v);
+        else atomicAdd(f.sums[0] + 6 * (size_t)k + (q - kLscFeat - 1), (uint32_t)v);
+    }
 }
 
-// ---- update ---------------------------------------------------------------------------------
-// One block per cluster: gather over the visited rows of the cluster's window the pixels labelled k: integer sums
-// (count, y, x, L, a, b) for the shared centroid update (src/context.cpp:301-373) and the weighted feature sums
-// sum w*F, sum w (src/lsc.cpp:256-269; FMA as the reference build contracts it).  C_f = sum w*F / sum w, 0/0 = NaN
-// for a memberless cluster exactly as src/lsc.cpp:309-316 produces it.  No atomics, fixed reduction order.
-__global__ __launch_bounds__(256) void k_lsc_update(FrameDev f, LscDev l, int rem, int stride) {
+// Two kernels over one body: the pass that is followed by an update carries the fused sums and needs about 100 VGPRs; the
+// final pass does not and fits 7 wavefronts per SIMD.  (Forcing the first to 96 VGPRs costs 5 spilled registers and gains 2 of 75 us.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_lsc_assign(FrameDev f, LscDev l, int rem, int stride, int Hv) {
+    lsc_assign_body<false>(f, l, rem, stride, Hv);
+}
+__global__ __launch_bounds__(256) void k_lsc_assign_sums(FrameDev f, LscDev l, int rem, int stride, int Hv) {
+    lsc_assign_body<true>(f, l, rem, stride, Hv);
+}
+
+// ---- update, second half ----------------------------------------------------------------------
+// C_f = sum w*F / sum w per cluster (src/lsc.cpp:256-269 then :309-316; 0/0 = NaN for a memberless cluster exactly as the
+// reference produces it) from the fixed-point accumulators the assign pass filled, which are cleared for the next pass.
+// The integer sums of the shared centroid update are in FrameDev::sums, where the cluster pass reads them.
+__global__ __launch_bounds__(256) void k_lsc_update(FrameDev f, LscDev l) {
     f.select(blockIdx.y);
     l.select(blockIdx.y);
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = LANE();      // one wavefront per cluster, four clusters per block
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = t >> 4, q = t & 15;                       // 16 threads per cluster: 10 features, the weight, 5 idle
     if (k >= f.K) return;
-    const uint32_t yx = f.cl_yx[k];
-    const int cy = (int)(yx >> 16), cx = (int)(yx & 0xFFFFu), S = f.S, W = f.W;
-    const size_t N = (size_t)f.N;
-    const int y_lo = max(cy - S, 0), y_hi = min(cy + S, f.H - 1);
-    const int x_lo = max(cx - S, 0), x_hi = min(cx + S, W - 1);
-    const int t = y_lo - rem;
-    const int v_first = t <= 0 ? 0 : (t + stride - 1) / stride;
-    // the stale-pixel contributions of the assign pass, fetched now so that the tail does not wait for them
-    uint32_t pre_sum = 0;
-    long long pre_ex = 0;
-    if (lane < 6) pre_sum = f.sums[0][6 * (size_t)k + lane];
-    if (lane <= kLscFeat) pre_ex = l.extra[(size_t)k * kLscExPitch + lane];
-    uint32_t in[6] = {0u, 0u, 0u, 0u, 0u, 0u};
-    float acc[kLscFeat + 1];
-#pragma unroll
-    for (int q = 0; q <= kLscFeat; ++q) acc[q] = 0.0f;
-    // kUpdRows visited rows of the window per trip, lanes over the columns.  Two memory round trips per trip: the labels
-    // of all rows, then the features of the matching pixels -- the loads of a non-matching lane are redirected to the
-    // window's first pixel (one cached line for all of them) so that they can be issued unconditionally and all at once.
-    constexpr int kUpdRows = 4;
-    const size_t p_first = (size_t)min(rem + stride * v_first, f.H - 1) * W + x_lo;
-    for (int y0 = rem + stride * v_first; y0 <= y_hi; y0 += kUpdRows * stride) {
-        for (int x = x_lo + lane; x - lane <= x_hi; x += 64) {
-            size_t p[kUpdRows];
-            uint32_t lb[kUpdRows];
-#pragma unroll
-            for (int u = 0; u < kUpdRows; ++u) {
-                const int y = y0 + u * stride;
-                p[u] = (y <= y_hi && x <= x_hi) ? (size_t)y * W + x : p_first;
-                lb[u] = f.labels[p[u]];
-            }
-            uint32_t pix[kUpdRows];
-            float w[kUpdRows], Fv[kUpdRows][kLscFeat];
-            bool m[kUpdRows];
-#pragma unroll
-            for (int u = 0; u < kUpdRows; ++u) {
-                const int y = y0 + u * stride;
-                m[u] = y <= y_hi && x <= x_hi && lb[u] == (uint32_t)k;
-                const size_t pp = m[u] ? p[u] : p_first;
-                pix[u] = f.lab[pp];
-                w[u] = l.weight[pp];
-#pragma unroll
-                for (int q = 0; q < kLscFeat; ++q) Fv[u][q] = l.feat[(size_t)q * N + pp];
-            }
-#pragma unroll
-            for (int u = 0; u < kUpdRows; ++u) {
-                if (!m[u]) continue;
-                const int y = y0 + u * stride;
-                in[0] += 1u; in[1] += (uint32_t)y; in[2] += (uint32_t)x;
-                in[3] += pix[u] & 255u; in[4] += (pix[u] >> 8) & 255u; in[5] += (pix[u] >> 16) & 255u;
-#pragma unroll
-                for (int q = 0; q < kLscFeat; ++q) acc[q] = __builtin_fmaf(w[u], Fv[u][q], acc[q]);
-                acc[kLscFeat] += w[u];
-            }
-        }
-    }
-    // fixed reduction order (DPP tree, then the four 16-lane rows): run-to-run identical
-#pragma unroll
-    for (int q = 0; q < 6; ++q) in[q] = wave_sum(in[q]);
-#pragma unroll
-    for (int q = 0; q <= kLscFeat; ++q) acc[q] = wave_sum(acc[q]);
-    uint32_t my_in = in[0];
-#pragma unroll
-    for (int q = 1; q < 6; ++q) my_in = lane == q ? in[q] : my_in;
-    if (lane < 6) f.sums[0][6 * (size_t)k + lane] = pre_sum + my_in;
-    float my_acc = acc[0];
-#pragma unroll
-    for (int q = 1; q <= kLscFeat; ++q) my_acc = lane == q ? acc[q] : my_acc;
-    if (lane <= kLscFeat && pre_ex != 0) {
-        my_acc += (float)((double)pre_ex / (double)kLscFixScale);
-        l.extra[(size_t)k * kLscExPitch + lane] = 0;
-    }
-    const float tot_w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_acc), kLscFeat));
-    if (lane < kLscFeat) l.cfeat[(size_t)k * kLscCfPitch + lane] = my_acc / tot_w;
+    long long* e = l.extra + (size_t)k * kLscExPitch;
+    const long long mine = q <= kLscFeat ? e[q] : 0ll;
+    const long long wsum = e[kLscFeat];
+    const float acc = (float)((double)mine / (double)kLscFixF), tot_w = (float)((double)wsum / (double)kLscFixW);
+    if (q < kLscFeat) l.cfeat[(size_t)k * kLscCfPitch + q] = acc / tot_w;
+    // every thread of the cluster has read what it needs before any of them clears (same wavefront: 16 consecutive lanes)
+    __builtin_amdgcn_wave_barrier();
+    if (q <= kLscFeat) e[q] = 0;
 }
 
 // ---- launches -------------------------------------------------------------------------------
@@ -405,13 +493,15 @@ void launch_lsc_assign(const FrameDev& f_, const LscDev& l, int nframes, int rem
     const FrameDev f = rotated(f_, buf, sbuf);
     const int Hv = (f.H - rem + stride - 1) / stride;
     if (Hv <= 0) return;
-    hipLaunchKernelGGL(k_lsc_assign, dim3((f.W + 63) / 64, (Hv + kLscBH - 1) / kLscBH, nframes), dim3(256), 0, st,
-                       f, l, rem, stride, Hv, stale_sums ? 1 : 0);
+    const dim3 grid((f.W + 63) / 64, (Hv + kLscBH - 1) / kLscBH, nframes);
+    if (stale_sums) hipLaunchKernelGGL(k_lsc_assign_sums, grid, dim3(256), 0, st, f, l, rem, stride, Hv);
+    else hipLaunchKernelGGL(k_lsc_assign, grid, dim3(256), 0, st, f, l, rem, stride, Hv);
 }
 
 void launch_lsc_update(const FrameDev& f_, const LscDev& l, int nframes, int rem, int stride, int sbuf, hipStream_t st) {
+    (void)rem; (void)stride;
     const FrameDev f = rotated(f_, 0, sbuf);
-    hipLaunchKernelGGL(k_lsc_update, dim3(f.K, nframes), dim3(256), 0, st, f, l, rem, stride);
+    hipLaunchKernelGGL(k_lsc_update, dim3((f.K * 16 + 255) / 256, nframes), dim3(256), 0, st, f, l);
 }
 
 }  // namespace fslic
