@@ -854,13 +854,13 @@ static void launch_assign_blk_t(const FrameDev& f_, int nframes, int rem, int Hv
     dim3 grid((f.W + kTileW - 1) / kTileW, (Hv + kWavesPerBlock * R - 1) / (kWavesPerBlock * R), nframes);
     const size_t lds = (size_t)f.tab_words * sizeof(uint32_t);
     if constexpr (R == 16 && !FUSE) {
-        if (f.tab_vmode) hipLaunchKernelGGL((k_assign_blk_w8<R, FUSE, STRIDE, true>), grid, dim3(256), lds, st, f, rem, Hv);
-        else hipLaunchKernelGGL((k_assign_blk_w8<R, FUSE, STRIDE, false>), grid, dim3(256), lds, st, f, rem, Hv);
+        if (f.tab_vmode) launch((k_assign_blk_w8<R, FUSE, STRIDE, true>), grid, dim3(256), lds, st, f, rem, Hv);
+        else launch((k_assign_blk_w8<R, FUSE, STRIDE, false>), grid, dim3(256), lds, st, f, rem, Hv);
     } else if constexpr (R == 16 && FUSE) {          // only launched with the row-vector table (launch_assign)
-        hipLaunchKernelGGL((k_assign_blk_w6<R, FUSE, STRIDE, true>), grid, dim3(256), lds, st, f, rem, Hv);
+        launch((k_assign_blk_w6<R, FUSE, STRIDE, true>), grid, dim3(256), lds, st, f, rem, Hv);
     } else {
-        if (f.tab_vmode) hipLaunchKernelGGL((k_assign_blk<R, FUSE, STRIDE, true>), grid, dim3(256), lds, st, f, rem, Hv);
-        else hipLaunchKernelGGL((k_assign_blk<R, FUSE, STRIDE, false>), grid, dim3(256), lds, st, f, rem, Hv);
+        if (f.tab_vmode) launch((k_assign_blk<R, FUSE, STRIDE, true>), grid, dim3(256), lds, st, f, rem, Hv);
+        else launch((k_assign_blk<R, FUSE, STRIDE, false>), grid, dim3(256), lds, st, f, rem, Hv);
     }
 }
 
@@ -875,11 +875,11 @@ static void launch_assign_r(const FrameDev& f, int nframes, int rem, int stride,
     dim3 grid((f.W + kTileW - 1) / kTileW, (Hv + kWavesPerBlock * R - 1) / (kWavesPerBlock * R), nframes);
     const size_t lds = (size_t)f.lut_words * sizeof(uint32_t);
     if (f.lut_words > 0) {
-        if (fuse_update) hipLaunchKernelGGL((k_assign<R, true, true>), grid, dim3(256), lds, st, f, rem, stride, Hv, buf, sbuf);
-        else hipLaunchKernelGGL((k_assign<R, false, true>), grid, dim3(256), lds, st, f, rem, stride, Hv, buf, sbuf);
+        if (fuse_update) launch((k_assign<R, true, true>), grid, dim3(256), lds, st, f, rem, stride, Hv, buf, sbuf);
+        else launch((k_assign<R, false, true>), grid, dim3(256), lds, st, f, rem, stride, Hv, buf, sbuf);
     } else {
-        if (fuse_update) hipLaunchKernelGGL((k_assign<R, true, false>), grid, dim3(256), 0, st, f, rem, stride, Hv, buf, sbuf);
-        else hipLaunchKernelGGL((k_assign<R, false, false>), grid, dim3(256), 0, st, f, rem, stride, Hv, buf, sbuf);
+        if (fuse_update) launch((k_assign<R, true, false>), grid, dim3(256), 0, st, f, rem, stride, Hv, buf, sbuf);
+        else launch((k_assign<R, false, false>), grid, dim3(256), 0, st, f, rem, stride, Hv, buf, sbuf);
     }
 }
 
@@ -975,8 +975,8 @@ void launch_assign_generic(const FrameDev& f_, int nframes, int rem, int stride,
     if (Hv <= 0) return;
     const size_t n = (size_t)Hv * f.W;
     const int blocks = (int)((n + 255) / 256);
-    if (fuse_update) hipLaunchKernelGGL(k_assign_generic<true>, dim3(blocks, nframes), dim3(256), 0, st, f, rem, stride, Hv, buf, sbuf);
-    else hipLaunchKernelGGL(k_assign_generic<false>, dim3(blocks, nframes), dim3(256), 0, st, f, rem, stride, Hv, buf, sbuf);
+    if (fuse_update) launch(k_assign_generic<true>, dim3(blocks, nframes), dim3(256), 0, st, f, rem, stride, Hv, buf, sbuf);
+    else launch(k_assign_generic<false>, dim3(blocks, nframes), dim3(256), 0, st, f, rem, stride, Hv, buf, sbuf);
 }
 
 }  // namespace fslic

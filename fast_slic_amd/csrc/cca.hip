@@ -747,11 +747,11 @@ static int root_pass_blocks(const CcaDev& c) {
 void launch_cca_phase1(const CcaDev& c, int nframes, hipStream_t st) {
     constexpr int T = kCcaTile;
     const int tx = (c.W + T - 1) / T, ty = (c.H + kCcaTileH - 1) / kCcaTileH;
-    hipLaunchKernelGGL(k_cca_local, dim3(tx * nframes, ty), dim3(256), 0, st, c, nframes);
+    launch(k_cca_local, dim3(tx * nframes, ty), dim3(256), 0, st, c, nframes);
     const int nh = (ty - 1) * c.W, nv = (tx - 1) * c.H;
     if (nh + nv > 0)
-        hipLaunchKernelGGL(k_cca_border, dim3((nh + nv + 255) / 256, nframes), dim3(256), 0, st, c, nh, nv);
-    hipLaunchKernelGGL(k_cca_compress, dim3(root_pass_blocks(c) * nframes), dim3(256), 0, st, c, nframes);
+        launch(k_cca_border, dim3((nh + nv + 255) / 256, nframes), dim3(256), 0, st, c, nh, nv);
+    launch(k_cca_compress, dim3(root_pass_blocks(c) * nframes), dim3(256), 0, st, c, nframes);
 }
 
 void launch_cca_select(const CcaDev& c, int nframes, hipStream_t st) {
@@ -765,7 +765,7 @@ void launch_cca_select(const CcaDev& c, int nframes, hipStream_t st) {
     static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(k_cca_select), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                            (int)((3 * (size_t)kSelCap + 3 * (size_t)kSelBuckets) * sizeof(uint32_t)));
     (void)attr_once;
-    hipLaunchKernelGGL(k_cca_select, dim3(nframes), dim3(1024), lds, st, c, cap);
+    launch(k_cca_select, dim3(nframes), dim3(1024), lds, st, c, cap);
 }
 
 // Host path only: forget what the device select / chain wrote, then set the host's choice.
@@ -786,13 +786,13 @@ __global__ void k_cca_gather_area(CcaDev c) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) c.cand_area[i] = c.area[c.cand_leader[i]];
 }
 void launch_cca_gather_area(const CcaDev& c, hipStream_t st) {
-    hipLaunchKernelGGL(k_cca_gather_area, dim3(64), dim3(256), 0, st, c);
+    launch(k_cca_gather_area, dim3(64), dim3(256), 0, st, c);
 }
 
 void launch_cca_set_kept(const CcaDev& c, const int32_t* d_leaders, const uint16_t* d_labels, int n, hipStream_t st) {
-    hipLaunchKernelGGL(k_cca_reset_final, dim3(root_pass_blocks(c)), dim3(256), 0, st, c);
+    launch(k_cca_reset_final, dim3(root_pass_blocks(c)), dim3(256), 0, st, c);
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_cca_set_kept, dim3((n + 255) / 256), dim3(256), 0, st, c, d_leaders, d_labels, n);
+    launch(k_cca_set_kept, dim3((n + 255) / 256), dim3(256), 0, st, c, d_leaders, d_labels, n);
 }
 
 // Every component that was not kept takes the final label of the component left of (or, in column 0,
@@ -866,7 +866,7 @@ __global__ __launch_bounds__(256) void k_cca_relabel(CcaDev c, ExportDev ex, int
 }
 
 void launch_cca_phase2(const CcaDev& c, int nframes, hipStream_t st, const ExportDev* ex_) {
-    hipLaunchKernelGGL(k_cca_chain, dim3(root_pass_blocks(c), nframes), dim3(256), 0, st, c);
+    launch(k_cca_chain, dim3(root_pass_blocks(c), nframes), dim3(256), 0, st, c);
     int blocks = (c.N / 4 + 255) / 256;
     const int cap = (4096 + nframes - 1) / nframes;
     if (blocks > cap) blocks = cap;
@@ -874,7 +874,7 @@ void launch_cca_phase2(const CcaDev& c, int nframes, hipStream_t st, const Expor
     ExportDev ex{};
     if (ex_) ex = *ex_;
     const int eb = ex.K > 0 ? (4 * ex.K + 1023) / 1024 : 0;          // a few blocks: 4K words per frame
-    hipLaunchKernelGGL(k_cca_relabel, dim3(blocks + eb, nframes), dim3(256), 0, st, c, ex, blocks);
+    launch(k_cca_relabel, dim3(blocks + eb, nframes), dim3(256), 0, st, c, ex, blocks);
 }
 
 }  // namespace fslic

@@ -154,10 +154,10 @@ void launch_bin_clusters(const FrameDev& f_, int nframes, int mode, int buf, int
     const FrameDev f = rotated(f_, buf, sbuf);
     if (mode == 0) {
         const int n = f.K > f.ncell ? f.K : f.ncell;
-        hipLaunchKernelGGL(k_bin_clusters<0>, dim3((n + 255) / 256, nframes), dim3(256), 0, st, f, pg, src_yx, src_stride);
+        launch(k_bin_clusters<0>, dim3((n + 255) / 256, nframes), dim3(256), 0, st, f, pg, src_yx, src_stride);
     } else {
         const int bk = (f.K + 254) / 255, bc = (f.ncell + 255) / 256;    // 255 clusters per block (see the kernel)
-        hipLaunchKernelGGL(k_bin_clusters<1>, dim3(bk > bc ? bk : bc, nframes), dim3(256), 0, st, f, pg, nullptr, (size_t)0);
+        launch(k_bin_clusters<1>, dim3(bk > bc ? bk : bc, nframes), dim3(256), 0, st, f, pg, nullptr, (size_t)0);
     }
 }
 

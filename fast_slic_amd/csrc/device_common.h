@@ -2,6 +2,7 @@
 // Internal to the library.
 #pragma once
 #include "kernels.h"
+#include "launch.h"
 #include <cstdlib>
 
 namespace fslic {

@@ -13,6 +13,7 @@
 // carries over between calls is the caller's Cluster[K].
 #pragma once
 #include "kernels.h"
+#include "launch.h"
 #include "../../include/fslic_hip.h"
 
 #include <condition_variable>
@@ -116,7 +117,9 @@ struct Slot {
     size_t h_cand_cap = 0;
     int hKeep = 0;
     uint32_t* d_gen = nullptr;       // device word: base of the bin generation stamps (FrameDev::gen_base)
-    uint64_t gen_host = 0;           // host mirror of *d_gen (every group advances it by max_iter + 3)
+    uint64_t gen_host = 0;           // host mirror of *d_gen
+    uint32_t gen_span_prev = 0;      // stamps the previous group used above its base (max_iter + 3): what the next group's first kernel adds to *d_gen
+    uint32_t gen_step = 0;           // ... for the group being enqueued
     int keyH = 0, keyW = 0, keyK = 0;
     size_t cand_capacity = 0;        // entries of the per-frame candidate arrays (>= N)
     // Captured launch sequences (hipGraph), one per distinct (geometry, options, group size, arena carving): a group

@@ -128,16 +128,16 @@ static inline int grid_for(unsigned long long items, unsigned long long per_bloc
 }
 void launch_mask_sums(const uint16_t* labels, const uint8_t* mask, uint32_t* sums, int H, int W, int K, hipStream_t st) {
     const unsigned long long tiles = (unsigned long long)((W + 63) / 64) * (unsigned long long)((H + kMaskRows - 1) / kMaskRows);
-    hipLaunchKernelGGL(k_mask_sums, dim3(grid_for(tiles, 4)), dim3(256), 0, st, labels, mask, sums, H, W, (uint32_t)(uint16_t)K);
+    launch(k_mask_sums, dim3(grid_for(tiles, 4)), dim3(256), 0, st, labels, mask, sums, H, W, (uint32_t)(uint16_t)K);
 }
 void launch_density_to_mask(const uint16_t* labels, const uint8_t* dens, uint8_t* out, size_t N, int K, hipStream_t st) {
-    hipLaunchKernelGGL(k_density_to_mask, dim3(grid_for(N, 256)), dim3(256), 0, st, labels, dens, out, (unsigned long long)N, (uint32_t)(uint16_t)K);
+    launch(k_density_to_mask, dim3(grid_for(N, 256)), dim3(256), 0, st, labels, dens, out, (unsigned long long)N, (uint32_t)(uint16_t)K);
 }
 void launch_adjacent_pairs(const uint16_t* labels, int H, int W, int K, uint32_t* tab_pair, unsigned long long* tab_key,
                            uint32_t cap, uint32_t* counters, hipStream_t st) {
     if (H < 2 || W < 2) return;
     const unsigned long long npx = (unsigned long long)(H - 1) * (unsigned long long)(W - 1);
-    hipLaunchKernelGGL(k_adjacent_pairs, dim3(grid_for(npx, 256)), dim3(256), 0, st, labels, H, W, (uint32_t)K, tab_pair, tab_key, cap - 1u, counters);
+    launch(k_adjacent_pairs, dim3(grid_for(npx, 256)), dim3(256), 0, st, labels, H, W, (uint32_t)K, tab_pair, tab_key, cap - 1u, counters);
 }
 
 }  // namespace fslic

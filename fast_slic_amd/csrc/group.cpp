@@ -124,15 +124,18 @@ int cca_finish_group(Slot& s, int first, int n, const uint16_t* d_in0, size_t in
         int32_t* sl = s.h_cand_leader + M;       // second half of the (2M-entry) host buffers
         uint32_t* sa = s.h_cand_area + M;
         for (uint32_t q = 0; q < M; q++) { sl[q] = s.h_cand_leader[order[q]]; sa[q] = s.h_cand_area[order[q]]; }
-        std::vector<int32_t> kl(std::min<size_t>(M, (size_t)K) + 1);
-        std::vector<uint16_t> kb(kl.size());
+        // the kept list goes into the first halves of the pinned buffers (their content was moved to the second halves above)
+        // and from there to the device on the slot's OWN stream: a copy on the default stream fails while another slot
+        // of the engine is capturing its graph
+        int32_t* kl = s.h_cand_leader;
+        uint16_t* kb = reinterpret_cast<uint16_t*>(s.h_cand_area);
         uint32_t n_keep = 0;
-        select_kept_sorted(sl, sa, M, K, kl.data(), kb.data(), n_keep);
+        select_kept_sorted(sl, sa, M, K, kl, kb, n_keep);
         int32_t* d_kl = s.at(s.d_keep_leader, i);
         uint16_t* d_kb = s.at(s.d_keep_label, i);
         if (n_keep) {
-            HIPCHK(hipMemcpy(d_kl, kl.data(), sizeof(int32_t) * n_keep, hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(d_kb, kb.data(), sizeof(uint16_t) * n_keep, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpyAsync(d_kl, kl, sizeof(int32_t) * n_keep, hipMemcpyHostToDevice, s.st));
+            HIPCHK(hipMemcpyAsync(d_kb, kb, sizeof(uint16_t) * n_keep, hipMemcpyHostToDevice, s.st));
         }
         launch_cca_set_kept(c1, d_kl, d_kb, (int)n_keep, s.st);
         launch_cca_phase2(c1, 1, s.st);
@@ -181,7 +184,7 @@ void stage_group(fslic_engine* e, Slot& s, int i0, int n, bool timed) {
 // the slot's stream: LAB, the first cluster pass (reads the staged centres), the assign/update loop, full assign,
 // connectivity, export of the cluster state.  Pure
 // stream work with no per-call values in any launch argument (caller pointers sit in the device pointer table, bin
-// generations come from device memory), so the same sequence can be captured once and replayed (group_begin).
+// generations come from device memory), so the same sequence can be recorded once as a graph and replayed (launch_group).
 int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool timed) {
     const fslic_params* p = &s.p;
     const int K = s.K, S = s.S;
@@ -191,6 +194,8 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     f.rgbs = reinterpret_cast<const uint8_t* const*>(s.d_ptrs + i0);
     const size_t fb = s.frame_bytes;
 
+    // copies the graph recorder has no node for (launch.h): such a group is always enqueued directly
+    if ((p->preemptive != 0 || p->variant == FSLIC_VARIANT_REALDIST_NOQ || (generic && !s.sp_patch_uploaded)) && recording_unsupported()) return FSLIC_OK;
     if (generic && !s.sp_patch_uploaded) {
         HIPCHK(hipMemcpyAsync(s.d_patch, s.h_patch, (size_t)(2 * S + 1) * (2 * S + 1) * sizeof(uint16_t), hipMemcpyHostToDevice, s.st));
         s.sp_patch_uploaded = true;
@@ -218,7 +223,7 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     if (timed) HIPCHK(hipEventRecord(s.ev[0], s.st));
     // + labels <- 0xFFFF (src/context.cpp:138-145); + a fresh range of bin generation stamps for this group's passes
     f.gen_base = s.d_gen;
-    launch_rgb_to_lab(f, n, p->convert_to_lab, e->tables, true, s.st, (uint32_t)p->max_iter + 3u,
+    launch_rgb_to_lab(f, n, p->convert_to_lab, e->tables, true, s.st, s.gen_step,
                       s.at(s.zero_block, i0), s.zero_bytes, f.cl_n, 2 * (size_t)K);
     if (timed) HIPCHK(hipEventRecord(s.ev[1], s.st));
     f.gen_off = 1;
@@ -236,7 +241,7 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     LscDev l = s.l;
     if (lsc) {
         l.select(i0);
-        HIPCHK(hipMemset2DAsync(s.lsc_zero + (size_t)i0 * s.lsc_frame_bytes, s.lsc_frame_bytes, 0, s.lsc_zero_bytes, (size_t)n, s.st));
+        HIPCHK(clear_rows(s.lsc_zero + (size_t)i0 * s.lsc_frame_bytes, s.lsc_frame_bytes, s.lsc_zero_bytes, (size_t)n, s.st));
         launch_lsc_prepare(f, l, n, s.st);                        // before_iteration, src/lsc.cpp:12-15
     }
     const bool rd = p->variant == FSLIC_VARIANT_REALDIST || p->variant == FSLIC_VARIANT_REALDIST_L2 || noq;
@@ -319,18 +324,27 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     return FSLIC_OK;
 }
 
-// The device half of a group start, replayed from a captured graph when this exact sequence has been seen before.
+GraphRecorder*& current_recorder() {
+    static thread_local GraphRecorder* rec = nullptr;
+    return rec;
+}
+
+// The device half of a group start, replayed from a graph when this exact sequence has been seen before.
 int launch_group(fslic_engine* e, Slot& s, int n) {
     s.last_launch_mode = 0;
-    {   // Bin slots are validated by a u32 generation stamp that every group advances by max_iter + 3 (device word
-        // *d_gen, mirrored here).  Long before it could wrap, start over: stamps and base back to zero.
-        const uint64_t step = (uint64_t)s.p.max_iter + 3u;
-        if (s.gen_host + 2 * step >= 0xC0000000ull) {
+    {   // Bin slots are validated by a u32 generation stamp; a group uses max_iter + 3 consecutive values above the base
+        // (device word *d_gen, mirrored here).  Long before it could wrap, start over: stamps and base back to zero.
+        // The base moves past the stamps of the PREVIOUS group at the start of this one (a group of fewer iterations after one
+        // of more would otherwise meet the earlier group's stamps inside its own range and take stale bin slots for live).
+        const uint64_t span = (uint64_t)s.p.max_iter + 3u;
+        if (s.gen_host + 2 * (s.gen_span_prev + span) >= 0xC0000000ull) {
             HIPCHK(hipMemsetAsync(s.d_gen, 0, 256, s.st));
             HIPCHK(hipMemset2DAsync(s.stamp_block, s.frame_bytes, 0, s.stamp_bytes, (size_t)s.cap_frames, s.st));
             s.gen_host = 0;
         }
-        s.gen_host += step;
+        s.gen_step = s.gen_span_prev ? s.gen_span_prev : (uint32_t)span;     // (first group of the slot: any step does)
+        s.gen_span_prev = (uint32_t)span;
+        s.gen_host += s.gen_step;
     }
     // Per-launch timing wants real event records between the launches; events replayed inside a graph keep the time
     // stamps of an earlier execution.  Timed groups therefore take the direct path.
@@ -338,7 +352,7 @@ int launch_group(fslic_engine* e, Slot& s, int n) {
     // everything a launch argument can depend on
     std::vector<unsigned char> key;
     auto put = [&](const void* p, size_t bytes) { const unsigned char* b = (const unsigned char*)p; key.insert(key.end(), b, b + bytes); };
-    const int hdr[8] = {s.H, s.W, s.K, s.S, n, s.generic ? 1 : 0, 0, s.sp_patch_uploaded ? 1 : 0};
+    const int hdr[8] = {s.H, s.W, s.K, s.S, n, s.generic ? 1 : 0, (int)s.gen_step, s.sp_patch_uploaded ? 1 : 0};
     const void* const ptrs[9] = {s.h_cl, s.h_misc, s.d_ptrs, s.h_patch, s.d_gen, s.lsc_zero, s.d_patchf, s.h_clf, s.h_upd};   // baked into copy nodes / arguments
     put(hdr, sizeof hdr); put(ptrs, sizeof ptrs); put(&s.p, sizeof s.p); put(&s.f, sizeof s.f); put(&s.c, sizeof s.c);
     if (s.p.variant == FSLIC_VARIANT_LSC) put(&s.l, sizeof s.l);
@@ -356,18 +370,20 @@ int launch_group(fslic_engine* e, Slot& s, int n) {
     }
     if (!ge->exec) {
         if (ge->failed || ge->seen++ == 0) return enqueue_frames(e, s, 0, n, s.generic, true);   // first sighting: direct (also warms one-time setup)
-        if (hipStreamBeginCapture(s.st, hipStreamCaptureModeThreadLocal) != hipSuccess) { ge->failed = true; (void)hipGetLastError(); return enqueue_frames(e, s, 0, n, s.generic, true); }
+        // second sighting: the same calls with a recorder current on this thread build the graph, node by node (launch.h)
+        GraphRecorder rec;
+        if (hipGraphCreate(&rec.graph, 0) != hipSuccess) { ge->failed = true; (void)hipGetLastError(); return enqueue_frames(e, s, 0, n, s.generic, true); }
+        current_recorder() = &rec;
         const int rc = enqueue_frames(e, s, 0, n, s.generic, false);     // no event records inside the graph
-        hipGraph_t g = nullptr;
-        const hipError_t ec = hipStreamEndCapture(s.st, &g);
-        if (rc != FSLIC_OK || ec != hipSuccess || !g || hipGraphInstantiate(&ge->exec, g, nullptr, nullptr, 0) != hipSuccess) {
-            if (g) hipGraphDestroy(g);
+        current_recorder() = nullptr;
+        if (rc != FSLIC_OK || rec.err != hipSuccess || rec.nodes == 0 || hipGraphInstantiate(&ge->exec, rec.graph, nullptr, nullptr, 0) != hipSuccess) {
+            hipGraphDestroy(rec.graph);
             ge->exec = nullptr; ge->failed = true;
             (void)hipGetLastError();
             if (rc != FSLIC_OK) return rc;
             return enqueue_frames(e, s, 0, n, s.generic, true);
         }
-        ge->graph = g;
+        ge->graph = rec.graph;
         s.last_launch_mode = 1;
     } else {
         s.last_launch_mode = 2;
@@ -457,7 +473,8 @@ int group_finish(fslic_engine* e, Slot& s) {
         if (!s.generic && s.h_misc[16 * (size_t)i + 2] != 0) {     // the tiled kernel overflowed an LDS candidate list
             if (knobs().host_timing) fprintf(stderr, "[fslic host] candidate-list overflow: frame %d redone with the generic kernel\n", i);
             stage_group(e, s, i, 1, false);
-            s.gen_host += (uint64_t)s.p.max_iter + 3u;
+            s.gen_step = s.gen_span_prev;                 // past the stamps of the pass just made (same span)
+            s.gen_host += s.gen_step;
             int rc = enqueue_frames(e, s, i, 1, true, false);
             if (rc) return rc;
             HIPCHK(hipStreamSynchronize(s.st));

@@ -115,9 +115,9 @@ void launch_rgb_to_lab(const FrameDev& f, int nframes, int convert, const LabTab
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     if (convert)
-        hipLaunchKernelGGL(k_rgb_to_lab<true>, dim3(blocks, nframes), dim3(1024), 0, st, f, t.gamma, t.labtbl, kc, init_labels ? 1 : 0, gen_step, (char*)zero_a, (unsigned)(zero_a_bytes / 16), zero_b, (unsigned)zero_b_words);
+        launch(k_rgb_to_lab<true>, dim3(blocks, nframes), dim3(1024), 0, st, f, t.gamma, t.labtbl, kc, init_labels ? 1 : 0, gen_step, (char*)zero_a, (unsigned)(zero_a_bytes / 16), zero_b, (unsigned)zero_b_words);
     else
-        hipLaunchKernelGGL(k_rgb_to_lab<false>, dim3(blocks, nframes), dim3(1024), 0, st, f, t.gamma, t.labtbl, kc, init_labels ? 1 : 0, gen_step, (char*)zero_a, (unsigned)(zero_a_bytes / 16), zero_b, (unsigned)zero_b_words);
+        launch(k_rgb_to_lab<false>, dim3(blocks, nframes), dim3(1024), 0, st, f, t.gamma, t.labtbl, kc, init_labels ? 1 : 0, gen_step, (char*)zero_a, (unsigned)(zero_a_bytes / 16), zero_b, (unsigned)zero_b_words);
 }
 
 }  // namespace fslic

@@ -483,10 +483,10 @@ __global__ __launch_bounds__(256) void k_lsc_update(FrameDev f, LscDev l) {
 // ---- launches -------------------------------------------------------------------------------
 void launch_lsc_prepare(const FrameDev& f, const LscDev& l, int nframes, hipStream_t st) {
     const unsigned N = (unsigned)f.N;
-    hipLaunchKernelGGL(k_lsc_hist, dim3((N + 4095) / 4096, nframes), dim3(256), 0, st, f, l);
-    hipLaunchKernelGGL(k_lsc_means, dim3(nframes), dim3(256), 0, st, f, l);
-    hipLaunchKernelGGL(k_lsc_features, dim3((N + 255) / 256, nframes), dim3(256), 0, st, f, l);
-    hipLaunchKernelGGL(k_lsc_seed, dim3((f.K + 3) / 4, nframes), dim3(256), 0, st, f, l);
+    launch(k_lsc_hist, dim3((N + 4095) / 4096, nframes), dim3(256), 0, st, f, l);
+    launch(k_lsc_means, dim3(nframes), dim3(256), 0, st, f, l);
+    launch(k_lsc_features, dim3((N + 255) / 256, nframes), dim3(256), 0, st, f, l);
+    launch(k_lsc_seed, dim3((f.K + 3) / 4, nframes), dim3(256), 0, st, f, l);
 }
 
 void launch_lsc_assign(const FrameDev& f_, const LscDev& l, int nframes, int rem, int stride, int buf, int sbuf, bool stale_sums, hipStream_t st) {
@@ -494,14 +494,14 @@ void launch_lsc_assign(const FrameDev& f_, const LscDev& l, int nframes, int rem
     const int Hv = (f.H - rem + stride - 1) / stride;
     if (Hv <= 0) return;
     const dim3 grid((f.W + 63) / 64, (Hv + kLscBH - 1) / kLscBH, nframes);
-    if (stale_sums) hipLaunchKernelGGL(k_lsc_assign_sums, grid, dim3(256), 0, st, f, l, rem, stride, Hv);
-    else hipLaunchKernelGGL(k_lsc_assign, grid, dim3(256), 0, st, f, l, rem, stride, Hv);
+    if (stale_sums) launch(k_lsc_assign_sums, grid, dim3(256), 0, st, f, l, rem, stride, Hv);
+    else launch(k_lsc_assign, grid, dim3(256), 0, st, f, l, rem, stride, Hv);
 }
 
 void launch_lsc_update(const FrameDev& f_, const LscDev& l, int nframes, int rem, int stride, int sbuf, hipStream_t st) {
     (void)rem; (void)stride;
     const FrameDev f = rotated(f_, 0, sbuf);
-    hipLaunchKernelGGL(k_lsc_update, dim3((f.K * 16 + 255) / 256, nframes), dim3(256), 0, st, f, l);
+    launch(k_lsc_update, dim3((f.K * 16 + 255) / 256, nframes), dim3(256), 0, st, f, l);
 }
 
 }  // namespace fslic

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(1024) void k_preempt_update(FrameDev f, int rebin_a
 
 void launch_preempt_update(const FrameDev& f_, int nframes, int buf, int sbuf, bool rebin_all, float l1_thres, hipStream_t st) {
     const FrameDev f = rotated(f_, buf, sbuf);
-    hipLaunchKernelGGL(k_preempt_update, dim3(nframes), dim3(1024), 0, st, f, rebin_all ? 1 : 0, l1_thres);
+    launch(k_preempt_update, dim3(nframes), dim3(1024), 0, st, f, rebin_all ? 1 : 0, l1_thres);
 }
 
 }  // namespace fslic

@@ -189,13 +189,13 @@ void launch_rd_assign(const FrameDev& f_, const float* patchf, bool l2, int nfra
     const int Hv = (f.H - rem + stride - 1) / stride;
     if (Hv <= 0) return;
     const dim3 grid((f.W + 63) / 64, (Hv + kRdBH - 1) / kRdBH, nframes);
-    if (l2) hipLaunchKernelGGL(k_rd_assign<true>, grid, dim3(256), 0, st, f, patchf, rem, stride, Hv, stale_sums ? 1 : 0);
-    else hipLaunchKernelGGL(k_rd_assign<false>, grid, dim3(256), 0, st, f, patchf, rem, stride, Hv, stale_sums ? 1 : 0);
+    if (l2) launch(k_rd_assign<true>, grid, dim3(256), 0, st, f, patchf, rem, stride, Hv, stale_sums ? 1 : 0);
+    else launch(k_rd_assign<false>, grid, dim3(256), 0, st, f, patchf, rem, stride, Hv, stale_sums ? 1 : 0);
 }
 
 void launch_member_sums(const FrameDev& f_, int nframes, int rem, int stride, int sbuf, int margin, hipStream_t st) {
     const FrameDev f = rotated(f_, 0, sbuf);
-    hipLaunchKernelGGL(k_member_sums, dim3((f.K + 3) / 4, nframes), dim3(256), 0, st, f, rem, stride, margin);
+    launch(k_member_sums, dim3((f.K + 3) / 4, nframes), dim3(256), 0, st, f, rem, stride, margin);
 }
 
 // ---- 'noq': ContextRealDistNoQ::assign_clusters_proto (src/context.cpp:461-499) ------------------------------
@@ -329,8 +329,8 @@ void launch_noq_assign(const FrameDev& f_, float coef, bool manhattan, int nfram
     const int Hv = (f.H - rem + stride - 1) / stride;
     if (Hv <= 0) return;
     const dim3 grid((f.W + 63) / 64, (Hv + kRdBH - 1) / kRdBH, nframes);
-    if (manhattan) hipLaunchKernelGGL(k_noq_assign<true>, grid, dim3(256), 0, st, f, coef, rem, stride, Hv, stale_sums ? 1 : 0);
-    else hipLaunchKernelGGL(k_noq_assign<false>, grid, dim3(256), 0, st, f, coef, rem, stride, Hv, stale_sums ? 1 : 0);
+    if (manhattan) launch(k_noq_assign<true>, grid, dim3(256), 0, st, f, coef, rem, stride, Hv, stale_sums ? 1 : 0);
+    else launch(k_noq_assign<false>, grid, dim3(256), 0, st, f, coef, rem, stride, Hv, stale_sums ? 1 : 0);
 }
 
 }  // namespace fslic

@@ -32,18 +32,18 @@ def _expected(frames, K):
     return out
 
 
-def _run_pipeline(H, W, K, seeds, group, nslots, rounds, expect_replay=True):
+def _run_pipeline(H, W, K, seeds, group, nslots, rounds, expect_replay=True, min_size_factor=0.25, max_iter=10, host_topk=False, engine=None):
     """Submit `rounds` times the groups cut from `seeds` through fslic_hip_pipeline_submit on `nslots` slots; every
     submission owns its label maps and cluster blocks, all of them are compared with the oracle after the drain."""
     import torch
-    p = make_params(10, 10.0, 0.25, 3)
+    p = make_params(max_iter, 10.0, min_size_factor, 3)
     frames = [variant("A", H, W, seed=s) for s in seeds]
-    exp = _expected(frames, K)
+    exp = [orc.slic_iterate(f, orc.initialize_clusters(f, K), max_iter=max_iter, min_size_factor=min_size_factor) for f in frames]
     cl0 = np.zeros((len(frames), K), B.CLUSTER_DTYPE)
     lib = B.load_library()
     for i, f in enumerate(frames):
         lib.fslic_hip_initialize_clusters(H, W, K, f.ctypes.data, cl0[i].ctypes.data)
-    e = Engine(0, nslots)
+    e = engine or Engine(0, nslots)
     try:
         d_rgb = [torch.from_numpy(f).cuda() for f in frames]
         torch.cuda.synchronize()
@@ -61,7 +61,8 @@ def _run_pipeline(H, W, K, seeds, group, nslots, rounds, expect_replay=True):
                 subs.append((r, idx, d_lab, cls, (a_rgb, a_lab, a_cls)))
         tot = e.pipeline_drain()
         assert tot["groups"] == len(subs) and tot["frames"] == rounds * len(frames)
-        assert tot["host_topk_frames"] == 0, tot            # ties are resolved on the device
+        if host_topk: assert tot["host_topk_frames"] > 0, tot
+        else: assert tot["host_topk_frames"] == 0, tot      # ties are resolved on the device
         assert tot["device_ms"] > 0.0
         for r, idx, d_lab, cls, _keep in subs:
             for j, i in enumerate(idx):
@@ -72,13 +73,32 @@ def _run_pipeline(H, W, K, seeds, group, nslots, rounds, expect_replay=True):
             modes = [e.last_launch_mode(s) for s in range(nslots)]
             assert 2 in modes, modes                        # slots that served more than two groups replay their graph
     finally:
-        e.close()
+        if engine is None: e.close()
 
 
 def test_bench_operating_point_8x720p_six_slots_three_rounds():
     # exactly bench.py's timed loop: one group = seeds 0..7 at 1280x720 K=1600; 6 slots; 18 groups so that every slot goes
     # direct -> capture -> replay; seeds 2 and 4 carry an area tie at the top-K cut
     _run_pipeline(720, 1280, 1600, list(range(8)), 8, 6, 18)
+
+
+def test_threshold_zero_takes_the_host_topk_path_while_other_slots_capture():
+    # min_size_factor = 0: every component is a candidate (src/cca.cpp:14-20 with thres 0), more than the device sorts, so the
+    # frames go through the host's partial_sort: while the other slots direct-launch, capture and replay their groups
+    _run_pipeline(360, 640, 400, list(range(6)), 2, 3, 4, min_size_factor=0.0, host_topk=True)
+
+
+def test_one_engine_serves_groups_of_different_iteration_counts():
+    # the bin slots carry generation stamps, max_iter + 3 per group: a group of fewer iterations after one of more must not
+    # find the earlier group's stamps inside its own range (it did: stale slots taken for live, a memory fault at 720p)
+    e = Engine(0, 2)
+    try:
+        for mi in (10, 5, 0, 12, 1, 10):
+            _run_pipeline(360, 640, 400, list(range(4)), 4, 2, 10, max_iter=mi, engine=e)      # replayed from the fourth group of a slot on
+        _run_pipeline(720, 1280, 1600, list(range(4)), 4, 2, 3, max_iter=10, engine=e, expect_replay=False)
+        _run_pipeline(720, 1280, 1600, list(range(4)), 4, 2, 3, max_iter=4, engine=e, expect_replay=False)
+    finally:
+        e.close()
 
 
 def test_config4_all_64_frames():
