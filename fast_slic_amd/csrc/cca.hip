@@ -17,7 +17,8 @@ namespace fslic {
 //   k_cca_select   top-K by area and ranking by leader in one block, including the area tie at the cut
 //   k_cca_chain    every other component takes the final label of the component left of (or
 //                  above) its leader, src/cca.cpp:240-254, resolved by chasing toward smaller leaders
-//   k_cca_relabel  out[p] = final[root(p)] (and the group's results to the host)
+//   k_cca_relabel  out[p] = final[parent[p]] (the chain pass leaves the label at every tile-local root too), and the
+//                  group's results to the host
 // =============================================================================================
 // LDS accessors.  They are relaxed workgroup-scope atomics rather than `volatile` accesses on purpose:
 // volatile blocks the address-space inference and the accesses become FLAT instructions, which reach the LDS
@@ -819,9 +820,14 @@ __global__ __launch_bounds__(256) void k_cca_chain(CcaDev c) {
     const uint32_t gstride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gstride) {
         const int32_t r = c.roots[i];
-        if (c.parent[r] != r) continue;
-        if (__hip_atomic_load(c.final_lab + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0xFFFFu) continue;   // kept
-        __hip_atomic_store(c.final_lab + r, (uint16_t)chase_final(c, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int32_t g = c.parent[r];
+        // the component's final label: set already when it was kept, or when its own thread got here first; otherwise
+        // chased from its leader (whoever computes it finds the same value)
+        uint32_t f = __hip_atomic_load(c.final_lab + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f == 0xFFFFu) f = chase_final(c, g);
+        // ... stored at the tile-local root as well (an entry nothing else reads or resets: the chase only ever looks at
+        // global roots), so that the relabel pass needs ONE dependent load per pixel: out[p] = final[parent[p]]
+        __hip_atomic_store(c.final_lab + r, (uint16_t)f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -852,8 +858,8 @@ __global__ __launch_bounds__(256) void k_cca_relabel(CcaDev c, ExportDev ex, int
         const int qn = q + gstride;
         int4 lrn = make_int4(0, 0, 0, 0);
         if (qn < nquad) lrn = reinterpret_cast<const int4*>(c.parent)[qn];
-        const uint32_t a = c.final_lab[c.parent[lr.x]], b = c.final_lab[c.parent[lr.y]];
-        const uint32_t d = c.final_lab[c.parent[lr.z]], e = c.final_lab[c.parent[lr.w]];
+        const uint32_t a = c.final_lab[lr.x], b = c.final_lab[lr.y];       // parent[p] is p's tile-local root (or, for such a
+        const uint32_t d = c.final_lab[lr.z], e = c.final_lab[lr.w];       // root itself, the global root): both carry the label
         uint2 o;
         o.x = a | (b << 16);
         o.y = d | (e << 16);
@@ -862,7 +868,7 @@ __global__ __launch_bounds__(256) void k_cca_relabel(CcaDev c, ExportDev ex, int
         q = qn;
     }
     for (int p = (nquad << 2) + blockIdx.x * blockDim.x + threadIdx.x; p < c.N; p += gstride)
-        st_stream(c.out + p, c.final_lab[c.parent[c.parent[p]]]);
+        st_stream(c.out + p, c.final_lab[c.parent[p]]);
 }
 
 void launch_cca_phase2(const CcaDev& c, int nframes, hipStream_t st, const ExportDev* ex_) {

@@ -19,7 +19,12 @@ if len(sys.argv) > 2:
 for name, p in cases:
     w.params = p
     w.sets = []
-    best = max(w.throughput(120, warm=12)[0] for _ in range(3))
+    runs = [w.throughput(120, warm=12) for _ in range(3)]
+    best, tot = max(runs, key=lambda r: r[0])
     us = H * W * 8 / best          # us per group of 8 frames
-    print("%-45s %9.1f MP/s   %7.1f us per group" % (name, best, us), flush=True)
+    # device time of a group (first kernel's start to last kernel's end on its slot's stream) against slots x the time per
+    # group: equal when every slot always has a group on the device, smaller when slots wait for the host
+    lat = 1e3 * tot["device_ms"] / max(tot["groups"], 1)
+    print("%-45s %9.1f MP/s   %7.1f us per group   device time of a group %7.1f us = %.2f x (slots x time per group)"
+          % (name, best, us, lat, lat / (slots * us)), flush=True)
 eng.close()
