@@ -1,9 +1,9 @@
 """profiles/rNN_pmc_fetch_write_*.csv (scripts/gpu_profiles.sh, step 3) -> profiles/rNN_pmc_assign_traffic.json, the per-launch
 HBM traffic of the assign kernels that bench.py reports as roofline.traffic.
-   python scripts/pmc_traffic_json.py [profiles/r01]"""
+   python scripts/pmc_traffic_json.py [profiles/r02]"""
 import csv, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-prefix = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r01")
+prefix = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02")
 SETS = {"720p_x8": ("1280x720_x8", 1280 * 720 * 8, 3), "4k_k1600": ("3840x2160_x1", 3840 * 2160, 3)}   # tag, pixels per launch, subsample stride
 
 
@@ -17,7 +17,7 @@ def read(path):
 
 
 out = {"note": "bytes per launch = FETCH_SIZE*1024*2 + WRITE_SIZE*1024 (gfx950 correction on the read side only); mean over the "
-               "dispatches of separate rocprofv3 --pmc passes (profiles/r01_pmc_fetch_write_*.csv)"}
+               "dispatches of separate rocprofv3 --pmc passes (profiles/%s_pmc_fetch_write_*.csv)" % os.path.basename(prefix)}
 for key, (tag, px, stride) in SETS.items():
     d = read("%s_pmc_fetch_write_%s.csv" % (prefix, tag))
     ent = {}
