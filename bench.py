@@ -338,10 +338,10 @@ def main():
     eng = Engine(local_rank, nslots)
     # this rank's shard of the synthetic frame stream: frames are independent, rank r owns seeds r*fpg .. r*fpg+fpg-1
     wl = Workload(eng, H, W, K, batch.weak_shard(fpg, rank))
-    n_setup = 2 * nslots                                     # every slot: first call direct (allocates), second captured
+    n_setup = 2 * nslots                                     # every slot: first call direct (allocates), second recorded as a graph
     wl.buffers(n_setup + args.warmup + args.steps)
     sync = torch.cuda.synchronize
-    # setup, not a step: every slot allocates and carves its arena on first use and captures its launch sequence on the
+    # setup, not a step: every slot allocates and carves its arena on first use and records its launch sequence as a hipGraph on the
     # second; otherwise a small --warmup would leave allocations in the timed region
     for j in range(n_setup):
         wl.submit(j)

@@ -280,7 +280,7 @@ class Engine(object):
         return load_library().fslic_hip_group_done(self._h, int(slot)) != 0
 
     def last_launch_mode(self, slot=0):
-        """0 direct enqueue, 1 captured into a hipGraph during the call, 2 graph replay."""
+        """0 direct enqueue, 1 recorded as a hipGraph during the call, 2 graph replay."""
         return int(load_library().fslic_hip_last_launch_mode(self._h, int(slot)))
 
     def last_prelabels(self, H, W, slot=0):

@@ -45,7 +45,7 @@ double now_us();
 
 // Environment switches, read ONCE when the library is loaded (never on a call path).
 //   FSLIC_GROUP        frames per launch group of fslic_hip_iterate_batch (default 8, at most 16)
-//   FSLIC_GRAPH=0      enqueue every group operation by operation instead of replaying a captured hipGraph
+//   FSLIC_GRAPH=0      enqueue every group operation by operation instead of replaying a recorded hipGraph
 //   FSLIC_POISON       testing aid: fill a freshly carved arena with 0xA5 (reads of never-written memory show up)
 //   FSLIC_HOST_TIMING  one stderr line per group start / completion with host-side durations
 struct Knobs {
@@ -122,9 +122,9 @@ struct Slot {
     uint32_t gen_step = 0;           // ... for the group being enqueued
     int keyH = 0, keyW = 0, keyK = 0;
     size_t cand_capacity = 0;        // entries of the per-frame candidate arrays (>= N)
-    // Captured launch sequences (hipGraph), one per distinct (geometry, options, group size, arena carving): a group
+    // Recorded launch sequences (hipGraph, launch.h), one per distinct (geometry, options, group size, arena carving): a group
     // start is ~45 stream operations at ~3 us of host time each when enqueued one by one, ~8 us as one graph launch
-    // (scripts/microbench/graph_launch.hip).  A key is captured the second time it is seen.
+    // (scripts/microbench/graph_launch.hip).  A key is recorded the second time it is seen.
     struct GraphEntry {
         std::vector<unsigned char> key;
         hipGraph_t graph = nullptr;
@@ -133,7 +133,7 @@ struct Slot {
         bool failed = false;
     };
     std::vector<GraphEntry> graphs;
-    int last_launch_mode = 0;        // 0 direct, 1 captured this call, 2 replayed
+    int last_launch_mode = 0;        // 0 direct, 1 recorded this call, 2 replayed
     bool launch_timing = false;      // the engine's flag as it stood when this slot's current group was submitted
     // per-call state
     int H = 0, W = 0, K = 0, S = 0;

@@ -126,7 +126,7 @@ int cca_finish_group(Slot& s, int first, int n, const uint16_t* d_in0, size_t in
         for (uint32_t q = 0; q < M; q++) { sl[q] = s.h_cand_leader[order[q]]; sa[q] = s.h_cand_area[order[q]]; }
         // the kept list goes into the first halves of the pinned buffers (their content was moved to the second halves above)
         // and from there to the device on the slot's OWN stream: a copy on the default stream fails while another slot
-        // of the engine is capturing its graph
+        // of the engine was capturing its graph (stream capture is gone since: launch.h)
         int32_t* kl = s.h_cand_leader;
         uint16_t* kb = reinterpret_cast<uint16_t*>(s.h_cand_area);
         uint32_t n_keep = 0;

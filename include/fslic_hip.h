@@ -202,8 +202,8 @@ int fslic_hip_last_assign_loop(fslic_engine* e, int slot, float* sum_ms, double*
 /* Number of frames in the last group on `slot` (1 for iterate / iterate_device). */
 int fslic_hip_last_group_frames(fslic_engine* e, int slot);
 
-/* How the last group on `slot` reached the GPU: 0 = operations enqueued one by one, 1 = captured into a hipGraph during
- * this call and launched, 2 = replay of a captured graph.  (The engine captures a launch sequence the second time it
+/* How the last group on `slot` reached the GPU: 0 = operations enqueued one by one, 1 = recorded as a hipGraph during
+ * this call and launched, 2 = replay of a recorded graph.  (The engine records a launch sequence the second time it
  * sees the same geometry / options / group size; the environment variable FSLIC_GRAPH=0, read when the library is
  * loaded, disables that.)  Testing / diagnostics aid. */
 int fslic_hip_last_launch_mode(fslic_engine* e, int slot);

@@ -361,7 +361,7 @@ def test_randomized_shapes_and_options_against_oracle(engine):
 
 
 def test_graph_replay_equals_direct_launches():
-    # the engine captures a group's launch sequence the second time it sees it and replays it afterwards; every mode must
+    # the engine records a group's launch sequence as a hipGraph the second time it sees it and replays it afterwards; every mode must
     # give the same result, with different frames and clusters on every call (nothing per-call may be baked into the graph)
     from fast_slic_amd import Engine
     H, W, K = 240, 320, 150
@@ -378,14 +378,14 @@ def test_graph_replay_equals_direct_launches():
             modes.append(e.last_launch_mode())
             assert np.array_equal(labels, exp[0]), describe_mismatch("rep %d (launch mode %d)" % (rep, modes[-1]), labels, exp[0])
             assert not cluster_fields_equal(cl, exp[1])
-            assert e.last_device_times()[0] > 0.0          # the events inside the captured sequence still time it
+            assert e.last_device_times()[0] > 0.0          # the events around the replayed sequence still time it
         assert modes[0] == 0 and 1 in modes and modes[-1] == 2, modes
     finally:
         e.close()
 
 
 def test_pipeline_of_replayed_groups_collected_in_completion_order():
-    # the bench's operating mode: several slots, every slot replaying its captured launch sequence, groups collected as
+    # the bench's operating mode: several slots, every slot replaying its recorded launch sequence, groups collected as
     # they complete; different frames on every submission, every result checked against the oracle
     import torch
     from fast_slic_amd import Engine

@@ -78,13 +78,13 @@ def _run_pipeline(H, W, K, seeds, group, nslots, rounds, expect_replay=True, min
 
 def test_bench_operating_point_8x720p_six_slots_three_rounds():
     # exactly bench.py's timed loop: one group = seeds 0..7 at 1280x720 K=1600; 6 slots; 18 groups so that every slot goes
-    # direct -> capture -> replay; seeds 2 and 4 carry an area tie at the top-K cut
+    # direct -> record -> replay; seeds 2 and 4 carry an area tie at the top-K cut
     _run_pipeline(720, 1280, 1600, list(range(8)), 8, 6, 18)
 
 
-def test_threshold_zero_takes_the_host_topk_path_while_other_slots_capture():
+def test_threshold_zero_takes_the_host_topk_path_while_other_slots_record_graphs():
     # min_size_factor = 0: every component is a candidate (src/cca.cpp:14-20 with thres 0), more than the device sorts, so the
-    # frames go through the host's partial_sort: while the other slots direct-launch, capture and replay their groups
+    # frames go through the host's partial_sort: while the other slots direct-launch, record and replay their groups
     _run_pipeline(360, 640, 400, list(range(6)), 2, 3, 4, min_size_factor=0.0, host_topk=True)
 
 
