@@ -362,13 +362,15 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
     }
     if (!stale_sums) return;
     // ---- update(), fused: the sums of src/context.cpp:301-354 (count, y, x, L, a, b) and of src/lsc.cpp:256-269 (sum w*F per
-    // feature, sum w) over this wavefront's pixels.  Two levels: every lane first folds the rows that carry ITS pending label
-    // (f32 FMA chain like the reference build; labels run in vertical stretches, so one or two rounds cover the lane); the
-    // labels present among the lanes are then served one by one: lanes of another label contribute zeros, a halving butterfly
-    // (lsc_fold: 43 cross-lane operations for the 17 values, against 102 for 17 full wave sums) leaves value q's total in the
-    // lanes of slot q, and ONE 64-bit LDS atomic instruction adds all 17 to the block's accumulators (the float sums in fixed
-    // point, so the totals do not depend on the order in which wavefronts arrive: run-to-run identical).  This replaces a
-    // kernel that re-scanned every cluster's window for its members (64 of 100 us per iteration at 8 x 1280x720).
+    // feature, sum w) over this wavefront's pixels, label by label: every lane folds its rows that carry the label (f32 FMA
+    // chain like the reference build; lanes without such a row contribute zeros), a halving butterfly (lsc_fold12 / lsc_fold6:
+    // 43 cross-lane operations for the 17 values, against 102 for 17 full wave sums) leaves value q's total in the lanes of
+    // slot q, and ONE 64-bit LDS atomic instruction adds all 17 to the block's accumulators (the float sums in fixed point, so
+    // the totals do not depend on the order in which wavefronts arrive: run-to-run identical).  A wavefront of the 1280x720
+    // K=1600 fixture meets 8 labels on average.  (Measured alternatives per launch of 8 x 720p: lanes first folding their OWN
+    // label and the labels then served from those partial sums 75 us -- 17 butterflies per wavefront instead of 8 --, full wave
+    // sums instead of the butterfly 87 us, 16-lane row sums and LDS atomics from every row's first lane 172 us; this form 61 us.)
+    // This replaces a kernel that re-scanned every cluster's window for its members (64 of 100 us per iteration).
     float wgt[kLscRows];
     uint32_t pix[kLscRows];
 #pragma unroll
@@ -394,48 +396,36 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
         uint32_t mine = 0xFFFFFFFFu;
 #pragma unroll
         for (int r = 0; r < kLscRows; ++r) mine = ((todo_rows >> r) & 1u) ? lbl[r] : mine;
-        if (!__ballot(mine != 0xFFFFFFFFu)) break;
-        uint32_t in[6] = {0u, 0u, 0u, 0u, 0u, 0u};
-        float acc[kLscFeat + 1];
+        const unsigned long long pend = __ballot(mine != 0xFFFFFFFFu);
+        if (!pend) break;
+        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)mine, __builtin_ctzll(pend));
+        float fv[kLscFeat + 2];
+        uint32_t uv[6] = {0u, 0u, 0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int q = 0; q <= kLscFeat; ++q) acc[q] = 0.0f;
+        for (int q = 0; q < kLscFeat + 2; ++q) fv[q] = 0.0f;
 #pragma unroll
         for (int r = 0; r < kLscRows; ++r) {
-            const bool m = ((todo_rows >> r) & 1u) && lbl[r] == mine;
+            const bool m = ((todo_rows >> r) & 1u) && lbl[r] == k0;
             if (m) {
-                in[0] += 1u; in[1] += (uint32_t)yr[r]; in[2] += (uint32_t)x;
-                in[3] += pix[r] & 255u; in[4] += (pix[r] >> 8) & 255u; in[5] += (pix[r] >> 16) & 255u;
+                uv[0] += 1u; uv[1] += (uint32_t)yr[r]; uv[2] += (uint32_t)x;
+                uv[3] += pix[r] & 255u; uv[4] += (pix[r] >> 8) & 255u; uv[5] += (pix[r] >> 16) & 255u;
 #pragma unroll
-                for (int q = 0; q < kLscFeat; ++q) acc[q] = __builtin_fmaf(wgt[r], F[r >> 1][q][r & 1], acc[q]);
-                acc[kLscFeat] += wgt[r];
+                for (int q = 0; q < kLscFeat; ++q) fv[q] = __builtin_fmaf(wgt[r], F[r >> 1][q][r & 1], fv[q]);
+                fv[kLscFeat] += wgt[r];
                 todo_rows &= ~(1u << r);
             }
         }
-        for (;;) {
-            const unsigned long long pend = __ballot(mine != 0xFFFFFFFFu);
-            if (!pend) break;
-            const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)mine, __builtin_ctzll(pend));
-            const bool sel = mine == k0;
-            mine = sel ? 0xFFFFFFFFu : mine;
-            float fv[kLscFeat + 2];
-            uint32_t uv[6];
-#pragma unroll
-            for (int q = 0; q <= kLscFeat; ++q) fv[q] = sel ? acc[q] : 0.0f;
-            fv[kLscFeat + 1] = 0.0f;
-#pragma unroll
-            for (int q = 0; q < 6; ++q) uv[q] = sel ? in[q] : 0u;
-            const float tf = lsc_fold12(fv);
-            const uint32_t tu = lsc_fold6(uv);
-            const unsigned long long v = adds_f ? (unsigned long long)(long long)(int)__builtin_rintf(tf * fix) : (unsigned long long)tu;
-            const unsigned long long hit = __ballot(my_k == k0);
-            if (adds_f || adds_u) {
-                if (hit) {                            // a candidate of the block's list: into the block's accumulators
-                    atomicAdd(&s_accx[__builtin_ctzll(hit) * kAccW + slot], v);
-                } else if (adds_f) {                  // a label kept from an earlier pass whose cluster is not in the list, or no list (pile-up): directly
-                    atomicAdd(reinterpret_cast<unsigned long long*>(l.extra + (size_t)k0 * kLscExPitch) + slot_f, v);
-                } else {
-                    atomicAdd(f.sums[0] + 6 * (size_t)k0 + slot_u, tu);
-                }
+        const float tf = lsc_fold12(fv);
+        const uint32_t tu = lsc_fold6(uv);
+        const unsigned long long v = adds_f ? (unsigned long long)(long long)(int)__builtin_rintf(tf * fix) : (unsigned long long)tu;
+        const unsigned long long hit = __ballot(my_k == k0);
+        if (adds_f || adds_u) {
+            if (hit) {
+                atomicAdd(&s_accx[__builtin_ctzll(hit) * kAccW + slot], v);
+            } else if (adds_f) {
+                atomicAdd(reinterpret_cast<unsigned long long*>(l.extra + (size_t)k0 * kLscExPitch) + slot_f, v);
+            } else {
+                atomicAdd(f.sums[0] + 6 * (size_t)k0 + slot_u, tu);
             }
         }
     }
@@ -451,8 +441,8 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
     }
 }
 
-// Two kernels over one body: the pass that is followed by an update carries the fused sums and needs about 100 VGPRs; the
-// final pass does not and fits 7 wavefronts per SIMD.  (Forcing the first to 96 VGPRs costs 5 spilled registers and gains 2 of 75 us.)
+// Two kernels over one body: the pass that is followed by an update carries the fused sums and needs 90 VGPRs (5 wavefronts per SIMD); the
+// final pass does not and fits 7 wavefronts per SIMD.  (Forcing the first to 80 VGPRs spills 7 registers: 66 instead of 60 us.)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_lsc_assign(FrameDev f, LscDev l, int rem, int stride, int Hv) {
     lsc_assign_body<false>(f, l, rem, stride, Hv);
 }
