@@ -30,6 +30,7 @@ CASES = [
     ("A_150x200_k50_iter0", "A", 150, 200, 50, dict(max_iter=0)),
     ("A_480x640_k200", "A", 480, 640, 200, {}),
     ("A_720x1280_k1600", "A", 720, 1280, 1600, {}),        # BASELINE.json configs[4]
+    ("A_96x128_k300_small_S", "A", 96, 128, 300, {}),      # S = 6: more than 64 clusters reach a block (no block list: every cluster is walked)
 ]
 
 
