@@ -119,7 +119,6 @@ __global__ __launch_bounds__(256) void k_lsc_features(FrameDev f, LscDev l) {
 }
 
 static __device__ __forceinline__ float wave_sum(float v) { return wave_reduce_add(v); }
-static __device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return wave_reduce_add(v); }
 // fixed point of the fused update's accumulators: a wavefront's partial sum (256 pixels) of w*F stays below 256 * 51 and
 // one of w below 256 * 23000, so these scales keep the rounded partials inside 32 bits; the accumulators themselves are 64-bit
 constexpr float kLscFixF = 65536.0f, kLscFixW = 128.0f;
