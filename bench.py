@@ -51,6 +51,27 @@ def gbs(nbytes, ms):
     return nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
 
 
+def measured_copy_bandwidth():
+    """Empirical HBM bandwidth of this box (SURVEY.md 8d asks for fractions against the measured peak as well as the spec):
+    a device-to-device copy of 1 GiB (read 1 GiB + write 1 GiB, far beyond the 256 MB infinity cache), best of 5, HIP events."""
+    import torch
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device="cuda").fill_(1)
+    b = torch.empty_like(a)
+    best = 0.0
+    for rep in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        if rep:
+            best = max(best, gbs(2.0 * n * 4, e0.elapsed_time(e1)))
+    del a, b
+    return round(best, 1)
+
+
 def pmc_traffic(key):
     """HBM bytes per launch of the assign kernels from the committed rocprofv3 --pmc passes of this workload
     (profiles/<round>_pmc_assign_traffic.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE); None when absent."""
@@ -404,6 +425,9 @@ def main():
             "full_assign": alone["full_assign"], "all_assign_launches": alone["all_assign_launches"],
             "device_ms_per_frame": alone["device_ms_per_frame"],
         }
+        copy_gbs = measured_copy_bandwidth()
+        out["hbm_copy_measured"] = {"value": copy_gbs, "unit": "GB/s", "what": "device-to-device copy of 1 GiB (bytes read + bytes written), best of 5"}
+        out["roofline"]["frac_of_measured_copy"] = round(fu["achieved"] / copy_gbs, 4) if copy_gbs else None
         # the same launch by rocprofv3's kernel duration (committed summary of `scripts/frames.py 720 1280 1600 6 slic 8` under
         # --kernel-trace): events on the stream also see the launch gap of the directly enqueued (timed) group
         rp = rocprof_avg_us("kernel_stats_1280x720_k1600_slic_x8.csv", "k_assign_blk<8, true, 3") if (args.workload == "720p" and fpg == 8) else None
@@ -443,7 +467,8 @@ def main():
                                   "traffic": pmc4["full_assign"]["bytes"] * 8 if pmc4 else None, "traffic_source": pmc4_src,
                                   "avg_launch_ms": fa["avg_launch_ms"], "fused_assign_update": four["fused_assign_update"],
                                   "all_assign_launches": four["all_assign_launches"], "device_ms_per_frame": four["device_ms_per_frame"],
-                                  "megapixels_per_sec_pipelined": w4.throughput(60)[0], "single_frame_launch": one}
+                                  "megapixels_per_sec_pipelined": w4.throughput(60)[0], "single_frame_launch": one,
+                                  "frac_of_measured_copy": round(fa["achieved"] / copy_gbs, 4) if copy_gbs else None}
             del w4
             # BASELINE configs[2]: 3840x2160 K=6000 (centre pile-up, tie at the cut)
             w6 = Workload(eng, 2160, 3840, 6000, list(range(4)))
