@@ -102,7 +102,9 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     const size_t o_ov0 = take((size_t)K * sizeof(ClusterRec)), o_ov1 = take((size_t)K * sizeof(ClusterRec));
     const size_t ntiles = (size_t)((W + kCcaTile - 1) / kCcaTile) * ((H + kCcaTileH - 1) / kCcaTileH);
     const size_t TT = (size_t)kCcaTilePx;
-    const size_t o_parent = take(N * 4), o_area = take(N * 4), o_final = take(N * 2), o_roots = take(ntiles * TT * 4);
+    const size_t NP = ntiles * TT;            // node capacity: every tile's full range
+    const size_t o_lid = take(N * 2), o_nparent = take(NP * 4), o_nleader = take(NP * 4), o_nlocal = take(NP * 4), o_narea = take(NP * 4);
+    const size_t o_nfinal = take(NP * 2), o_roots = take(NP * 4);
     const size_t o_candl = take(ntiles * TT * 4), o_canda = take(ntiles * TT * 4);
     const size_t o_keepl = take((size_t)K * 4), o_keepb = take((size_t)K * 2);
     const size_t o_rgb = take(N * 3), o_out = take(N * 2);
@@ -151,8 +153,10 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     CcaDev& c = s.c;
     c.frame_bytes = frame_bytes;
     c.H = H; c.W = W; c.N = (int)N; c.K = K;
-    c.parent = (int32_t*)(b + o_parent); c.area = (uint32_t*)(b + o_area);
-    c.final_lab = (uint16_t*)(b + o_final); c.roots = (int32_t*)(b + o_roots);
+    c.tiles_x = (W + kCcaTile - 1) / kCcaTile;
+    c.lid = (uint16_t*)(b + o_lid); c.nparent = (uint32_t*)(b + o_nparent); c.nleader = (uint32_t*)(b + o_nleader);
+    c.nlocal = (uint32_t*)(b + o_nlocal); c.narea = (uint32_t*)(b + o_narea);
+    c.nfinal = (uint16_t*)(b + o_nfinal); c.roots = (uint32_t*)(b + o_roots);
     c.counters = misc + 4;
     c.cand_leader = (int32_t*)(b + o_candl); c.cand_area = (uint32_t*)(b + o_canda);
     s.cand_capacity = ntiles * TT;

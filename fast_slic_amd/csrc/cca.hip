@@ -6,19 +6,23 @@
 namespace fslic {
 
 // =============================================================================================
-// Connectivity / min-size pass (src/cca.cpp).  GPU union-find whose roots are the minimum raster
+// Connectivity / min-size pass (src/cca.cpp).  GPU union-find whose roots carry the minimum raster
 // index of each component, exactly the "leader" the reference ends up with (src/cca.h:36-57).
+// A pixel knows its component through a 16-bit number inside its tile (the `lid` plane, 2 B per pixel); everything per
+// component lives in NODE arrays indexed by tile * 2048 + that number: a tile's nodes are contiguous, so the passes over
+// the components read and write dense memory (until this layout every component was addressed by the raster index of its
+// first pixel in N-entry planes: one 64-byte sector fetched or rewritten per component and access).
 //   k_cca_local    64x32 tiles resolved entirely in LDS (row runs by ballot, vertical unions by LDS
-//                  atomicMin), writes parent[p] = global index of the tile-local root, tile-local
-//                  areas, and appends the tile-local roots to the frame's dense root list
-//   k_cca_border   unions across tile borders (global atomicMin)
-//   k_cca_compress tile-local roots -> global roots, areas summed into the global root; the components whose
+//                  atomicMin), writes lid[p], the tile's nodes (leader, area, parent = self) and appends them
+//                  to the frame's dense node list
+//   k_cca_border   unions across tile borders: the root with the larger leader is hooked under the other (CAS)
+//   k_cca_compress node -> global root, areas summed into the global root; the components whose
 //                  area reaches the threshold are appended to the candidate list as they cross it
 //   k_cca_select   top-K by area and ranking by leader in one block, including the area tie at the cut
 //   k_cca_chain    every other component takes the final label of the component left of (or
 //                  above) its leader, src/cca.cpp:240-254, resolved by chasing toward smaller leaders
-//   k_cca_relabel  out[p] = final[parent[p]] (the chain pass leaves the label at every tile-local root too), and the
-//                  group's results to the host
+//   k_cca_relabel  out[p] = final[node of p] (the chain pass leaves the label at every node), and the group's
+//                  results to the host
 // =============================================================================================
 // LDS accessors.  They are relaxed workgroup-scope atomics rather than `volatile` accesses on purpose:
 // volatile blocks the address-space inference and the accesses become FLAT instructions, which reach the LDS
@@ -202,50 +206,63 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cc
     __syncthreads();                              // every wavefront's share of s_nroots and every run's area are in
     LOC_STAMP(4);
     if (threadIdx.x == 0) s_base = s_nroots ? atomicAdd(&c.counters[0], s_nroots) : 0u;
+    // the component numbers inside the tile: a root publishes its number where the pixels of its component look for
+    // their root (s_par is dead: every wavefront has flattened, barrier above)
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+        if (pos[i] != 0xFFFFFFFFu) lds_st(s_par + ((ly0 + i) * T + lane), wbase + pos[i]);
     __syncthreads();
     LOC_STAMP(5);
+    const uint32_t nbase = (uint32_t)(blockIdx.y * (gridDim.x / (unsigned)nframes) + (unsigned)tile_x) * (uint32_t)kCcaTilePx;
     const uint32_t gbase = s_base + wbase;
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
         const int ly = ly0 + i;
         const int y = ty0 + ly;
-        if (okx && y < c.H) {
-            const uint32_t r = root[i];
-            st_stream(c.parent + (size_t)y * c.W + x, (int32_t)((size_t)(ty0 + (int)(r / T)) * c.W + tx0 + (int)(r % T)));
-        }
+        if (okx && y < c.H) st_stream(c.lid + (size_t)y * c.W + x, (uint16_t)lds_ld(s_par + root[i]));
         if (pos[i] != 0xFFFFFFFFu) {
-            const int32_t g = (int32_t)((size_t)y * c.W + x);
+            const uint32_t n = nbase + wbase + pos[i];
             const uint32_t a = s_area[ly * T + lane];
-            c.area[g] = a;
-            c.roots[gbase + pos[i]] = g;
-            c.cand_area[gbase + pos[i]] = a;      // the root's own (tile-local) area, dense: what k_cca_compress adds to the global root
+            c.nleader[n] = (uint32_t)((size_t)y * c.W + x);
+            c.nparent[n] = n;
+            c.nlocal[n] = a;                      // what k_cca_compress adds to the global root
+            c.narea[n] = a;                       // ... and where it adds it when this node is the global root
+            c.roots[gbase + pos[i]] = n;
         }
     }
     LOC_STAMP(6);
 }
 
-static __device__ __forceinline__ int32_t g_load(int32_t* p) {
+static __device__ __forceinline__ uint32_t g_load(uint32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-static __device__ __forceinline__ int32_t g_find(int32_t* parent, int32_t x) {
+// node of the pixel (y, x) = p: its tile's first node + its component's number inside the tile
+static __device__ __forceinline__ uint32_t node_at(const CcaDev& c, int y, int x, size_t p) {
+    return (uint32_t)((y / kCcaTileH) * c.tiles_x + x / kCcaTile) * (uint32_t)kCcaTilePx + (uint32_t)c.lid[p];
+}
+static __device__ __forceinline__ uint32_t node_of(const CcaDev& c, uint32_t p) {
+    const int y = (int)(p / (uint32_t)c.W);
+    return node_at(c, y, (int)(p - (uint32_t)y * (uint32_t)c.W), p);
+}
+static __device__ __forceinline__ uint32_t g_find(uint32_t* parent, uint32_t x) {
     for (;;) {
-        const int32_t p = g_load(parent + x);
+        const uint32_t p = g_load(parent + x);
         if (p == x) return x;
-        const int32_t gp = g_load(parent + p);
+        const uint32_t gp = g_load(parent + p);
         if (gp == p) return p;
         __hip_atomic_store(parent + x, gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         x = gp;
     }
 }
-static __device__ __forceinline__ void g_union(int32_t* parent, int32_t a, int32_t b) {
+// The root whose leader (first pixel in raster order) is larger goes under the other: the root of a finished component is
+// the node that holds the component's leader, which is what src/cca.h:36-57 ends up with.  A node's leader never changes.
+static __device__ __forceinline__ void g_union(const CcaDev& c, uint32_t a, uint32_t b) {
     for (;;) {
-        a = g_find(parent, a);
-        b = g_find(parent, b);
+        a = g_find(c.nparent, a);
+        b = g_find(c.nparent, b);
         if (a == b) return;
-        if (a < b) { const int32_t t = a; a = b; b = t; }
-        const int32_t old = atomicMin(parent + a, b);
-        if (old == a) return;
-        a = old;
+        if (c.nleader[a] < c.nleader[b]) { const uint32_t t = a; a = b; b = t; }
+        if (atomicCAS(c.nparent + a, a, b) == a) return;
     }
 }
 
@@ -261,7 +278,7 @@ __global__ __launch_bounds__(256) void k_cca_border(CcaDev c, int nh, int nv) {
         const uint16_t lbl = c.in[p];
         if (c.in[p - W] == lbl) {
             const bool first = (x % T == 0) || c.in[p - 1] != lbl || c.in[p - W - 1] != lbl;
-            if (first) g_union(c.parent, p, p - W);
+            if (first) g_union(c, node_at(c, by * TH, x, (size_t)p), node_at(c, by * TH - 1, x, (size_t)(p - W)));
         }
     } else if (i < nh + nv) { // pixel on the first column of a tile column, merge with the pixel to the left
         const int j = i - nh;
@@ -270,7 +287,7 @@ __global__ __launch_bounds__(256) void k_cca_border(CcaDev c, int nh, int nv) {
         const uint16_t lbl = c.in[p];
         if (c.in[p - 1] == lbl) {
             const bool first = (y % TH == 0) || c.in[p - W] != lbl || c.in[p - W - 1] != lbl;
-            if (first) g_union(c.parent, p, p - 1);
+            if (first) g_union(c, node_at(c, y, bx * T, (size_t)p), node_at(c, y, bx * T - 1, (size_t)(p - 1)));
         }
     }
 }
@@ -295,29 +312,29 @@ __global__ __launch_bounds__(256) void k_cca_compress(CcaDev c, int nframes) {
     for (uint32_t w0 = bx * blockDim.x + (threadIdx.x & ~63u); w0 < n; w0 += gstride) {
         const uint32_t i = w0 + (uint32_t)lane;
         const bool live = i < n;
-        const int32_t r = c.roots[min(i, n - 1)];
-        const uint32_t a = c.cand_area[min(i, n - 1)];
+        const uint32_t r = c.roots[min(i, n - 1)];
+        const uint32_t a = c.nlocal[r];
         // READ-ONLY walk: a path-halving store of another thread (parent[r] = some ancestor) could land after this
-        // thread's parent[r] = g and leave r one level short of flat, and chain / relabel rely on parent[parent[p]]
+        // thread's parent[r] = g and leave r one level short of flat, and chain / relabel rely on parent[node]
         // being the global root (an intermittent wrong label at 4K, about one run in six, was exactly that)
-        int32_t g = r;
+        uint32_t g = r;
         for (;;) {
-            const int32_t p = g_load(c.parent + g);
+            const uint32_t p = g_load(c.nparent + g);
             if (p == g) break;
             g = p;
         }
         bool cand = false;
-        int32_t leader = g;
         if (live) {
             if (g == r) {
-                c.final_lab[r] = 0xFFFFu;
+                c.nfinal[r] = 0xFFFFu;
                 cand = (int64_t)a >= thr;
             } else {
-                __hip_atomic_store(c.parent + r, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t old = atomicAdd(&c.area[g], a);
+                __hip_atomic_store(c.nparent + r, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t old = atomicAdd(&c.narea[g], a);
                 cand = (int64_t)old < thr && (int64_t)old + (int64_t)a >= thr;
             }
         }
+        const int32_t leader = cand ? (int32_t)c.nleader[g] : 0;
         const unsigned long long m = __ballot(cand);
         if (m) {
             const int first = __ffsll((long long)m) - 1;
@@ -621,7 +638,7 @@ static __device__ __forceinline__ void tie_heap_select(const CcaDev& c, uint32_t
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         const uint32_t i = (uint32_t)tid * PER + (uint32_t)q;
-        if (fl[q]) c.final_lab[c.cand_leader[i]] = (uint16_t)run;
+        if (fl[q]) c.nfinal[node_of(c, (uint32_t)c.cand_leader[i])] = (uint16_t)run;
         run += fl[q];
     }
     SEL_STAMP(6);
@@ -654,7 +671,7 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int cap) {
     uint32_t amax = 0;
     for (uint32_t i = tid; i < M; i += 1024) {
         const uint32_t l = (uint32_t)c.cand_leader[i];
-        const uint32_t a = c.area[l];
+        const uint32_t a = c.narea[node_of(c, l)];     // (a leader's node is its component's root)
         s_area[i] = a;
         s_lead[i] = l;
         amax = max(amax, a);
@@ -733,7 +750,7 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int cap) {
             const uint32_t lo = s_bstart[b], hi = lo + s_bcnt[b];
             uint32_t r = lo;
             for (uint32_t j = lo; j < hi; ++j) r += (uint32_t)(s_key[j] < me);
-            c.final_lab[me] = (uint16_t)r;
+            c.nfinal[node_of(c, me)] = (uint16_t)r;
         }
     if (tid == 0) c.counters[3] = 0u;
 }
@@ -773,18 +790,18 @@ void launch_cca_select(const CcaDev& c, int nframes, hipStream_t st) {
 __global__ __launch_bounds__(256) void k_cca_reset_final(CcaDev c) {
     const uint32_t n = c.counters[0];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int32_t r = c.roots[i];
-        if (c.parent[r] == r) c.final_lab[r] = 0xFFFFu;
+        const uint32_t r = c.roots[i];
+        if (c.nparent[r] == r) c.nfinal[r] = 0xFFFFu;
     }
 }
 __global__ void k_cca_set_kept(CcaDev c, const int32_t* __restrict__ leaders, const uint16_t* __restrict__ labels, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) c.final_lab[leaders[i]] = labels[i];
+    if (i < n) c.nfinal[node_of(c, (uint32_t)leaders[i])] = labels[i];
 }
 // Host top-K path: areas of the candidates, dense next to their leaders (the device path reads them in place).
 __global__ void k_cca_gather_area(CcaDev c) {
     const uint32_t M = c.counters[1];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) c.cand_area[i] = c.area[c.cand_leader[i]];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) c.cand_area[i] = c.narea[node_of(c, (uint32_t)c.cand_leader[i])];
 }
 void launch_cca_gather_area(const CcaDev& c, hipStream_t st) {
     launch(k_cca_gather_area, dim3(64), dim3(256), 0, st, c);
@@ -802,15 +819,15 @@ void launch_cca_set_kept(const CcaDev& c, const int32_t* d_leaders, const uint16
 // leader, followed along the chain until a component with a final label or pixel 0 is reached.  Leaders strictly decrease
 // along the chain, so it terminates.  (Evaluating this per pixel inside the relabel pass instead of once per root was
 // measured: 59 us instead of 18 + 20 for eight 1280x720 frames -- a wavefront waits for its longest chain.)
-static __device__ __forceinline__ uint32_t chase_final(const CcaDev& c, int32_t cur) {
-    const int W = c.W;
+static __device__ __forceinline__ uint32_t chase_final(const CcaDev& c, uint32_t cur) {
+    const uint32_t W = (uint32_t)c.W;
     for (;;) {
         if (cur == 0) return 0u;                        // src/cca.cpp:238
-        const int32_t t = (cur % W > 0) ? cur - 1 : cur - W;   // src/cca.cpp:243-248
-        const int32_t g = c.parent[c.parent[t]];
-        const uint32_t f = __hip_atomic_load(c.final_lab + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t t = (cur % W > 0) ? cur - 1 : cur - W;   // src/cca.cpp:243-248
+        const uint32_t g = c.nparent[node_of(c, t)];
+        const uint32_t f = __hip_atomic_load(c.nfinal + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (f != 0xFFFFu) return f;
-        cur = g;
+        cur = c.nleader[g];
     }
 }
 
@@ -819,15 +836,15 @@ __global__ __launch_bounds__(256) void k_cca_chain(CcaDev c) {
     const uint32_t n = c.counters[0];
     const uint32_t gstride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gstride) {
-        const int32_t r = c.roots[i];
-        const int32_t g = c.parent[r];
+        const uint32_t r = c.roots[i];
+        const uint32_t g = c.nparent[r];
         // the component's final label: set already when it was kept, or when its own thread got here first; otherwise
         // chased from its leader (whoever computes it finds the same value)
-        uint32_t f = __hip_atomic_load(c.final_lab + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (f == 0xFFFFu) f = chase_final(c, g);
-        // ... stored at the tile-local root as well (an entry nothing else reads or resets: the chase only ever looks at
-        // global roots), so that the relabel pass needs ONE dependent load per pixel: out[p] = final[parent[p]]
-        __hip_atomic_store(c.final_lab + r, (uint16_t)f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t f = __hip_atomic_load(c.nfinal + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f == 0xFFFFu) f = chase_final(c, c.nleader[g]);
+        // ... stored at EVERY node (an entry of a node that is not a global root is read by nothing else: the chase only
+        // ever looks at global roots), so that the relabel pass needs one table look-up per pixel
+        __hip_atomic_store(c.nfinal + r, (uint16_t)f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -847,34 +864,54 @@ __global__ __launch_bounds__(256) void k_cca_relabel(CcaDev c, ExportDev ex, int
         return;
     }
     c.select(z);
-    const int gstride = relabel_blocks * blockDim.x;
-    const int nquad = c.N >> 2;
-    // the next quad's parents are requested before this quad's labels are stored: a load issued after a written-through
-    // store cannot be waited for without waiting for the store's acknowledgement as well
-    int q = blockIdx.x * blockDim.x + threadIdx.x;
-    int4 lr = make_int4(0, 0, 0, 0);
-    if (q < nquad) lr = reinterpret_cast<const int4*>(c.parent)[q];
-    while (q < nquad) {
-        const int qn = q + gstride;
-        int4 lrn = make_int4(0, 0, 0, 0);
-        if (qn < nquad) lrn = reinterpret_cast<const int4*>(c.parent)[qn];
-        const uint32_t a = c.final_lab[lr.x], b = c.final_lab[lr.y];       // parent[p] is p's tile-local root (or, for such a
-        const uint32_t d = c.final_lab[lr.z], e = c.final_lab[lr.w];       // root itself, the global root): both carry the label
-        uint2 o;
-        o.x = a | (b << 16);
-        o.y = d | (e << 16);
-        st_stream(reinterpret_cast<uint2*>(c.out) + q, o);
-        lr = lrn;
-        q = qn;
+    // One block = one 64x32 tile, thread = 4 consecutive pixels of one row, two rows per thread: 8-byte loads of the component numbers, a look-up in the tile's (contiguous, at most
+    // 4 KB) table of final labels, 8-byte stores.  Frames whose width is not a multiple of 4 take the scalar form.
+    constexpr int T = kCcaTile, TH = kCcaTileH;
+    const int tiles_x = c.tiles_x, tiles_y = (c.H + TH - 1) / TH;
+    const int ntiles = tiles_x * tiles_y;
+    const bool vec = (c.W & 3) == 0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += relabel_blocks) {
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const uint16_t* __restrict__ fin = c.nfinal + (size_t)tile * kCcaTilePx;
+        const int x0 = tx * T + 4 * (int)(threadIdx.x & 15);
+        const int r0 = (int)(threadIdx.x >> 4);                 // rows r0 and r0 + 16 of the tile
+        if (vec) {
+            uint2 v[2];
+            bool ok[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int y = ty * TH + r0 + 16 * h;
+                ok[h] = y < c.H && x0 < c.W;
+                v[h] = make_uint2(0u, 0u);
+                if (ok[h]) v[h] = *reinterpret_cast<const uint2*>(c.lid + (size_t)y * c.W + x0);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (!ok[h]) continue;
+                const int y = ty * TH + r0 + 16 * h;
+                uint2 o;
+                o.x = (uint32_t)fin[v[h].x & 0xFFFFu] | ((uint32_t)fin[v[h].x >> 16] << 16);
+                o.y = (uint32_t)fin[v[h].y & 0xFFFFu] | ((uint32_t)fin[v[h].y >> 16] << 16);
+                st_stream(reinterpret_cast<uint2*>(c.out + (size_t)y * c.W + x0), o);
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int y = ty * TH + r0 + 16 * h;
+                if (y >= c.H) continue;
+                for (int q = 0; q < 4; ++q) {
+                    const int x = x0 + q;
+                    if (x < c.W) st_stream(c.out + (size_t)y * c.W + x, fin[c.lid[(size_t)y * c.W + x]]);
+                }
+            }
+        }
     }
-    for (int p = (nquad << 2) + blockIdx.x * blockDim.x + threadIdx.x; p < c.N; p += gstride)
-        st_stream(c.out + p, c.final_lab[c.parent[p]]);
 }
 
 void launch_cca_phase2(const CcaDev& c, int nframes, hipStream_t st, const ExportDev* ex_) {
     launch(k_cca_chain, dim3(root_pass_blocks(c), nframes), dim3(256), 0, st, c);
-    int blocks = (c.N / 4 + 255) / 256;
-    const int cap = (4096 + nframes - 1) / nframes;
+    int blocks = c.tiles_x * ((c.H + kCcaTileH - 1) / kCcaTileH);      // one tile per block (tile-stride loop beyond the cap)
+    const int cap = (16384 + nframes - 1) / nframes;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     ExportDev ex{};

@@ -138,19 +138,25 @@ struct CcaDev {
     int min_threshold;
     const uint16_t* in;   // N labels
     uint16_t* out;        // N labels (set by select)
-    int32_t* parent;      // N
-    uint32_t* area;       // N (sparse: valid at tile-local roots)
-    uint16_t* final_lab;  // N (sparse: valid at global roots)
-    int32_t* roots;       // the frame's tile-local roots, dense: counters[0] of them (capacity N)
-    uint32_t* counters;   // [0] number of tile-local roots (append cursor of k_cca_local), [1] M = number of candidates (append cursor of k_cca_collect), [2] M again, [3] select status
-    int32_t* cand_leader; // dense candidate list (global roots with area >= threshold): leaders,
-    uint32_t* cand_area;  //   same capacity (>= N): the tile-local areas next to `roots` until k_cca_compress has run, then free
-                          //   (the host top-K path gathers the candidates' areas into it)
+    int tiles_x;          // 64-pixel tile columns per row of tiles
+    // A pixel's component: the node tile * kCcaTilePx + lid[p] (tiles in raster order).  Node arrays hold NP = number of
+    // tiles * kCcaTilePx entries, used from the front of every tile's range.
+    uint16_t* lid;        // N: number of the pixel's component inside its tile
+    uint32_t* nparent;    // NP: union-find over the nodes (after k_cca_compress: the global root, directly)
+    uint32_t* nleader;    // NP: raster index of the node's first pixel; a global root's = the component's leader (src/cca.h:36-57)
+    uint32_t* nlocal;     // NP: the node's own (tile-local) area
+    uint32_t* narea;      // NP: component areas, valid at global roots once k_cca_compress has run
+    uint16_t* nfinal;     // NP: final labels (global roots: select / chain; every node after k_cca_chain)
+    uint32_t* roots;      // the frame's nodes, dense: counters[0] of them (capacity NP)
+    uint32_t* counters;   // [0] number of nodes (append cursor of k_cca_local), [1] M = number of candidates (append cursor of k_cca_compress), [2] M again, [3] select status
+    int32_t* cand_leader; // dense candidate list (components with area >= threshold): their leaders (capacity NP)
+    uint32_t* cand_area;  //   same capacity: the host top-K path gathers the candidates' areas into it
     __host__ __device__ __forceinline__ void select(int z) {
         out = outs[z];
         FrameDev::adv(in, (size_t)z * in_stride);
         const size_t d = (size_t)z * frame_bytes;
-        FrameDev::adv(parent, d); FrameDev::adv(area, d); FrameDev::adv(final_lab, d); FrameDev::adv(roots, d);
+        FrameDev::adv(lid, d); FrameDev::adv(nparent, d); FrameDev::adv(nleader, d); FrameDev::adv(nlocal, d); FrameDev::adv(narea, d);
+        FrameDev::adv(nfinal, d); FrameDev::adv(roots, d);
         FrameDev::adv(counters, d);
         FrameDev::adv(cand_leader, d); FrameDev::adv(cand_area, d);
     }
