@@ -103,8 +103,8 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     const size_t ntiles = (size_t)((W + kCcaTile - 1) / kCcaTile) * ((H + kCcaTileH - 1) / kCcaTileH);
     const size_t TT = (size_t)kCcaTilePx;
     const size_t NP = ntiles * TT;            // node capacity: every tile's full range
-    const size_t o_lid = take(N * 2), o_nparent = take(NP * 4), o_nleader = take(NP * 4), o_nlocal = take(NP * 4), o_narea = take(NP * 4);
-    const size_t o_nfinal = take(NP * 2), o_roots = take(NP * 4);
+    const size_t o_lid = take(N * 2), o_nrec = take(NP * 16), o_narea = take(NP * 4);
+    const size_t o_nfinal = take(NP * 2), o_vedge = take(ntiles * 2 * kCcaTileH * 4), o_roots = take(NP * 4);
     const size_t o_candl = take(ntiles * TT * 4), o_canda = take(ntiles * TT * 4);
     const size_t o_keepl = take((size_t)K * 4), o_keepb = take((size_t)K * 2);
     const size_t o_rgb = take(N * 3), o_out = take(N * 2);
@@ -154,9 +154,8 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     c.frame_bytes = frame_bytes;
     c.H = H; c.W = W; c.N = (int)N; c.K = K;
     c.tiles_x = (W + kCcaTile - 1) / kCcaTile;
-    c.lid = (uint16_t*)(b + o_lid); c.nparent = (uint32_t*)(b + o_nparent); c.nleader = (uint32_t*)(b + o_nleader);
-    c.nlocal = (uint32_t*)(b + o_nlocal); c.narea = (uint32_t*)(b + o_narea);
-    c.nfinal = (uint16_t*)(b + o_nfinal); c.roots = (uint32_t*)(b + o_roots);
+    c.lid = (uint16_t*)(b + o_lid); c.nrec = (uint4*)(b + o_nrec); c.narea = (uint32_t*)(b + o_narea);
+    c.nfinal = (uint16_t*)(b + o_nfinal); c.vedge = (uint32_t*)(b + o_vedge); c.roots = (uint32_t*)(b + o_roots);
     c.counters = misc + 4;
     c.cand_leader = (int32_t*)(b + o_candl); c.cand_area = (uint32_t*)(b + o_canda);
     s.cand_capacity = ntiles * TT;

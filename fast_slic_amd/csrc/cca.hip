@@ -24,6 +24,13 @@ namespace fslic {
 //   k_cca_relabel  out[p] = final[node of p] (the chain pass leaves the label at every node), and the group's
 //                  results to the host
 // =============================================================================================
+constexpr uint32_t kNoAdopt = 0xFFFFFFFFu;      // node record, adopt: the neighbour has to be looked up by pixel
+// Node record (CcaDev::nrec, 16 bytes, written by k_cca_local with ONE store): x parent, y leader, z tile-local area, w adopt
+static __device__ __forceinline__ uint32_t* n_parent(const CcaDev& c, uint32_t n) { return reinterpret_cast<uint32_t*>(c.nrec + n); }
+static __device__ __forceinline__ uint32_t n_leader(const CcaDev& c, uint32_t n) { return reinterpret_cast<const uint32_t*>(c.nrec + n)[1]; }
+static __device__ __forceinline__ uint32_t n_local(const CcaDev& c, uint32_t n) { return reinterpret_cast<const uint32_t*>(c.nrec + n)[2]; }
+static __device__ __forceinline__ uint32_t n_adopt(const CcaDev& c, uint32_t n) { return reinterpret_cast<const uint32_t*>(c.nrec + n)[3]; }
+
 // LDS accessors.  They are relaxed workgroup-scope atomics rather than `volatile` accesses on purpose:
 // volatile blocks the address-space inference and the accesses become FLAT instructions, which reach the LDS
 // through the vector-memory path at global-memory latency (measured: 1.2 ms instead of tens of us for the
@@ -79,7 +86,8 @@ static __device__ __forceinline__ uint32_t lds_find_ro(uint32_t* par, uint32_t x
 #define LOC_STAMP(i_) do { } while (0)
 #endif
 // (at most 80 SGPRs: with the ~105 the compiler takes by itself only six wavefronts fit a SIMD's scalar register file
-// instead of eight -- measured with per-block time stamps: 1500 blocks resident instead of 2048, 39 us instead of 2 rounds)
+// instead of eight -- measured with per-block time stamps: 1500 blocks resident instead of 2048, 39 us instead of 2 rounds;
+// 88 and 96 were measured too: 35 instead of 33.7 us per 8 x 1280x720, although they spill fewer scalars)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cca_local(CcaDev c, int nframes) {
     // The frame is the FASTEST-varying part of the block index: blocks that start together then reserve their root ranges on
     // different frames' counters (with the frame slowest, the first 1800 blocks of a 4K group all hit frame 0's counter at
@@ -215,21 +223,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cc
     LOC_STAMP(5);
     const uint32_t nbase = (uint32_t)(blockIdx.y * (gridDim.x / (unsigned)nframes) + (unsigned)tile_x) * (uint32_t)kCcaTilePx;
     const uint32_t gbase = s_base + wbase;
+    // Vector-memory instructions are what this kernel is short of (a wavefront's memory instruction occupies the CU's address
+    // path for about 16 cycles however few lanes are active; with one store per row and node field the tile pass issued 72 of
+    // them per wavefront and took 34 us for eight 1280x720 frames).  So: a node is ONE 16-byte record, the nodes of several rows
+    // share a store (a lane holds at most one pending node; a row whose node would land on an occupied lane flushes first),
+    // and the sixteen edge values of the wavefront's rows leave through sixteen lanes of one store.
+    uint32_t up_id = 0, ev = 0;                               // ev: lanes 0..15 collect (row, side) edge words
+    uint32_t h_pos = 0, h_adopt = 0, h_yx = 0;                // the lane's pending node: position, adopt, row
+    bool have = false;
+    auto flush = [&]() {
+        if (have) {
+            const int ly = (int)h_yx;
+            const uint32_t n = nbase + wbase + h_pos;
+            const uint32_t a = s_area[ly * T + lane];
+            c.nrec[n] = make_uint4(n, (uint32_t)((size_t)(ty0 + ly) * c.W + x), a, h_adopt);
+            c.narea[n] = a;                       // where k_cca_compress adds the other nodes' areas when this one is the global root
+            c.roots[gbase + h_pos] = n;
+        }
+        have = false;
+    };
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
         const int ly = ly0 + i;
         const int y = ty0 + ly;
-        if (okx && y < c.H) st_stream(c.lid + (size_t)y * c.W + x, (uint16_t)lds_ld(s_par + root[i]));
-        if (pos[i] != 0xFFFFFFFFu) {
-            const uint32_t n = nbase + wbase + pos[i];
-            const uint32_t a = s_area[ly * T + lane];
-            c.nleader[n] = (uint32_t)((size_t)y * c.W + x);
-            c.nparent[n] = n;
-            c.nlocal[n] = a;                      // what k_cca_compress adds to the global root
-            c.narea[n] = a;                       // ... and where it adds it when this node is the global root
-            c.roots[gbase + pos[i]] = n;
+        const bool ok = okx && y < c.H;
+        const uint32_t id = ok ? lds_ld(s_par + root[i]) : 0u;
+        const uint32_t left_id = lane_left(id);                          // (every lane takes part in the shift)
+        if (ok) st_stream(c.lid + (size_t)y * c.W + x, (uint16_t)id);
+        // the tile's first and last column, row by row: what the pass over the vertical tile seams reads (a column of the
+        // label plane is one 64-byte sector per pixel)
+        const uint32_t e = (lbl[i] & 0xFFFFu) | (id << 16);
+        const uint32_t e_first = (uint32_t)__builtin_amdgcn_readlane((int)e, 0), e_last = (uint32_t)__builtin_amdgcn_readlane((int)e, T - 1);
+        ev = lane == 2 * i ? e_first : (lane == 2 * i + 1 ? e_last : ev);
+        const bool isroot = pos[i] != 0xFFFFFFFFu;
+        if (__ballot(isroot && have)) flush();                           // uniform
+        if (isroot) {
+            // the node of the pixel left of this node's first pixel (in image column 0: above it), where that pixel lies in
+            // this tile and this wavefront's rows: what k_cca_chain follows (src/cca.cpp:243-248) without a look-up by pixel
+            uint32_t adopt = kNoAdopt;
+            if (lane > 0) adopt = nbase + left_id;
+            else if (x == 0 && i > 0) adopt = nbase + up_id;
+            h_pos = pos[i]; h_adopt = adopt; h_yx = (uint32_t)ly; have = true;
         }
+        up_id = id;
     }
+    flush();
+    if (lane < 2 * RW) (c.vedge + (size_t)(nbase / (uint32_t)kCcaTilePx) * (2 * TH))[2 * ly0 + lane] = ev;
     LOC_STAMP(6);
 }
 
@@ -244,13 +283,13 @@ static __device__ __forceinline__ uint32_t node_of(const CcaDev& c, uint32_t p) 
     const int y = (int)(p / (uint32_t)c.W);
     return node_at(c, y, (int)(p - (uint32_t)y * (uint32_t)c.W), p);
 }
-static __device__ __forceinline__ uint32_t g_find(uint32_t* parent, uint32_t x) {
+static __device__ __forceinline__ uint32_t g_find(const CcaDev& c, uint32_t x) {
     for (;;) {
-        const uint32_t p = g_load(parent + x);
+        const uint32_t p = g_load(n_parent(c, x));
         if (p == x) return x;
-        const uint32_t gp = g_load(parent + p);
+        const uint32_t gp = g_load(n_parent(c, p));
         if (gp == p) return p;
-        __hip_atomic_store(parent + x, gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(n_parent(c, x), gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         x = gp;
     }
 }
@@ -258,11 +297,11 @@ static __device__ __forceinline__ uint32_t g_find(uint32_t* parent, uint32_t x) 
 // the node that holds the component's leader, which is what src/cca.h:36-57 ends up with.  A node's leader never changes.
 static __device__ __forceinline__ void g_union(const CcaDev& c, uint32_t a, uint32_t b) {
     for (;;) {
-        a = g_find(c.nparent, a);
-        b = g_find(c.nparent, b);
+        a = g_find(c, a);
+        b = g_find(c, b);
         if (a == b) return;
-        if (c.nleader[a] < c.nleader[b]) { const uint32_t t = a; a = b; b = t; }
-        if (atomicCAS(c.nparent + a, a, b) == a) return;
+        if (n_leader(c, a) < n_leader(c, b)) { const uint32_t t = a; a = b; b = t; }
+        if (atomicCAS(n_parent(c, a), a, b) == a) return;
     }
 }
 
@@ -283,11 +322,15 @@ __global__ __launch_bounds__(256) void k_cca_border(CcaDev c, int nh, int nv) {
     } else if (i < nh + nv) { // pixel on the first column of a tile column, merge with the pixel to the left
         const int j = i - nh;
         const int bx = j / H + 1, y = j - (bx - 1) * H;
-        const int p = y * W + bx * T;
-        const uint16_t lbl = c.in[p];
-        if (c.in[p - 1] == lbl) {
-            const bool first = (y % TH == 0) || c.in[p - W] != lbl || c.in[p - W - 1] != lbl;
-            if (first) g_union(c, node_at(c, y, bx * T, (size_t)p), node_at(c, y, bx * T - 1, (size_t)(p - 1)));
+        const int r = y % TH;
+        const uint32_t tile_r = (uint32_t)((y / TH) * c.tiles_x + bx), tile_l = tile_r - 1u;
+        const uint32_t* er = c.vedge + ((size_t)tile_r * TH + r) * 2;           // this pixel: first column of the right tile
+        const uint32_t* el = c.vedge + ((size_t)tile_l * TH + r) * 2 + 1;       // its left neighbour: last column of the left tile
+        const uint32_t a = er[0], b = el[0];
+        if (((a ^ b) & 0xFFFFu) == 0u) {
+            const uint32_t lbl = a & 0xFFFFu;
+            const bool first = (r == 0) || (er[-2] & 0xFFFFu) != lbl || (el[-2] & 0xFFFFu) != lbl;
+            if (first) g_union(c, tile_r * (uint32_t)kCcaTilePx + (a >> 16), tile_l * (uint32_t)kCcaTilePx + (b >> 16));
         }
     }
 }
@@ -313,13 +356,13 @@ __global__ __launch_bounds__(256) void k_cca_compress(CcaDev c, int nframes) {
         const uint32_t i = w0 + (uint32_t)lane;
         const bool live = i < n;
         const uint32_t r = c.roots[min(i, n - 1)];
-        const uint32_t a = c.nlocal[r];
+        const uint32_t a = n_local(c, r);
         // READ-ONLY walk: a path-halving store of another thread (parent[r] = some ancestor) could land after this
         // thread's parent[r] = g and leave r one level short of flat, and chain / relabel rely on parent[node]
         // being the global root (an intermittent wrong label at 4K, about one run in six, was exactly that)
         uint32_t g = r;
         for (;;) {
-            const uint32_t p = g_load(c.nparent + g);
+            const uint32_t p = g_load(n_parent(c, g));
             if (p == g) break;
             g = p;
         }
@@ -329,12 +372,12 @@ __global__ __launch_bounds__(256) void k_cca_compress(CcaDev c, int nframes) {
                 c.nfinal[r] = 0xFFFFu;
                 cand = (int64_t)a >= thr;
             } else {
-                __hip_atomic_store(c.nparent + r, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(n_parent(c, r), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t old = atomicAdd(&c.narea[g], a);
                 cand = (int64_t)old < thr && (int64_t)old + (int64_t)a >= thr;
             }
         }
-        const int32_t leader = cand ? (int32_t)c.nleader[g] : 0;
+        const int32_t leader = cand ? (int32_t)n_leader(c, g) : 0;
         const unsigned long long m = __ballot(cand);
         if (m) {
             const int first = __ffsll((long long)m) - 1;
@@ -791,7 +834,7 @@ __global__ __launch_bounds__(256) void k_cca_reset_final(CcaDev c) {
     const uint32_t n = c.counters[0];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t r = c.roots[i];
-        if (c.nparent[r] == r) c.nfinal[r] = 0xFFFFu;
+        if (*n_parent(c, r) == r) c.nfinal[r] = 0xFFFFu;
     }
 }
 __global__ void k_cca_set_kept(CcaDev c, const int32_t* __restrict__ leaders, const uint16_t* __restrict__ labels, int n) {
@@ -819,15 +862,19 @@ void launch_cca_set_kept(const CcaDev& c, const int32_t* d_leaders, const uint16
 // leader, followed along the chain until a component with a final label or pixel 0 is reached.  Leaders strictly decrease
 // along the chain, so it terminates.  (Evaluating this per pixel inside the relabel pass instead of once per root was
 // measured: 59 us instead of 18 + 20 for eight 1280x720 frames -- a wavefront waits for its longest chain.)
-static __device__ __forceinline__ uint32_t chase_final(const CcaDev& c, uint32_t cur) {
+static __device__ __forceinline__ uint32_t chase_final(const CcaDev& c, uint32_t g) {
     const uint32_t W = (uint32_t)c.W;
     for (;;) {
+        const uint32_t cur = n_leader(c, g);
         if (cur == 0) return 0u;                        // src/cca.cpp:238
-        const uint32_t t = (cur % W > 0) ? cur - 1 : cur - W;   // src/cca.cpp:243-248
-        const uint32_t g = c.nparent[node_of(c, t)];
+        uint32_t a = n_adopt(c, g);
+        if (a == kNoAdopt) {                            // the neighbour lies in another tile (or another wavefront's rows)
+            const uint32_t t = (cur % W > 0) ? cur - 1 : cur - W;   // src/cca.cpp:243-248
+            a = node_of(c, t);
+        }
+        g = *n_parent(c, a);
         const uint32_t f = __hip_atomic_load(c.nfinal + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (f != 0xFFFFu) return f;
-        cur = c.nleader[g];
     }
 }
 
@@ -837,11 +884,11 @@ __global__ __launch_bounds__(256) void k_cca_chain(CcaDev c) {
     const uint32_t gstride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gstride) {
         const uint32_t r = c.roots[i];
-        const uint32_t g = c.nparent[r];
+        const uint32_t g = *n_parent(c, r);
         // the component's final label: set already when it was kept, or when its own thread got here first; otherwise
         // chased from its leader (whoever computes it finds the same value)
         uint32_t f = __hip_atomic_load(c.nfinal + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (f == 0xFFFFu) f = chase_final(c, c.nleader[g]);
+        if (f == 0xFFFFu) f = chase_final(c, g);
         // ... stored at EVERY node (an entry of a node that is not a global root is read by nothing else: the chase only
         // ever looks at global roots), so that the relabel pass needs one table look-up per pixel
         __hip_atomic_store(c.nfinal + r, (uint16_t)f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -70,8 +70,8 @@ CcaDev cca_view(const Slot& s, int i0, const uint16_t* d_in0, size_t in_stride, 
     // host-side advance to frame i0 (CcaDev::select dereferences the device array, so spell it out here)
     FrameDev::adv(c.in, (size_t)i0 * in_stride);
     const size_t d = (size_t)i0 * c.frame_bytes;
-    FrameDev::adv(c.lid, d); FrameDev::adv(c.nparent, d); FrameDev::adv(c.nleader, d); FrameDev::adv(c.nlocal, d); FrameDev::adv(c.narea, d);
-    FrameDev::adv(c.nfinal, d); FrameDev::adv(c.roots, d);
+    FrameDev::adv(c.lid, d); FrameDev::adv(c.nrec, d); FrameDev::adv(c.narea, d);
+    FrameDev::adv(c.nfinal, d); FrameDev::adv(c.vedge, d); FrameDev::adv(c.roots, d);
     FrameDev::adv(c.counters, d);
     FrameDev::adv(c.cand_leader, d); FrameDev::adv(c.cand_area, d);
     c.outs = reinterpret_cast<uint16_t* const*>(s.d_ptrs + kMaxGroup + i0);

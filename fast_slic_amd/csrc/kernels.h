@@ -142,11 +142,12 @@ struct CcaDev {
     // A pixel's component: the node tile * kCcaTilePx + lid[p] (tiles in raster order).  Node arrays hold NP = number of
     // tiles * kCcaTilePx entries, used from the front of every tile's range.
     uint16_t* lid;        // N: number of the pixel's component inside its tile
-    uint32_t* nparent;    // NP: union-find over the nodes (after k_cca_compress: the global root, directly)
-    uint32_t* nleader;    // NP: raster index of the node's first pixel; a global root's = the component's leader (src/cca.h:36-57)
-    uint32_t* nlocal;     // NP: the node's own (tile-local) area
+    uint4* nrec;          // NP node records: x parent (union-find over the nodes; after k_cca_compress the global root, directly),
+                          //   y raster index of the node's first pixel (a global root's = the component's leader, src/cca.h:36-57),
+                          //   z the node's own (tile-local) area, w node of the pixel left of (image column 0: above) the first pixel, or ~0
     uint32_t* narea;      // NP: component areas, valid at global roots once k_cca_compress has run
     uint16_t* nfinal;     // NP: final labels (global roots: select / chain; every node after k_cca_chain)
+    uint32_t* vedge;      // tiles * 2 * kCcaTileH: (label | number << 16) of every tile's first and last column, row by row
     uint32_t* roots;      // the frame's nodes, dense: counters[0] of them (capacity NP)
     uint32_t* counters;   // [0] number of nodes (append cursor of k_cca_local), [1] M = number of candidates (append cursor of k_cca_compress), [2] M again, [3] select status
     int32_t* cand_leader; // dense candidate list (components with area >= threshold): their leaders (capacity NP)
@@ -155,8 +156,8 @@ struct CcaDev {
         out = outs[z];
         FrameDev::adv(in, (size_t)z * in_stride);
         const size_t d = (size_t)z * frame_bytes;
-        FrameDev::adv(lid, d); FrameDev::adv(nparent, d); FrameDev::adv(nleader, d); FrameDev::adv(nlocal, d); FrameDev::adv(narea, d);
-        FrameDev::adv(nfinal, d); FrameDev::adv(roots, d);
+        FrameDev::adv(lid, d); FrameDev::adv(nrec, d); FrameDev::adv(narea, d);
+        FrameDev::adv(nfinal, d); FrameDev::adv(vedge, d); FrameDev::adv(roots, d);
         FrameDev::adv(counters, d);
         FrameDev::adv(cand_leader, d); FrameDev::adv(cand_area, d);
     }
