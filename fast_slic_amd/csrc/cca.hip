@@ -125,7 +125,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cc
     // Per row: every pixel whose upper neighbour has the same label folds the (possibly stale) root carried in
     // its VGPR into its run's node with a non-returning ds_min; one dependent ds_read then yields the run's
     // root.  Only where a run joins two so-far distinct components (U shapes) is a real union needed.
-    uint32_t up_root = 0;
+    // Where a run joins two so-far distinct components, the union (two finds and a returning atomic: four or more dependent LDS
+    // round trips, and one lane that needs it holds up the whole wavefront) is not done on the spot: the lane keeps the pair and
+    // the wavefront executes the pending pairs together -- when a lane would need to keep a second one, and after the last row.
+    // The order of the unions does not matter for the result (the next row only needs SOME root of the pixel above, possibly a
+    // stale one, exactly as before).  Row loop: one round trip per row instead of five (4.5 -> 2 us of a 13 us block life).
+    uint32_t up_root = 0, pend_a = 0, pend_b = 0;
+    bool pending = false;
+    auto run_pending = [&]() {
+        if (pending) lds_union(s_par, pend_a, pend_b);
+        pending = false;
+    };
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
         const int ly = ly0 + i;
@@ -151,10 +161,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cc
             const bool rep = up_same && (start || left_root != up_root || left_same == 0u);
             if (rep) __hip_atomic_fetch_min(s_par + node, up_root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (ok) cur_root = lds_ld(s_par + node);
-            if (rep && up_root != cur_root) lds_union(s_par, up_root, cur_root);
+            const bool need = rep && up_root != cur_root;
+            if (__ballot(need && pending)) run_pending();                 // uniform
+            if (need) { pend_a = up_root; pend_b = cur_root; pending = true; }
         }
         up_root = cur_root;
     }
+    run_pending();
     __syncthreads();
     LOC_STAMP(1);
     // ---- B ----
@@ -223,11 +236,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cc
     LOC_STAMP(5);
     const uint32_t nbase = (uint32_t)(blockIdx.y * (gridDim.x / (unsigned)nframes) + (unsigned)tile_x) * (uint32_t)kCcaTilePx;
     const uint32_t gbase = s_base + wbase;
-    // Vector-memory instructions are what this kernel is short of (a wavefront's memory instruction occupies the CU's address
-    // path for about 16 cycles however few lanes are active; with one store per row and node field the tile pass issued 72 of
-    // them per wavefront and took 34 us for eight 1280x720 frames).  So: a node is ONE 16-byte record, the nodes of several rows
-    // share a store (a lane holds at most one pending node; a row whose node would land on an occupied lane flushes first),
-    // and the sixteen edge values of the wavefront's rows leave through sixteen lanes of one store.
+    // The kernel is bound by vector-ALU instructions (about 810 per wavefront of 512 pixels; the SIMDs are 65 % busy issuing them at
+    // eight wavefronts each: SQ counters) and every memory instruction of a wavefront occupies the CU's address path however few
+    // lanes are active, so the outputs are organised for few instructions of either kind: a node is ONE 16-byte record, the
+    // nodes of several rows share a store (a lane holds at most one pending node; a row whose node would land on an occupied
+    // lane flushes first), and the sixteen edge words of the wavefront's rows leave through sixteen lanes of one store (two-lane
+    // stores row by row were measured: 31.2 instead of 30.8 us per 8 x 1280x720).
     uint32_t up_id = 0, ev = 0;                               // ev: lanes 0..15 collect (row, side) edge words
     uint32_t h_pos = 0, h_adopt = 0, h_yx = 0;                // the lane's pending node: position, adopt, row
     bool have = false;
