@@ -77,9 +77,10 @@ static __device__ __forceinline__ uint32_t lds_find_ro(uint32_t* par, uint32_t x
 //     horizontal overlap with the row above; the (possibly stale) root of the pixel above travels in a VGPR,
 //     so a row costs a handful of dependent LDS operations instead of chain walks
 //  B  the three strip seams inside the tile are merged in LDS
-//  C  flatten: every pixel -> tile-local root (min raster index), parent plane written, run lengths added
+//  C  flatten: every pixel -> tile-local root (min raster index), run lengths added
 //     to the root's area
-//  D  tile-local roots appended to the root list (one global atomic per wavefront row)
+//  D  the tile-local roots become the tile's nodes (numbered, appended to the frame's node list: one returning global atomic per
+//     tile), every pixel gets its root's number
 #if defined(FSLIC_LAB) && FSLIC_LAB == 2      // lab build 2: time stamps of the tile kernel (100 MHz ticks since the block's start), 8 words per block at the end of the (idle) candidate array
 #define LOC_STAMP(i_) do { __syncthreads(); if (threadIdx.x == 0) c.cand_leader[(size_t)c.N - 8 * (size_t)(blockIdx.y * (gridDim.x / nframes) + tile_x + 1) + (i_)] = (int32_t)((uint32_t)__builtin_amdgcn_s_memrealtime() - loc_t); } while (0)
 #else
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cc
     // the tile's range, ONE returning global atomic per tile reserves that range (a returning atomic per wavefront row
     // saturated a single word near 88 ops/us: 1.2 ms at 4K in the first version of this kernel).  The global stores of the
     // kernel come AFTER it: a wavefront waiting for the atomic's result would also wait for every store it has in flight
-    // (the parent plane is written through), and the other three wait for it at the barrier -- that wait was 8 - 14 us of a
+    // (the per-pixel plane is written through), and the other three wait for it at the barrier -- that wait was 8 - 14 us of a
     // 25 us block life.  A dense list lets the passes over the roots run as flat, evenly loaded grids.
     uint32_t wbase = 0;
     if (lane == 0 && wcount) wbase = atomicAdd(&s_nroots, wcount);
@@ -349,8 +350,8 @@ __global__ __launch_bounds__(256) void k_cca_border(CcaDev c, int nh, int nv) {
     }
 }
 
-// Pass over the frame's tile-local roots (counters[0] of them, dense): flat grid, one root per thread.
-//   * tile-local root -> global root (read-only walk), parent flattened, its tile-local area added to the global root's
+// Pass over the frame's nodes (counters[0] of them, dense): flat grid, one node per thread.
+//   * node -> global root (read-only walk), parent flattened, its tile-local area added to the global root's
 //   * global roots get their final label reset
 //   * candidates (components with area >= threshold, src/cca.cpp:213-217) are found HERE, without a second pass over
 //     complete areas: a component's area only grows, so it crosses the threshold exactly once -- either it starts at or
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(256) void k_cca_compress(CcaDev c, int nframes) {
 //                       select.  If only part of the components with area == a* fit, which ones
 //                       std::partial_sort keeps depends on libstdc++'s heap order -> status = 1 and the host
 //                       redoes the step with std::partial_sort itself.
-// Kept leaders are sorted (bitonic, LDS) and final_lab[leader] = rank, i.e. labels 0,1,2.. in raster order
+// Kept leaders are ranked (raster buckets, LDS) and nfinal[node of the leader] = rank, i.e. labels 0,1,2.. in raster order
 // of each component's first pixel (src/cca.cpp:229-237).
 // status word (counters[3]): 0 = done here; 1 = area tie at the cut: the candidates have been written to
 // dense_leader / dense_area SORTED BY LEADER (counters[1] = M), which is the order the reference feeds to

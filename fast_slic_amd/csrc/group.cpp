@@ -109,7 +109,7 @@ int cca_finish_group(Slot& s, int first, int n, const uint16_t* d_in0, size_t in
         uint32_t* hm = s.h_misc + 16 * (size_t)i;
         if (hm[4 + 3] != 2) continue;
         const CcaDev c1 = cca_view(s, i, d_in0, in_stride, K, thres);
-        int32_t* d_dl = s.at(s.c.cand_leader, i);      // dense already (k_cca_collect), unordered
+        int32_t* d_dl = s.at(s.c.cand_leader, i);      // dense (appended by k_cca_compress), unordered
         uint32_t* d_da = s.at(s.c.cand_area, i);
         const uint32_t M = hm[4 + 1];
         int rc = ensure_cand_capacity(s, std::max<size_t>(M, 1) * 2);
