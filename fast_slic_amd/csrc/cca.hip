@@ -241,9 +241,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cc
     // eight wavefronts each: SQ counters) and every memory instruction of a wavefront occupies the CU's address path however few
     // lanes are active, so the outputs are organised for few instructions of either kind: a node is ONE 16-byte record, the
     // nodes of several rows share a store (a lane holds at most one pending node; a row whose node would land on an occupied
-    // lane flushes first), and the sixteen edge words of the wavefront's rows leave through sixteen lanes of one store (two-lane
-    // stores row by row were measured: 31.2 instead of 30.8 us per 8 x 1280x720).
-    uint32_t up_id = 0, ev = 0;                               // ev: lanes 0..15 collect (row, side) edge words
+    // lane flushes first), and the sixteen edge words of the wavefront's rows are collected in LDS and leave through sixteen lanes
+    // of one store (two-lane stores row by row were measured: 31.2 instead of 30.8 us per 8 x 1280x720).
+    uint32_t up_id = 0;
+    const bool edge_lane = lane == 0 || lane == T - 1;
+    uint32_t* const s_edge = &s_last[wave][lane ? 1 : 0];     // this wavefront's 2 * RW edge words: (row, side) at 2 * row + side
     uint32_t h_pos = 0, h_adopt = 0, h_yx = 0;                // the lane's pending node: position, adopt, row
     bool have = false;
     auto flush = [&]() {
@@ -267,9 +269,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cc
         if (ok) st_stream(c.lid + (size_t)y * c.W + x, (uint16_t)id);
         // the tile's first and last column, row by row: what the pass over the vertical tile seams reads (a column of the
         // label plane is one 64-byte sector per pixel)
-        const uint32_t e = (lbl[i] & 0xFFFFu) | (id << 16);
-        const uint32_t e_first = (uint32_t)__builtin_amdgcn_readlane((int)e, 0), e_last = (uint32_t)__builtin_amdgcn_readlane((int)e, T - 1);
-        ev = lane == 2 * i ? e_first : (lane == 2 * i + 1 ? e_last : ev);
+        if (edge_lane) lds_st(s_edge + 2 * i, (lbl[i] & 0xFFFFu) | (id << 16));      // (s_last is dead since phase B)
         const bool isroot = pos[i] != 0xFFFFFFFFu;
         if (__ballot(isroot && have)) flush();                           // uniform
         if (isroot) {
@@ -283,7 +283,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cc
         up_id = id;
     }
     flush();
-    if (lane < 2 * RW) (c.vedge + (size_t)(nbase / (uint32_t)kCcaTilePx) * (2 * TH))[2 * ly0 + lane] = ev;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 2 * RW) (c.vedge + (size_t)(nbase / (uint32_t)kCcaTilePx) * (2 * TH))[2 * ly0 + lane] = lds_ld(&s_last[wave][lane]);
     LOC_STAMP(6);
 }
 
