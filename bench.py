@@ -25,6 +25,7 @@ Prints ONE JSON line on rank 0.  Beyond the contract's keys:
   cpu_baseline  the unmodified reference (SlicAvx2 + OpenMP; plain-C port if oracle/_ref is absent) on this host's cores
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -193,6 +194,11 @@ class Workload(object):
         _, _, a_lab, a_cls = self.sets[j]
         self.eng.pipeline_submit(self.a_rgb, a_cls, a_lab, n or self.n, self.H, self.W, self.K, self.params)
 
+    def submit_to_slot(self, slot, j, n=None):
+        """Submission j on a slot of the caller's choice (setup: every slot must have seen the geometry three times)."""
+        _, _, a_lab, a_cls = self.sets[j]
+        self.eng.submit_group(slot, self.a_rgb, a_cls, a_lab, n or self.n, self.H, self.W, self.K, self.params)
+
     def timed_groups(self, reps, n=None, bytes_per_px=ASSIGN_BYTES_PER_PX):
         """`reps` groups one after the other with the GPU to themselves and every subsampled assign launch and the
         full-assign launch bracketed by HIP events on the slot's stream: averages over the groups after the first two."""
@@ -232,20 +238,26 @@ class Workload(object):
     def throughput(self, steps, warm=None):
         """Pipelined megapixels/sec over `steps` groups (fresh buffers per submission).  Untimed first: three groups per slot
         (a slot carves its arena on the first group of a geometry, records its graph on the second, replays from the third)."""
+        ns = self.eng.n_slots
         if warm is None:
-            warm = 3 * self.eng.n_slots
+            warm = 3 * ns
         base = len(self.sets)
         self.buffers(steps + warm)
-        for j in range(warm):
-            self.submit(base + j)
-        self.eng.pipeline_drain()
+        for j in range(warm):                     # slot by slot (see the setup of the timed region in main())
+            self.submit_to_slot(j % ns, base + j)
+            if j % ns == ns - 1 or j == warm - 1:
+                for sl in range(j % ns + 1):
+                    self.eng.wait_group(sl)
         self.torch.cuda.synchronize()
+        gc.collect()
+        gc.disable()                              # (see the timed region of main())
         t0 = time.perf_counter()
         for j in range(steps):
             self.submit(base + warm + j)
         tot = self.eng.pipeline_drain()
         self.torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        gc.enable()
         return round(self.H * self.W * self.n * steps / el / 1e6, 1), tot
 
 
@@ -310,7 +322,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--workload", default="720p", choices=sorted(WORKLOADS))
     ap.add_argument("--frames-per-gpu", type=int, default=0)
-    ap.add_argument("--slots", type=int, default=6, help="groups in flight per GPU (stream + host thread each)")
+    ap.add_argument("--slots", type=int, default=8, help="groups in flight per GPU (stream + host thread each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-4k", action="store_true", help="skip the 4K, K=6000, LSC and end-to-end sub-objects")
     ap.add_argument("--no-parity", action="store_true")
@@ -364,17 +376,26 @@ def main():
     eng = Engine(local_rank, nslots)
     # this rank's shard of the synthetic frame stream: frames are independent, rank r owns seeds r*fpg .. r*fpg+fpg-1
     wl = Workload(eng, H, W, K, batch.weak_shard(fpg, rank))
-    n_setup = 2 * nslots                                     # every slot: first call direct (allocates), second recorded as a graph
+    n_setup = 3 * nslots                                     # every slot: first group direct (allocates), second recorded as a graph, third replayed
     wl.buffers(n_setup + args.warmup + args.steps)
     sync = torch.cuda.synchronize
-    # setup, not a step: every slot allocates and carves its arena on first use and records its launch sequence as a hipGraph on the
-    # second; otherwise a small --warmup would leave allocations in the timed region
+    # setup, not a step: every slot allocates and carves its arena on its first group and records (and instantiates) its launch
+    # sequence as a hipGraph on its second.  The groups are addressed to the slots one by one -- handed to "whichever slot
+    # is free" a fast slot takes several and another is still unprepared when a short --warmup ends (the driver's 5 warm-up
+    # steps left graph instantiation inside its 20 timed steps: 17 instead of 40 GP/s).
     for j in range(n_setup):
-        wl.submit(j)
-    eng.pipeline_drain()
+        wl.submit_to_slot(j % nslots, j)
+        if j % nslots == nslots - 1:
+            for sl in range(nslots):
+                eng.wait_group(sl)
     for j in range(args.warmup):
         wl.submit(n_setup + j)
     eng.pipeline_drain()
+    # The interpreter's cyclic garbage collector stays out of the timed region (as timeit does): a full collection of a process
+    # that has imported torch takes about 50 ms, and whether one fell into the region depended on the number of buffer sets
+    # created before it (192 - 217 steps: 18 instead of 44 GP/s).
+    gc.collect()
+    gc.disable()
     barrier(sync)
     t0 = time.perf_counter()
     first = n_setup + args.warmup
@@ -383,6 +404,7 @@ def main():
     totals = eng.pipeline_drain()                            # every step of the timed region is complete here
     barrier(sync)
     elapsed = batch.max_over_ranks(time.perf_counter() - t0, dist)
+    gc.enable()
 
     if rank == 0:
         total_px = float(H) * W * fpg * world * args.steps
