@@ -316,9 +316,9 @@ def end_to_end(H, W, K, budget_s=4.0, threads=4):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000,
+    ap.add_argument("--steps", type=int, default=None,
                     help="timed steps (groups).  The timed region starts with an empty pipeline and ends with a drain: about 1.5 ms "
-                         "of ramp-up and tail, 0.8 %% of 1000 steps (4 %% of the 200 of round 1)")
+                         "of ramp-up and tail, 0.8 %% of the default 1000 steps (200 for the 4K workloads, whose buffer sets are 9 x larger)")
     ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--workload", default="720p", choices=sorted(WORKLOADS))
     ap.add_argument("--frames-per-gpu", type=int, default=0)
@@ -329,6 +329,8 @@ def main():
     ap.add_argument("--timed-only", action="store_true", help="the timed region and nothing else (profiling runs: no roofline / parity / baseline legs)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / timing reduction only (no GPU work): CPU test of the N>1 path")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 1000 if args.workload == "720p" else 200
 
     from fast_slic_amd import batch
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
