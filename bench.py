@@ -194,10 +194,40 @@ class Workload(object):
         _, _, a_lab, a_cls = self.sets[j]
         self.eng.pipeline_submit(self.a_rgb, a_cls, a_lab, n or self.n, self.H, self.W, self.K, self.params)
 
-    def submit_to_slot(self, slot, j, n=None):
-        """Submission j on a slot of the caller's choice (setup: every slot must have seen the geometry three times)."""
-        _, _, a_lab, a_cls = self.sets[j]
-        self.eng.submit_group(slot, self.a_rgb, a_cls, a_lab, n or self.n, self.H, self.W, self.K, self.params)
+    def submit_to_slot(self, slot, j, n=None, merged=1):
+        """Submission j (or, merged > 1, submissions j .. j+merged-1 as ONE group, the form dynamic batching produces) on a
+        slot of the caller's choice (setup: every slot must have seen every form of group three times)."""
+        if merged == 1:
+            _, _, a_lab, a_cls = self.sets[j]
+            self.eng.submit_group(slot, self.a_rgb, a_cls, a_lab, n or self.n, self.H, self.W, self.K, self.params)
+            return
+        rgb, lab, cls = [], [], []
+        for q in range(merged):
+            d_lab, c, _, _ = self.sets[j + q]
+            rgb += [t.data_ptr() for t in self.d_rgb]
+            lab += [t.data_ptr() for t in d_lab]
+            cls += [c[i].ctypes.data for i in range(self.n)]
+        arrs = (self.eng.pointer_array(rgb), self.eng.pointer_array(cls), self.eng.pointer_array(lab))
+        self._keep = getattr(self, "_keep", []) + [arrs]          # the engine copies the pointer arrays at submit; kept anyway
+        self.eng.submit_group(slot, arrs[0], arrs[1], arrs[2], self.n * merged, self.H, self.W, self.K, self.params)
+
+    def prepare_slots(self, base, merged_max):
+        """Setup, not a step: every slot sees every form of group the pipeline can produce (1 .. merged_max submissions per
+        group) three times -- the first carves its arena, the second records and instantiates its hipGraph, the third
+        replays it -- addressed slot by slot.  Uses buffer sets base .. base + sets_for_setup(merged_max) - 1."""
+        ns = self.eng.n_slots
+        j = base
+        for merged in range(1, merged_max + 1):
+            for rnd in range(3):
+                for sl in range(ns):
+                    self.submit_to_slot(sl, j, merged=merged)
+                    j += merged
+                for sl in range(ns):
+                    self.eng.wait_group(sl)
+        return j - base
+
+    def sets_for_setup(self, merged_max):
+        return 3 * self.eng.n_slots * sum(range(1, merged_max + 1))
 
     def timed_groups(self, reps, n=None, bytes_per_px=ASSIGN_BYTES_PER_PX):
         """`reps` groups one after the other with the GPU to themselves and every subsampled assign launch and the
@@ -235,19 +265,15 @@ class Workload(object):
                 "device_ms_per_frame": round(tot / n, 4),
                 "megapixels_per_sec_one_group_at_a_time": round(self.H * self.W * n / (tot * 1e-3) / 1e6, 1)}
 
+    merged_max = 1          # submissions a launch group may gather (dynamic batching of the pipeline): set by main()
+
     def throughput(self, steps, warm=None):
-        """Pipelined megapixels/sec over `steps` groups (fresh buffers per submission).  Untimed first: three groups per slot
-        (a slot carves its arena on the first group of a geometry, records its graph on the second, replays from the third)."""
-        ns = self.eng.n_slots
-        if warm is None:
-            warm = 3 * ns
+        """Pipelined megapixels/sec over `steps` submissions (fresh buffers per submission), after prepare_slots()."""
+        merged_max = self.merged_max
+        warm = self.sets_for_setup(merged_max)
         base = len(self.sets)
         self.buffers(steps + warm)
-        for j in range(warm):                     # slot by slot (see the setup of the timed region in main())
-            self.submit_to_slot(j % ns, base + j)
-            if j % ns == ns - 1 or j == warm - 1:
-                for sl in range(j % ns + 1):
-                    self.eng.wait_group(sl)
+        self.prepare_slots(base, merged_max)
         self.torch.cuda.synchronize()
         gc.collect()
         gc.disable()                              # (see the timed region of main())
@@ -323,6 +349,7 @@ def main():
     ap.add_argument("--workload", default="720p", choices=sorted(WORKLOADS))
     ap.add_argument("--frames-per-gpu", type=int, default=0)
     ap.add_argument("--slots", type=int, default=8, help="groups in flight per GPU (stream + host thread each)")
+    ap.add_argument("--no-batching", action="store_true", help="one submission per launch group (no dynamic batching in the pipeline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-4k", action="store_true", help="skip the 4K, K=6000, LSC and end-to-end sub-objects")
     ap.add_argument("--no-parity", action="store_true")
@@ -376,20 +403,23 @@ def main():
     fpg = args.frames_per_gpu or cfg["fpg"]
     nslots = max(1, args.slots)
     eng = Engine(local_rank, nslots)
+    # Dynamic batching: a slot thread that finds two submissions waiting serves them as one group (16 frames per launch instead
+    # of 8).  Results are per frame and do not change; the parity gate below checks a submission of the timed region.
+    merged_max = 1 if args.no_batching else max(1, min(2, 16 // fpg))
+    if merged_max > 1:
+        eng.pipeline_batching(merged_max * fpg)
+    Workload.merged_max = merged_max
     # this rank's shard of the synthetic frame stream: frames are independent, rank r owns seeds r*fpg .. r*fpg+fpg-1
     wl = Workload(eng, H, W, K, batch.weak_shard(fpg, rank))
-    n_setup = 3 * nslots                                     # every slot: first group direct (allocates), second recorded as a graph, third replayed
+    n_setup = wl.sets_for_setup(merged_max)
     wl.buffers(n_setup + args.warmup + args.steps)
     sync = torch.cuda.synchronize
     # setup, not a step: every slot allocates and carves its arena on its first group and records (and instantiates) its launch
-    # sequence as a hipGraph on its second.  The groups are addressed to the slots one by one -- handed to "whichever slot
-    # is free" a fast slot takes several and another is still unprepared when a short --warmup ends (the driver's 5 warm-up
-    # steps left graph instantiation inside its 20 timed steps: 17 instead of 40 GP/s).
-    for j in range(n_setup):
-        wl.submit_to_slot(j % nslots, j)
-        if j % nslots == nslots - 1:
-            for sl in range(nslots):
-                eng.wait_group(sl)
+    # sequence as a hipGraph on its second, for every form of group the pipeline can produce.  The groups are addressed to the
+    # slots one by one -- handed to "whichever slot is free" a fast slot takes several and another is still unprepared when
+    # a short --warmup ends (the driver's 5 warm-up steps left graph instantiation inside its 20 timed steps: 17 instead of
+    # 40 GP/s).
+    wl.prepare_slots(0, merged_max)
     for j in range(args.warmup):
         wl.submit(n_setup + j)
     eng.pipeline_drain()
@@ -419,7 +449,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u16/i32 (integer SLIC)", "data": "synthetic",
             "config": {"workload": cfg["name"], "frames_per_gpu": fpg, "global_frames": fpg * world,
-                       "slots_per_gpu": eng.n_slots, "inputs": "device-resident uint8 RGB, device int16 labels",
+                       "slots_per_gpu": eng.n_slots, "submissions_per_launch_group": "up to %d (dynamic batching of the pipeline)" % merged_max,
+                       "inputs": "device-resident uint8 RGB, device int16 labels",
                        "parallelism": "frames sharded across GPUs, no collective",
                        "host_cpus_of_this_rank": len(pinned) if pinned else None},
             "device_ms_per_frame": round(totals["device_ms"] / max(totals["frames"], 1), 4),

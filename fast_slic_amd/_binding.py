@@ -43,7 +43,7 @@ EXPORTS = [
     "fslic_hip_enforce_connectivity", "fslic_hip_last_prelabels", "fslic_hip_last_timing_report",
     "fslic_hip_last_device_times", "fslic_hip_set_launch_timing", "fslic_hip_last_assign_loop", "fslic_hip_last_group_frames", "fslic_hip_last_path", "fslic_hip_last_launch_mode", "fslic_hip_group_done", "fslic_hip_last_error", "fslic_hip_version",
     "fslic_hip_get_connectivity", "fslic_hip_knn_connectivity", "fslic_hip_get_mask_density", "fslic_hip_cluster_density_to_mask",
-    "fslic_hip_pipeline_submit", "fslic_hip_pipeline_drain", "fslic_hip_last_host_topk_frames",
+    "fslic_hip_pipeline_submit", "fslic_hip_pipeline_drain", "fslic_hip_pipeline_batching", "fslic_hip_last_host_topk_frames",
 ]
 
 _lib = None
@@ -107,6 +107,7 @@ def load_library():
         lib.fslic_hip_wait_group.argtypes = [vp, i32]
         lib.fslic_hip_pipeline_submit.argtypes = [vp, C.POINTER(Params), i32, i32, i32, i32, vp, vp, vp]
         lib.fslic_hip_pipeline_drain.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+        lib.fslic_hip_pipeline_batching.argtypes = [vp, i32]
         lib.fslic_hip_last_host_topk_frames.argtypes = [vp, i32]
         if hasattr(lib, "fslic_hip_group_done"):
             lib.fslic_hip_group_done.argtypes = [vp, i32]
@@ -265,6 +266,11 @@ class Engine(object):
         _check(load_library().fslic_hip_pipeline_submit(self._h, C.byref(params), H, W, K, n,
                                                         C.cast(a_rgb, C.c_void_p), C.cast(a_clusters, C.c_void_p),
                                                         C.cast(a_labels, C.c_void_p)))
+
+    def pipeline_batching(self, max_frames_per_group):
+        """Let a slot thread serve several waiting submissions of identical geometry / options as one group of up to
+        `max_frames_per_group` (<= 16) frames; 0 switches it off (the default).  Call before the first pipeline_submit."""
+        _check(load_library().fslic_hip_pipeline_batching(self._h, int(max_frames_per_group)))
 
     def pipeline_drain(self):
         """Wait for every submitted group; dict of the totals since the previous drain."""

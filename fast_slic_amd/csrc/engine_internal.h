@@ -16,7 +16,9 @@
 #include "launch.h"
 #include "../../include/fslic_hip.h"
 
+#include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <cstdint>
 #include <memory>
 #include <mutex>
@@ -163,6 +165,8 @@ struct Slot {
         uint16_t* d_out[kMaxGroup] = {};
         int rc = 0;
         std::string err;
+        bool from_queue = false;      // the job was taken from the engine's submit queue (the thread collects it itself)
+        int jobs = 0;                 // ... and is this many submissions in one group
     };
     std::unique_ptr<Async> async;
     uint32_t* d_pre = nullptr;       // frame 0's preemptive state: is_updatable[K], is_active[K], cells, flags
@@ -213,6 +217,21 @@ struct fslic_engine {
     std::string pipe_err;
     double pipe_device_ms = 0;
     long long pipe_groups = 0, pipe_frames = 0, pipe_host_topk = 0;
+    // Submissions wait here for a slot thread (guarded by mu).  With batching on (fslic_hip_pipeline_batching), a thread
+    // that finds several compatible submissions waiting serves them as ONE group: fewer, fuller launches when the
+    // caller submits faster than the device finishes.
+    struct PipeJob {
+        fslic_params p{};
+        int H = 0, W = 0, K = 0, n = 0;
+        const uint8_t* d_rgb[fslic::kMaxGroup] = {};
+        fslic_cluster* clusters[fslic::kMaxGroup] = {};
+        uint16_t* d_out[fslic::kMaxGroup] = {};
+    };
+    std::deque<PipeJob> pipe_q;
+    int pipe_inflight = 0;           // groups taken from the queue and not yet collected
+    int pipe_batch_frames = 0;       // 0: one submission per group; otherwise the most frames a group may gather
+    bool pipe_gathering = false;     // a slot thread is waiting briefly for a companion of the submission it took
+    std::atomic<int> reserve_frames{0};   // arenas are carved for at least this many frames per group
 };
 
 namespace fslic {

@@ -405,14 +405,15 @@ int group_begin(fslic_engine* e, Slot& s, const fslic_params* p, int H, int W, i
     if (n < 1 || n > kMaxGroup) return fail(FSLIC_E_INTERNAL, "bad group size");
     for (int i = 0; i < n; i++)
         if (!clusters[i] || !d_rgb[i] || !d_out[i]) return fail(FSLIC_E_INVALID, "NULL pointer argument");
-    rc = ensure_prepared(e, s, H, W, K, S, n);
+    const int cap_frames = std::max(n, std::min(e->reserve_frames.load(), (int)kMaxGroup));     // (batching: room for the groups to come)
+    rc = ensure_prepared(e, s, H, W, K, S, cap_frames);
     if (rc) return rc;
     s.H = H; s.W = W; s.K = K; s.S = S; s.p = *p; s.nframes = n;
     for (int i = 0; i < n; i++) { s.clusters[i] = clusters[i]; s.d_rgb[i] = d_rgb[i]; s.d_out[i] = d_out[i]; }
     rc = configure_spatial(s, S, p);
     if (rc) return rc;
     if (p->variant == FSLIC_VARIANT_LSC) {
-        rc = prepare_lsc(s, H, W, K, S, n, p->compactness);
+        rc = prepare_lsc(s, H, W, K, S, cap_frames, p->compactness);
         if (rc) return rc;
     }
     if (p->variant == FSLIC_VARIANT_REALDIST || p->variant == FSLIC_VARIANT_REALDIST_L2) {

@@ -9,8 +9,10 @@
 #include "engine_internal.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 namespace fslic {
 
@@ -97,15 +99,67 @@ void release_all_slots(fslic_engine* e) {
 // ---- the slot's host thread: one group at a time, begin + finish ---------------------------------------------------
 namespace {
 
+// caller holds e->mu: fold a completed pipeline group into the engine's totals and free its slot
+void pipeline_collect(fslic_engine* e, Slot& s) {
+    Slot::Async& a = *s.async;
+    if (a.rc != FSLIC_OK && e->pipe_rc == FSLIC_OK) { e->pipe_rc = a.rc; e->pipe_err = a.err; }
+    e->pipe_device_ms += s.total_ms;
+    e->pipe_groups += 1;
+    e->pipe_frames += s.nframes;
+    e->pipe_host_topk += s.n_host_topk;
+    s.pending = false;
+}
+
+bool same_work(const fslic_engine::PipeJob& j, const Slot::Async& a) {
+    return j.H == a.H && j.W == a.W && j.K == a.K && memcmp(&j.p, &a.p, sizeof(fslic_params)) == 0;
+}
+
 void slot_worker(fslic_engine* e, Slot* s) {
     Slot::Async& a = *s->async;
     (void)hipSetDevice(e->device);
     for (;;) {
+        bool took = false;
         {
             std::unique_lock<std::mutex> lk(e->mu);
-            e->cv.wait(lk, [&] { return a.has_job || a.quit; });
+            e->cv.wait(lk, [&] { return a.has_job || a.quit || (!e->pipe_q.empty() && !e->pipe_gathering && !s->busy && !s->pending); });
             if (a.quit) return;
+            if (!a.has_job) {
+                // the submit queue's head, plus -- with batching on -- the submissions behind it that ask for the same work,
+                // as long as the group stays within the frame limit
+                const fslic_engine::PipeJob& j0 = e->pipe_q.front();
+                a.p = j0.p; a.H = j0.H; a.W = j0.W; a.K = j0.K; a.n = 0; a.jobs = 0;
+                const int limit = std::min(e->pipe_batch_frames, (int)kMaxGroup);
+                const int unit = j0.n;
+                auto gather = [&]() {
+                    while (!e->pipe_q.empty()) {
+                        const fslic_engine::PipeJob& j = e->pipe_q.front();
+                        if (a.jobs > 0 && (!same_work(j, a) || a.n + j.n > limit)) break;
+                        for (int i = 0; i < j.n; i++) { a.d_rgb[a.n + i] = j.d_rgb[i]; a.clusters[a.n + i] = j.clusters[i]; a.d_out[a.n + i] = j.d_out[i]; }
+                        a.n += j.n; a.jobs++;
+                        e->pipe_q.pop_front();
+                    }
+                };
+                gather();
+                // the slot is taken and the group counted BEFORE the wait below: a drain must not take the queue for served
+                // meanwhile, nor a synchronous call this slot for free
+                s->pending = true;
+                a.done = false; a.from_queue = true;
+                e->pipe_inflight++;
+                // Room for another submission of this size and nothing waiting: a caller in the middle of a burst delivers the
+                // next one within microseconds.  This thread waits for it briefly (the other idle threads leave the queue alone
+                // meanwhile), so that the first groups of a burst are as full as the later ones.
+                if (a.n + unit <= limit && e->pipe_q.empty() && !e->pipe_gathering) {
+                    e->pipe_gathering = true;
+                    e->cv.wait_for(lk, std::chrono::microseconds(40), [&] { return !e->pipe_q.empty() || a.quit; });
+                    e->pipe_gathering = false;
+                    gather();
+                }
+                s->launch_timing = e->launch_timing;
+                a.has_job = true;
+                took = true;
+            }
         }
+        if (took) e->cv.notify_all();            // room in the queue
         int rc = group_begin(e, *s, &a.p, a.H, a.W, a.K, a.n, a.d_rgb, a.clusters, a.d_out);
         if (rc == FSLIC_OK) rc = group_finish(e, *s);
         {
@@ -114,20 +168,29 @@ void slot_worker(fslic_engine* e, Slot* s) {
             a.err = rc ? last_error() : std::string();
             a.has_job = false;
             a.done = true;
+            if (a.from_queue) {                  // nobody waits for this slot by number: collected here
+                pipeline_collect(e, *s);
+                a.from_queue = false;
+                e->pipe_inflight--;
+            }
         }
         e->cv.notify_all();
     }
 }
 
+// caller holds e->mu
+void ensure_worker(fslic_engine* e, Slot& s) {
+    if (s.async) return;
+    s.async.reset(new Slot::Async());
+    s.async->worker = std::thread(slot_worker, e, &s);
+}
+
 // caller holds e->mu; the slot is neither busy nor pending
 void hand_over(fslic_engine* e, Slot& s, const fslic_params* p, int H, int W, int K, int n,
                const uint8_t* const* d_rgb, fslic_cluster* const* clusters, uint16_t* const* d_labels) {
-    if (!s.async) {
-        s.async.reset(new Slot::Async());
-        s.async->worker = std::thread(slot_worker, e, &s);
-    }
+    ensure_worker(e, s);
     Slot::Async& a = *s.async;
-    a.p = *p; a.H = H; a.W = W; a.K = K; a.n = n;
+    a.p = *p; a.H = H; a.W = W; a.K = K; a.n = n; a.from_queue = false; a.jobs = 1;
     s.launch_timing = e->launch_timing;      // sampled on the caller's thread: the worker may start later
     for (int i = 0; i < n; i++) { a.d_rgb[i] = d_rgb[i]; a.clusters[i] = clusters[i]; a.d_out[i] = d_labels[i]; }
     a.done = false;
@@ -145,17 +208,6 @@ int check_group_args(fslic_engine* e, const fslic_params* p, int H, int W, int K
     for (int i = 0; i < n_frames; i++)
         if (!clusters[i] || !d_rgb[i] || !d_labels[i]) return fail(FSLIC_E_INVALID, "NULL pointer argument");
     return FSLIC_OK;
-}
-
-// caller holds e->mu: fold a completed pipeline group into the engine's totals and free its slot
-void pipeline_collect(fslic_engine* e, Slot& s) {
-    Slot::Async& a = *s.async;
-    if (a.rc != FSLIC_OK && e->pipe_rc == FSLIC_OK) { e->pipe_rc = a.rc; e->pipe_err = a.err; }
-    e->pipe_device_ms += s.total_ms;
-    e->pipe_groups += 1;
-    e->pipe_frames += s.nframes;
-    e->pipe_host_topk += s.n_host_topk;
-    s.pending = false;
 }
 
 }  // namespace
@@ -220,27 +272,33 @@ int fslic_hip_group_done(fslic_engine* e, int slot) {
     return s.async->done ? 1 : 0;
 }
 
-// The submit / drain pipeline: the engine picks the slot.  submit returns as soon as the group has been handed to a
-// slot thread; it blocks only while every slot is occupied, and collects completed groups itself.
+// The submit / drain pipeline: submissions go into the engine's queue and the slot threads serve it; submit blocks only
+// while the queue is full (two submissions per slot).
 int fslic_hip_pipeline_submit(fslic_engine* e, const fslic_params* p, int H, int W, int K, int n_frames,
                               const uint8_t* const* d_rgb, fslic_cluster* const* clusters, uint16_t* const* d_labels) {
     int rc = check_group_args(e, p, H, W, K, n_frames, d_rgb, clusters, d_labels);
     if (rc) return rc;
     {
         std::unique_lock<std::mutex> lk(e->mu);
-        Slot* pick = nullptr;
-        for (;;) {
-            for (Slot& s : e->slots)                          // completed groups first: their slots become free
-                if (s.pending && s.async && s.async->done) pipeline_collect(e, s);
-            if (e->pipe_rc != FSLIC_OK) { set_last_error(e->pipe_err); return e->pipe_rc; }   // reported once more by drain
-            for (Slot& s : e->slots)
-                if (!s.pending && !s.busy) { pick = &s; break; }
-            if (pick) break;
-            e->cv.wait(lk);
-        }
-        hand_over(e, *pick, p, H, W, K, n_frames, d_rgb, clusters, d_labels);
+        for (Slot& s : e->slots) ensure_worker(e, s);
+        const size_t cap = 2 * e->slots.size();
+        e->cv.wait(lk, [&] { return e->pipe_rc != FSLIC_OK || e->pipe_q.size() < cap; });
+        if (e->pipe_rc != FSLIC_OK) { set_last_error(e->pipe_err); return e->pipe_rc; }   // reported once more by drain
+        e->pipe_q.emplace_back();
+        fslic_engine::PipeJob& j = e->pipe_q.back();
+        j.p = *p; j.H = H; j.W = W; j.K = K; j.n = n_frames;
+        for (int i = 0; i < n_frames; i++) { j.d_rgb[i] = d_rgb[i]; j.clusters[i] = clusters[i]; j.d_out[i] = d_labels[i]; }
     }
     e->cv.notify_all();
+    return FSLIC_OK;
+}
+
+int fslic_hip_pipeline_batching(fslic_engine* e, int max_frames_per_group) {
+    if (!e) return fail(FSLIC_E_INVALID, "engine is NULL");
+    if (max_frames_per_group < 0 || max_frames_per_group > (int)kMaxGroup) return fail(FSLIC_E_INVALID, "frames per group out of range");
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->pipe_batch_frames = max_frames_per_group;
+    e->reserve_frames.store(max_frames_per_group);
     return FSLIC_OK;
 }
 
@@ -249,12 +307,9 @@ int fslic_hip_pipeline_drain(fslic_engine* e, double* device_ms, long long* grou
     int rc;
     {
         std::unique_lock<std::mutex> lk(e->mu);
-        for (Slot& s : e->slots) {
-            if (!s.pending) continue;
-            Slot::Async& a = *s.async;
-            e->cv.wait(lk, [&] { return a.done; });
-            pipeline_collect(e, s);
-        }
+        // everything submitted has been taken by a slot thread and collected (a slot that a caller drives by number, or a
+        // synchronous call, may keep a queued submission waiting: the queue is served as soon as a slot is free)
+        e->cv.wait(lk, [&] { return e->pipe_q.empty() && e->pipe_inflight == 0; });
         rc = e->pipe_rc;
         if (rc) set_last_error(e->pipe_err);
         if (device_ms) *device_ms = e->pipe_device_ms;

@@ -129,16 +129,24 @@ int fslic_hip_wait_group(fslic_engine* e, int slot);
  * order instead of submission order (groups with a top-K tie take longer than the others). */
 int fslic_hip_group_done(fslic_engine* e, int slot);
 
-/* The same, with the engine choosing the slot (NEW surface): submit hands one group of n_frames (1..16)
- * device-resident frames to whichever slot is free and returns; it blocks only while every slot is occupied and
- * collects completed groups itself (their clusters are written back by then).  drain waits for everything submitted
- * so far and returns the first error of any group since the previous drain; the optional outputs receive the totals
- * over those groups: device time (ms, HIP events per group), groups, frames, and the number of frames whose top-K
- * step fell back to the host.  A video pipeline calls submit once per group of frames and drain at the end. */
+/* The same, with the engine choosing the slot (NEW surface): submit puts one submission of n_frames (1..16)
+ * device-resident frames into the engine's queue and returns; it blocks only while the queue is full (two submissions
+ * per slot).  The slot threads serve the queue; the clusters of a submission are written back when its group is complete.
+ * drain waits for everything submitted so far and returns the first error of any group since the previous drain (a
+ * submit after a failed group returns that error as well); the optional outputs receive the totals over those groups:
+ * device time (ms, HIP events per group), groups (launch groups: with batching on, fewer than submissions), frames, and
+ * the number of frames whose top-K step fell back to the host.  A video pipeline calls submit once per batch of frames
+ * and drain at the end. */
 int fslic_hip_pipeline_submit(fslic_engine* e, const fslic_params* p, int H, int W, int K, int n_frames,
                               const uint8_t* const* d_rgb, fslic_cluster* const* clusters, uint16_t* const* d_labels);
 int fslic_hip_pipeline_drain(fslic_engine* e, double* device_ms, long long* groups, long long* frames,
                              long long* host_topk_frames);
+/* Dynamic batching of the pipeline (off by default: max_frames_per_group = 0): a slot thread that finds several
+ * submissions of identical geometry and options waiting serves them as ONE group of up to max_frames_per_group (<= 16)
+ * frames -- every launch of the group then covers all of them.  Frames are independent, so results do not change; a
+ * caller that submits faster than the device finishes gets fewer, fuller launches (1280x720: +10 %).  Arenas are carved
+ * for max_frames_per_group frames from then on.  Call it before the first submit. */
+int fslic_hip_pipeline_batching(fslic_engine* e, int max_frames_per_group);
 
 /* Stage entry points (used by the parity tests; each mirrors one stage of iterate()). */
 

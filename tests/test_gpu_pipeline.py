@@ -32,7 +32,7 @@ def _expected(frames, K):
     return out
 
 
-def _run_pipeline(H, W, K, seeds, group, nslots, rounds, expect_replay=True, min_size_factor=0.25, max_iter=10, host_topk=False, engine=None):
+def _run_pipeline(H, W, K, seeds, group, nslots, rounds, expect_replay=True, min_size_factor=0.25, max_iter=10, host_topk=False, engine=None, batching=0):
     """Submit `rounds` times the groups cut from `seeds` through fslic_hip_pipeline_submit on `nslots` slots; every
     submission owns its label maps and cluster blocks, all of them are compared with the oracle after the drain."""
     import torch
@@ -45,6 +45,7 @@ def _run_pipeline(H, W, K, seeds, group, nslots, rounds, expect_replay=True, min
         lib.fslic_hip_initialize_clusters(H, W, K, f.ctypes.data, cl0[i].ctypes.data)
     e = engine or Engine(0, nslots)
     try:
+        if batching: e.pipeline_batching(batching)
         d_rgb = [torch.from_numpy(f).cuda() for f in frames]
         torch.cuda.synchronize()
         subs = []
@@ -60,7 +61,9 @@ def _run_pipeline(H, W, K, seeds, group, nslots, rounds, expect_replay=True, min
                 e.pipeline_submit(a_rgb, a_cls, a_lab, len(idx), H, W, K, p)
                 subs.append((r, idx, d_lab, cls, (a_rgb, a_lab, a_cls)))
         tot = e.pipeline_drain()
-        assert tot["groups"] == len(subs) and tot["frames"] == rounds * len(frames)
+        assert tot["frames"] == rounds * len(frames)
+        if batching: assert tot["groups"] <= len(subs)
+        else: assert tot["groups"] == len(subs)
         if host_topk: assert tot["host_topk_frames"] > 0, tot
         else: assert tot["host_topk_frames"] == 0, tot      # ties are resolved on the device
         assert tot["device_ms"] > 0.0
@@ -80,6 +83,20 @@ def test_bench_operating_point_8x720p_eight_slots_four_rounds():
     # exactly bench.py's timed loop: one group = seeds 0..7 at 1280x720 K=1600; 8 slots (bench.py's default); 32 groups so that
     # every slot goes direct -> record -> replay; seeds 2 and 4 carry an area tie at the top-K cut
     _run_pipeline(720, 1280, 1600, list(range(8)), 8, 8, 32)
+
+
+def test_dynamic_batching_serves_several_submissions_as_one_group():
+    # bench.py's mode: submissions of 8 frames, a slot thread gathers up to two of them into one group of 16 (every launch then
+    # covers 16 frames); every submission's label maps and Cluster bytes against the oracle, fewer groups than submissions
+    import torch
+    e = Engine(0, 3)
+    try:
+        _run_pipeline(720, 1280, 1600, list(range(8)), 8, 3, 12, engine=e, expect_replay=False, batching=16)
+        # other geometries and submission sizes through the same engine (its arenas are re-carved)
+        _run_pipeline(360, 640, 400, list(range(6)), 2, 3, 8, engine=e, expect_replay=False, batching=16)
+        _run_pipeline(720, 1280, 1600, list(range(8)), 8, 3, 6, engine=e, expect_replay=False, batching=16)
+    finally:
+        e.close()
 
 
 def test_threshold_zero_takes_the_host_topk_path_while_other_slots_record_graphs():
