@@ -136,7 +136,8 @@ int fslic_hip_group_done(fslic_engine* e, int slot);
  * submit after a failed group returns that error as well); the optional outputs receive the totals over those groups:
  * device time (ms, HIP events per group), groups (launch groups: with batching on, fewer than submissions), frames, and
  * the number of frames whose top-K step fell back to the host.  A video pipeline calls submit once per batch of frames
- * and drain at the end. */
+ * and drain at the end.  (A slot that is serving the queue counts as owning an unfinished group: drain before addressing
+ * slots by number with fslic_hip_submit_group.) */
 int fslic_hip_pipeline_submit(fslic_engine* e, const fslic_params* p, int H, int W, int K, int n_frames,
                               const uint8_t* const* d_rgb, fslic_cluster* const* clusters, uint16_t* const* d_labels);
 int fslic_hip_pipeline_drain(fslic_engine* e, double* device_ms, long long* groups, long long* frames,
