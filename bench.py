@@ -229,19 +229,25 @@ class Workload(object):
     def sets_for_setup(self, merged_max):
         return 3 * self.eng.n_slots * sum(range(1, merged_max + 1))
 
-    def timed_groups(self, reps, n=None, bytes_per_px=ASSIGN_BYTES_PER_PX):
+    def timed_groups(self, reps, n=None, bytes_per_px=ASSIGN_BYTES_PER_PX, merged=1):
         """`reps` groups one after the other with the GPU to themselves and every subsampled assign launch and the
-        full-assign launch bracketed by HIP events on the slot's stream: averages over the groups after the first two."""
+        full-assign launch bracketed by HIP events on the slot's stream: averages over the groups after the first two.
+        merged > 1: groups of `merged` submissions, the form dynamic batching produces (merged * n frames per launch)."""
         eng, n = self.eng, n or self.n
-        if len(self.sets) == 0:
-            self.buffers(1)
+        if len(self.sets) < merged:
+            self.buffers(merged - len(self.sets))
         d_lab, cls, a_lab, a_cls = self.sets[0]
         rec = []
         eng.set_launch_timing(True)
         try:
             for i in range(reps + 2):
-                np.copyto(cls.view(np.uint8).reshape(-1), self.cl0.view(np.uint8).reshape(-1))
-                eng.submit_group(0, self.a_rgb, a_cls, a_lab, n, self.H, self.W, self.K, self.params)
+                for q in range(merged):
+                    c = self.sets[q][1]
+                    np.copyto(c.view(np.uint8).reshape(-1), self.cl0.view(np.uint8).reshape(-1))
+                if merged == 1:
+                    eng.submit_group(0, self.a_rgb, a_cls, a_lab, n, self.H, self.W, self.K, self.params)
+                else:
+                    self.submit_to_slot(0, 0, merged=merged)
                 eng.wait_group(0)
                 if i >= 2:
                     tot, fa = eng.last_device_times(0)
@@ -250,6 +256,7 @@ class Workload(object):
         finally:
             eng.set_launch_timing(False)
         tot, fa, lm, lp, nl = [float(np.mean([r[q] for r in rec])) for q in range(5)]
+        n = n * merged
         fa_bytes = bytes_per_px * self.H * self.W * n
         lp_bytes = bytes_per_px * lp
         per_launch = lm / max(nl, 1.0)
@@ -469,28 +476,34 @@ def main():
         # ---- roofline of the dominant kernel: the fused assign+update launch, GPU to itself (reproducible: agrees with the
         # rocprofv3 kernel-trace summary under profiles/), then the same launches inside a pipelined (contended) run
         alone = wl.timed_groups(6)
-        pmc, pmc_src = pmc_traffic("720p_x8") if (args.workload == "720p" and fpg == 8) else (None, None)
-        fu = alone["fused_assign_update"]
+        per_launch_frames = fpg * merged_max
+        big = wl.timed_groups(6, merged=merged_max) if merged_max > 1 else alone      # the launches the timed region is made of
+        pmc, pmc_src = pmc_traffic("720p_x%d" % per_launch_frames) if args.workload == "720p" else (None, None)
+        fu = big["fused_assign_update"]
         out["roofline"] = {
-            "kernel": "k_assign_blk<8,true,3,*> (fused assign + centroid sums; %d launches per group, %dx%d x %d frames per launch), "
-                      "GPU to itself" % (fu["launches_per_group"], W, H, fpg),
+            "kernel": "k_assign_blk<8,true,3,*> (fused assign + centroid sums; %d launches per group, %dx%d x %d frames per launch: "
+                      "%s), GPU to itself" % (fu["launches_per_group"], W, H, per_launch_frames,
+                                              "two submissions per group, as the pipelined region runs them" if merged_max > 1 else "one submission per group"),
             "bound": "hbm", "achieved": fu["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fu["frac"],
             "traffic": pmc["fused_assign_update"]["bytes"] if pmc else None, "traffic_source": pmc_src,
             "bytes_per_launch": fu["bytes_per_launch"], "avg_launch_ms": fu["avg_launch_ms"],
-            "full_assign": alone["full_assign"], "all_assign_launches": alone["all_assign_launches"],
-            "device_ms_per_frame": alone["device_ms_per_frame"],
+            "full_assign": big["full_assign"], "all_assign_launches": big["all_assign_launches"],
+            "device_ms_per_frame": big["device_ms_per_frame"],
         }
+        if merged_max > 1:
+            out["roofline"]["launch_of_one_submission"] = {"frames_per_launch": fpg, "fused_assign_update": alone["fused_assign_update"],
+                                                           "full_assign": alone["full_assign"], "device_ms_per_frame": alone["device_ms_per_frame"]}
         copy_gbs = measured_copy_bandwidth()
         out["hbm_copy_measured"] = {"value": copy_gbs, "unit": "GB/s", "what": "device-to-device copy of 1 GiB (bytes read + bytes written), best of 5"}
         out["roofline"]["frac_of_measured_copy"] = round(fu["achieved"] / copy_gbs, 4) if copy_gbs else None
         # the same launch by rocprofv3's kernel duration (committed summary of `scripts/frames.py 720 1280 1600 6 slic 8` under
         # --kernel-trace): events on the stream also see the launch gap of the directly enqueued (timed) group
-        rp = rocprof_avg_us("kernel_stats_1280x720_k1600_slic_x8.csv", "k_assign_blk<8, true, 3") if (args.workload == "720p" and fpg == 8) else None
+        rp = rocprof_avg_us("kernel_stats_1280x720_k1600_slic_x%d.csv" % per_launch_frames, "k_assign_blk<8, true, 3") if args.workload == "720p" else None
         if rp:
             out["roofline"]["by_rocprofv3_kernel_duration"] = {
                 "avg_launch_us": rp, "achieved": round(gbs(fu["bytes_per_launch"], rp * 1e-3), 2),
                 "frac": round(gbs(fu["bytes_per_launch"], rp * 1e-3) / HBM_PEAK_GBS, 4),
-                "source": "profiles/%s_kernel_stats_1280x720_k1600_slic_x8.csv" % PROFILE_TAG}
+                "source": "profiles/%s_kernel_stats_1280x720_k1600_slic_x%d.csv" % (PROFILE_TAG, per_launch_frames)}
         # contended: slot 0's groups carry per-launch events while the other slots keep the GPU busy
         base = len(wl.sets)
         wl.buffers(6 * nslots)

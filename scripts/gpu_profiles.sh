@@ -20,23 +20,23 @@ python $R/scripts/rocpd_stats.py overlap $DB 0.4 > $OUT/bench_stream_overlap.txt
 python $R/scripts/rocpd_stats.py window $DB 4000 500 > $OUT/bench_all_streams_window.txt
 rm -rf $OUT/p
 # 2. single-stream groups of the BASELINE configurations
-for cfg in "720 1280 1600 6 slic 8" "2160 3840 1600 4 slic 8" "2160 3840 1600 4 slic 1" "2160 3840 6000 4 slic 4" "720 1280 1600 4 lsc 8"; do
+for cfg in "720 1280 1600 6 slic 8" "720 1280 1600 6 slic 16" "2160 3840 1600 4 slic 8" "2160 3840 1600 4 slic 1" "2160 3840 6000 4 slic 4" "720 1280 1600 4 lsc 8"; do
   set -- $cfg
   tag=${2}x${1}_k${3}_${5}_x${6}
   rm -rf $OUT/p
-  timeout 300 rocprofv3 --kernel-trace -d $OUT/p -o t -- python $R/scripts/frames.py $cfg > /dev/null 2>&1
+  FSLIC_GROUP=$6 timeout 300 rocprofv3 --kernel-trace -d $OUT/p -o t -- python $R/scripts/frames.py $cfg > /dev/null 2>&1      # (one launch group of all G frames)
   DB=$(find $OUT/p -name '*_results.db' | head -1)
   python $R/scripts/rocpd_stats.py timeline $DB | cut -c1-170 > $OUT/timeline_$tag.txt
   python $R/scripts/rocpd_stats.py stats $DB | cut -c1-170 > $OUT/kernel_stats_$tag.csv
   rm -rf $OUT/p
 done
 # 3. HBM traffic of the assign launches (separate --pmc passes, as the MI355X guide prescribes)
-for cfg in "720 1280 1600 3 slic 8" "2160 3840 1600 3 slic 1"; do
+for cfg in "720 1280 1600 3 slic 8" "720 1280 1600 3 slic 16" "2160 3840 1600 3 slic 1"; do
   set -- $cfg
   tag=${2}x${1}_x${6}
   for set in FETCH_SIZE WRITE_SIZE; do
     rm -rf $OUT/p
-    timeout 300 rocprofv3 --kernel-trace --pmc $set -d $OUT/p -o p -- python $R/scripts/frames.py $cfg > /dev/null 2>&1
+    FSLIC_GROUP=$6 timeout 300 rocprofv3 --kernel-trace --pmc $set -d $OUT/p -o p -- python $R/scripts/frames.py $cfg > /dev/null 2>&1
     DB=$(find $OUT/p -name '*_results.db' | head -1)
     python $R/scripts/rocpd_pmc.py $DB >> $OUT/pmc_fetch_write_$tag.csv
     rm -rf $OUT/p

@@ -4,7 +4,7 @@ HBM traffic of the assign kernels that bench.py reports as roofline.traffic.
 import csv, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prefix = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02")
-SETS = {"720p_x8": ("1280x720_x8", 1280 * 720 * 8, 3), "4k_k1600": ("3840x2160_x1", 3840 * 2160, 3)}   # tag, pixels per launch, subsample stride
+SETS = {"720p_x8": ("1280x720_x8", 1280 * 720 * 8, 3), "720p_x16": ("1280x720_x16", 1280 * 720 * 16, 3), "4k_k1600": ("3840x2160_x1", 3840 * 2160, 3)}   # tag, pixels per launch, subsample stride
 
 
 def read(path):
@@ -19,6 +19,8 @@ def read(path):
 out = {"note": "bytes per launch = FETCH_SIZE*1024*2 + WRITE_SIZE*1024 (gfx950 correction on the read side only); mean over the "
                "dispatches of separate rocprofv3 --pmc passes (profiles/%s_pmc_fetch_write_*.csv)" % os.path.basename(prefix)}
 for key, (tag, px, stride) in SETS.items():
+    if not os.path.exists("%s_pmc_fetch_write_%s.csv" % (prefix, tag)):
+        continue
     d = read("%s_pmc_fetch_write_%s.csv" % (prefix, tag))
     ent = {}
     for name, fused in (("full_assign", False), ("fused_assign_update", True)):
