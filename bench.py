@@ -355,7 +355,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--workload", default="720p", choices=sorted(WORKLOADS))
     ap.add_argument("--frames-per-gpu", type=int, default=0)
-    ap.add_argument("--slots", type=int, default=8, help="groups in flight per GPU (stream + host thread each)")
+    ap.add_argument("--slots", type=int, default=6, help="groups in flight per GPU (stream + host thread each)")
     ap.add_argument("--no-batching", action="store_true", help="one submission per launch group (no dynamic batching in the pipeline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-4k", action="store_true", help="skip the 4K, K=6000, LSC and end-to-end sub-objects")

@@ -1,6 +1,6 @@
 """GPU parity at the benchmark's own operating point, the device-side top-K tie, and concurrent callers (-m gpu).
 
-* the submit / drain pipeline exactly as bench.py drives it: 8 x 1280x720 K=1600 per group (seeds 0..7), 8 slots,
+* the submit / drain pipeline exactly as bench.py drives it: 8 x 1280x720 K=1600 per submission (seeds 0..7), 6 slots, dynamic batching,
   hipGraph replay, several rounds, EVERY label map and EVERY Cluster byte against the oracle; then the 64 frames of
   BASELINE.json configs[3] (seeds 0..63) and one group of eight 3840x2160 frames
 * area ties at the top-K cut (src/cca.cpp:225-228) are resolved on the device by replaying libstdc++'s
@@ -79,9 +79,14 @@ def _run_pipeline(H, W, K, seeds, group, nslots, rounds, expect_replay=True, min
         if engine is None: e.close()
 
 
-def test_bench_operating_point_8x720p_eight_slots_four_rounds():
-    # exactly bench.py's timed loop: one group = seeds 0..7 at 1280x720 K=1600; 8 slots (bench.py's default); 32 groups so that
-    # every slot goes direct -> record -> replay; seeds 2 and 4 carry an area tie at the top-K cut
+def test_bench_operating_point_8x720p_six_slots_batching():
+    # exactly bench.py's timed loop: one submission = seeds 0..7 at 1280x720 K=1600; 6 slots (bench.py's default) with dynamic
+    # batching of up to two submissions per launch group; 60 submissions so that slots reach graph replay for the 16-frame form;
+    # seeds 2 and 4 carry an area tie at the top-K cut
+    _run_pipeline(720, 1280, 1600, list(range(8)), 8, 6, 60, batching=16)
+
+
+def test_pipeline_without_batching_8x720p_eight_slots():
     _run_pipeline(720, 1280, 1600, list(range(8)), 8, 8, 32)
 
 
