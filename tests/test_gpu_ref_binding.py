@@ -1,7 +1,8 @@
 """The REFERENCE's own Cython binding with the arch "hip/gfx950" patched in (integration/hip_arch.patch, built by
-integration/build_ref_binding.sh into integration/_build/fast-slic and shipped to the GPU box like oracle/_ref):
-`fast_slic.hip.SlicHip(K).iterate(img)` must equal `fast_slic.Slic(K).iterate(img)` through the real cfast_slic
-(cfast_slic.pyx:150-260, fast_slic/avx2.py:1-14 is the pattern fast_slic/hip.py follows)."""
+integration/build_ref_binding.sh from a scratch copy of the reference; only the built module, integration/_build/cfast_slic*.so,
+ships to the GPU box, like oracle/_ref): through the real cfast_slic.SlicModel (cfast_slic.pyx:14-328) the arch
+"hip/gfx950" must give what the arch "standard" / "x64/avx2" give.  The models are driven the way fast_slic/base_slic.py:18-52
+drives them (attributes, initialize on first use, iterate)."""
 import glob
 import os
 import subprocess
@@ -11,7 +12,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BUILD = os.path.join(ROOT, "integration", "_build", "fast-slic")
+BUILD = os.path.join(ROOT, "integration", "_build")
 
 pytestmark = pytest.mark.gpu
 
@@ -21,14 +22,27 @@ import numpy as np
 sys.path.insert(0, %(build)r)
 sys.path.insert(1, %(root)r)
 import cfast_slic
-from fast_slic import Slic, LSC
-from fast_slic.avx2 import SlicAvx2
-from fast_slic.hip import SlicHip, LSCHip
 from fast_slic_amd.synth import variant
+
+class Model(object):
+    """What fast_slic.base_slic.BaseSlic does with a SlicModel (base_slic.py:18-52, :55-56, :64-72, :84-88)."""
+    def __init__(self, arch, K, lsc=False, num_threads=-1, compactness=10):
+        m = cfast_slic.SlicModel(K, arch)
+        if lsc:
+            m.real_dist = True
+            m.real_dist_type = "lsc"
+        m.convert_to_lab = True; m.preemptive = False; m.preemptive_thres = 0.05
+        m.manhattan_spatial_dist = True; m.num_threads = num_threads; m.debug_mode = False
+        self.slic_model, self.compactness = m, compactness
+    def iterate(self, image, max_iter=10):
+        if not self.slic_model.initialized:
+            self.slic_model.initialize(image)
+        return self.slic_model.iterate(image, max_iter, self.compactness, 0.25, 3)
+
 out = {"archs": cfast_slic.get_supported_archs()}
 for (H, W, K, kind) in [(240, 320, 150, "A"), (480, 640, 200, "A"), (720, 1280, 1600, "A"), (200, 264, 120, "C")]:
     img = variant(kind, H, W)
-    a, b = Slic(num_components=K, compactness=10, num_threads=8), SlicHip(num_components=K, compactness=10)
+    a, b = Model("standard", K, num_threads=8), Model("hip/gfx950", K)
     la, lb = a.iterate(img), b.iterate(img)
     ca, cb = a.slic_model.clusters, b.slic_model.clusters
     out["%%dx%%d_k%%d_%%s" %% (W, H, K, kind)] = {"labels_equal": bool(np.array_equal(la, lb)), "dtype": str(lb.dtype),
@@ -36,14 +50,14 @@ for (H, W, K, kind) in [(240, 320, 150, "A"), (480, 640, 200, "A"), (720, 1280, 
     la2, lb2 = a.iterate(img), b.iterate(img)                      # warm start: the Cluster block carried over
     out["%%dx%%d_k%%d_%%s" %% (W, H, K, kind)]["second_call_equal"] = bool(np.array_equal(la2, lb2)) and a.slic_model.clusters == b.slic_model.clusters
 img = variant("A", 720, 1280)
-out["avx2_equal"] = bool(np.array_equal(SlicAvx2(num_components=1600, compactness=10, num_threads=8).iterate(img), SlicHip(num_components=1600, compactness=10).iterate(img)))
-l1, l2 = LSC(num_components=400, compactness=10, num_threads=1).iterate(img), LSCHip(num_components=400, compactness=10).iterate(img)
+out["avx2_equal"] = bool(np.array_equal(Model("x64/avx2", 1600, num_threads=8).iterate(img), Model("hip/gfx950", 1600).iterate(img)))
+l1, l2 = Model("standard", 400, lsc=True, num_threads=1).iterate(img), Model("hip/gfx950", 400, lsc=True).iterate(img)
 sys.path.insert(2, %(root)r + "/tests")
 from util import best_overlap, boundary_iou                       # labels are renumbered by the connectivity pass: compare partitions
 out["lsc_best_overlap"] = min(best_overlap(l1, l2), best_overlap(l2, l1))
 out["lsc_boundary_iou"] = boundary_iou(l1, l2)
 try:
-    SlicHip(num_components=10).iterate(np.zeros((4, 4, 4), np.uint8))
+    Model("hip/gfx950", 10).iterate(np.zeros((4, 4, 4), np.uint8))
     out["nchan_error"] = False
 except ValueError:
     out["nchan_error"] = True
