@@ -150,7 +150,7 @@ void slot_worker(fslic_engine* e, Slot* s) {
                 // meanwhile), so that the first groups of a burst are as full as the later ones.
                 if (a.n + unit <= limit && e->pipe_q.empty() && !e->pipe_gathering) {
                     e->pipe_gathering = true;
-                    e->cv.wait_for(lk, std::chrono::microseconds(40), [&] { return !e->pipe_q.empty() || a.quit; });
+                    e->cv.wait_for(lk, std::chrono::microseconds(100), [&] { return !e->pipe_q.empty() || a.quit; });
                     e->pipe_gathering = false;
                     gather();
                 }
