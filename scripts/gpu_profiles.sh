@@ -13,10 +13,10 @@ timeout 900 python bench.py 2> $OUT/bench.err > $OUT/bench.json; echo "bench rc=
 cd /tmp && export TMPDIR=/tmp
 # 1. the pipelined timed region under rocprofv3: per-kernel statistics and how the streams overlap
 rm -rf $OUT/p
-timeout 600 rocprofv3 --kernel-trace -d $OUT/p -o b -- python $R/bench.py --steps 60 --warmup 12 --timed-only > $OUT/bench_profiled.json 2>$OUT/bench_profiled.err
+timeout 600 rocprofv3 --kernel-trace -d $OUT/p -o b -- python $R/bench.py --steps 1500 --warmup 12 --timed-only > $OUT/bench_profiled.json 2>$OUT/bench_profiled.err
 DB=$(find $OUT/p -name '*_results.db' | head -1)
 python $R/scripts/rocpd_stats.py stats $DB $OUT/bench_kernel_stats.csv > /dev/null
-python $R/scripts/rocpd_stats.py overlap $DB 0.4 > $OUT/bench_stream_overlap.txt
+python $R/scripts/rocpd_stats.py overlap $DB 0.1 > $OUT/bench_stream_overlap.txt      # (the last tenth of the trace: all of it inside the timed region)
 python $R/scripts/rocpd_stats.py window $DB 4000 500 > $OUT/bench_all_streams_window.txt
 rm -rf $OUT/p
 # 2. single-stream groups of the BASELINE configurations
