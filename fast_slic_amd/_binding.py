@@ -32,7 +32,7 @@ class Params(C.Structure):
         ("subsample_stride", C.c_int32), ("convert_to_lab", C.c_int32),
         ("manhattan_spatial_dist", C.c_int32), ("preemptive", C.c_int32),
         ("preemptive_thres", C.c_float), ("num_threads", C.c_int32), ("debug_mode", C.c_int32),
-        ("force_generic", C.c_int32), ("variant", C.c_int32), ("reserved", C.c_int32 * 4),
+        ("variant", C.c_int32), ("reserved", C.c_int32 * 5),
     ]
 
 
@@ -109,8 +109,7 @@ def load_library():
         lib.fslic_hip_pipeline_drain.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
         lib.fslic_hip_pipeline_batching.argtypes = [vp, i32]
         lib.fslic_hip_last_host_topk_frames.argtypes = [vp, i32]
-        if hasattr(lib, "fslic_hip_group_done"):
-            lib.fslic_hip_group_done.argtypes = [vp, i32]
+        lib.fslic_hip_group_done.argtypes = [vp, i32]
         lib.fslic_hip_rgb_to_lab.argtypes = [vp, i32, i32, vp, i32, vp]
         lib.fslic_hip_enforce_connectivity.argtypes = [vp, vp, i32, i32, i32, i32]
         lib.fslic_hip_last_prelabels.argtypes = [vp, i32, vp]
@@ -121,15 +120,14 @@ def load_library():
         lib.fslic_hip_last_assign_loop.argtypes = [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int)]
         lib.fslic_hip_last_group_frames.argtypes = [vp, i32]
         lib.fslic_hip_last_path.argtypes = [vp, i32]
-        if hasattr(lib, "fslic_hip_last_launch_mode"):      # absent in older builds loaded through FSLIC_LIB
-            lib.fslic_hip_last_launch_mode.argtypes = [vp, i32]
+        lib.fslic_hip_last_launch_mode.argtypes = [vp, i32]
+        lib.fslic_hip_lab_force_generic.argtypes = [vp, i32]      # testing aid, not in include/fslic_hip.h
         lib.fslic_hip_last_error.restype = C.c_char_p
         lib.fslic_hip_version.restype = C.c_char_p
-        if hasattr(lib, "fslic_hip_get_connectivity"):
-            lib.fslic_hip_get_connectivity.argtypes = [vp, i32, i32, i32, vp, vp, vp]
-            lib.fslic_hip_knn_connectivity.argtypes = [i32, i32, i32, vp, C.c_size_t, vp, vp]
-            lib.fslic_hip_get_mask_density.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
-            lib.fslic_hip_cluster_density_to_mask.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+        lib.fslic_hip_get_connectivity.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+        lib.fslic_hip_knn_connectivity.argtypes = [i32, i32, i32, vp, C.c_size_t, vp, vp]
+        lib.fslic_hip_get_mask_density.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
+        lib.fslic_hip_cluster_density_to_mask.argtypes = [vp, i32, i32, i32, vp, vp, vp]
         _lib = lib
         return lib
 
@@ -317,6 +315,10 @@ class Engine(object):
     def last_path(self, slot=0):
         return load_library().fslic_hip_last_path(self._h, int(slot))
 
+    def lab_force_generic(self, on):
+        """Testing aid (not in include/fslic_hip.h): the following Slic groups of this engine take the brute-force gather kernel."""
+        _check(load_library().fslic_hip_lab_force_generic(self._h, int(bool(on))))
+
 
 _default_engines = {}
 _engine_lock = threading.Lock()
@@ -352,7 +354,7 @@ def get_supported_archs():
 
 def make_params(max_iter, compactness, min_size_factor, subsample_stride, convert_to_lab=True,
                 manhattan_spatial_dist=True, preemptive=False, preemptive_thres=0.05, num_threads=-1,
-                debug_mode=False, force_generic=False, variant=0):
+                debug_mode=False, variant=0):
     p = Params()
     p.variant = int(variant)        # 0: Slic (Context), 1: LSC (ContextLSC)
     p.max_iter = int(max_iter)
@@ -365,7 +367,6 @@ def make_params(max_iter, compactness, min_size_factor, subsample_stride, conver
     p.preemptive_thres = float(preemptive_thres)
     p.num_threads = int(num_threads)
     p.debug_mode = int(bool(debug_mode))
-    p.force_generic = int(bool(force_generic))
     return p
 
 
@@ -399,7 +400,6 @@ class SlicModel(object):
         self.manhattan_spatial_dist = True
         self.last_timing_report = ""
         self.last_recorder_report = ""
-        self.force_generic = False
         self.device = int(device)
         self._clusters = np.zeros(self.num_components, CLUSTER_DTYPE)              # pyx:38-39
         self._engine = default_engine(self.device)   # raises when no GPU / library: no CPU fallback
@@ -518,7 +518,7 @@ class SlicModel(object):
             variant = _REAL_DIST_VARIANTS[self.real_dist_type]
         p = make_params(max_iter, compactness, min_size_factor, subsample_stride, self.convert_to_lab,
                         self.manhattan_spatial_dist, self.preemptive, self.preemptive_thres,
-                        self.num_threads, self.debug_mode, self.force_generic, variant)
+                        self.num_threads, self.debug_mode, variant)
         labels = self._engine.iterate(image, self._clusters, p)
         self.last_timing_report = self._engine.last_timing_report()
         result = labels.astype(np.int16)                                           # pyx:258-260

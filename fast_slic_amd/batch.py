@@ -3,8 +3,8 @@
 Frames of a batch have no data dependency on each other (every frame owns its Cluster[K] and its label
 map), so the multi-GPU path is: one process per GPU, each process runs its own shard
 through `Engine.iterate_batch`, and NO data-path collective exists.  `torch.distributed` carries only the
-barrier around the timed region and the max-over-ranks of the elapsed time (RCCL on the GPU box, gloo in
-the CPU tests).  Nothing here touches a kernel; tests/test_batch_sharding.py runs it at world_size 2.
+barrier around the timed region and the max-over-ranks of the elapsed time, over gloo everywhere (RCCL is never
+initialised: `north_star` says "RCCL unused").  Nothing here touches a kernel; tests/test_batch_sharding.py runs it at world_size 2.
 """
 import os
 

@@ -159,6 +159,9 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     c.counters = misc + 4;
     c.cand_leader = (int32_t*)(b + o_candl); c.cand_area = (uint32_t*)(b + o_canda);
     s.cand_capacity = ntiles * TT;
+#if defined(FSLIC_LAB) && FSLIC_LAB == 4
+    f.lab_stamps = c.cand_area;
+#endif
     s.d_keep_leader = (int32_t*)(b + o_keepl); s.d_keep_label = (uint16_t*)(b + o_keepb);
     s.d_rgb_stage = (uint8_t*)(b + o_rgb); s.d_out_stage = (uint16_t*)(b + o_out);
     s.keyH = H; s.keyW = W; s.keyK = K;
@@ -175,6 +178,9 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
 }
 
 int ensure_prepared(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
+    // room for the groups batching will form later (fslic_hip_pipeline_batching): applied HERE, so that every caller --
+    // including the host-memory entry points, which stage frames into the arena before group_begin runs -- carves once
+    G = std::max(G, std::min(e->reserve_frames.load(), (int)kMaxGroup));
     if (s.keyH == H && s.keyW == W && s.keyK == K && s.cap_frames >= G) return FSLIC_OK;
     HIPCHK(hipStreamSynchronize(s.st));
     return prepare(e, s, H, W, K, S, G);

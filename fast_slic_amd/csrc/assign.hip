@@ -406,6 +406,13 @@ static __device__ __forceinline__ void row_masks(uint32_t inv, uint32_t (&m)[R /
 // row lies inside the wavefront's rows is walked twice (rows above, rows below).  Lanes outside the x window use
 // ux = 2S+1, which lands beyond 2S for every row; rows outside the y window are switched off by a per-pair scalar
 // mask OR-ed into the idx operand on the scalar unit (0xffff + anything saturates: no extra VALU).
+#if defined(FSLIC_LAB) && FSLIC_LAB == 4      // lab build 4: phase time stamps (100 MHz ticks since the block's start), 16 words per (pass, block)
+#define ASG_STAMP(i_, cond_) do { if ((cond_) && lane == 0) { asm volatile("" ::: "memory"); asg_w[(i_)] = (uint32_t)__builtin_amdgcn_s_memrealtime() - asg_t0; asm volatile("" ::: "memory"); } } while (0)
+#define ASG_PUT(i_, cond_, v_) do { if ((cond_) && lane == 0) asg_w[(i_)] = (uint32_t)(v_); } while (0)
+#else
+#define ASG_STAMP(i_, cond_) do { } while (0)
+#define ASG_PUT(i_, cond_, v_) do { } while (0)
+#endif
 template <int R, bool FUSE, int STRIDE, bool VT>
 static __device__ __forceinline__ void assign_blk_body(FrameDev& f, int rem, int Hv) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];   // spatial table (u16), f.tab_words dwords; 16-byte aligned: the row-vector reads are ds_read_b128
@@ -436,6 +443,11 @@ static __device__ __forceinline__ void assign_blk_body(FrameDev& f, int rem, int
     const bool okx = x < W;
     const int nrows = max(0, min(R, Hv - vrow_w0));      // 0: this wavefront has no rows (bottom edge)
     const int yw_lo = rem + vrow_w0 * STRIDE;
+#if defined(FSLIC_LAB) && FSLIC_LAB == 4
+    const uint32_t asg_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    volatile uint32_t* const asg_w = f.lab_stamps + ((size_t)(f.gen_off - 1u) * 2048u + (size_t)(blockIdx.y * gridDim.x + blockIdx.x)) * 16u;
+    ASG_PUT(0, wave == 0, asg_t0);
+#endif
 
     // 1. pixel loads: nothing depends on them until the argmin, but they are issued AFTER the loads the prologue waits
     // for (bins, table).  Every wavefront of the chip starts at the same time; with the pixel loads first the few bytes on the
@@ -550,6 +562,7 @@ static __device__ __forceinline__ void assign_blk_body(FrameDev& f, int rem, int
             }
         }
         if (lane == 0) s_bn = (uint32_t)bn;
+        ASG_STAMP(1, true);
     } else {
         // 2b. spatial table -> LDS, four 16-byte loads in flight per thread; centroid accumulators <- 0
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(f.tab);
@@ -575,8 +588,10 @@ static __device__ __forceinline__ void assign_blk_body(FrameDev& f, int rem, int
 #pragma unroll
             for (int i = 0; i < (64 * kBlkCopies * 2 + 191) / 192; ++i) s_acc[min(i * 192 + t, 64 * kBlkCopies * 2 - 1)] = 0ull;
         }
+        ASG_STAMP(2, wave == ((gwave + 1) & 3));
     }
     __syncthreads();
+    ASG_STAMP(3, wave == 0);
     const int bn = (int)rfl(s_bn);
     if (bn > 64) {                            // more live candidates than idx bits: the host redoes the frame generically
         if (tid == 0) *f.err_flag = 1u;
@@ -725,6 +740,9 @@ static __device__ __forceinline__ void assign_blk_body(FrameDev& f, int rem, int
     }
     }
 
+    ASG_STAMP(4, wave == 0);
+    ASG_PUT(9, wave == 0, __popcll(todo));
+    ASG_PUT(10, wave == 0, bn);
     // 5. write labels (+ fused centroid sums)
     uint32_t slot[R];
     {
@@ -775,6 +793,7 @@ static __device__ __forceinline__ void assign_blk_body(FrameDev& f, int rem, int
         }
     }
     }
+    ASG_STAMP(5, wave == 0);
     if (FUSE) {
         {
             // A column's rows fall into one or two runs of equal slot (a superpixel is taller than a wavefront's rows), so the
@@ -804,7 +823,9 @@ static __device__ __forceinline__ void assign_blk_body(FrameDev& f, int rem, int
             }
             flush();
         }
+        ASG_STAMP(6, wave == 0);
         __syncthreads();
+        ASG_STAMP(7, wave == 0);
         // one plain store per (candidate, quantity): entry reserved for (cluster, this block), zeros included
         const uint32_t yb0 = (uint32_t)(rem + vrow_b0 * STRIDE);
         for (int i = tid; i < bn * 6; i += 256) {
@@ -826,6 +847,447 @@ static __device__ __forceinline__ void assign_blk_body(FrameDev& f, int rem, int
             }
         }
     }
+    ASG_STAMP(8, wave == 0);
+}
+
+// =============================================================================================
+// Block assign kernel, second form (round 3).  Same tile, same argmin loops, same fused sums as assign_blk_body above; what
+// changed is everything around them, which the phase stamps of lab build 4 (profiles/r03_lab_assign_phases_*.txt) showed to be
+// a third of a block's life as one wavefront's serial work:
+//   * the candidate list is gathered by ALL four wavefronts (one 16-byte bin slot per thread and trip, ballot compaction into
+//     per-wavefront parts of an LDS array: no atomics, no serial walk over six cell rows by one wavefront)
+//   * the (phase, k) ranks are counted in four partial sums, one per wavefront, and meet in LDS (second barrier); the list stays
+//     in arrival order, the rank of a candidate rides in the top byte of its colour word
+//   * the spatial table is brought in by LDS-DMA (global_load_lds_dwordx4, 1 KB per wavefront instruction): no staging
+//     registers and no ds_write pass
+// =============================================================================================
+// One LDS-DMA piece: 64 lanes x 16 bytes from per-lane global addresses to LDS at `lds_byte_addr` + lane * 16 (M0 carries the
+// LDS base and is restored).  Issued through inline assembly on purpose: with the builtin the compiler waits for EVERY
+// outstanding load (vmcnt(0)) at the next use of an ordinary load's result; like this its counters simply do not include the
+// piece (loads return in order, so its own waits stay sufficient) and the one wait the piece needs is stated before the barrier.
+static __device__ __forceinline__ void lds_dma_16(const void* gsrc, uint32_t lds_byte_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+
+template <int R, bool FUSE, int STRIDE, bool VT>
+static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, int Hv) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];   // spatial table (u16), whole KB (LDS-DMA lands 1 KB per wavefront instruction); 16-byte aligned: the row-vector reads are ds_read_b128
+    __shared__ __attribute__((aligned(16))) uint4 s_raw[kWavesPerBlock][64];       // every wavefront's kept records {yx, lab, tag, -}
+    __shared__ __attribute__((aligned(16))) uint32_t s_part[64][4];                // partial ranks: [candidate][wavefront]
+    __shared__ __attribute__((aligned(16))) uint32_t s_wcnt[4];                    // kept records per wavefront
+    __shared__ __attribute__((aligned(16))) uint16_t s_k16[kWavesPerBlock][64];    // per wavefront (no barrier lies between its writes and the epilogue's reads): cluster number by rank
+    __shared__ __attribute__((aligned(16))) uint32_t s_entry[FUSE ? 64 : 4];       // cpart entry by rank | kNoSlot
+    // centroid accumulators: per (candidate, copy) two 64-bit words of three 20-bit-spaced fields each,
+    //   A = sum L | sum a << 20 | sum b << 40        B = sum (x - x0) | sum (y - y0) << 20 | count << 40
+    __shared__ __attribute__((aligned(16))) unsigned long long s_acc[FUSE ? 64 * kBlkCopies * 2 : 2];
+    static_assert(R % 2 == 0, "rows are processed in pairs");
+    constexpr int BH = kWavesPerBlock * R;
+    static_assert(!FUSE || (BH * 64 * 255 < (1 << 20) && (BH - 1) * STRIDE * BH * 64 < (1 << 20)), "accumulator fields overflow");
+
+    f.select(blockIdx.z);
+    const uint32_t gen = f.generation();
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = (int)rfl((uint32_t)(tid >> 6));
+    const int W = f.W, S = f.S;
+    const int x0 = blockIdx.x * kTileW;
+    const int x = x0 + lane;
+    const int vrow_b0 = blockIdx.y * BH;
+    const int vrow_w0 = vrow_b0 + wave * R;
+    const bool okx = x < W;
+    const int nrows = max(0, min(R, Hv - vrow_w0));      // 0: this wavefront has no rows (bottom edge)
+    const int yw_lo = rem + vrow_w0 * STRIDE;
+#if defined(FSLIC_LAB) && FSLIC_LAB == 4
+    const uint32_t asg_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    volatile uint32_t* const asg_w = f.lab_stamps + ((size_t)(f.gen_off - 1u) * 2048u + (size_t)(blockIdx.y * gridDim.x + blockIdx.x)) * 16u;
+    ASG_PUT(0, wave == 0, asg_t0);
+#endif
+
+    // 1. pixel loads: nothing depends on them until the argmin, but they are issued AFTER the loads the prologue waits
+    // for (bins, table).  Every wavefront of the chip starts at the same time; with the pixel loads first the few bytes on the
+    // critical path queued behind the whole frame's pixel traffic (prologue 4 us of a wavefront life of 8 us at 4K).
+    // Out-of-image lanes and rows re-read the last valid column / row instead of being masked off: no exec juggling
+    // around the loads (their results are never stored and never reach the centroid sums).
+    uint32_t pix[R];
+    auto load_pixels = [&]() {
+        const uint32_t xc = (uint32_t)min(x, W - 1);
+        const int nr1 = (int)rfl((uint32_t)(max(nrows, 1) - 1));      // a wavefront without rows (bottom edge) re-reads the image's last visited row
+        const int ybase = (int)rfl((uint32_t)(nrows > 0 ? yw_lo : rem + (Hv - 1) * STRIDE));   // (both wave-uniform: stated, the scalar offsets below must be SGPRs)
+        // buffer loads: the row goes into the instruction's scalar offset, the column into ONE shared vector offset, so a
+        // row costs no vector instruction beyond the load itself (a 64-bit address per row was 6 scalar + 1 vector)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(f.lab), 0, (int)((uint32_t)f.N * 4u), kRawBuffer);
+        const uint32_t pitch = (uint32_t)(STRIDE * W) * 4u, soff0 = (uint32_t)ybase * (uint32_t)W * 4u;
+        const int vo = (int)(xc * 4u);
+#pragma unroll
+        for (int r = 0; r < R; ++r) pix[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (int)(soff0 + (uint32_t)min(r, nr1) * pitch), 0);
+    };
+
+    // 2. The block's candidates, by all four wavefronts: every thread fetches ONE 16-byte bin slot per trip (all the slots the
+    // block's pixels can see: 240 at 1280x720 K=1600, i.e. one trip), keeps the live records inside the window and appends them
+    // to its wavefront's part of s_raw (ballot compaction, no atomics).  Meanwhile the spatial table arrives by LDS-DMA and the
+    // pixel loads are in flight.
+    const int sh = f.cs_shift;
+    TileWindow win;
+    {
+        const int vlast = min(vrow_b0 + BH - 1, Hv - 1);
+        win.wy_lo = rem + vrow_b0 * STRIDE - S; win.wy_hi = rem + vlast * STRIDE + S;
+        win.wx_lo = x0 - S;                     win.wx_hi = min(x0 + kTileW - 1, W - 1) + S;
+    }
+    const int cxa = max(win.wx_lo, 0) >> sh, cxb = min(win.wx_hi, W - 1) >> sh;
+    const int cya = max(win.wy_lo, 0) >> sh, cyb = min(win.wy_hi, f.H - 1) >> sh;
+    const uint32_t ncxr = (uint32_t)(cxb - cxa + 1);
+    const uint32_t nslots = ncxr * (uint32_t)(cyb - cya + 1) * (uint32_t)kCellCap;
+    const uint32_t inv = (uint32_t)(65536.0f * __builtin_amdgcn_rcpf((float)ncxr)) + 1u;      // cell / ncxr == (cell * inv) >> 16 for the few hundred cells here (guarded below)
+    const char* const cbase = reinterpret_cast<const char*>(f.cell_items[0]);
+    auto slot_ptr = [&](uint32_t e) -> const ClusterRec* {      // slot e of the block's cell range, cells row-major (slots past the end re-read slot 0..7 of the first cell)
+        const uint32_t cell = e < nslots ? e >> 3 : 0u;
+        uint32_t cyi = (cell * inv) >> 16;
+        if (cyi * ncxr > cell) cyi--;
+        const uint32_t cxi = cell - cyi * ncxr;
+        const uint32_t off = (((uint32_t)cya + cyi) * (uint32_t)f.ncx + (uint32_t)cxa + cxi) * (uint32_t)(kCellCap * sizeof(ClusterRec)) + (e & 7u) * (uint32_t)sizeof(ClusterRec);
+        return reinterpret_cast<const ClusterRec*>(cbase + off);
+    };
+    const ClusterRec rec0 = *slot_ptr((uint32_t)tid);
+    const uint32_t novf = *f.ovf_cnt[0];
+    ClusterRec rec1;
+    rec1.yx = 0; rec1.lab = 0; rec1.tag = 0; rec1.pad = 0;
+    if (nslots > 256u) rec1 = *slot_ptr(256u + (uint32_t)tid);                // (uniform)
+    {   // spatial table -> LDS, 1 KB per wavefront instruction (no staging registers, no ds_write pass); the last piece re-reads the
+        // table's last 16 bytes for the lanes past its end (they land in the padding of the KB)
+        const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)s_dyn;
+        const int nq = f.tab_words >> 2, nkb = (nq + 63) >> 6;
+        for (int i = wave; i < nkb; i += kWavesPerBlock)
+            lds_dma_16(reinterpret_cast<const uint4*>(f.tab) + min(i * 64 + lane, nq - 1), lds0 + (uint32_t)i * 1024u);
+    }
+    if (FUSE) reinterpret_cast<uint4*>(s_acc)[tid] = make_uint4(0u, 0u, 0u, 0u);    // 64 * kBlkCopies * 2 * 8 bytes = 256 threads x 16
+    static_assert(64 * kBlkCopies * 2 * 8 == 256 * 16, "one 16-byte store per thread clears the accumulators");
+    load_pixels();
+    {
+        int cnt = 0;
+        uint4* const myraw = s_raw[wave];
+        auto visit = [&](const ClusterRec& rec, bool keep) {
+            const unsigned long long m = __ballot(keep);
+            const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)cnt));
+            if (keep && pos < 64) myraw[pos] = make_uint4(rec.yx, rec.lab, rec.tag, 0u);
+            cnt += __popcll(m);
+        };
+        visit(rec0, (uint32_t)tid < nslots && rec0.pad == gen && in_window(rec0, win));
+        if (nslots > 256u) visit(rec1, 256u + (uint32_t)tid < nslots && rec1.pad == gen && in_window(rec1, win));
+        for (uint32_t e0 = 512u; e0 < nslots; e0 += 256u) {                        // (blocks that see more than 64 cells: S < 16)
+            const ClusterRec rec = *slot_ptr(e0 + (uint32_t)tid);
+            visit(rec, e0 + (uint32_t)tid < nslots && rec.pad == gen && in_window(rec, win));
+        }
+        if (wave == kWavesPerBlock - 1) {                                          // the spill list (cells with more than kCellCap centres)
+            const ClusterRec* __restrict__ oitems = f.ovf_items[0];
+            for (uint32_t i0 = 0; i0 < novf; i0 += 64) {
+                const uint32_t i = i0 + (uint32_t)lane;
+                ClusterRec rec;
+                rec.yx = 0; rec.lab = 0; rec.tag = 0; rec.pad = 0;
+                if (i < novf) rec = oitems[i];
+                visit(rec, i < novf && in_window(rec, win));
+            }
+        }
+        if (lane == 0) s_wcnt[wave] = (uint32_t)cnt;
+    }
+    ASG_STAMP(1, wave == 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the table has landed (the compiler's counters do not include the LDS-DMA loads)
+    __syncthreads();
+    ASG_STAMP(2, wave == 0);
+    // lane j = candidate j of the block (raw order: wavefront 0's records, then wavefront 1's, ...)
+    int bn;
+    uint4 mine;
+    {
+        const uint4 wc = *reinterpret_cast<const uint4*>(s_wcnt);
+        const int c0 = (int)rfl(wc.x), c1 = (int)rfl(wc.y), c2 = (int)rfl(wc.z), c3 = (int)rfl(wc.w);
+        bn = c0 + c1 + c2 + c3;
+        if (bn > 64) {                        // more live candidates than idx bits: the host redoes the frame generically
+            if (tid == 0) *f.err_flag = 1u;
+            return;
+        }
+        const int p1 = c0, p2 = c0 + c1, p3 = c0 + c1 + c2;
+        const int idx = lane + (lane >= p1 ? 64 - c0 : 0) + (lane >= p2 ? 64 - c1 : 0) + (lane >= p3 ? 64 - c2 : 0);     // [wavefront][position] flattened
+        mine = (&s_raw[0][0])[lane < bn ? idx : 0];
+        if (lane >= bn) mine.z = 0xFFFFFFFFu;
+    }
+    // rank by (phase, k) = visit order of the reference's scatter (src/context.cpp:214-242): wavefront w compares every
+    // candidate with candidates w, w+4, ..; the four partial counts meet in LDS
+    {
+        const uint32_t tag_j = mine.z;
+        uint32_t part = 0;
+        for (int i = wave; i < bn; i += kWavesPerBlock) part += (uint32_t)(__builtin_amdgcn_readlane(tag_j, i) < tag_j);
+        s_part[lane][wave] = part;
+    }
+    __syncthreads();
+    uint32_t rank_j;
+    {
+        const uint4 pr = *reinterpret_cast<const uint4*>(s_part[lane]);
+        rank_j = pr.x + pr.y + pr.z + pr.w;
+    }
+    if (lane < bn) s_k16[wave][rank_j] = (uint16_t)(mine.z & 0xFFFFu);
+    if (FUSE && wave == 0) {
+        uint32_t entry = kNoSlot;
+        const SlotGeom g = slot_geom((int)(mine.x >> 16), (int)(mine.x & 0xFFFFu), S, f.H, W, rem, STRIDE, BH, Hv);
+        const int by = (int)blockIdx.y, bx = (int)blockIdx.x;
+        if (g.any && by >= g.by0 && by <= g.by1)
+            entry = ((mine.z & 0xFFFFu) * (uint32_t)f.cpart_ns + (uint32_t)((by - g.by0) * f.nbx + (bx - g.bx0))) * 6u;
+        if (lane < bn) s_entry[rank_j] = entry;
+    }
+    ASG_STAMP(3, wave == 0);
+
+    // 3. the block list in registers: lane j = candidate j; candidates whose window reaches this wavefront's rows
+    // (the rank travels in the top byte of the colour word: one v_readlane fetches both)
+    const uint32_t yx_j = mine.x, lab_j = mine.y | (rank_j << 24);
+    const int yw_hi = yw_lo + (nrows - 1) * STRIDE;
+    unsigned long long todo;
+    {
+        const int cyj = (int)(yx_j >> 16);
+        todo = __ballot(lane < bn && nrows > 0 && cyj + S >= yw_lo && cyj - S <= yw_hi);
+    }
+
+    // 4. the argmin, two rows per instruction
+    us2 best[R / 2];
+#pragma unroll
+    for (int q = 0; q < R / 2; ++q) best[q] = (us2){0xFFFF, 0xFFFF};
+    const uint32_t nrpad = (uint32_t)f.tab_nrpad;
+    const int dyoff = f.tab_dyoff;
+    if (VT) {
+        const int Cc = f.tab_dyoff;                 // centre index of the V table
+        const uint32_t xout = (uint32_t)f.tab_xout;
+        constexpr int BIAS = 32768;                 // makes the numerators of the row-range divisions positive
+        constexpr uint32_t full = (1u << R) - 1u;
+        // Per-candidate row ranges, computed ONCE in the vector unit with lane j = candidate j (the scalar unit is
+        // shared by the whole CU and issues about as many instructions per clock as the four SIMDs together).
+        //   rows r with dy_r = dy0 + r*STRIDE: above the centre r < rs, inside the window ra <= r <= rb
+        uint32_t vab_j;                             // rows above (low half) | rows at/below (high half) that are in the window
+        {
+            const int dy0 = yw_lo - (int)(yx_j >> 16);
+            const int rs = min(max((-dy0 + STRIDE * BIAS + STRIDE - 1) / STRIDE - BIAS, 0), R);
+            const int ra = min(max((-S - dy0 + STRIDE * BIAS + STRIDE - 1) / STRIDE - BIAS, 0), R);
+            const int rb = min(max((S - dy0 + STRIDE * BIAS) / STRIDE - BIAS, -1), R - 1);
+            const uint32_t upto_rs = (1u << rs) - 1u;
+            const uint32_t in_win = rb < 0 ? 0u : (((2u << rb) - 1u) & ~((1u << ra) - 1u) & full);
+            vab_j = (in_win & upto_rs) | ((in_win & ~upto_rs) << 16);
+        }
+        // row-vector table: entry t = (V[t], V[t+STRIDE], .. V[t+7*STRIDE]) as one 16-byte word, so the spatial terms of
+        // eight rows are ONE 16-byte-ALIGNED ds_read_b128 (a 2-byte-aligned b128 read costs 64 clk of the CU's LDS pipe
+        // instead of 8, scripts/microbench/lds_unaligned.hip)
+        const uint4* const s_rv = reinterpret_cast<const uint4*>(s_dyn);
+        auto pass = [&](uint32_t clab, uint32_t base, uint32_t idx01, const uint32_t* mq) {
+            uint32_t spw[R / 2];
+            {
+                const uint4 e0 = s_rv[base];
+                spw[0] = e0.x; spw[1] = e0.y; spw[2] = e0.z; spw[3] = e0.w;
+                if (R == 16) {
+                    const uint4 e1 = s_rv[base + 8 * STRIDE];
+                    spw[R / 2 - 4] = e1.x; spw[R / 2 - 3] = e1.y; spw[R / 2 - 2] = e1.z; spw[R / 2 - 1] = e1.w;
+                }
+            }
+            // sweeps over the row pairs instead of one chain per pair: a packed op that consumes the result of the
+            // packed op issued just before it costs a wait state (s_nop) on this target
+            uint32_t t[R / 2];
+#pragma unroll
+            for (int q = 0; q < R / 2; ++q) {
+                const uint32_t s0 = __builtin_amdgcn_sad_u8(pix[2 * q], clab, spw[q]);          // spatial pair + colour distance of row 2q
+                t[q] = __builtin_amdgcn_sad_hi_u8(pix[2 * q + 1], clab, s0);                     // + colour distance of row 2q+1 in the high half
+            }
+            us2 key[R / 2];
+#pragma unroll
+            for (int q = 0; q < R / 2; ++q) key[q] = key_pair(t[q], mq ? (mq[q] | idx01) : idx01);
+#pragma unroll
+            for (int q = 0; q < R / 2; ++q) min_in_place(best[q], key[q]);
+        };
+        // Four loops, each with ONE straight-line form of the pass (the order of the candidates is irrelevant: the key
+        // carries idx).  With the forms as branches of one loop body the compiler linearised them into guarded blocks,
+        // kept the running minima in two register sets and copied between them: 8-16 v_mov per candidate.
+        //   whole : every row inside the window and on one side of the centre (above: index k0 - |dx|, below: k0 + |dx|): no masks
+        //   above : some rows above the centre, masked          below : some rows at/below the centre, masked
+        // (a candidate whose centre row lies inside this wavefront's rows is in both masked loops)
+        const bool mine_todo = (todo >> lane) & 1ull;
+        const uint32_t va_j = vab_j & 0xFFFFu, vb_j = vab_j >> 16;
+        unsigned long long todo_wa = __ballot(mine_todo && va_j == full);      // whole, above the centre
+        unsigned long long todo_wb = __ballot(mine_todo && vb_j == full);      // whole, at/below
+        unsigned long long todo_above = __ballot(mine_todo && va_j != 0u && va_j != full);
+        unsigned long long todo_below = __ballot(mine_todo && vb_j != 0u && vb_j != full);
+        // CLAMP: lanes outside the x window get |dx| = xout (every row then reads the marker); !CLAMP: the caller runs the pass
+        // under `if (uxc <= S)` instead, i.e. with those lanes switched off (one vector instruction less per candidate)
+        auto fetch = [&](int c, uint32_t& clab, uint32_t& uxc, uint32_t& k0, uint32_t& idx01, auto clamp_tag) {
+            constexpr bool CLAMP = decltype(clamp_tag)::value;
+            const uint32_t cyx = __builtin_amdgcn_readlane(yx_j, c);
+            const uint32_t clabx = __builtin_amdgcn_readlane(lab_j, c);
+            clab = clabx & 0x00FFFFFFu;
+            const int cy = (int)(cyx >> 16), cx = (int)(cyx & 0xFFFFu);
+            const uint32_t ux = __builtin_amdgcn_sad_u16((uint32_t)x, (uint32_t)cx, 0u);      // |x - cx|
+            uxc = CLAMP ? (ux <= (uint32_t)S ? ux : xout) : ux;
+            k0 = (uint32_t)(Cc + yw_lo - cy);                                                  // wave-uniform
+            idx01 = (clabx >> 24) * 0x10001u;                                                  // rank | rank << 16
+        };
+#pragma unroll 1
+        while (todo_wa) {
+            const int c = __builtin_ctzll(todo_wa);
+            todo_wa &= todo_wa - 1ull;
+            uint32_t clab, uxc, k0, idx01;
+            fetch(c, clab, uxc, k0, idx01, std::false_type{});
+            if (uxc <= (uint32_t)S) pass(clab, k0 - uxc, idx01, nullptr);
+        }
+#pragma unroll 1
+        while (todo_wb) {
+            const int c = __builtin_ctzll(todo_wb);
+            todo_wb &= todo_wb - 1ull;
+            uint32_t clab, uxc, k0, idx01;
+            fetch(c, clab, uxc, k0, idx01, std::false_type{});
+            if (uxc <= (uint32_t)S) pass(clab, k0 + uxc, idx01, nullptr);
+        }
+#pragma unroll 1
+        while (todo_above) {
+            const int c = __builtin_ctzll(todo_above);
+            todo_above &= todo_above - 1ull;
+            uint32_t clab, uxc, k0, idx01, mq[R / 2];
+            fetch(c, clab, uxc, k0, idx01, std::true_type{});
+            row_masks<R>(~__builtin_amdgcn_readlane(va_j, c) & full, mq);
+            pass(clab, k0 - uxc, idx01, mq);
+        }
+#pragma unroll 1
+        while (todo_below) {
+            const int c = __builtin_ctzll(todo_below);
+            todo_below &= todo_below - 1ull;
+            uint32_t clab, uxc, k0, idx01, mq[R / 2];
+            fetch(c, clab, uxc, k0, idx01, std::true_type{});
+            row_masks<R>(~__builtin_amdgcn_readlane(vb_j, c) & full, mq);
+            pass(clab, k0 + uxc, idx01, mq);
+        }
+    } else {
+#pragma unroll 1
+    while (todo) {
+        const int c = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const uint32_t cyx = __builtin_amdgcn_readlane(yx_j, c);
+        const uint32_t clabx = __builtin_amdgcn_readlane(lab_j, c);
+        const uint32_t clab = clabx & 0x00FFFFFFu;
+        const int cy = (int)(cyx >> 16), cx = (int)(cyx & 0xFFFFu);
+        const uint32_t ux = __builtin_amdgcn_sad_u16((uint32_t)x, (uint32_t)cx, 0u);      // |x - cx|
+        const uint32_t uxc = min(ux, (uint32_t)(S + 1));
+        const uint32_t a0 = __umul24(uxc, nrpad) + (uint32_t)(yw_lo - cy + dyoff);        // dword index of the pair (row 0, row 1)
+        const uint32_t idx01 = (clabx >> 24) * 0x10001u;                                  // rank | rank << 16
+#pragma unroll
+        for (int q = 0; q < R / 2; ++q) {
+            const uint32_t sp = s_dyn[a0 + (2 * q) * STRIDE];                                 // one aligned ds_read_b32 per row pair
+            const uint32_t s0 = __builtin_amdgcn_sad_u8(pix[2 * q], clab, sp);
+            const uint32_t s01 = __builtin_amdgcn_sad_hi_u8(pix[2 * q + 1], clab, s0);
+            min_in_place(best[q], key_pair(s01, idx01));
+        }
+    }
+    }
+
+    ASG_STAMP(4, wave == 0);
+    ASG_PUT(9, wave == 0, __popcll(todo));
+    ASG_PUT(10, wave == 0, bn);
+    // 5. write labels (+ fused centroid sums)
+    uint32_t slot[R];
+    {
+        uint32_t kk[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t key = (r & 1) ? (uint32_t)best[r / 2].y : (uint32_t)best[r / 2].x;
+            kk[r] = s_k16[wave][key & 63u];                         // entry 63 when not found: read, never used
+        }
+        uint16_t* rowp = f.labels + (size_t)yw_lo * W;
+        const uint32_t xo = (uint32_t)x;
+        // Interior wavefront with every pixel assigned (the rule, by far): straight-line stores under one column mask.
+        // Otherwise (bottom rows missing, or a pixel no window reached: it keeps its label and still takes part in the
+        // update) row by row with the full rules.
+        us2 worst = best[0];
+#pragma unroll
+        for (int q = 1; q < R / 2; ++q) worst = __builtin_elementwise_max(worst, best[q]);
+        const bool all_found = __ballot(worst.x == 0xFFFF || worst.y == 0xFFFF) == 0ull;
+        if (all_found && nrows == R) {
+            if (okx) {      // written through (sc1, see st_stream), row in the scalar offset, column in one shared vector offset
+                const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(f.labels, 0, (int)((uint32_t)f.N * 2u), kRawBuffer);
+                const uint32_t so0 = (uint32_t)yw_lo * (uint32_t)W * 2u, pitch2 = (uint32_t)(STRIDE * W) * 2u;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b16((uint16_t)kk[r], ws, (int)(xo * 2u), (int)(so0 + (uint32_t)r * pitch2), kAuxSc1);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t key = (r & 1) ? (uint32_t)best[r / 2].y : (uint32_t)best[r / 2].x;
+                slot[r] = (FUSE && okx) ? (key & 63u) : kNoSlot;
+            }
+        } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool ok = okx && r < nrows;
+            const uint32_t key = (r & 1) ? (uint32_t)best[r / 2].y : (uint32_t)best[r / 2].x;
+            const bool found = key != 0xFFFFu;
+            slot[r] = kNoSlot;
+            if (ok && found) st_stream(rowp + xo, (uint16_t)kk[r]);
+            if (FUSE && ok) {
+                if (found) slot[r] = key & 63u;
+                else {
+                    const uint32_t old = rowp[xo];     // stale label still takes part in update()
+                    if (old != 0xFFFFu) global_accumulate(f.sums[0], old, (uint32_t)(yw_lo + r * STRIDE), xo, pix[r]);
+                }
+            }
+            rowp += (size_t)STRIDE * W;
+        }
+    }
+    }
+    ASG_STAMP(5, wave == 0);
+    if (FUSE) {
+        {
+            // A column's rows fall into one or two runs of equal slot (a superpixel is taller than a wavefront's rows), so the
+            // sums are kept in registers per run and flushed when the slot changes: 2 LDS atomics per run instead of 2 per
+            // pixel (the 64-bit words as two 32-bit halves: no field carries across bit 32, see s_acc).
+            const uint32_t copy = (uint32_t)lane & (kBlkCopies - 1);
+            const uint32_t dyw = (uint32_t)(wave * R * STRIDE);            // first row of this wavefront relative to the block's
+            uint32_t cur = slot[0], a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0;
+            auto flush = [&]() {
+                if (cur != kNoSlot) {
+                    unsigned long long* a = s_acc + (cur * kBlkCopies + copy) * 2;
+                    atomicAdd(a, (unsigned long long)a_lo | ((unsigned long long)a_hi << 32));
+                    atomicAdd(a + 1, (unsigned long long)b_lo | ((unsigned long long)b_hi << 32));
+                }
+            };
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (r > 0 && slot[r] != cur) {
+                    flush();
+                    cur = slot[r]; a_lo = 0; a_hi = 0; b_lo = 0; b_hi = 0;
+                }
+                const uint32_t p = pix[r];
+                a_lo += (p & 255u) | ((p & 0xFF00u) << 12);                // sum L | sum a << 20
+                a_hi += (p >> 8) & 0xFF00u;                               // sum b << 40
+                b_lo += (uint32_t)lane | ((dyw + (uint32_t)(r * STRIDE)) << 20);   // sum (x - x0) | sum (y - y0) << 20
+                b_hi += 256u;                                             // count << 40
+            }
+            flush();
+        }
+        ASG_STAMP(6, wave == 0);
+        __syncthreads();
+        ASG_STAMP(7, wave == 0);
+        // one plain store per (candidate, quantity): entry reserved for (cluster, this block), zeros included
+        const uint32_t yb0 = (uint32_t)(rem + vrow_b0 * STRIDE);
+        for (int i = tid; i < bn * 6; i += 256) {
+            const int c = i / 6, q = i - c * 6;
+            const uint32_t entry = s_entry[c];
+            if (entry != kNoSlot) {
+                unsigned long long A = 0, B = 0;
+#pragma unroll
+                for (int cpy = 0; cpy < kBlkCopies; ++cpy) { A += s_acc[(c * kBlkCopies + cpy) * 2]; B += s_acc[(c * kBlkCopies + cpy) * 2 + 1]; }
+                const uint32_t cnt = (uint32_t)(B >> 40);
+                uint32_t v;
+                if (q == 0) v = cnt;
+                else if (q == 1) v = ((uint32_t)(B >> 20) & 0xFFFFFu) + yb0 * cnt;
+                else if (q == 2) v = ((uint32_t)B & 0xFFFFFu) + (uint32_t)x0 * cnt;
+                else if (q == 3) v = (uint32_t)A & 0xFFFFFu;
+                else if (q == 4) v = (uint32_t)(A >> 20) & 0xFFFFFu;
+                else v = (uint32_t)(A >> 40);
+                f.cpart[(size_t)entry + (uint32_t)q] = v;
+            }
+        }
+    }
+    ASG_STAMP(8, wave == 0);
 }
 
 // The kernels proper.  Register budgets are part of the design: left to itself the compiler schedules these bodies into
@@ -847,11 +1309,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_wav
     assign_blk_body<R, FUSE, STRIDE, VT>(f, rem, Hv);
 }
 
+template <int R, bool FUSE, int STRIDE, bool VT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(7, 8))) void k_assign_blk2(FrameDev f, int rem, int Hv) {
+    assign_blk2_body<R, FUSE, STRIDE, VT>(f, rem, Hv);
+}
+template <int R, bool FUSE, int STRIDE, bool VT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void k_assign_blk2_w8(FrameDev f, int rem, int Hv) {
+    assign_blk2_body<R, FUSE, STRIDE, VT>(f, rem, Hv);
+}
+template <int R, bool FUSE, int STRIDE, bool VT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(6, 8))) void k_assign_blk2_w6(FrameDev f, int rem, int Hv) {
+    assign_blk2_body<R, FUSE, STRIDE, VT>(f, rem, Hv);
+}
+
+// FSLIC_ASSIGN=1 (read once): the first form of the block kernel (round 2), kept for A/B measurements
+static const bool g_assign_v1 = [] { const char* v = getenv("FSLIC_ASSIGN"); return v && atoi(v) == 1; }();
+
 template <int R, bool FUSE, int STRIDE>
 static void launch_assign_blk_t(const FrameDev& f_, int nframes, int rem, int Hv, hipStream_t st) {
     FrameDev f = f_;
     if (FUSE) { f.tab = f.tabs; f.tab_words = f.tabs_words; f.tab_dyoff = f.tabs_dyoff; f.tab_nrpad = f.tabs_nrpad; }   // table of the subsampled stride
     dim3 grid((f.W + kTileW - 1) / kTileW, (Hv + kWavesPerBlock * R - 1) / (kWavesPerBlock * R), nframes);
+    if (!g_assign_v1) {
+        const size_t lds2 = ((size_t)f.tab_words * sizeof(uint32_t) + 1023) / 1024 * 1024;       // whole KB: what the LDS-DMA pieces fill
+        if constexpr (R == 16 && !FUSE) {
+            if (f.tab_vmode) launch((k_assign_blk2_w8<R, FUSE, STRIDE, true>), grid, dim3(256), lds2, st, f, rem, Hv);
+            else launch((k_assign_blk2_w8<R, FUSE, STRIDE, false>), grid, dim3(256), lds2, st, f, rem, Hv);
+        } else if constexpr (R == 16 && FUSE) {
+            launch((k_assign_blk2_w6<R, FUSE, STRIDE, true>), grid, dim3(256), lds2, st, f, rem, Hv);
+        } else {
+            if (f.tab_vmode) launch((k_assign_blk2<R, FUSE, STRIDE, true>), grid, dim3(256), lds2, st, f, rem, Hv);
+            else launch((k_assign_blk2<R, FUSE, STRIDE, false>), grid, dim3(256), lds2, st, f, rem, Hv);
+        }
+        return;
+    }
     const size_t lds = (size_t)f.tab_words * sizeof(uint32_t);
     if constexpr (R == 16 && !FUSE) {
         if (f.tab_vmode) launch((k_assign_blk_w8<R, FUSE, STRIDE, true>), grid, dim3(256), lds, st, f, rem, Hv);

@@ -79,9 +79,15 @@ int fslic_hip_iterate_device(fslic_engine* e, int slot, const fslic_params* p, i
     Slot& s = e->slots[slot];
     s.launch_timing = e->launch_timing;
     rc = group_begin(e, s, p, H, W, K, 1, &d_rgb, &clusters, &d_labels);
-    if (rc) return rc;
-    rc = group_finish(e, s);
-    if (rc == FSLIC_OK) set_thread_timing_report(make_timing_report(s));
+    if (rc == FSLIC_OK) rc = group_finish(e, s);
+    if (rc != FSLIC_OK) {            // a failure after a partial enqueue: nothing may still touch the caller's buffers on return
+        const std::string msg = last_error();
+        (void)hipStreamSynchronize(s.st);
+        (void)hipGetLastError();
+        set_last_error(msg);
+        return rc;
+    }
+    set_thread_timing_report(make_timing_report(s));
     return rc;
 }
 
@@ -234,6 +240,12 @@ int fslic_hip_set_launch_timing(fslic_engine* e, int on) {
     return FSLIC_OK;
 }
 
+int fslic_hip_lab_force_generic(fslic_engine* e, int on) {
+    if (!e) return fail(FSLIC_E_INVALID, "engine is NULL");
+    e->lab_force_generic.store(on != 0);
+    return FSLIC_OK;
+}
+
 int fslic_hip_last_assign_loop(fslic_engine* e, int slot, float* sum_ms, double* visited_px, int* launches) {
     if (!e || slot < 0 || slot >= (int)e->slots.size()) return fail(FSLIC_E_INVALID, "bad engine/slot");
     const Slot& s = e->slots[slot];
@@ -277,6 +289,13 @@ int fslic_hip_debug_cand_tail(fslic_engine* e, int slot, int frame, int nwords, 
     Slot& s = e->slots[slot];
     const int32_t* base = s.at(s.c.cand_leader, frame) + (size_t)s.c.N - nwords;
     return hipMemcpy(out, base, sizeof(int32_t) * (size_t)nwords, hipMemcpyDeviceToHost) == hipSuccess ? FSLIC_OK : FSLIC_E_HIP;
+}
+// lab build 4: `nwords` words from the start of frame `frame`'s candidate-area array (phase stamps of the block assign kernel)
+int fslic_hip_debug_cand_area_head(fslic_engine* e, int slot, int frame, int nwords, uint32_t* out) {
+    if (!e || slot < 0 || slot >= (int)e->slots.size() || !out) return FSLIC_E_INVALID;
+    Slot& s = e->slots[slot];
+    const uint32_t* base = s.at(s.c.cand_area, frame);
+    return hipMemcpy(out, base, sizeof(uint32_t) * (size_t)nwords, hipMemcpyDeviceToHost) == hipSuccess ? FSLIC_OK : FSLIC_E_HIP;
 }
 #endif
 

@@ -232,7 +232,12 @@ struct fslic_engine {
     int pipe_batch_frames = 0;       // 0: one submission per group; otherwise the most frames a group may gather
     bool pipe_gathering = false;     // a slot thread is waiting briefly for a companion of the submission it took
     std::atomic<int> reserve_frames{0};   // arenas are carved for at least this many frames per group
+    std::atomic<int> lab_force_generic{0};   // testing aid (fslic_hip_lab_force_generic): the brute-force gather kernels instead of the tiled ones
 };
+
+// Testing aid, exported but deliberately NOT part of include/fslic_hip.h: every following group of the Slic variant on this engine
+// runs the brute-force gather kernel (k_assign_generic) instead of the tiled one -- the tests' independent cross-check.
+extern "C" int fslic_hip_lab_force_generic(fslic_engine* e, int on);
 
 namespace fslic {
 

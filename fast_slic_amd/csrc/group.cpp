@@ -405,9 +405,9 @@ int group_begin(fslic_engine* e, Slot& s, const fslic_params* p, int H, int W, i
     if (n < 1 || n > kMaxGroup) return fail(FSLIC_E_INTERNAL, "bad group size");
     for (int i = 0; i < n; i++)
         if (!clusters[i] || !d_rgb[i] || !d_out[i]) return fail(FSLIC_E_INVALID, "NULL pointer argument");
-    const int cap_frames = std::max(n, std::min(e->reserve_frames.load(), (int)kMaxGroup));     // (batching: room for the groups to come)
-    rc = ensure_prepared(e, s, H, W, K, S, cap_frames);
+    rc = ensure_prepared(e, s, H, W, K, S, n);           // (carves for at least the engine's batching reserve)
     if (rc) return rc;
+    const int cap_frames = s.cap_frames;
     s.H = H; s.W = W; s.K = K; s.S = S; s.p = *p; s.nframes = n;
     for (int i = 0; i < n; i++) { s.clusters[i] = clusters[i]; s.d_rgb[i] = d_rgb[i]; s.d_out[i] = d_out[i]; }
     rc = configure_spatial(s, S, p);
@@ -428,7 +428,7 @@ int group_begin(fslic_engine* e, Slot& s, const fslic_params* p, int H, int W, i
     }
     rc = upload_ptrs(s, n, d_rgb, d_out);
     if (rc) return rc;
-    s.generic = p->variant == FSLIC_VARIANT_SLIC && (p->force_generic || !s.sp_tiled_ok || p->preemptive);
+    s.generic = p->variant == FSLIC_VARIANT_SLIC && (e->lab_force_generic.load() != 0 || !s.sp_tiled_ok || p->preemptive);
     if (p->preemptive && s.h_upd_words < (size_t)s.cap_frames * K) {
         if (s.h_upd) hipHostFree(s.h_upd);
         s.h_upd = nullptr; s.h_upd_words = 0;

@@ -100,6 +100,9 @@ struct FrameDev {
     // outside the window, row pitch tab_nrpad dwords, j = dy + tab_dyoff
     // generic-path tables
     const uint16_t* patch2d;   // (2S+1)^2, src/context.cpp:22-40
+#if defined(FSLIC_LAB) && FSLIC_LAB == 4
+    uint32_t* lab_stamps;      // lab build 4: phase time stamps of the block assign kernel (the idle candidate-area array of the connectivity pass)
+#endif
 
     // byte offset by POINTER arithmetic (not through an integer): the compiler then still knows the pointer came from a
     // kernel argument, i.e. points to global memory, and emits global_load / global_store instead of FLAT instructions
@@ -120,6 +123,9 @@ struct FrameDev {
         adv(cell_cnt[0], d); adv(cell_cnt[1], d); adv(cell_items[0], d); adv(cell_items[1], d);
         adv(ovf_cnt[0], d); adv(ovf_cnt[1], d); adv(ovf_items[0], d); adv(ovf_items[1], d);
         adv(err_flag, d);
+#if defined(FSLIC_LAB) && FSLIC_LAB == 4
+        adv(lab_stamps, d);
+#endif
     }
 };
 

@@ -42,20 +42,27 @@ const Knobs g_knobs = read_knobs();      // once, when the library is loaded
 const Knobs& knobs() { return g_knobs; }
 
 // ---- slot ownership ------------------------------------------------------------------------------------------------
+namespace {
+// caller holds e->mu: the slot's pending group came from the submit queue, i.e. its own thread collects it
+bool self_collecting(const Slot& s) { return s.pending && s.async && s.async->from_queue; }
+}  // namespace
+
 int acquire_slot(fslic_engine* e, int want, int& slot) {
     std::unique_lock<std::mutex> lk(e->mu);
     const int ns = (int)e->slots.size();
     if (want >= ns) return fail(FSLIC_E_INVALID, "slot out of range");
     for (;;) {
+        // A slot serving the submit / drain queue collects its group itself: it is busy for a while, not lost.  Only a
+        // group submitted by slot number (collected by the caller's fslic_hip_wait_group) is a reason to refuse.
         if (want >= 0) {
             Slot& s = e->slots[want];
-            if (s.pending) return fail(FSLIC_E_INVALID, "the slot still owns an unfinished group (call fslic_hip_wait_group first)");
-            if (!s.busy) { s.busy = true; slot = want; return FSLIC_OK; }
+            if (s.pending && !self_collecting(s)) return fail(FSLIC_E_INVALID, "the slot still owns an unfinished group (call fslic_hip_wait_group first)");
+            if (!s.pending && !s.busy) { s.busy = true; slot = want; return FSLIC_OK; }
         } else {
             bool any_usable = false;
             for (int i = 0; i < ns; i++) {
                 Slot& s = e->slots[i];
-                if (s.pending) continue;
+                if (s.pending) { any_usable = any_usable || self_collecting(s); continue; }
                 any_usable = true;
                 if (!s.busy) { s.busy = true; slot = i; return FSLIC_OK; }
             }
@@ -70,8 +77,8 @@ int acquire_all_slots(fslic_engine* e) {
     for (;;) {
         bool free_all = true;
         for (const Slot& s : e->slots) {
-            if (s.pending) return fail(FSLIC_E_INVALID, "a slot still owns an unfinished group");
-            free_all = free_all && !s.busy;
+            if (s.pending && !self_collecting(s)) return fail(FSLIC_E_INVALID, "a slot still owns an unfinished group");
+            free_all = free_all && !s.busy && !s.pending;
         }
         if (free_all) break;
         e->cv.wait(lk);
@@ -162,6 +169,12 @@ void slot_worker(fslic_engine* e, Slot* s) {
         if (took) e->cv.notify_all();            // room in the queue
         int rc = group_begin(e, *s, &a.p, a.H, a.W, a.K, a.n, a.d_rgb, a.clusters, a.d_out);
         if (rc == FSLIC_OK) rc = group_finish(e, *s);
+        if (rc != FSLIC_OK) {        // nothing may still run against the caller's buffers once the group is reported done
+            const std::string msg = last_error();
+            (void)hipStreamSynchronize(s->st);
+            (void)hipGetLastError();
+            set_last_error(msg);
+        }
         {
             std::lock_guard<std::mutex> lk(e->mu);
             a.rc = rc;
@@ -237,8 +250,13 @@ int fslic_hip_submit_group(fslic_engine* e, int slot, const fslic_params* p, int
     {
         std::unique_lock<std::mutex> lk(e->mu);
         Slot& s = e->slots[slot];
-        if (s.pending) return fail(FSLIC_E_INVALID, "the slot still owns an unfinished group (call fslic_hip_wait_group first)");
-        e->cv.wait(lk, [&] { return !s.busy; });             // a synchronous call of another thread is using the slot
+        // checked again after every wake-up: while this thread waited for a synchronous call to leave the slot, the slot's
+        // own thread may have taken a submission from the queue, or another thread's submit_group may have got in first
+        for (;;) {
+            if (s.pending && !self_collecting(s)) return fail(FSLIC_E_INVALID, "the slot still owns an unfinished group (call fslic_hip_wait_group first)");
+            if (!s.busy && !s.pending) break;
+            e->cv.wait(lk);
+        }
         hand_over(e, s, p, H, W, K, n_frames, d_rgb, clusters, d_labels);
     }
     e->cv.notify_all();

@@ -60,10 +60,9 @@ typedef struct fslic_params {
     float preemptive_thres;        /* src/context.h:33; ignored while preemptive == 0 */
     int32_t num_threads;           /* src/context.h:27; ignored on the GPU */
     int32_t debug_mode;            /* src/context.h:36; ignored (no recorder report) */
-    int32_t force_generic;         /* testing aid: run the brute-force gather kernel instead of the tiled one */
     int32_t variant;               /* FSLIC_VARIANT_SLIC: Context (src/context.h:127); FSLIC_VARIANT_LSC: ContextLSC
                                     * (src/lsc.h:6-26), picked by cfast_slic.pyx:199-216 from real_dist_type */
-    int32_t reserved[4];
+    int32_t reserved[5];
 } fslic_params;
 
 enum {

@@ -16,9 +16,12 @@ pytestmark = pytest.mark.gpu
 def run_hip(engine, img, cl0, force_generic=False, max_iter=10, compactness=10.0, min_size_factor=0.25,
             subsample_stride=3, convert_to_lab=True, manhattan=True):
     cl = cl0.copy()
-    p = make_params(max_iter, compactness, min_size_factor, subsample_stride, convert_to_lab, manhattan,
-                    force_generic=force_generic)
-    labels = engine.iterate(np.ascontiguousarray(img), cl, p)
+    p = make_params(max_iter, compactness, min_size_factor, subsample_stride, convert_to_lab, manhattan)
+    engine.lab_force_generic(force_generic)          # testing aid of the library (not in include/fslic_hip.h)
+    try:
+        labels = engine.iterate(np.ascontiguousarray(img), cl, p)
+    finally:
+        engine.lab_force_generic(False)
     pre = engine.last_prelabels(img.shape[0], img.shape[1])
     return labels, cl, pre, engine.last_path()
 
