@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 ASSIGN_BYTES_PER_PX = 6.0      # 4 B LAB read + 2 B label write per visited pixel
 LSC_ASSIGN_BYTES_PER_PX = 46.0 # 40 B features + 4 B weight + 2 B label (materialised features)
-PROFILE_TAG = "r02"
+PROFILE_TAG = "r03"
 
 WORKLOADS = {
     "720p": dict(H=720, W=1280, K=1600, fpg=8, name="1280x720 RGB, K=1600, 10 iters (configs[1]), 8 frames/GPU"),
@@ -76,7 +76,7 @@ def measured_copy_bandwidth():
 def pmc_traffic(key):
     """HBM bytes per launch of the assign kernels from the committed rocprofv3 --pmc passes of this workload
     (profiles/<round>_pmc_assign_traffic.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE); None when absent."""
-    for tag in (PROFILE_TAG, "r01"):
+    for tag in (PROFILE_TAG, "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", "%s_pmc_assign_traffic.json" % tag)) as f:
                 return json.load(f)[key], "profiles/%s_pmc_assign_traffic.json" % tag
@@ -291,6 +291,7 @@ class Workload(object):
         self.torch.cuda.synchronize()
         el = time.perf_counter() - t0
         gc.enable()
+        self.last_timed = base + warm + steps - 1          # buffer set of the last submission of the timed region (parity gates)
         return round(self.H * self.W * self.n * steps / el / 1e6, 1), tot
 
 
@@ -307,6 +308,123 @@ def parity_of(wl, j):
         if cls[i].tobytes() != cl.tobytes():
             bad.append("frame %d: Cluster bytes differ" % i)
     return bad
+
+
+def lsc_parity_of(wl, j, j_other):
+    """LSC (f32 path, tolerance-based parity): the label maps of submission j against the committed fixture of
+    the unmodified reference (tests/golden/lsc_cases.npz, frame seed 0 of this workload: agreement >= 0.99 as in
+    tests/test_gpu_lsc.py) and against submission j_other of the same inputs (run-to-run identity: the sums are fixed point)."""
+    bad = []
+    try:
+        fx = np.load(os.path.join(ROOT, "tests", "golden", "lsc_cases.npz"), allow_pickle=False)
+        want = fx["A_%dx%d_k%d/labels" % (wl.H, wl.W, wl.K)]
+    except (OSError, KeyError):
+        want = None
+    a = [t.cpu().numpy().view(np.uint16) for t in wl.sets[j][0]]
+    b = [t.cpu().numpy().view(np.uint16) for t in wl.sets[j_other][0]]
+
+    def best_overlap(p, q):          # fraction of pixels whose segment in p lies in the segment of q it overlaps most (labels are renumbered by the connectivity pass)
+        p = p.astype(np.int64).ravel(); q = q.astype(np.int64).ravel()
+        nq = int(q.max()) + 1
+        u, c = np.unique(p * nq + q, return_counts=True)
+        best = np.zeros(int(p.max()) + 1, np.int64)
+        np.maximum.at(best, u // nq, c)
+        return float(best.sum()) / p.size
+    if want is not None:
+        agree = min(best_overlap(a[0], want), best_overlap(want, a[0]))
+        if agree < 0.99:
+            bad.append("frame 0: best overlap with the reference fixture %.4f (< 0.99)" % agree)
+    else:
+        bad.append("fixture A_%dx%d_k%d missing" % (wl.H, wl.W, wl.K))
+    for i in range(wl.n):
+        if not np.array_equal(a[i], b[i]):
+            bad.append("frame %d differs between two submissions of the same input" % i)
+        if wl.sets[j][1][i].tobytes() != wl.sets[j_other][1][i].tobytes():
+            bad.append("frame %d: Cluster bytes differ between two submissions of the same input" % i)
+    return bad
+
+
+def single_frame_latency(eng, wl, reps=24):
+    """Device time of ONE frame per call (the reference's own calling pattern, cfast_slic.pyx:150-260): groups of one frame on
+    slot 0, GPU to itself, replayed from the slot's hipGraph; HIP events around the replay (median of `reps` after 4 warm calls)."""
+    if not wl.sets:
+        wl.buffers(1)
+    d_lab, cls, a_lab, a_cls = wl.sets[0]
+    ms, modes = [], set()
+    for i in range(reps + 4):
+        np.copyto(cls.view(np.uint8).reshape(-1), wl.cl0.view(np.uint8).reshape(-1))
+        eng.submit_group(0, wl.a_rgb, a_cls, a_lab, 1, wl.H, wl.W, wl.K, wl.params)
+        eng.wait_group(0)
+        if i >= 4:
+            ms.append(eng.last_device_times(0)[0])
+            modes.add(eng.last_launch_mode(0))
+    med = float(np.median(ms))
+    return {"device_ms": round(med, 4), "device_ms_min": round(float(np.min(ms)), 4), "megapixels_per_sec": round(wl.H * wl.W / (med * 1e-3) / 1e6, 1),
+            "launch": "hipGraph replay" if modes == {2} else "modes %s" % sorted(modes),
+            "what": "one %dx%d K=%d frame per group, device-resident, GPU to itself (HIP events around the group)" % (wl.W, wl.H, wl.K)}
+
+
+def end_to_end_ref_binding(H, W, K, budget_s=3.0, threads=4):
+    """The same through the drop-in itself: the REFERENCE's Cython binding with the arch "hip/gfx950" patched in
+    (integration/_build, built by integration/build_ref_binding.sh), driven through its own fast_slic.hip.SlicHip facade when the
+    compiled package travelled with it, else through cfast_slic.SlicModel the way fast_slic/base_slic.py:18-52 drives it.  Runs in
+    a separate interpreter (the patched module links libfslic_hip.so itself).  None when integration/_build is absent."""
+    import glob
+    import subprocess
+    build = os.path.join(ROOT, "integration", "_build")
+    if not glob.glob(os.path.join(build, "cfast_slic*.so")):
+        return None
+    code = r"""
+import sys, time, json, threading
+import numpy as np
+sys.path.insert(0, %(build)r); sys.path.insert(1, %(root)r)
+from fast_slic_amd.synth import variant
+H, W, K, budget, threads = %(H)d, %(W)d, %(K)d, %(budget)f, %(threads)d
+imgs = [variant("A", H, W, seed=s) for s in range(4)]
+try:
+    from fast_slic.hip import SlicHip
+    facade = "fast_slic.hip.SlicHip"
+    def make():
+        return SlicHip(num_components=K, compactness=10)
+except ImportError:
+    import cfast_slic
+    facade = "cfast_slic.SlicModel('hip/gfx950') driven like fast_slic/base_slic.py"
+    class _M(object):
+        def __init__(self):
+            m = cfast_slic.SlicModel(K, "hip/gfx950")
+            m.convert_to_lab = True; m.preemptive = False; m.preemptive_thres = 0.05
+            m.manhattan_spatial_dist = True; m.num_threads = -1; m.debug_mode = False
+            self.slic_model = m
+        def iterate(self, image, max_iter=10):
+            if not self.slic_model.initialized:
+                self.slic_model.initialize(image)
+            return self.slic_model.iterate(image, max_iter, 10, 0.25, 3)
+    def make():
+        return _M()
+def run(nt):
+    counts = [0] * nt
+    stop = time.perf_counter() + budget / 2
+    def work(t):
+        s = make(); s.iterate(imgs[t %% 4]); i = 0
+        while time.perf_counter() < stop:
+            s.slic_model.initialized = False
+            s.iterate(imgs[(t + i) %% 4]); i += 1
+        counts[t] = i
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(nt)]
+    t0 = time.perf_counter()
+    [th.start() for th in ths]; [th.join() for th in ths]
+    return H * W * sum(counts) / (time.perf_counter() - t0) / 1e6, sum(counts)
+one, n1 = run(1); many, nm = run(threads)
+print("RESULT " + json.dumps({"facade": facade, "one_thread": round(one, 1), "threads_%%d" %% threads: round(many, 1), "frames": [n1, nm]}))
+""" % {"build": build, "root": ROOT, "H": H, "W": W, "K": K, "budget": budget_s, "threads": threads}
+    try:
+        r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        line = [l for l in r.stdout.decode().splitlines() if l.startswith("RESULT ")]
+        if r.returncode != 0 or not line:
+            return {"error": r.stderr.decode()[-400:]}
+        return json.loads(line[-1][7:])
+    except Exception as ex:       # noqa: BLE001 - a reported leg, never the bench's failure
+        return {"error": repr(ex)[:400]}
 
 
 def end_to_end(H, W, K, budget_s=4.0, threads=4):
@@ -355,6 +473,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--workload", default="720p", choices=sorted(WORKLOADS))
     ap.add_argument("--frames-per-gpu", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=0,
+                    help="strong scaling: a FIXED batch of this many frames per step split over the GPUs (BASELINE configs[3]: 64); "
+                         "default 0 = weak scaling, --frames-per-gpu frames on every GPU")
     ap.add_argument("--slots", type=int, default=6, help="groups in flight per GPU (stream + host thread each)")
     ap.add_argument("--no-batching", action="store_true", help="one submission per launch group (no dynamic batching in the pipeline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -373,7 +494,9 @@ def main():
     rank, local_rank, world = batch.env_rank_world()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    pinned = batch.pin_to_gpu_numa_node(local_rank, world) if not args.dry_run else None
+    # one HIP context per rank: the rank's GPU becomes the only visible device before anything initialises HIP
+    dev = batch.bind_rank_to_its_gpu(local_rank) if (world > 1 and not args.dry_run) else local_rank
+    pinned = batch.pin_to_gpu_numa_node(local_rank, world, device_index=dev) if not args.dry_run else None
     dist = batch.init_process_group("gloo", rank, world)     # barrier + timing reduction only; no data-path collective
 
     def barrier(sync=None):
@@ -389,12 +512,15 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             time.sleep(0.001 * (1 + rank))                   # the slowest rank decides
+        mine = time.perf_counter() - t0                      # this rank's own clock, before the closing barrier
         barrier()
         elapsed = batch.max_over_ranks(time.perf_counter() - t0, dist)
+        per_rank = batch.gather_over_ranks(mine, dist, world)
         units = batch.sum_over_ranks(float(args.steps), dist)
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                              "ms_per_step": round(elapsed / args.steps * 1e3, 4), "units_all_ranks": units}))
+                              "ms_per_step": round(elapsed / args.steps * 1e3, 4), "units_all_ranks": units,
+                              "per_rank_ms": [round(t * 1e3, 3) for t in per_rank]}))
             sys.stdout.flush()
         if dist is not None:
             dist.barrier()
@@ -402,14 +528,19 @@ def main():
         return
 
     import torch
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(dev)
     from fast_slic_amd import Engine
 
     cfg = WORKLOADS[args.workload]
     H, W, K = cfg["H"], cfg["W"], cfg["K"]
-    fpg = args.frames_per_gpu or cfg["fpg"]
+    strong = args.batch > 0
+    if strong and args.batch % world:
+        raise SystemExit("--batch %d does not split evenly over %d GPUs" % (args.batch, world))
+    fpg = (args.batch // world) if strong else (args.frames_per_gpu or cfg["fpg"])
+    if fpg < 1 or fpg > 16:
+        raise SystemExit("frames per GPU and step must be in 1..16 (one launch group), got %d" % fpg)
     nslots = max(1, args.slots)
-    eng = Engine(local_rank, nslots)
+    eng = Engine(dev, nslots)
     # Dynamic batching: a slot thread that finds two submissions waiting serves them as one group (16 frames per launch instead
     # of 8).  Results are per frame and do not change; the parity gate below checks a submission of the timed region.
     merged_max = 1 if args.no_batching else max(1, min(2, 16 // fpg))
@@ -417,7 +548,7 @@ def main():
         eng.pipeline_batching(merged_max * fpg)
     Workload.merged_max = merged_max
     # this rank's shard of the synthetic frame stream: frames are independent, rank r owns seeds r*fpg .. r*fpg+fpg-1
-    wl = Workload(eng, H, W, K, batch.weak_shard(fpg, rank))
+    wl = Workload(eng, H, W, K, batch.frame_shard(args.batch, rank, world) if strong else batch.weak_shard(fpg, rank))
     n_setup = wl.sets_for_setup(merged_max)
     wl.buffers(n_setup + args.warmup + args.steps)
     sync = torch.cuda.synchronize
@@ -441,8 +572,10 @@ def main():
     for j in range(args.steps):
         wl.submit(first + j)
     totals = eng.pipeline_drain()                            # every step of the timed region is complete here
+    mine = time.perf_counter() - t0                          # this rank's own clock over its steps (drained, synchronised)
     barrier(sync)
     elapsed = batch.max_over_ranks(time.perf_counter() - t0, dist)
+    per_rank = batch.gather_over_ranks(mine, dist, world)
     gc.enable()
 
     if rank == 0:
@@ -453,7 +586,7 @@ def main():
             "unit": "megapixels/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u8/u16/i32 (integer SLIC)", "data": "synthetic",
             "config": {"workload": cfg["name"], "frames_per_gpu": fpg, "global_frames": fpg * world,
                        "slots_per_gpu": eng.n_slots, "submissions_per_launch_group": "up to %d (dynamic batching of the pipeline)" % merged_max,
@@ -463,11 +596,15 @@ def main():
             "device_ms_per_frame": round(totals["device_ms"] / max(totals["frames"], 1), 4),
             "host_topk_frames": totals["host_topk_frames"],
         }
-        if args.timed_only:
-            print(json.dumps(out))
-            sys.stdout.flush()
-            eng.close()
-            return
+        if strong:
+            out["config"]["workload"] = "%s: fixed batch of %d frames per step over %d GPU(s), %d per GPU" % (cfg["name"].split(",")[0] + ", K=%d, 10 iters" % K, args.batch, world, fpg)
+        if world > 1:        # each rank's own time over ITS steps (before the closing barrier) and its own rate
+            out["per_rank_ms"] = {"min": round(min(per_rank) * 1e3, 3), "max": round(max(per_rank) * 1e3, 3), "all": [round(t * 1e3, 3) for t in per_rank]}
+            out["per_rank_megapixels_per_sec"] = [round(float(H) * W * fpg * args.steps / t / 1e6, 1) for t in per_rank]
+    if rank == 0 and args.timed_only:
+        print(json.dumps(out))
+        sys.stdout.flush()
+    elif rank == 0:
         if not args.no_parity:
             bad = parity_of(wl, first + args.steps - 1)
             out["parity"] = not bad
@@ -481,7 +618,7 @@ def main():
         pmc, pmc_src = pmc_traffic("720p_x%d" % per_launch_frames) if args.workload == "720p" else (None, None)
         fu = big["fused_assign_update"]
         out["roofline"] = {
-            "kernel": "k_assign_blk<8,true,3,*> (fused assign + centroid sums; %d launches per group, %dx%d x %d frames per launch: "
+            "kernel": "k_assign_blk2<8,true,3,*> (fused assign + centroid sums; %d launches per group, %dx%d x %d frames per launch: "
                       "%s), GPU to itself" % (fu["launches_per_group"], W, H, per_launch_frames,
                                               "two submissions per group, as the pipelined region runs them" if merged_max > 1 else "one submission per group"),
             "bound": "hbm", "achieved": fu["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fu["frac"],
@@ -498,7 +635,7 @@ def main():
         out["roofline"]["frac_of_measured_copy"] = round(fu["achieved"] / copy_gbs, 4) if copy_gbs else None
         # the same launch by rocprofv3's kernel duration (committed summary of `scripts/frames.py 720 1280 1600 6 slic 8` under
         # --kernel-trace): events on the stream also see the launch gap of the directly enqueued (timed) group
-        rp = rocprof_avg_us("kernel_stats_1280x720_k1600_slic_x%d.csv" % per_launch_frames, "k_assign_blk<8, true, 3") if args.workload == "720p" else None
+        rp = rocprof_avg_us("kernel_stats_1280x720_k1600_slic_x%d.csv" % per_launch_frames, "k_assign_blk2<8, true, 3") if args.workload == "720p" else None
         if rp:
             out["roofline"]["by_rocprofv3_kernel_duration"] = {
                 "avg_launch_us": rp, "achieved": round(gbs(fu["bytes_per_launch"], rp * 1e-3), 2),
@@ -530,13 +667,19 @@ def main():
             four, one = w4.timed_groups(5), w4.timed_groups(4, n=1)
             pmc4, pmc4_src = pmc_traffic("4k_k1600")
             fa = four["full_assign"]
-            out["roofline_4k"] = {"kernel": "k_assign_blk<16,false,1,true> (full_assign launch, 3840x2160, K=1600), 8 frames per launch",
+            out["roofline_4k"] = {"kernel": "k_assign_blk2_w8<16,false,1,true> (full_assign launch, 3840x2160, K=1600), 8 frames per launch",
                                   "bound": "hbm", "achieved": fa["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fa["frac"],
                                   "traffic": pmc4["full_assign"]["bytes"] * 8 if pmc4 else None, "traffic_source": pmc4_src,
                                   "avg_launch_ms": fa["avg_launch_ms"], "fused_assign_update": four["fused_assign_update"],
                                   "all_assign_launches": four["all_assign_launches"], "device_ms_per_frame": four["device_ms_per_frame"],
                                   "megapixels_per_sec_pipelined": w4.throughput(60)[0], "single_frame_launch": one,
                                   "frac_of_measured_copy": round(fa["achieved"] / copy_gbs, 4) if copy_gbs else None}
+            if not args.no_parity:      # the last submission of that pipelined region (6 slots, batching, graph replay) against the oracle
+                bad = parity_of(w4, w4.last_timed)
+                out["roofline_4k"]["parity"] = not bad
+                if bad:
+                    out["roofline_4k"]["parity_failures"] = bad[:8]
+            out["roofline_4k"]["single_frame"] = single_frame_latency(eng, w4)
             del w4
             # BASELINE configs[2]: 3840x2160 K=6000 (centre pile-up, tie at the cut)
             w6 = Workload(eng, 2160, 3840, 6000, list(range(4)))
@@ -545,6 +688,11 @@ def main():
                                "dominant_kernel": "k_assign_blk fused assign+update", "fused_assign_update": t6["fused_assign_update"],
                                "full_assign": t6["full_assign"], "all_assign_launches": t6["all_assign_launches"],
                                "device_ms_per_frame": t6["device_ms_per_frame"]}
+            if not args.no_parity:      # frame seed 0 ties at the top-K cut (a[K-1] = a[K] = 374): resolved on the device, inside the pipeline
+                bad = parity_of(w6, w6.last_timed)
+                out["c3_k6000"]["parity"] = not bad
+                if bad:
+                    out["c3_k6000"]["parity_failures"] = bad[:8]
             del w6
             # BASELINE configs[4]: LSC variant at 1280x720 K=1600 (f32 path; 46 B per visited pixel-assignment)
             wlsc = Workload(eng, 720, 1280, 1600, list(range(8)), variant_id=1)
@@ -553,8 +701,19 @@ def main():
                              "dominant_kernel": "k_lsc_assign_sums (10-D distance + the fused update sums; priced at 46 B per visited pixel, it also reads the 4 B LAB word)",
                              "fused_assign_update": tl["fused_assign_update"],
                              "full_assign": tl["full_assign"], "device_ms_per_frame": tl["device_ms_per_frame"]}
+            if not args.no_parity:      # tolerance-based (f32 path): fixture floor of the unmodified reference + run-to-run identity
+                bad = lsc_parity_of(wlsc, wlsc.last_timed, wlsc.last_timed - 3)
+                out["lsc_c5"]["parity"] = not bad
+                out["lsc_c5"]["parity_rule"] = "best overlap (both ways) >= 0.99 with tests/golden/lsc_cases.npz (fast_slic.LSC, 1 thread) on frame 0, as tests/test_gpu_lsc.py; every frame and Cluster byte identical between two submissions"
+                if bad:
+                    out["lsc_c5"]["parity_failures"] = bad[:8]
             del wlsc
+            # BASELINE configs[1] says "single-image": one frame per call, device-resident, and through the Python surface
+            out["single_frame"] = single_frame_latency(eng, wl)
             out["end_to_end"] = end_to_end(H, W, K)
+            ref_e2e = end_to_end_ref_binding(H, W, K)
+            if ref_e2e is not None:
+                out["end_to_end"]["through_reference_binding"] = ref_e2e
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(H, W, K)
         print(json.dumps(out))

@@ -324,7 +324,7 @@ _default_engines = {}
 _engine_lock = threading.Lock()
 
 
-DEFAULT_ENGINE_SLOTS = 4      # concurrent iterate() calls (different SlicModels, different threads) per GPU before they queue
+DEFAULT_ENGINE_SLOTS = 8      # concurrent iterate() calls (different SlicModels, different threads) per GPU before they queue
 
 
 def default_engine(device=0):
@@ -521,9 +521,9 @@ class SlicModel(object):
                         self.num_threads, self.debug_mode, variant)
         labels = self._engine.iterate(image, self._clusters, p)
         self.last_timing_report = self._engine.last_timing_report()
-        result = labels.astype(np.int16)                                           # pyx:258-260
-        result[labels == 0xFFFF] = -1
-        return result
+        # pyx:258-260 makes an int16 copy and turns 0xFFFF into -1; the int16 VIEW of the same bytes is that array (0xFFFF is -1
+        # already), without three passes over the map (250 us at 1280x720, more than the device-side work)
+        return labels.view(np.int16)
 
 
 class NodeConnectivity(object):

@@ -64,6 +64,34 @@ def sum_over_ranks(value, dist, device="cpu"):
     return float(t.item())
 
 
+def gather_over_ranks(value, dist, world):
+    """Every rank's value, in rank order (the per-rank elapsed times of the bench line: a sub-linear scaling point is only
+    attributable when the line says which rank was slow)."""
+    if dist is None:
+        return [float(value)]
+    import torch
+    mine = torch.tensor([float(value)], dtype=torch.float64)
+    out = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]
+
+
+def bind_rank_to_its_gpu(local_rank):
+    """Before HIP is initialised in this process: make the rank's GPU the ONLY visible device (it then is device 0), so that a
+    rank creates one context instead of one per GPU of the node.  An existing HIP_VISIBLE_DEVICES list is narrowed to its
+    local_rank-th entry.  Returns the device index to use afterwards (always 0)."""
+    cur = os.environ.get("HIP_VISIBLE_DEVICES")
+    if cur:
+        ids = [x for x in cur.split(",") if x != ""]
+        if len(ids) > 1 and local_rank < len(ids):
+            os.environ["HIP_VISIBLE_DEVICES"] = ids[local_rank]
+        elif len(ids) > 1:
+            return local_rank              # cannot narrow: keep the node's numbering
+    else:
+        os.environ["HIP_VISIBLE_DEVICES"] = str(local_rank)
+    return 0
+
+
 # ---- launching one process per GPU ----------------------------------------------------------------------------------
 def free_port():
     import socket
@@ -91,16 +119,33 @@ def spawn_ranks(world, argv, extra_env=None):
             env.update(extra_env)
         procs.append(subprocess.Popen([sys.executable] + list(argv), env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    return max(p.wait() for p in procs)
+    # a rank that dies takes the others with it (they would sit in the barrier until the rendezvous times out)
+    import time
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0:
+                rc = max(rc, code if code > 0 else 1)
+                for q in live:
+                    q.terminate()
+        if live:
+            time.sleep(0.05)
+    return rc
 
 
-def gpu_numa_cpus(local_rank):
-    """CPUs of the NUMA node the rank's GPU hangs off (sysfs: the PCI device's numa_node and that node's cpulist), or
+def gpu_numa_cpus(local_rank, device_index=None):
+    """CPUs of the NUMA node the rank's GPU hangs off (device_index: the GPU's index in THIS process when the visible devices
+    have been narrowed to the rank's own, bind_rank_to_its_gpu) (sysfs: the PCI device's numa_node and that node's cpulist), or
     None when the topology cannot be read (containers without sysfs, CPU-only test runs)."""
     bdf = None
     try:
         import torch
-        pr = torch.cuda.get_device_properties(local_rank)
+        pr = torch.cuda.get_device_properties(local_rank if device_index is None else device_index)
         if hasattr(pr, "pci_bus_id"):
             bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, getattr(pr, "pci_device_id", 0))
     except Exception:       # noqa: BLE001 - no GPU / no torch: no pinning
@@ -126,14 +171,14 @@ def gpu_numa_cpus(local_rank):
         return None
 
 
-def pin_to_gpu_numa_node(local_rank, world):
+def pin_to_gpu_numa_node(local_rank, world, device_index=None):
     """Keep this rank's host threads (slot threads, staging, write-back) on the NUMA node of its GPU; when the node is
     unknown, on an equal share of the visible CPUs.  Returns the CPU set chosen (for the bench line)."""
     try:
         avail = sorted(os.sched_getaffinity(0))
     except AttributeError:
         return None
-    cpus = gpu_numa_cpus(local_rank)
+    cpus = gpu_numa_cpus(local_rank, device_index)
     if cpus:
         cpus = [c for c in cpus if c in set(avail)]
     if not cpus and world > 1:

@@ -1158,26 +1158,58 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
             pass(clab, k0 + uxc, idx01, mq);
         }
     } else {
-#pragma unroll 1
-    while (todo) {
-        const int c = __builtin_ctzll(todo);
-        todo &= todo - 1ull;
-        const uint32_t cyx = __builtin_amdgcn_readlane(yx_j, c);
-        const uint32_t clabx = __builtin_amdgcn_readlane(lab_j, c);
-        const uint32_t clab = clabx & 0x00FFFFFFu;
-        const int cy = (int)(cyx >> 16), cx = (int)(cyx & 0xFFFFu);
-        const uint32_t ux = __builtin_amdgcn_sad_u16((uint32_t)x, (uint32_t)cx, 0u);      // |x - cx|
-        const uint32_t uxc = min(ux, (uint32_t)(S + 1));
-        const uint32_t a0 = __umul24(uxc, nrpad) + (uint32_t)(yw_lo - cy + dyoff);        // dword index of the pair (row 0, row 1)
-        const uint32_t idx01 = (clabx >> 24) * 0x10001u;                                  // rank | rank << 16
-#pragma unroll
-        for (int q = 0; q < R / 2; ++q) {
-            const uint32_t sp = s_dyn[a0 + (2 * q) * STRIDE];                                 // one aligned ds_read_b32 per row pair
-            const uint32_t s0 = __builtin_amdgcn_sad_u8(pix[2 * q], clab, sp);
-            const uint32_t s01 = __builtin_amdgcn_sad_hi_u8(pix[2 * q + 1], clab, s0);
-            min_in_place(best[q], key_pair(s01, idx01));
+        // 2-D table.  The wavefront's rows in two halves (R/2 visited rows each): a candidate whose window reaches only one half is
+        // walked over that half alone -- at 1280x720 K=1600 (S = 24, eight rows spanning 22) a third of the candidates, i.e. a
+        // sixth of the distance / key / min instructions.  Three loops with straight-line bodies (see the row-vector loops above).
+        constexpr int HQ = R / 4;                        // row pairs per half
+        static_assert(R % 4 == 0, "two halves of whole row pairs");
+        unsigned long long todo_b, todo_u, todo_l;
+        {
+            const int cyj = (int)(yx_j >> 16);
+            const int yh = yw_lo + (R / 2) * STRIDE;     // first row of the lower half
+            const bool mine_todo = (todo >> lane) & 1ull;
+            const bool up = cyj + S >= yw_lo && cyj - S <= yw_lo + (R / 2 - 1) * STRIDE;
+            const bool lo = cyj + S >= yh && cyj - S <= yh + (R / 2 - 1) * STRIDE;
+            todo_b = __ballot(mine_todo && up && lo);
+            todo_u = __ballot(mine_todo && up && !lo);
+            todo_l = __ballot(mine_todo && !up && lo);
         }
-    }
+        // byte pitch of a table column in a VGPR: |dx| * pitch + row offset is then ONE v_mad_u32_u24 (two scalar operands would
+        // not fit one VALU instruction) and the result is the LDS byte address itself (no shift)
+        uint32_t pitch_v;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(pitch_v) : "s"(nrpad * 4u));
+        const char* const tab_b = reinterpret_cast<const char*>(s_dyn);
+        auto walk = [&](unsigned long long m, auto q0_tag, auto nq_tag) {
+            constexpr int Q0 = decltype(q0_tag)::value, NQ = decltype(nq_tag)::value;
+#pragma unroll 1
+            while (m) {
+                const int c = __builtin_ctzll(m);
+                m &= m - 1ull;
+                const uint32_t cyx = __builtin_amdgcn_readlane(yx_j, c);
+                const uint32_t clabx = __builtin_amdgcn_readlane(lab_j, c);
+                const uint32_t clab = clabx & 0x00FFFFFFu;
+                const int cy = (int)(cyx >> 16), cx = (int)(cyx & 0xFFFFu);
+                const uint32_t ux = __builtin_amdgcn_sad_u16((uint32_t)x, (uint32_t)cx, 0u);      // |x - cx|
+                const uint32_t uxc = min(ux, (uint32_t)(S + 1));
+                const uint32_t a0 = __umul24(uxc, pitch_v) + (uint32_t)(yw_lo - cy + dyoff) * 4u;  // byte offset of the pair (row 0, row 1)
+                const uint32_t idx01 = (clabx >> 24) * 0x10001u;                                   // rank | rank << 16
+                uint32_t t[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const uint32_t sp = *reinterpret_cast<const uint32_t*>(tab_b + a0 + (uint32_t)((2 * (Q0 + q)) * STRIDE * 4));   // one aligned ds_read_b32 per row pair
+                    const uint32_t s0 = __builtin_amdgcn_sad_u8(pix[2 * (Q0 + q)], clab, sp);
+                    t[q] = __builtin_amdgcn_sad_hi_u8(pix[2 * (Q0 + q) + 1], clab, s0);
+                }
+                us2 key[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) key[q] = key_pair(t[q], idx01);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) min_in_place(best[Q0 + q], key[q]);
+            }
+        };
+        walk(todo_b, std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * HQ>{});
+        walk(todo_u, std::integral_constant<int, 0>{}, std::integral_constant<int, HQ>{});
+        walk(todo_l, std::integral_constant<int, HQ>{}, std::integral_constant<int, HQ>{});
     }
 
     ASG_STAMP(4, wave == 0);

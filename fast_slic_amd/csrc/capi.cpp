@@ -4,11 +4,36 @@
 #include "engine_internal.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 using namespace fslic;
 
 static_assert(sizeof(fslic_cluster) == 32, "Cluster ABI (src/fast-slic-common.h:10-23)");
+
+namespace {
+// FSLIC_HOST_STAGING (read once): how the host-memory entry points move frames and label maps.  0 (default): pageable
+// hipMemcpyAsync on the slot's stream (the runtime's own staging).  1: the engine's copy pool + pinned staging that the LAB /
+// relabel kernels read and write in place.  2: copy pool + pinned staging + copy commands to / from the arena.  Measured
+// (profiles/r03_e2e_probe.txt, 1280x720 K=1600, one caller thread): 432 / 490 / 543 us per call -- kernels working on host memory
+// over PCIe take 84 us longer than on HBM, and the copy pool moves a frame no faster than the runtime does; 1 and 2 stay for
+// measurements.  FSLIC_COPY_THREADS: helper threads of the copy pool (default 3)
+int host_staging_mode() {
+    static const int mode = [] { const char* v = getenv("FSLIC_HOST_STAGING"); return v ? atoi(v) : 0; }();
+    return mode;
+}
+bool host_staging_enabled() { return host_staging_mode() != 0; }
+fslic::CopyPool* engine_copy_pool(fslic_engine* e) {
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!e->copy_pool) {
+        const char* v = getenv("FSLIC_COPY_THREADS");
+        const int n = v ? std::min(std::max(atoi(v), 0), 16) : 3;
+        e->copy_pool = copy_pool_create(n);
+    }
+    return e->copy_pool;
+}
+}  // namespace
 
 extern "C" {
 
@@ -65,6 +90,7 @@ void fslic_hip_destroy(fslic_engine* e) {
     }
     if (e->d_gamma) hipFree(e->d_gamma);
     if (e->d_labtbl) hipFree(e->d_labtbl);
+    copy_pool_destroy(e->copy_pool);
     delete e;
 }
 
@@ -108,16 +134,47 @@ int fslic_hip_iterate(fslic_engine* e, const fslic_params* p, int H, int W, int 
     const size_t N = (size_t)H * W;
     rc = ensure_prepared(e, s, H, W, K, S, 1);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(s.d_rgb_stage, rgb, N * 3, hipMemcpyHostToDevice, s.st));
     const uint8_t* d_rgb = s.d_rgb_stage;
     uint16_t* d_out = s.d_out_stage;
+    const bool pinned_path = host_staging_enabled();
+    const bool dma = host_staging_mode() == 2;
+    const double t0 = knobs().host_timing ? now_us() : 0.0;
+    if (pinned_path) {
+        // the frame goes into pinned, device-accessible staging (the engine's copy pool: several threads) and the LAB kernel reads
+        // it from there; the relabel kernel writes the label map into pinned staging: no copy command on the stream either way
+        rc = ensure_pinned_staging(s, N, 1);
+        if (rc) return rc;
+        copy_pool_run(engine_copy_pool(e), s.h_rgb_pin, rgb, N * 3);
+        if (dma) {
+            HIPCHK(hipMemcpyAsync(s.d_rgb_stage, s.h_rgb_pin, N * 3, hipMemcpyHostToDevice, s.st));
+        } else {
+            d_rgb = s.h_rgb_pin;
+            d_out = s.h_out_pin;
+        }
+    } else {
+        HIPCHK(hipMemcpyAsync(s.d_rgb_stage, rgb, N * 3, hipMemcpyHostToDevice, s.st));
+    }
+    const double t1 = knobs().host_timing ? now_us() : 0.0;
     s.launch_timing = e->launch_timing;
     rc = group_begin(e, s, p, H, W, K, 1, &d_rgb, &clusters, &d_out);
     if (rc) { (void)hipStreamSynchronize(s.st); return rc; }
+    const double t2 = knobs().host_timing ? now_us() : 0.0;
     rc = group_finish(e, s);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(labels, s.d_out_stage, N * 2, hipMemcpyDeviceToHost, s.st));
-    HIPCHK(hipStreamSynchronize(s.st));
+    const double t3 = knobs().host_timing ? now_us() : 0.0;
+    if (pinned_path) {
+        if (dma) {
+            HIPCHK(hipMemcpyAsync(s.h_out_pin, s.d_out_stage, N * 2, hipMemcpyDeviceToHost, s.st));
+            HIPCHK(hipStreamSynchronize(s.st));
+        }
+        copy_pool_run(engine_copy_pool(e), labels, s.h_out_pin, N * 2);
+        if (knobs().host_timing)
+            fprintf(stderr, "[fslic host] iterate: frame in %.1f us, group begin %.1f, group finish (wait + write-back) %.1f, labels out %.1f (device %.1f us)\n",
+                    t1 - t0, t2 - t1, t3 - t2, now_us() - t3, s.total_ms * 1e3);
+    } else {
+        HIPCHK(hipMemcpyAsync(labels, s.d_out_stage, N * 2, hipMemcpyDeviceToHost, s.st));
+        HIPCHK(hipStreamSynchronize(s.st));
+    }
     set_thread_timing_report(make_timing_report(s));
     return FSLIC_OK;
 }
@@ -148,7 +205,9 @@ int fslic_hip_iterate_batch(fslic_engine* e, const fslic_params* p, int H, int W
         Slot& s = e->slots[pd.slot];
         int r = group_finish(e, s);
         if (r) return r;
-        if (!device_ptrs) {
+        if (!device_ptrs && host_staging_enabled()) {
+            for (int i = 0; i < pd.n; i++) copy_pool_run(engine_copy_pool(e), labels[pd.first + i], s.h_out_pin + (size_t)i * N, N * 2);
+        } else if (!device_ptrs) {
             for (int i = 0; i < pd.n; i++)
                 HIPCHK(hipMemcpyAsync(labels[pd.first + i], s.at(s.d_out_stage, i), N * 2, hipMemcpyDeviceToHost, s.st));
             HIPCHK(hipStreamSynchronize(s.st));
@@ -182,7 +241,16 @@ int fslic_hip_iterate_batch(fslic_engine* e, const fslic_params* p, int H, int W
         Slot& s = e->slots[si];
         const uint8_t* d_rgb[kMaxGroup];
         uint16_t* d_out[kMaxGroup];
-        if (!device_ptrs) {
+        if (!device_ptrs && host_staging_enabled()) {
+            rc = ensure_prepared(e, s, H, W, K, S, n);
+            if (rc == FSLIC_OK) rc = ensure_pinned_staging(s, N, n);
+            if (rc) return bail(rc);
+            for (int i = 0; i < n; i++) {
+                copy_pool_run(engine_copy_pool(e), s.h_rgb_pin + (size_t)i * N * 3, rgb[first + i], N * 3);
+                d_rgb[i] = s.h_rgb_pin + (size_t)i * N * 3;
+                d_out[i] = s.h_out_pin + (size_t)i * N;
+            }
+        } else if (!device_ptrs) {
             rc = ensure_prepared(e, s, H, W, K, S, n);
             if (rc) return bail(rc);
             for (int i = 0; i < n; i++) {

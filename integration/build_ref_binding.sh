@@ -13,7 +13,7 @@ if [ ! -d "$REF" ]; then echo "[integration] $REF absent: keeping the prebuilt i
 B=$HERE/_build
 STAMP=$B/.stamp
 NEW=$(cat "$HERE/hip_arch.patch" "$ROOT/include/fslic_hip.h" "$0" | sha1sum | cut -c1-16)
-if [ -f "$STAMP" ] && [ "$(cat $STAMP)" = "$NEW" ] && ls $B/cfast_slic*.so >/dev/null 2>&1; then exit 0; fi
+if [ -f "$STAMP" ] && [ "$(cat $STAMP)" = "$NEW" ] && ls $B/cfast_slic*.so >/dev/null 2>&1 && [ -f $B/fast_slic/hip.pyc ]; then exit 0; fi
 rm -rf "$B"; mkdir -p "$B"
 T=$(mktemp -d /tmp/fslic_refbuild.XXXXXX)
 trap 'rm -rf "$T"' EXIT
@@ -26,5 +26,10 @@ export FSLIC_HIP_LIBDIR=$ROOT/fast_slic_amd
 export FSLIC_HIP_RPATH='$ORIGIN/../../fast_slic_amd'
 python3 setup.py -q build_ext --inplace > "$B/build.log" 2>&1 || { tail -30 "$B/build.log"; exit 1; }
 cp cfast_slic*.so "$B/"
+# the facade package as the reference ships it plus fast_slic/hip.py from the patch, COMPILED (sourceless .pyc, like the .so: a
+# built form of the patched reference, git-ignored): lets the GPU box import fast_slic.hip.SlicHip / LSCHip
+python3 -m compileall -q -b fast_slic > /dev/null
+mkdir -p "$B/fast_slic"
+cp fast_slic/*.pyc "$B/fast_slic/"
 echo "$NEW" > "$STAMP"
 echo "[integration] built $(ls $B/cfast_slic*.so)"

@@ -74,6 +74,43 @@ def test_bench_launches_its_own_ranks_bare():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 20 and out["units_all_ranks"] == 40.0
     assert out["ms_per_step"] >= 2.0                      # rank 1 sleeps 2 ms per step: the slowest rank decides
+    assert len(out["per_rank_ms"]) == 2 and out["per_rank_ms"][1] > out["per_rank_ms"][0]     # every rank's own clock is in the line
+
+
+def test_bench_launches_four_ranks_bare_and_reports_each_rank():
+    """World size 4 (the driver's N = 1, 2, 4, 8 ladder), bare launch: per-rank times in rank order, the slowest decides."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "10", "--warmup", "1", "--dry-run"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    out = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 4 and out["units_all_ranks"] == 40.0 and out["ms_per_step"] >= 4.0
+    pr = out["per_rank_ms"]
+    assert len(pr) == 4 and pr == sorted(pr) and pr[3] >= 40.0
+
+
+def test_a_dying_rank_takes_the_launch_down():
+    """spawn_ranks: one rank exiting non-zero terminates the others instead of leaving them in the barrier until the rendezvous
+    times out; the launcher returns a non-zero code."""
+    import time
+    t0 = time.time()
+    code = "import os, sys, time\nif os.environ['RANK'] == '1': sys.exit(3)\ntime.sleep(120)"
+    rc = batch.spawn_ranks(3, ["-c", code])
+    assert rc != 0 and time.time() - t0 < 60
+
+
+def test_rank_binds_to_its_own_gpu():
+    """bind_rank_to_its_gpu: the rank's GPU becomes the only visible device (one HIP context per rank, not one per GPU of the node)."""
+    import subprocess
+    code = ("import os, sys; sys.path.insert(0, %r); from fast_slic_amd import batch\n"
+            "os.environ.pop('HIP_VISIBLE_DEVICES', None); d = batch.bind_rank_to_its_gpu(5); print(d, os.environ['HIP_VISIBLE_DEVICES'])\n"
+            "os.environ['HIP_VISIBLE_DEVICES'] = '4,5,6,7'; d = batch.bind_rank_to_its_gpu(2); print(d, os.environ['HIP_VISIBLE_DEVICES'])\n"
+            "os.environ['HIP_VISIBLE_DEVICES'] = '3'; d = batch.bind_rank_to_its_gpu(0); print(d, os.environ['HIP_VISIBLE_DEVICES'])" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout.decode().split() == ["0", "5", "0", "6", "0", "3"]
 
 
 def test_torchrun_environment_is_respected():

@@ -42,6 +42,7 @@ def run_lsc(engine, img, K, **kw):
 
 # per case: (min pre-connectivity pixel agreement, min best-overlap both ways, min boundary IoU)
 FLOORS = {"default": (0.99, 0.99, 0.95)}
+CENTRE_SHIFT_FLOOR_PX = 0.1      # mean |centre - reference centre| over the K clusters, in pixels
 
 
 def test_lsc_agrees_with_reference_fixtures(engine, lsc_cases):
@@ -59,6 +60,10 @@ def test_lsc_agrees_with_reference_fixtures(engine, lsc_cases):
         report.append("%s: pre-agree %.4f best-overlap %.4f boundary-IoU %.4f mean centre shift %.3f px" % (name, agree, bo, iou, dyx))
         lo = FLOORS.get(name, FLOORS["default"])
         assert agree >= lo[0] and bo >= lo[1] and iou >= lo[2], "\n".join(report)
+        # centroids: `north_star` asks 1e-3 for the integer path (exact there); this f32 path differs from the reference in the
+        # order of its sums, which moves a few boundary pixels and with them a few centres by a pixel:
+        # measured 0.000 px on eight fixtures and 0.044 px mean at 1280x720 K=1600; the floor is twice the worst case
+        assert dyx <= CENTRE_SHIFT_FLOOR_PX, "\n".join(report)
     print("\n".join(report))
 
 
@@ -90,6 +95,53 @@ def test_lsc_is_deterministic_and_group_equals_single(engine):
     for z in range(len(imgs)):
         assert np.array_equal(out[z], singles[z][0]), "frame %d of the group differs from its single run" % z
         assert cls[z].tobytes() == singles[z][1].tobytes()
+
+
+def test_lsc_bench_operating_point_8x720p_batching16():
+    # bench.py's `lsc_c5` leg (BASELINE.json configs[4]): 8 x 1280x720 K=1600 LSC per submission through the submit / drain pipeline
+    # on 6 slots with batching 16 (two submissions per launch group), graph replay, 24 submissions: every frame of every submission
+    # identical to its single-frame run (labels and Cluster bytes: the sums are fixed point, so order does not matter), and frame
+    # seed 0 within the fixture floors (best overlap >= 0.99, boundary IoU >= 0.95) of the unmodified reference's A_720x1280_k1600
+    import torch
+    from fast_slic_amd import Engine
+    H, W, K = 720, 1280, 1600
+    lib = B.load_library()
+    p = make_params(10, 10.0, 0.25, 3, True, variant=B.VARIANT_LSC)
+    frames = [np.ascontiguousarray(variant("A", H, W, seed=s)) for s in range(8)]
+    cl0 = np.zeros((8, K), B.CLUSTER_DTYPE)
+    for i, f in enumerate(frames):
+        lib.fslic_hip_initialize_clusters(H, W, K, f.ctypes.data, cl0[i].ctypes.data)
+    e = Engine(0, 6)
+    try:
+        singles = []
+        for i, f in enumerate(frames):
+            cl = cl0[i].copy()
+            singles.append((e.iterate(f, cl, p), cl))
+        want = np.load(os.path.join(ROOT, "tests", "golden", "lsc_cases.npz"), allow_pickle=False)["A_720x1280_k1600/labels"]
+        bo = min(best_overlap(singles[0][0], want), best_overlap(want, singles[0][0]))    # (the connectivity pass renumbers: compare partitions)
+        assert bo >= 0.99 and boundary_iou(singles[0][0], want) >= 0.95, (bo, boundary_iou(singles[0][0], want))
+        e.pipeline_batching(16)
+        d_rgb = [torch.from_numpy(f).cuda() for f in frames]
+        torch.cuda.synchronize()
+        a_rgb = e.pointer_array([t.data_ptr() for t in d_rgb])
+        subs = []
+        for r in range(24):
+            d_lab = [torch.full((H, W), -7, dtype=torch.int16, device="cuda") for _ in frames]
+            cls = cl0.copy()
+            arrs = (e.pointer_array([cls[j].ctypes.data for j in range(8)]), e.pointer_array([t.data_ptr() for t in d_lab]))
+            torch.cuda.synchronize()
+            e.pipeline_submit(a_rgb, arrs[0], arrs[1], 8, H, W, K, p)
+            subs.append((d_lab, cls, arrs))
+        tot = e.pipeline_drain()
+        assert tot["frames"] == 24 * 8 and tot["groups"] <= 24
+        for r, (d_lab, cls, _) in enumerate(subs):
+            for j in range(8):
+                got = d_lab[j].cpu().numpy().view(np.uint16)
+                assert np.array_equal(got, singles[j][0]), "submission %d frame %d: %d pixels differ from the single-frame run" % (r, j, int((got != singles[j][0]).sum()))
+                assert cls[j].tobytes() == singles[j][1].tobytes(), "submission %d frame %d: Cluster bytes differ" % (r, j)
+        assert 2 in [e.last_launch_mode(sl) for sl in range(6)]
+    finally:
+        e.close()
 
 
 def test_lsc_facade_matches_reference_surface(engine):

@@ -132,6 +132,91 @@ def test_one_group_of_eight_4k_frames():
     _run_pipeline(2160, 3840, 1600, list(range(8)), 8, 2, 5)
 
 
+# ---- the other operating points bench.py prints: same pipeline, same slots, same batching, every frame --
+def test_bench_operating_point_c3_four_4k_k6000_frames_six_slots():
+    # BASELINE.json configs[2] as bench.py's `c3_k6000` leg runs it: 4 x 3840x2160 K=6000 per submission, 6 slots with batching
+    # (4 + 4 + .. frames gathered up to 16 per launch group), graph replay; seed 0 carries an area tie at the top-K cut
+    # (a[K-1] = a[K] = 374), resolved on the device inside the pipeline; 225 seeds pile up on the image centre
+    _run_pipeline(2160, 3840, 6000, list(range(4)), 4, 6, 14, batching=16)
+
+
+def test_bench_operating_point_eight_4k_frames_six_slots_batching_off_and_on():
+    # bench.py's `roofline_4k` leg: 8 x 3840x2160 K=1600 per submission on 6 slots; without batching and with (16 frames per group)
+    _run_pipeline(2160, 3840, 1600, list(range(8)), 8, 6, 12)
+    _run_pipeline(2160, 3840, 1600, list(range(8)), 8, 6, 12, batching=16)
+
+
+def test_host_memory_calls_after_batching_reserve():
+    # fslic_hip_pipeline_batching(16) raises the arena reserve; the host-memory entry points stage their frames into
+    # the arena BEFORE group_begin, so the reserve must be applied when they carve (it was applied later: staged frames lost)
+    H, W, K = 240, 320, 150
+    imgs = [variant("A", H, W, seed=s) for s in range(5)]
+    exp = [orc.slic_iterate(im, orc.initialize_clusters(im, K)) for im in imgs]
+    e = Engine(0, 2)
+    try:
+        e.pipeline_batching(16)
+        p = make_params(10, 10.0, 0.25, 3)
+        cl = orc.initialize_clusters(imgs[0], K).view(B.CLUSTER_DTYPE).copy()
+        labels = e.iterate(imgs[0], cl, p)                                        # fresh engine, first call on its slot
+        assert np.array_equal(labels, exp[0][0]) and cl.tobytes() == exp[0][1].tobytes()
+        cls = [orc.initialize_clusters(im, K).view(B.CLUSTER_DTYPE).copy() for im in imgs]
+        outs = [np.zeros((H, W), np.uint16) for _ in imgs]
+        e.iterate_batch([im.ctypes.data for im in imgs], cls, [o.ctypes.data for o in outs], H, W, p, False)
+        for i in range(len(imgs)):
+            assert np.array_equal(outs[i], exp[i][0]), "frame %d" % i
+            assert cls[i].tobytes() == exp[i][1].tobytes(), "frame %d clusters" % i
+    finally:
+        e.close()
+
+
+def test_synchronous_calls_wait_while_the_pipeline_occupies_every_slot():
+    # a slot serving the submit / drain queue collects its group itself; a synchronous call from another thread must
+    # wait for it (the header says so), not fail with "every slot owns an unfinished asynchronous group"
+    import torch
+    H, W, K = 360, 640, 400
+    frames = [variant("A", H, W, seed=s) for s in range(4)]
+    exp = [orc.slic_iterate(f, orc.initialize_clusters(f, K)) for f in frames]
+    small = variant("B", 120, 160)
+    exp_small = orc.slic_iterate(small, orc.initialize_clusters(small, 40))
+    e = Engine(0, 2)
+    errors = []
+    try:
+        p = make_params(10, 10.0, 0.25, 3)
+        d_rgb = [torch.from_numpy(f).cuda() for f in frames]
+        torch.cuda.synchronize()
+        stop = threading.Event()
+
+        def sync_caller():
+            try:
+                while not stop.is_set():
+                    cl = orc.initialize_clusters(small, 40).view(B.CLUSTER_DTYPE).copy()
+                    labels = e.iterate(small, cl, p)
+                    if not np.array_equal(labels, exp_small[0]) or cl.tobytes() != exp_small[1].tobytes():
+                        errors.append("synchronous call differs")
+            except Exception as ex:                          # noqa: BLE001
+                errors.append("synchronous caller: %r" % (ex,))
+
+        th = threading.Thread(target=sync_caller)
+        th.start()
+        subs = []
+        for r in range(40):
+            d_lab = [torch.empty((H, W), dtype=torch.int16, device="cuda") for _ in frames]
+            cls = np.stack([orc.initialize_clusters(f, K).view(B.CLUSTER_DTYPE) for f in frames]).copy()
+            arrs = (e.pointer_array([t.data_ptr() for t in d_rgb]), e.pointer_array([cls[j].ctypes.data for j in range(4)]),
+                    e.pointer_array([t.data_ptr() for t in d_lab]))
+            e.pipeline_submit(arrs[0], arrs[1], arrs[2], 4, H, W, K, p)
+            subs.append((d_lab, cls, arrs))
+        e.pipeline_drain()
+        stop.set()
+        th.join()
+        for d_lab, cls, _ in subs:
+            for j in range(4):
+                assert np.array_equal(d_lab[j].cpu().numpy().view(np.uint16), exp[j][0]) and cls[j].tobytes() == exp[j][1].tobytes()
+    finally:
+        e.close()
+    assert not errors, "\n".join(errors[:5])
+
+
 # ---- the area tie at the top-K cut, on the device ---------------------------------------------------------------
 def _tie_maps():
     rng = np.random.RandomState(5)

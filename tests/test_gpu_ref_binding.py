@@ -80,3 +80,35 @@ def test_reference_binding_with_hip_arch_equals_reference_cpu_path():
     assert out["avx2_equal"] and out["nchan_error"]
     # the f32 LSC path is tolerance-based: no worse than the reference's own AVX2 variant against its scalar one
     assert out["lsc_best_overlap"] >= 0.90 and out["lsc_boundary_iou"] >= 0.75, (out["lsc_best_overlap"], out["lsc_boundary_iou"])
+
+
+_HIP_FACADE = r'''
+import sys, json
+import numpy as np
+sys.path.insert(0, %(build)r)
+sys.path.insert(1, %(root)r)
+from fast_slic.hip import SlicHip, LSCHip              # the patch's fast_slic/hip.py (mirrors fast_slic/avx2.py:1-14) over the reference's facade
+from fast_slic import Slic
+from fast_slic_amd.synth import variant
+img = variant("A", 480, 640)
+a = Slic(num_components=200, compactness=10, num_threads=4)
+b = SlicHip(num_components=200, compactness=10)
+la, lb = a.iterate(img), b.iterate(img)
+out = {"arch": SlicHip.arch_name, "labels_equal": bool(np.array_equal(la, lb)), "clusters_equal": a.slic_model.clusters == b.slic_model.clusters,
+       "dtype": str(lb.dtype), "lsc_arch": LSCHip.arch_name}
+l = LSCHip(num_components=100, compactness=10).iterate(img)
+out["lsc_shape"] = list(l.shape)
+print("RESULT " + json.dumps(out))
+'''
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(BUILD, "fast_slic", "hip.pyc")), reason="integration/_build holds no compiled fast_slic package")
+def test_fast_slic_hip_facade_classes():
+    # the drop-in as a user of the reference types it: `from fast_slic.hip import SlicHip` (hunk fast_slic/hip.py of
+    # integration/hip_arch.patch on top of the reference's own facade, fast_slic/base_slic.py:18-88), next to fast_slic.Slic
+    r = subprocess.run([sys.executable, "-c", _HIP_FACADE % {"build": BUILD, "root": ROOT}], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    import json
+    out = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert out["arch"] == "hip/gfx950" and out["lsc_arch"] == "hip/gfx950"
+    assert out["labels_equal"] and out["clusters_equal"] and out["dtype"] == "int16" and out["lsc_shape"] == [480, 640]
