@@ -44,6 +44,7 @@ EXPORTS = [
     "fslic_hip_last_device_times", "fslic_hip_set_launch_timing", "fslic_hip_last_assign_loop", "fslic_hip_last_group_frames", "fslic_hip_last_path", "fslic_hip_last_launch_mode", "fslic_hip_group_done", "fslic_hip_last_error", "fslic_hip_version",
     "fslic_hip_get_connectivity", "fslic_hip_knn_connectivity", "fslic_hip_get_mask_density", "fslic_hip_cluster_density_to_mask",
     "fslic_hip_pipeline_submit", "fslic_hip_pipeline_drain", "fslic_hip_pipeline_batching", "fslic_hip_last_host_topk_frames",
+    "fslic_hip_separate_pass_redos",
 ]
 
 _lib = None
@@ -109,6 +110,7 @@ def load_library():
         lib.fslic_hip_pipeline_drain.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
         lib.fslic_hip_pipeline_batching.argtypes = [vp, i32]
         lib.fslic_hip_last_host_topk_frames.argtypes = [vp, i32]
+        lib.fslic_hip_separate_pass_redos.argtypes = [vp, i32]
         lib.fslic_hip_group_done.argtypes = [vp, i32]
         lib.fslic_hip_rgb_to_lab.argtypes = [vp, i32, i32, vp, i32, vp]
         lib.fslic_hip_enforce_connectivity.argtypes = [vp, vp, i32, i32, i32, i32]
@@ -278,6 +280,10 @@ class Engine(object):
 
     def last_host_topk_frames(self, slot=0):
         return int(load_library().fslic_hip_last_host_topk_frames(self._h, int(slot)))
+
+    def separate_pass_redos(self):
+        """Frames (all slots, since the engine was created) redone with the separate cluster pass because of a stale pixel."""
+        return sum(int(load_library().fslic_hip_separate_pass_redos(self._h, s)) for s in range(self.n_slots))
 
     def group_done(self, slot):
         """True when wait_group(slot) would not block."""

@@ -98,10 +98,11 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     const size_t o_zero = off;
     const size_t o_sums = take((size_t)K * 6 * 4), o_sums1 = take((size_t)K * 6 * 4);
     const size_t o_cc0 = take(ncell * 4), o_cc1 = take(ncell * 4);
-    const size_t o_misc = take(256);                                 // ovf_cnt[2], err, cca counters
+    const size_t o_misc = take(256);                                 // ovf_cnt[0..1], err, ovf_cnt[2], cca counters
+    const size_t o_arrive = take((size_t)K * 4);                     // fused cluster pass: arrival counters
     const size_t zero_bytes = off - o_zero;
     const size_t o_ci0 = take(ncell * kCellCap * sizeof(ClusterRec)), o_ci1 = take(ncell * kCellCap * sizeof(ClusterRec));
-    const size_t o_ov0 = take((size_t)K * sizeof(ClusterRec)), o_ov1 = take((size_t)K * sizeof(ClusterRec));
+    const size_t o_ov0 = take((size_t)K * sizeof(ClusterRec)), o_ov1 = take((size_t)K * sizeof(ClusterRec)), o_ov2 = take((size_t)K * sizeof(ClusterRec));
     const size_t ntiles = (size_t)((W + kCcaTile - 1) / kCcaTile) * ((H + kCcaTileH - 1) / kCcaTileH);
     const size_t TT = (size_t)kCcaTilePx;
     const size_t NP = ntiles * TT;            // node capacity: every tile's full range
@@ -142,9 +143,10 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     f.cell_cnt[0] = (uint32_t*)(b + o_cc0); f.cell_cnt[1] = (uint32_t*)(b + o_cc1);
     uint32_t* misc = (uint32_t*)(b + o_misc);
     s.d_misc = misc;
-    f.ovf_cnt[0] = misc + 0; f.ovf_cnt[1] = misc + 1; f.err_flag = misc + 2;
+    f.ovf_cnt[0] = misc + 0; f.ovf_cnt[1] = misc + 1; f.err_flag = misc + 2; f.ovf_cnt[2] = misc + 3;
+    f.cl_arrive = (uint32_t*)(b + o_arrive);
     f.cell_items[0] = (ClusterRec*)(b + o_ci0); f.cell_items[1] = (ClusterRec*)(b + o_ci1);
-    f.ovf_items[0] = (ClusterRec*)(b + o_ov0); f.ovf_items[1] = (ClusterRec*)(b + o_ov1);
+    f.ovf_items[0] = (ClusterRec*)(b + o_ov0); f.ovf_items[1] = (ClusterRec*)(b + o_ov1); f.ovf_items[2] = (ClusterRec*)(b + o_ov2);
     s.d_patch = (uint16_t*)(s.arena + o_patch);
     f.patch2d = s.d_patch;
     s.d_lut = (uint32_t*)(s.arena + o_lut);

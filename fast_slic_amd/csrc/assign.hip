@@ -871,8 +871,108 @@ static __device__ __forceinline__ void lds_dma_16(const void* gsrc, uint32_t lds
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
 }
 
-template <int R, bool FUSE, int STRIDE, bool VT>
-static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, int Hv) {
+// ---- fused cluster pass (FBIN): what the LAST assign block to deliver partial sums of a cluster does for it ----------------------
+// src/context.cpp:356-373 (round_int means of the pass's sums, num_members written even when 0, position kept then) and the binning
+// for the next pass (the role of k_bin_clusters<1>, clusters.hip).  One lane per cluster; lanes of a wavefront finalise different
+// clusters side by side.  Every read of another block's data is an agent-scope load (sc1): the writers stored write-through
+// and drained before they counted themselves in (MI355X guide: sc1 loads may stand in for the acquire when the producer stored sc1).
+static __device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static __device__ __forceinline__ unsigned long long ld_agent64(const void* p) {
+    return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// floor(x / n) for x < 2^31, n >= 1, through the reciprocal r = floor((2^32 - 1) / n): the estimate is at most one short
+static __device__ __forceinline__ uint32_t div_by(uint32_t x, uint32_t n, uint32_t r) {
+    uint32_t q = __umulhi(x, r);
+    uint32_t rest = x - q * n;
+    if (rest >= n) { q++; rest -= n; }
+    if (rest >= n) q++;
+    return q;
+}
+static __device__ __forceinline__ void bin_insert_next(const FrameDev& f, uint32_t k, uint32_t yx, uint32_t lab) {
+    const int y = (int)(yx >> 16), x = (int)(yx & 0xFFFFu);
+    const uint32_t phase = (uint32_t)(2 * ((y / f.T) & 1) + ((x / f.T) & 1));      // visit order of the reference scatter: phase, then k
+    ClusterRec rec;
+    rec.yx = yx; rec.lab = lab; rec.tag = (phase << 16) | k; rec.pad = f.generation() + 1u;       // the NEXT pass's stamp
+    f.cl_tag[k] = rec.tag;
+    const int cell = (y >> f.cs_shift) * f.ncx + (x >> f.cs_shift);
+    const uint32_t slot = atomicAdd(&f.cell_cnt[1][cell], 1u);
+    if (slot < (uint32_t)kCellCap) f.cell_items[1][(size_t)cell * kCellCap + slot] = rec;
+    else f.ovf_items[1][atomicAdd(f.ovf_cnt[1], 1u)] = rec;
+}
+static __device__ __forceinline__ void fused_finalize(const FrameDev& f, uint32_t k, uint32_t yx, uint32_t lab, uint32_t nx, uint32_t ny) {
+    // the pass's sums of cluster k: what went through global atomics plus one entry per assign block its window overlaps
+    uint32_t* const s0 = f.sums[0] + 6 * (size_t)k;
+    uint32_t s[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) s[q] = ld_agent(s0 + q);
+    const uint32_t* const cp = f.cpart + (size_t)k * f.cpart_ns * 6;
+    for (uint32_t ey = 0; ey < ny; ++ey)
+        for (uint32_t ex = 0; ex < nx; ++ex) {
+            const uint32_t* e = cp + (ey * (uint32_t)f.nbx + ex) * 6;             // 24-byte entries, 8-byte aligned
+            const unsigned long long a = ld_agent64(e), b = ld_agent64(e + 2), c = ld_agent64(e + 4);
+            s[0] += (uint32_t)a; s[1] += (uint32_t)(a >> 32); s[2] += (uint32_t)b; s[3] += (uint32_t)(b >> 32); s[4] += (uint32_t)c; s[5] += (uint32_t)(c >> 32);
+        }
+    const uint32_t n = s[0];
+    f.cl_n[k] = n;
+    if (n != 0) {
+        const uint32_t h = n >> 1, r = 0xFFFFFFFFu / n;
+        int y = (int)div_by(s[1] + h, n, r), x = (int)div_by(s[2] + h, n, r);
+        y = min(max(y, 0), f.H - 1);            // (a centroid of in-image pixels is in the image: no-op on valid sums, see k_bin_clusters)
+        x = min(max(x, 0), f.W - 1);
+        const uint32_t L = div_by(s[3] + h, n, r), a = div_by(s[4] + h, n, r), b = div_by(s[5] + h, n, r);
+        yx = ((uint32_t)y << 16) | (uint32_t)x;
+        lab = (L & 255u) | ((a & 255u) << 8) | ((b & 255u) << 16);
+        f.cl_lab[k] = lab;
+        f.cl_moved[k] = 1;
+        f.cl_yx[k] = yx;                        // positions live in ONE buffer here (only this lane ever writes entry k during the pass)
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) s0[q] = 0u;     // this accumulator set serves the pass after next
+    f.cl_arrive[k] = 0u;
+    bin_insert_next(f, k, yx, lab);
+    // A cluster kept out of the bins because it equals its predecessor (cl_shadow, see k_bin_clusters) has no block working for
+    // it; its predecessor's finaliser looks after it.  While the predecessor receives no member it stays identical and the
+    // follower stays out (exact: it can never win a pixel).  Once the predecessor has members the follower goes back into the
+    // bins (src/context.cpp:362-364: no members, position unchanged) -- the rest of a run of equals keeps hiding behind IT.
+    if (n != 0 && k + 1u < (uint32_t)f.K && f.cl_shadow[k + 1u]) {
+        f.cl_shadow[k + 1u] = 0u;
+        bin_insert_next(f, k + 1u, f.cl_yx[k + 1u], f.cl_lab[k + 1u]);
+    }
+}
+
+// Blocks -> tiles, XCD-aware.  The hardware hands consecutive workgroups (x fastest) to the eight XCDs in turn, and every XCD has
+// its own L2: with the natural (tile column, tile row, frame) grid the eight neighbours that share a frame's bins and table
+// rows sit on eight different L2s (measured: 1.32 x the algorithmic bytes at 1280x720).  With FSLIC_XCD=1 the launch grid is
+// 8 * per workgroups in one dimension instead: workgroup b takes tile (b % 8) * per + b / 8, so that an XCD works through a
+// contiguous eighth of the tiles (whole frames).  Measured (profiles/r03_xcd_mapping.txt): the traffic of the fused launch at
+// 8 x 1280x720 falls to 1.15 x the algorithmic bytes, its duration does not (11.8 vs 11.5 us), and the HBM-bound 3840x2160
+// launches get SLOWER (fused 55.1 vs 46.7 us, full assignment 74.4 vs 67.6): tiles that run at the same time then lie in
+// eight different frames instead of next to each other in memory.  Off by default.
+struct BlkMap { uint32_t gx, gy, total, per; };
+static const bool g_xcd_chunks = [] { const char* v = getenv("FSLIC_XCD"); return v && atoi(v) == 1; }();
+static inline BlkMap blk_map(dim3 g) {
+    BlkMap m; m.gx = g.x; m.gy = g.y; m.total = g.x * g.y * g.z; m.per = g_xcd_chunks ? (m.total + 7u) / 8u : 0u;
+    return m;
+}
+static inline dim3 blk_grid(dim3 g) { return g_xcd_chunks ? dim3(8 * blk_map(g).per) : g; }
+static __device__ __forceinline__ void div_rem(uint32_t x, uint32_t n, uint32_t& q, uint32_t& rest) {     // x < 2^31, n >= 1
+    q = __umulhi(x, 0xFFFFFFFFu / n);
+    rest = x - q * n;
+    if (rest >= n) { q++; rest -= n; }
+    if (rest >= n) { q++; rest -= n; }
+}
+
+template <int R, bool FUSE, int STRIDE, bool VT, bool FBIN = false>
+static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, int Hv, const BlkMap& bm) {
+    static_assert(!FBIN || FUSE, "the cluster pass rides on the fused centroid sums");
+    uint32_t bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;      // per == 0: the natural grid (tile column, tile row, frame)
+    if (bm.per != 0u) {
+        const uint32_t t = (blockIdx.x & 7u) * bm.per + (blockIdx.x >> 3);
+        if (t >= bm.total) return;                  // (up to seven workgroups of the last row have no tile)
+        uint32_t rest;
+        div_rem(t, bm.gx * bm.gy, bzi, rest);
+        div_rem(rest, bm.gx, byi, bxi);
+    }
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];   // spatial table (u16), whole KB (LDS-DMA lands 1 KB per wavefront instruction); 16-byte aligned: the row-vector reads are ds_read_b128
     __shared__ __attribute__((aligned(16))) uint4 s_raw[kWavesPerBlock][64];       // every wavefront's kept records {yx, lab, tag, -}
     __shared__ __attribute__((aligned(16))) uint32_t s_part[64][4];                // partial ranks: [candidate][wavefront]
@@ -886,22 +986,29 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
     constexpr int BH = kWavesPerBlock * R;
     static_assert(!FUSE || (BH * 64 * 255 < (1 << 20) && (BH - 1) * STRIDE * BH * 64 < (1 << 20)), "accumulator fields overflow");
 
-    f.select(blockIdx.z);
+    f.select((int)bzi);
     const uint32_t gen = f.generation();
     const int tid = threadIdx.x;
+    if (FBIN) {
+        // housekeeping the separate cluster pass used to do: the counters of the bins this pass READS (nobody looks at them
+        // while the records are stamped) are cleared for the pass after next; likewise the spill counter nobody uses in this pass
+        const uint32_t gi = (byi * bm.gx + bxi) * 256u + (uint32_t)tid;
+        if (gi < (uint32_t)f.ncell) f.cell_cnt[0][gi] = 0u;
+        if (gi == 0u) *f.ovf_cnt[2] = 0u;
+    }
     const int lane = tid & 63;
     const int wave = (int)rfl((uint32_t)(tid >> 6));
     const int W = f.W, S = f.S;
-    const int x0 = blockIdx.x * kTileW;
+    const int x0 = (int)bxi * kTileW;
     const int x = x0 + lane;
-    const int vrow_b0 = blockIdx.y * BH;
+    const int vrow_b0 = (int)byi * BH;
     const int vrow_w0 = vrow_b0 + wave * R;
     const bool okx = x < W;
     const int nrows = max(0, min(R, Hv - vrow_w0));      // 0: this wavefront has no rows (bottom edge)
     const int yw_lo = rem + vrow_w0 * STRIDE;
 #if defined(FSLIC_LAB) && FSLIC_LAB == 4
     const uint32_t asg_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
-    volatile uint32_t* const asg_w = f.lab_stamps + ((size_t)(f.gen_off - 1u) * 2048u + (size_t)(blockIdx.y * gridDim.x + blockIdx.x)) * 16u;
+    volatile uint32_t* const asg_w = f.lab_stamps + ((size_t)(f.gen_off - 1u) * 2048u + (size_t)(byi * bm.gx + bxi)) * 16u;
     ASG_PUT(0, wave == 0, asg_t0);
 #endif
 
@@ -1003,7 +1110,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
         const int c0 = (int)rfl(wc.x), c1 = (int)rfl(wc.y), c2 = (int)rfl(wc.z), c3 = (int)rfl(wc.w);
         bn = c0 + c1 + c2 + c3;
         if (bn > 64) {                        // more live candidates than idx bits: the host redoes the frame generically
-            if (tid == 0) *f.err_flag = 1u;
+            if (tid == 0) atomicOr(f.err_flag, 1u);
             return;
         }
         const int p1 = c0, p2 = c0 + c1, p3 = c0 + c1 + c2;
@@ -1026,12 +1133,15 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
         rank_j = pr.x + pr.y + pr.z + pr.w;
     }
     if (lane < bn) s_k16[wave][rank_j] = (uint16_t)(mine.z & 0xFFFFu);
+    uint32_t fin_nx = 0, fin_ny = 0;             // FBIN, wavefront 0, lane j: blocks that deliver sums of candidate j (0: not this block)
     if (FUSE && wave == 0) {
         uint32_t entry = kNoSlot;
         const SlotGeom g = slot_geom((int)(mine.x >> 16), (int)(mine.x & 0xFFFFu), S, f.H, W, rem, STRIDE, BH, Hv);
-        const int by = (int)blockIdx.y, bx = (int)blockIdx.x;
-        if (g.any && by >= g.by0 && by <= g.by1)
+        const int by = (int)byi, bx = (int)bxi;
+        if (g.any && by >= g.by0 && by <= g.by1) {
             entry = ((mine.z & 0xFFFFu) * (uint32_t)f.cpart_ns + (uint32_t)((by - g.by0) * f.nbx + (bx - g.bx0))) * 6u;
+            if (FBIN && lane < bn) { fin_nx = (uint32_t)(g.bx1 - g.bx0 + 1); fin_ny = (uint32_t)(g.by1 - g.by0 + 1); }
+        }
         if (lane < bn) s_entry[rank_j] = entry;
     }
     ASG_STAMP(3, wave == 0);
@@ -1258,7 +1368,12 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
                 if (found) slot[r] = key & 63u;
                 else {
                     const uint32_t old = rowp[xo];     // stale label still takes part in update()
-                    if (old != 0xFFFFu) global_accumulate(f.sums[0], old, (uint32_t)(yw_lo + r * STRIDE), xo, pix[r]);
+                    if (old != 0xFFFFu) {
+                        global_accumulate(f.sums[0], old, (uint32_t)(yw_lo + r * STRIDE), xo, pix[r]);
+                        // the owner of that label may lie outside this block's candidates: nothing orders these atomics before its
+                        // finaliser.  Rare (no window covers the pixel); the host redoes the frame with the separate cluster pass.
+                        if (FBIN) atomicOr(f.err_flag, 2u);
+                    }
                 }
             }
             rowp += (size_t)STRIDE * W;
@@ -1315,7 +1430,17 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
                 else if (q == 3) v = (uint32_t)A & 0xFFFFFu;
                 else if (q == 4) v = (uint32_t)(A >> 20) & 0xFFFFFu;
                 else v = (uint32_t)(A >> 40);
-                f.cpart[(size_t)entry + (uint32_t)q] = v;
+                if (FBIN) st_stream(f.cpart + (size_t)entry + (uint32_t)q, v);      // written through: another block's lane reads it
+                else f.cpart[(size_t)entry + (uint32_t)q] = v;
+            }
+        }
+        if (FBIN) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wavefront drains (sums, stale-pixel atomics) ..
+            __syncthreads();                                       // .. before the block counts itself in
+            if (wave == 0 && fin_nx != 0u) {
+                const uint32_t k = mine.z & 0xFFFFu;
+                const uint32_t before = __hip_atomic_fetch_add(f.cl_arrive + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (before + 1u == fin_nx * fin_ny) fused_finalize(f, k, mine.x, mine.y, fin_nx, fin_ny);
             }
         }
     }
@@ -1342,16 +1467,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_wav
 }
 
 template <int R, bool FUSE, int STRIDE, bool VT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(7, 8))) void k_assign_blk2(FrameDev f, int rem, int Hv) {
-    assign_blk2_body<R, FUSE, STRIDE, VT>(f, rem, Hv);
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(7, 8))) void k_assign_blk2(FrameDev f, int rem, int Hv, BlkMap bm) {
+    assign_blk2_body<R, FUSE, STRIDE, VT>(f, rem, Hv, bm);
 }
 template <int R, bool FUSE, int STRIDE, bool VT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void k_assign_blk2_w8(FrameDev f, int rem, int Hv) {
-    assign_blk2_body<R, FUSE, STRIDE, VT>(f, rem, Hv);
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void k_assign_blk2_w8(FrameDev f, int rem, int Hv, BlkMap bm) {
+    assign_blk2_body<R, FUSE, STRIDE, VT>(f, rem, Hv, bm);
 }
 template <int R, bool FUSE, int STRIDE, bool VT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(6, 8))) void k_assign_blk2_w6(FrameDev f, int rem, int Hv) {
-    assign_blk2_body<R, FUSE, STRIDE, VT>(f, rem, Hv);
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(6, 8))) void k_assign_blk2_w6(FrameDev f, int rem, int Hv, BlkMap bm) {
+    assign_blk2_body<R, FUSE, STRIDE, VT>(f, rem, Hv, bm);
+}
+
+template <int R, int STRIDE, bool VT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(7, 8))) void k_assign_bin(FrameDev f, int rem, int Hv, BlkMap bm) {
+    assign_blk2_body<R, true, STRIDE, VT, true>(f, rem, Hv, bm);
+}
+template <int R, int STRIDE, bool VT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(6, 8))) void k_assign_bin_w6(FrameDev f, int rem, int Hv, BlkMap bm) {
+    assign_blk2_body<R, true, STRIDE, VT, true>(f, rem, Hv, bm);
 }
 
 // FSLIC_ASSIGN=1 (read once): the first form of the block kernel (round 2), kept for A/B measurements
@@ -1365,13 +1499,13 @@ static void launch_assign_blk_t(const FrameDev& f_, int nframes, int rem, int Hv
     if (!g_assign_v1) {
         const size_t lds2 = ((size_t)f.tab_words * sizeof(uint32_t) + 1023) / 1024 * 1024;       // whole KB: what the LDS-DMA pieces fill
         if constexpr (R == 16 && !FUSE) {
-            if (f.tab_vmode) launch((k_assign_blk2_w8<R, FUSE, STRIDE, true>), grid, dim3(256), lds2, st, f, rem, Hv);
-            else launch((k_assign_blk2_w8<R, FUSE, STRIDE, false>), grid, dim3(256), lds2, st, f, rem, Hv);
+            if (f.tab_vmode) launch((k_assign_blk2_w8<R, FUSE, STRIDE, true>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
+            else launch((k_assign_blk2_w8<R, FUSE, STRIDE, false>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
         } else if constexpr (R == 16 && FUSE) {
-            launch((k_assign_blk2_w6<R, FUSE, STRIDE, true>), grid, dim3(256), lds2, st, f, rem, Hv);
+            launch((k_assign_blk2_w6<R, FUSE, STRIDE, true>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
         } else {
-            if (f.tab_vmode) launch((k_assign_blk2<R, FUSE, STRIDE, true>), grid, dim3(256), lds2, st, f, rem, Hv);
-            else launch((k_assign_blk2<R, FUSE, STRIDE, false>), grid, dim3(256), lds2, st, f, rem, Hv);
+            if (f.tab_vmode) launch((k_assign_blk2<R, FUSE, STRIDE, true>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
+            else launch((k_assign_blk2<R, FUSE, STRIDE, false>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
         }
         return;
     }
@@ -1384,6 +1518,43 @@ static void launch_assign_blk_t(const FrameDev& f_, int nframes, int rem, int Hv
     } else {
         if (f.tab_vmode) launch((k_assign_blk<R, FUSE, STRIDE, true>), grid, dim3(256), lds, st, f, rem, Hv);
         else launch((k_assign_blk<R, FUSE, STRIDE, false>), grid, dim3(256), lds, st, f, rem, Hv);
+    }
+}
+
+template <int R, int STRIDE>
+static void launch_assign_bin_t(const FrameDev& f_, int nframes, int rem, int Hv, hipStream_t st) {
+    FrameDev f = f_;
+    f.tab = f.tabs; f.tab_words = f.tabs_words; f.tab_dyoff = f.tabs_dyoff; f.tab_nrpad = f.tabs_nrpad;     // table of the subsampled stride
+    dim3 grid((f.W + kTileW - 1) / kTileW, (Hv + kWavesPerBlock * R - 1) / (kWavesPerBlock * R), nframes);
+    const size_t lds2 = ((size_t)f.tab_words * sizeof(uint32_t) + 1023) / 1024 * 1024;
+    if constexpr (R == 16) {
+        launch((k_assign_bin_w6<R, STRIDE, true>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
+    } else {
+        if (f.tab_vmode) launch((k_assign_bin<R, STRIDE, true>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
+        else launch((k_assign_bin<R, STRIDE, false>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
+    }
+}
+
+static bool blk_kernel_applies(const FrameDev& f, int stride) {
+    return f.tab_words > 0 && stride >= 1 && stride <= 3 && (unsigned long long)f.N * 4ull < 0x7FFFFFFFull;
+}
+
+bool assign_fuses_cluster_pass(const FrameDev& f, int stride) { return !g_assign_v1 && blk_kernel_applies(f, stride); }
+
+void launch_assign_fused_bin(const FrameDev& f_, int nframes, int rem, int stride, int it, hipStream_t st) {
+    const FrameDev f = rotated(f_, it & 1, it & 1, it % 3);
+    const int Hv = (f.H - rem + stride - 1) / stride;
+    if (Hv <= 0) return;
+    const int tiles_x = (f.W + kTileW - 1) / kTileW;
+    const bool r16 = f.tab_vmode && nframes * tiles_x * ((Hv + kWavesPerBlock * 8 - 1) / (kWavesPerBlock * 8)) > 3072;      // as launch_assign
+    if (r16) {
+        if (stride == 1) launch_assign_bin_t<16, 1>(f, nframes, rem, Hv, st);
+        else if (stride == 2) launch_assign_bin_t<16, 2>(f, nframes, rem, Hv, st);
+        else launch_assign_bin_t<16, 3>(f, nframes, rem, Hv, st);
+    } else {
+        if (stride == 1) launch_assign_bin_t<8, 1>(f, nframes, rem, Hv, st);
+        else if (stride == 2) launch_assign_bin_t<8, 2>(f, nframes, rem, Hv, st);
+        else launch_assign_bin_t<8, 3>(f, nframes, rem, Hv, st);
     }
 }
 
@@ -1406,8 +1577,8 @@ static void launch_assign_r(const FrameDev& f, int nframes, int rem, int stride,
     }
 }
 
-PassGeom launch_assign(const FrameDev& f_, int nframes, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st) {
-    const FrameDev f = rotated(f_, buf, sbuf);
+PassGeom launch_assign(const FrameDev& f_, int nframes, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st, int obuf) {
+    const FrameDev f = rotated(f_, buf, sbuf, obuf);
     const int Hv = (f.H - rem + stride - 1) / stride;
     PassGeom pg;
     pg.rem = rem; pg.stride = stride; pg.Hv = Hv; pg.BH = kWavesPerBlock * 8; pg.use_slots = 0;

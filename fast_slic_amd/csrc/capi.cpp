@@ -343,6 +343,11 @@ int fslic_hip_last_host_topk_frames(fslic_engine* e, int slot) {
     return e->slots[slot].n_host_topk;
 }
 
+int fslic_hip_separate_pass_redos(fslic_engine* e, int slot) {
+    if (!e || slot < 0 || slot >= (int)e->slots.size()) return -1;
+    return e->slots[slot].n_separate_redo;
+}
+
 #ifdef FSLIC_LAB
 // lab build only: the 16 status words of frame `frame` of the last group on `slot` as the export left them in pinned memory
 int fslic_hip_debug_status_words(fslic_engine* e, int slot, int frame, uint32_t* out16) {

@@ -12,12 +12,16 @@ namespace fslic {
 // Kernels index the double-buffered members with the constants 0 (this pass) and 1 (the other parity): a
 // run-time index into the by-value FrameDev argument would push the whole struct into scratch memory once
 // select() has modified it.  The launchers rotate the arrays accordingly.
-static inline FrameDev rotated(const FrameDev& f, int buf, int sbuf) {
+static inline FrameDev rotated(const FrameDev& f, int buf, int sbuf, int obuf = -1) {
     FrameDev g = f;
     g.cell_cnt[0] = f.cell_cnt[buf]; g.cell_cnt[1] = f.cell_cnt[buf ^ 1];
     g.cell_items[0] = f.cell_items[buf]; g.cell_items[1] = f.cell_items[buf ^ 1];
-    g.ovf_cnt[0] = f.ovf_cnt[buf]; g.ovf_cnt[1] = f.ovf_cnt[buf ^ 1];
-    g.ovf_items[0] = f.ovf_items[buf]; g.ovf_items[1] = f.ovf_items[buf ^ 1];
+    if (obuf < 0) {      // two-buffer rotation (separate cluster pass): the spill lists follow the bins
+        g.ovf_cnt[0] = f.ovf_cnt[buf]; g.ovf_cnt[1] = f.ovf_cnt[buf ^ 1];
+        g.ovf_items[0] = f.ovf_items[buf]; g.ovf_items[1] = f.ovf_items[buf ^ 1];
+    } else {             // three-buffer rotation (fused cluster pass): [0] read, [1] appended to, [2] cleared
+        for (int q = 0; q < 3; q++) { g.ovf_cnt[q] = f.ovf_cnt[(obuf + q) % 3]; g.ovf_items[q] = f.ovf_items[(obuf + q) % 3]; }
+    }
     g.sums[0] = f.sums[sbuf]; g.sums[1] = f.sums[sbuf ^ 1];
     return g;
 }

@@ -50,9 +50,13 @@ double now_us();
 //   FSLIC_GRAPH=0      enqueue every group operation by operation instead of replaying a recorded hipGraph
 //   FSLIC_POISON       testing aid: fill a freshly carved arena with 0xA5 (reads of never-written memory show up)
 //   FSLIC_HOST_TIMING  one stderr line per group start / completion with host-side durations
+//   FSLIC_FUSEBIN      the cluster pass between two assign passes: 1 (default) fused into the assign kernel for launches that do
+//                      not fill the chip and a separate launch (k_bin_clusters<1>) otherwise; 0 always separate (round 2; also what
+//                      a frame with a stale pixel is redone with); 2 always fused (A/B measurements)
 struct Knobs {
     int group_size;
     bool use_graphs, poison, host_timing;
+    int fuse_bin;
 };
 const Knobs& knobs();
 
@@ -89,7 +93,7 @@ struct Slot {
     size_t zero_bytes = 0;
     char* stamp_block = nullptr;     // the bin slots' generation stamps (cleared when carved and when the stamps wrap)
     size_t stamp_bytes = 0;
-    uint32_t* d_misc = nullptr;      // 64 B: ovf_cnt[2], err flag, pad, cca counters[4]
+    uint32_t* d_misc = nullptr;      // 64 B: ovf_cnt[0..1], err flags (bit 0: candidate-list overflow, bit 1: stale pixel under the fused cluster pass), ovf_cnt[2], cca counters[4]
     uint32_t* d_yx_alt[2] = {nullptr, nullptr};   // the cluster pass's alternating position buffers (frame 0)
     uint8_t* d_rgb_stage = nullptr;
     uint16_t* d_out_stage = nullptr;
@@ -155,6 +159,7 @@ struct Slot {
     float total_ms = 0, fa_ms = 0, lab_ms = 0, loop_ms = 0, cca_ms = 0;
     int last_path = 0;
     int n_host_topk = 0;             // frames of the last group whose top-K step ran on the host
+    int n_separate_redo = 0;         // frames (since the slot was created) redone with the separate cluster pass because of a stale pixel
     bool have_pre = false;
     // Ownership (guarded by fslic_engine::mu): `busy` while a synchronous call or a stage utility runs on the slot,
     // `pending` from the submission of an asynchronous group until it has been collected.

@@ -186,7 +186,7 @@ void stage_group(fslic_engine* e, Slot& s, int i0, int n, bool timed) {
 // connectivity, export of the cluster state.  Pure
 // stream work with no per-call values in any launch argument (caller pointers sit in the device pointer table, bin
 // generations come from device memory), so the same sequence can be recorded once as a graph and replayed (launch_group).
-int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool timed) {
+int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool timed, bool separate_cluster_pass = false) {
     const fslic_params* p = &s.p;
     const int K = s.K, S = s.S;
     FrameDev f = s.f;
@@ -278,7 +278,31 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
         yx_cur = f.cl_yx_out;
         rem = (rem + 1) % stride;
     }
-    for (int it = 0; !lsc && !rd && it < p->max_iter; it++) {   // src/context.cpp:158-175
+    // The cluster pass between two assign passes (centroids from the sums, re-binning) is done by the assign kernel itself where
+    // the block kernel applies: its last block to deliver sums of a cluster finalises it (launch_assign_fused_bin), so the loop is
+    // max_iter launches instead of 2 * max_iter.  Positions then live in ONE buffer (yx_a, where the first cluster pass put them).
+    // Measured (profiles/r03_fused_cluster_pass.txt): one 1280x720 frame per group 168 instead of 183 us (the loop is ten launches
+    // of 9.9 us instead of twenty of 6.7 + 4.9), eight frames 315 instead of 333 us -- but the pipelined rate of 16-frame groups
+    // drops from 51.8 to 45.3 GP/s: the finaliser is a chain of dependent memory round trips at the end of every block and
+    // vector work a 1600-thread cluster pass does once.  So: fused where a launch does not fill the chip (latency-bound: the
+    // reference's own one-frame-per-call pattern), separate where it does.  FSLIC_FUSEBIN=0 / 2: never / always.
+    const int assign_blocks = n * ((s.W + kTileW - 1) / kTileW) * (((s.H + stride - 1) / stride + 31) / 32);
+    const bool fuse_wanted = knobs().fuse_bin == 2 || (knobs().fuse_bin == 1 && assign_blocks <= 640);
+    const bool fusebin = fuse_wanted && !separate_cluster_pass && !lsc && !rd && !generic && !pre && assign_fuses_cluster_pass(f, stride);
+    int full_obuf = -1;
+    for (int it = 0; fusebin && it < p->max_iter; it++) {
+        const bool tme = timed && s.launch_timing && it < Slot::kMaxTimedIters;
+        f.cl_yx = yx_a; f.cl_yx_out = yx_a;
+        if (tme) HIPCHK(hipEventRecord(s.ev_it[2 * it], s.st));
+        launch_assign_fused_bin(f, n, rem, stride, it, s.st);
+        if (tme) HIPCHK(hipEventRecord(s.ev_it[2 * it + 1], s.st));
+        f.gen_off++;
+        yx_cur = yx_a;
+        rem = (rem + 1) % stride;
+        full_obuf = (it + 1) % 3;
+    }
+    if (fusebin && full_obuf < 0) full_obuf = 0;
+    for (int it = 0; !fusebin && !lsc && !rd && it < p->max_iter; it++) {   // src/context.cpp:158-175
         pg = PassGeom{};
         const bool tme = timed && s.launch_timing && it < Slot::kMaxTimedIters;
         if (tme) HIPCHK(hipEventRecord(s.ev_it[2 * it], s.st));
@@ -305,7 +329,7 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     else if (noq) { f.cl_yx = yx_cur; launch_noq_assign(f, noq_coef, noq_manhattan, n, 0, 1, p->max_iter & 1, 0, false, s.st); }
     else if (rd) { f.cl_yx = yx_cur; launch_rd_assign(f, s.d_patchf, rd_l2, n, 0, 1, p->max_iter & 1, 0, false, s.st); }
     else if (generic) launch_assign_generic(f, n, 0, 1, full_buf, 0, false, s.st);
-    else (void)launch_assign(f, n, 0, 1, p->max_iter & 1, 0, false, s.st);
+    else (void)launch_assign(f, n, 0, 1, p->max_iter & 1, 0, false, s.st, full_obuf);
     if (timed) HIPCHK(hipEventRecord(s.ev[3], s.st));
     // enforce_connectivity, src/context.cpp:14-20
     const int thres = (int)round((double)(S * S) * (double)p->min_size_factor);
@@ -472,17 +496,27 @@ int group_finish(fslic_engine* e, Slot& s) {
     int n_host_topk = 0;
     for (int i = 0; i < n; i++) {
         n_host_topk += s.h_misc[16 * (size_t)i + 4 + 3] == 2;
-        if (!s.generic && s.h_misc[16 * (size_t)i + 2] != 0) {     // the tiled kernel overflowed an LDS candidate list
-            if (knobs().host_timing) fprintf(stderr, "[fslic host] candidate-list overflow: frame %d redone with the generic kernel\n", i);
+        // Flags of the tiled kernels.  Bit 1: a visited pixel that no window covered kept its label while the cluster pass was
+        // fused into the assign kernel (its sums reached the owner through global atomics that nothing orders before the owner's
+        // finaliser): that frame alone is redone with the separate cluster pass.  Bit 0: a block's candidate list overflowed: that
+        // frame alone is redone with the generic kernel.
+        for (int attempt = 0; attempt < 2 && !s.generic && s.h_misc[16 * (size_t)i + 2] != 0; attempt++) {
+            const bool overflow = (s.h_misc[16 * (size_t)i + 2] & 1u) != 0;
+            if (knobs().host_timing) fprintf(stderr, "[fslic host] frame %d redone with %s\n", i, overflow ? "the generic kernel (candidate-list overflow)" : "the separate cluster pass (stale pixel)");
             stage_group(e, s, i, 1, false);
             s.gen_step = s.gen_span_prev;                 // past the stamps of the pass just made (same span)
             s.gen_host += s.gen_step;
-            int rc = enqueue_frames(e, s, i, 1, true, false);
+            int rc = enqueue_frames(e, s, i, 1, overflow, false, true);
             if (rc) return rc;
             HIPCHK(hipStreamSynchronize(s.st));
-            if (s.h_misc[16 * (size_t)i + 2] != 0) return fail(FSLIC_E_INTERNAL, "generic path reported a candidate overflow");
-            s.last_path = 1;
+            if (overflow) {
+                if (s.h_misc[16 * (size_t)i + 2] != 0) return fail(FSLIC_E_INTERNAL, "generic path reported a candidate overflow");
+                s.last_path = 1;
+            } else {
+                s.n_separate_redo++;
+            }
         }
+        if (!s.generic && s.h_misc[16 * (size_t)i + 2] != 0) return fail(FSLIC_E_INTERNAL, "a redone frame still carries a kernel flag");
     }
     {
         int rc = cca_finish_group(s, 0, n, s.f.labels, s.frame_bytes, K, thres);

@@ -82,8 +82,9 @@ struct FrameDev {
     // coarse bins, double buffered by iteration parity
     uint32_t* cell_cnt[2];     // ncell
     ClusterRec* cell_items[2]; // ncell * kCellCap
-    uint32_t* ovf_cnt[2];      // 1
-    ClusterRec* ovf_items[2];  // K
+    uint32_t* ovf_cnt[3];      // 1    (the third buffer serves the fused cluster pass only: read / append / clear rotate over three)
+    ClusterRec* ovf_items[3];  // K
+    uint32_t* cl_arrive;       // K  fused cluster pass: assign blocks that have delivered their partial sums of the cluster in this pass
     uint32_t* err_flag;        // != 0: a block overflowed its LDS candidate list -> host reruns generic
     // LDS spatial table of the tiled kernel (lut_words == 0: fixed-point mode, no table)
     const uint32_t* lut;       // lut_words entries: patch value << 16, or kHuge for out-of-window indices
@@ -121,7 +122,8 @@ struct FrameDev {
         if (cell_act) { adv(cl_upd, d); adv(cl_act, d); adv(cell_act, d); adv(pre_flags, d); }
         adv(sums[0], d); adv(sums[1], d); adv(cpart, d);
         adv(cell_cnt[0], d); adv(cell_cnt[1], d); adv(cell_items[0], d); adv(cell_items[1], d);
-        adv(ovf_cnt[0], d); adv(ovf_cnt[1], d); adv(ovf_items[0], d); adv(ovf_items[1], d);
+        adv(ovf_cnt[0], d); adv(ovf_cnt[1], d); adv(ovf_cnt[2], d); adv(ovf_items[0], d); adv(ovf_items[1], d); adv(ovf_items[2], d);
+        adv(cl_arrive, d);
         adv(err_flag, d);
 #if defined(FSLIC_LAB) && FSLIC_LAB == 4
         adv(lab_stamps, d);
@@ -216,7 +218,14 @@ void launch_bin_clusters(const FrameDev& f, int nframes, int mode, int buf, int 
 
 // One assign pass over rows == rem (mod stride); fuse_update also accumulates the centroid sums
 // of src/context.cpp:301-354 for the same rows.  Returns the geometry the following cluster pass needs.
-PassGeom launch_assign(const FrameDev& f, int nframes, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st);
+// obuf: which of the three spill lists the pass reads (buf for the two-buffer rotation of the separate cluster pass).
+PassGeom launch_assign(const FrameDev& f, int nframes, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st, int obuf = -1);
+// The same with the cluster pass fused in (src/context.cpp:356-373 + the binning of src/context.cpp:214-221): the LAST assign block
+// that delivers partial sums of a cluster finalises it (integer means, re-binning for the next pass) -- no k_bin_clusters<1> launch
+// between two passes.  Pass `it` reads bins [it & 1] / spill list [it % 3], appends to [(it+1) & 1] / [(it+1) % 3].  Only for
+// geometries assign_fuses_cluster_pass() accepts; positions live in FrameDev::cl_yx (updated in place).
+bool assign_fuses_cluster_pass(const FrameDev& f, int stride);
+void launch_assign_fused_bin(const FrameDev& f, int nframes, int rem, int stride, int it, hipStream_t st);
 void launch_assign_generic(const FrameDev& f, int nframes, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st);
 // LSC variant (lsc.hip).  prepare: feature map + seed centroids (src/lsc.cpp:12-15), after LAB and the mode-0 cluster pass.
 void launch_lsc_prepare(const FrameDev& f, const LscDev& l, int nframes, hipStream_t st);

@@ -35,6 +35,8 @@ Knobs read_knobs() {
     k.use_graphs = !(gr && atoi(gr) == 0);
     k.poison = getenv("FSLIC_POISON") != nullptr;
     k.host_timing = getenv("FSLIC_HOST_TIMING") != nullptr;
+    const char* fb = getenv("FSLIC_FUSEBIN");
+    k.fuse_bin = fb ? std::min(std::max(atoi(fb), 0), 2) : 1;
     return k;
 }
 const Knobs g_knobs = read_knobs();      // once, when the library is loaded

@@ -223,6 +223,12 @@ int fslic_hip_last_path(fslic_engine* e, int slot);
  * components than the device sorts in one block; an area tie at the cut is resolved on the device). */
 int fslic_hip_last_host_topk_frames(fslic_engine* e, int slot);
 
+/* Frames redone on `slot` since it was created because a visited pixel that no cluster window covered kept its label
+ * (src/context.cpp:138-145 resets the assignment plane once per call, not per iteration) while the cluster pass
+ * (src/context.cpp:356-373) ran fused into the assign kernel: such a frame is recomputed with the separate cluster pass,
+ * the results are those of the reference either way.  Testing / diagnostics aid. */
+int fslic_hip_separate_pass_redos(fslic_engine* e, int slot);
+
 const char* fslic_hip_last_error(void);
 const char* fslic_hip_version(void);
 

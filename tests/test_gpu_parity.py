@@ -447,3 +447,42 @@ def test_huge_cluster_counts(engine, H, W, K):
     o_labels, o_cl, o_lab, o_pre = orc.slic_iterate(img, cl0, stages=True)
     assert path == 1
     assert_same("%dx%d K=%d" % (H, W, K), (labels, cl, pre), (o_labels, o_cl, o_pre))
+
+
+def test_warm_starts_with_stale_pixels_under_the_fused_cluster_pass():
+    """A caller may hand in any Cluster block (cfast_slic.pyx:94-97).  With centres scattered at random, windows leave gaps and
+    move: visited pixels keep labels whose owner's window has left them (src/context.cpp:138-145 resets the assignment plane once
+    per call) and still take part in update().  Under the fused cluster pass such a frame is detected and redone with the separate
+    pass; every label and Cluster byte must be the oracle's, and the detection must have fired on these inputs (the oracle counts
+    the stale visited pixels: tests chosen by a CPU search where it is > 0)."""
+    from fast_slic_amd import Engine
+    lib = orc.lib()
+    import ctypes
+    lib.orc_last_stale_pixels.restype = ctypes.c_long
+    rng = np.random.RandomState(1)
+    e = Engine(0, 2)
+    n_stale_cases = 0
+    try:
+        for trial in range(40):
+            H, W = int(rng.choice([96, 128, 160, 200])), int(rng.choice([96, 128, 176, 240]))
+            K = int(rng.choice([8, 12, 20, 30, 48]))
+            img = variant("ABC"[trial % 3], H, W, seed=trial)
+            if orc.S_of(H, W, K) < 8:
+                continue
+            cl0 = orc.initialize_clusters(img, K)
+            cl0["y"] = rng.randint(0, H, K).astype(np.float32)
+            cl0["x"] = rng.randint(0, W, K).astype(np.float32)
+            o_labels, o_cl = orc.slic_iterate(img, cl0.copy())
+            stale = int(lib.orc_last_stale_pixels())
+            before = e.separate_pass_redos()
+            cl = cl0.copy().view(B.CLUSTER_DTYPE) if cl0.dtype != B.CLUSTER_DTYPE else cl0.copy()
+            labels = e.iterate(np.ascontiguousarray(img), cl, make_params(10, 10.0, 0.25, 3))
+            assert np.array_equal(labels, o_labels), describe_mismatch("trial %d (%dx%d K=%d, %d stale px)" % (trial, W, H, K, stale), labels, o_labels)
+            assert cl.tobytes() == o_cl.tobytes(), "trial %d: %s" % (trial, "; ".join(cluster_fields_equal(cl, o_cl)))
+            if stale > 0:
+                n_stale_cases += 1
+                if e.last_path() == 0:
+                    assert e.separate_pass_redos() > before, "trial %d: %d stale pixels and no redo" % (trial, stale)
+        assert n_stale_cases >= 5
+    finally:
+        e.close()

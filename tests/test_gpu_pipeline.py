@@ -352,3 +352,21 @@ def test_enforce_connectivity_rejects_more_labels_than_uint16():
             e.enforce_connectivity(np.zeros((8, 8), np.uint16), 65537, 0)
     finally:
         e.close()
+
+
+def test_parity_with_the_cluster_pass_always_fused():
+    """By default the cluster pass is fused into the assign kernel only where a launch does not fill the chip (group.cpp); the
+    larger operating points therefore never see it.  FSLIC_FUSEBIN=2 (read when the library is loaded: a separate interpreter)
+    fuses it everywhere: BASELINE sizes incl. the 225-seed pile-up of C3 (clusters hidden behind an identical predecessor re-enter
+    the bins one per pass), the 16-frame pipeline and a group of 4K frames must be bit-equal all the same."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FSLIC_FUSEBIN="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"),
+                        os.path.join(root, "tests", "test_gpu_pipeline.py"), "-k",
+                        "baseline_sizes or small_golden or option or bench_operating_point_8x720p or one_group_of_eight_4k or warm or c3_four"],
+                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
+    tail = r.stdout.decode()[-2500:]
+    assert r.returncode == 0 and " passed" in tail, tail
