@@ -973,6 +973,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
         div_rem(t, bm.gx * bm.gy, bzi, rest);
         div_rem(rest, bm.gx, byi, bxi);
     }
+    bxi = rfl(bxi); byi = rfl(byi); bzi = rfl(bzi);      // wave-uniform: keep them (and everything derived) in scalar registers
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];   // spatial table (u16), whole KB (LDS-DMA lands 1 KB per wavefront instruction); 16-byte aligned: the row-vector reads are ds_read_b128
     __shared__ __attribute__((aligned(16))) uint4 s_raw[kWavesPerBlock][64];       // every wavefront's kept records {yx, lab, tag, -}
     __shared__ __attribute__((aligned(16))) uint32_t s_part[64][4];                // partial ranks: [candidate][wavefront]
@@ -1488,6 +1489,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_wav
     assign_blk2_body<R, true, STRIDE, VT, true>(f, rem, Hv, bm);
 }
 
+// FSLIC_R16=0 (read once): fused passes never take 16 rows per wavefront (A/B measurements)
+static const bool g_fused_r16 = [] { const char* v = getenv("FSLIC_R16"); return !(v && atoi(v) == 0); }();
 // FSLIC_ASSIGN=1 (read once): the first form of the block kernel (round 2), kept for A/B measurements
 static const bool g_assign_v1 = [] { const char* v = getenv("FSLIC_ASSIGN"); return v && atoi(v) == 1; }();
 
@@ -1546,7 +1549,7 @@ void launch_assign_fused_bin(const FrameDev& f_, int nframes, int rem, int strid
     const int Hv = (f.H - rem + stride - 1) / stride;
     if (Hv <= 0) return;
     const int tiles_x = (f.W + kTileW - 1) / kTileW;
-    const bool r16 = f.tab_vmode && nframes * tiles_x * ((Hv + kWavesPerBlock * 8 - 1) / (kWavesPerBlock * 8)) > 3072;      // as launch_assign
+    const bool r16 = g_fused_r16 && f.tab_vmode && nframes * tiles_x * ((Hv + kWavesPerBlock * 8 - 1) / (kWavesPerBlock * 8)) > 3072;      // as launch_assign
     if (r16) {
         if (stride == 1) launch_assign_bin_t<16, 1>(f, nframes, rem, Hv, st);
         else if (stride == 2) launch_assign_bin_t<16, 2>(f, nframes, rem, Hv, st);
@@ -1596,7 +1599,7 @@ PassGeom launch_assign(const FrameDev& f_, int nframes, int rem, int stride, int
             // 2048.  Small launches keep 8 rows (more, shorter-lived blocks fill the chip better); so does the 2-D table,
             // whose LDS footprint grows with the rows a wavefront spans.
             const int tiles_x = (f.W + kTileW - 1) / kTileW;
-            const bool r16 = f.tab_vmode && nframes * tiles_x * ((Hv + kWavesPerBlock * 8 - 1) / (kWavesPerBlock * 8)) > 3072;
+            const bool r16 = g_fused_r16 && f.tab_vmode && nframes * tiles_x * ((Hv + kWavesPerBlock * 8 - 1) / (kWavesPerBlock * 8)) > 3072;
             if (r16) {
                 pg.BH = kWavesPerBlock * 16;
                 if (stride == 1) launch_assign_blk_t<16, true, 1>(f, nframes, rem, Hv, st);
