@@ -10,6 +10,7 @@ cd $R
 rocminfo 2>/dev/null | grep -E 'Marketing Name|Compute Unit|Max Clock' | head -8 > $OUT/rocminfo.txt
 nproc >> $OUT/rocminfo.txt; grep -m1 'model name' /proc/cpuinfo >> $OUT/rocminfo.txt
 timeout 900 python bench.py 2> $OUT/bench.err > $OUT/bench.json; echo "bench rc=$?"
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2> $OUT/bench_driver_cmdline.err > $OUT/bench_driver_cmdline.json; echo "bench (driver command line) rc=$?"
 cd /tmp && export TMPDIR=/tmp
 # 1. the pipelined timed region under rocprofv3: per-kernel statistics and how the streams overlap
 rm -rf $OUT/p
@@ -20,7 +21,7 @@ python $R/scripts/rocpd_stats.py overlap $DB 0.1 > $OUT/bench_stream_overlap.txt
 python $R/scripts/rocpd_stats.py window $DB 4000 500 > $OUT/bench_all_streams_window.txt
 rm -rf $OUT/p
 # 2. single-stream groups of the BASELINE configurations
-for cfg in "720 1280 1600 6 slic 8" "720 1280 1600 6 slic 16" "2160 3840 1600 4 slic 8" "2160 3840 1600 4 slic 1" "2160 3840 6000 4 slic 4" "720 1280 1600 4 lsc 8"; do
+for cfg in "720 1280 1600 6 slic 8" "720 1280 1600 6 slic 16" "720 1280 1600 6 slic 1" "2160 3840 1600 4 slic 8" "2160 3840 1600 4 slic 1" "2160 3840 6000 4 slic 4" "720 1280 1600 4 lsc 8"; do
   set -- $cfg
   tag=${2}x${1}_k${3}_${5}_x${6}
   rm -rf $OUT/p
@@ -47,6 +48,12 @@ cd $R
 [ -f fast_slic_amd/libfslic_hip_lab1.so ] && FSLIC_LIB=$R/fast_slic_amd/libfslic_hip_lab1.so timeout 200 python scripts/lab_select_stamps.py > $OUT/lab_select_stamps.txt 2>&1
 [ -f fast_slic_amd/libfslic_hip_lab2.so ] && FSLIC_LIB=$R/fast_slic_amd/libfslic_hip_lab2.so timeout 200 python scripts/lab_local_phases.py 720 1280 1600 8 > $OUT/lab_tile_ccl_phases_720p.txt 2>&1
 [ -f fast_slic_amd/libfslic_hip_lab2.so ] && FSLIC_LIB=$R/fast_slic_amd/libfslic_hip_lab2.so timeout 200 python scripts/lab_local_phases.py 2160 3840 1600 8 > $OUT/lab_tile_ccl_phases_4k.txt 2>&1
+[ -f fast_slic_amd/libfslic_hip_lab4.so ] && for cfg in "720 1280 1600 8" "720 1280 1600 1" "2160 3840 1600 8" "2160 3840 6000 4"; do
+  echo "== $cfg" >> $OUT/lab_assign_phases.txt
+  FSLIC_LIB=$R/fast_slic_amd/libfslic_hip_lab4.so timeout 200 python scripts/lab_assign_phases.py $cfg 2>&1 | grep -v amdgpu.ids >> $OUT/lab_assign_phases.txt
+done
+# 4b. instruction mix of every kernel of an 8 x 1280x720 group (SQ counters, separate --pmc passes)
+PMC_G=8 bash scripts/gpu_pmc_group.sh > /dev/null 2>&1; cp $R/gpurun_out/pmc_group.txt $OUT/pmc_group_instruction_mix_720p_x8.txt
 # 5. microbenchmarks
 for m in ${MICROBENCH:-frame_barrier kernel_rate}; do
   [ -x scripts/microbench/$m.out ] && timeout 200 scripts/microbench/$m.out > $OUT/microbench_$m.txt 2>&1

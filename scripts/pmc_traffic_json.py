@@ -1,9 +1,9 @@
 """profiles/rNN_pmc_fetch_write_*.csv (scripts/gpu_profiles.sh, step 3) -> profiles/rNN_pmc_assign_traffic.json, the per-launch
 HBM traffic of the assign kernels that bench.py reports as roofline.traffic.
-   python scripts/pmc_traffic_json.py [profiles/r02]"""
+   python scripts/pmc_traffic_json.py [profiles/r03]"""
 import csv, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-prefix = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02")
+prefix = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03")
 SETS = {"720p_x8": ("1280x720_x8", 1280 * 720 * 8, 3), "720p_x16": ("1280x720_x16", 1280 * 720 * 16, 3), "4k_k1600": ("3840x2160_x1", 3840 * 2160, 3)}   # tag, pixels per launch, subsample stride
 
 
