@@ -36,11 +36,11 @@ def timeline(db, marker="rgb_to_lab"):
 
 
 def overlap(db, frac=0.5):
-    """Concurrency over the last `frac` of the trace: busy time (union of kernel intervals), summed kernel time, and
-    how both split between the streams."""
+    """Concurrency over the last `frac` of the trace (frac > 1: over the last `frac` microseconds): busy time (union of kernel
+    intervals), summed kernel time, and how both split between the streams."""
     c = sqlite3.connect(db)
     rows = c.execute("select name, start, end, stream_id from kernels order by start").fetchall()
-    t_lo = rows[0][1] + (rows[-1][2] - rows[0][1]) * (1.0 - frac)
+    t_lo = rows[0][1] + (rows[-1][2] - rows[0][1]) * (1.0 - frac) if frac <= 1.0 else rows[-1][2] - frac * 1e3
     rows = [r for r in rows if r[1] >= t_lo]
     span = rows[-1][2] - rows[0][1]
     ev = sorted([(r[1], 1) for r in rows] + [(r[2], -1) for r in rows])
