@@ -336,14 +336,10 @@ typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 //     best= v_pk_min_u16(best, key)
 // i.e. 2 VALU per pixel-candidate + one aligned LDS read per pair (or per 8 rows).  The spatial pair comes from an LDS copy of the
 // reference's patch (src/context.cpp:22-40) laid out so that the rows of a wavefront are immediate offsets from one
-// per-lane address (two layouts, see VT below).  The prologue is paid once per BLOCK and costs one memory round trip:
-//   wavefront 0   fetches every bin slot the block's pixels can see (all loads in flight at once), compacts the
-//                 live records by ballot, ranks them by (phase, k) with readlane broadcasts and writes the sorted
-//                 block list to LDS: idx = position in that list = visit order of the reference's scatter
-//   wavefronts 1-3 stage the spatial table (and clear the centroid accumulators) meanwhile
-//   one barrier
-//   every wavefront takes the list into registers (lane j = candidate j), ballots the candidates whose window
-//   reaches its own rows and walks that bit mask: cluster fields arrive by v_readlane, no LDS latency per candidate.
+// per-lane address (two layouts, see VT below).  The prologue is paid once per BLOCK (assign_blk2_body: the candidate list is
+// gathered and ranked by all four wavefronts, the table arrives by LDS-DMA); then every wavefront holds the list in registers
+// (lane j = candidate j), ballots the candidates whose window reaches its own rows and walks that bit mask: cluster fields arrive
+// by v_readlane, no LDS latency per candidate.
 // Fused update (src/context.cpp:301-354): block-level LDS accumulators (privatised copies, LDS atomics), then ONE
 // plain store per (candidate, quantity) into FrameDev::cpart at the entry reserved for (cluster, this block).
 // No global atomic on the common path: device-scope atomics cost 21 of the 39 us of the per-wavefront-flush
@@ -413,447 +409,10 @@ static __device__ __forceinline__ void row_masks(uint32_t inv, uint32_t (&m)[R /
 #define ASG_STAMP(i_, cond_) do { } while (0)
 #define ASG_PUT(i_, cond_, v_) do { } while (0)
 #endif
-template <int R, bool FUSE, int STRIDE, bool VT>
-static __device__ __forceinline__ void assign_blk_body(FrameDev& f, int rem, int Hv) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];   // spatial table (u16), f.tab_words dwords; 16-byte aligned: the row-vector reads are ds_read_b128
-    __shared__ uint32_t s_braw[3 * 128];                 // compaction buffer: entries 0..63 kept records, 64..127 scratch
-    __shared__ uint4 s_list[64];                         // {yx, lab, k, cpart entry | kNoSlot}
-    __shared__ uint16_t s_k16[256];                      // cluster number by the low BYTE of a key: entry e = k of candidate e & 63 (four replicas), so
-                                                         // the epilogue's address is one SDWA shift of the key instead of mask + shift
-    __shared__ uint32_t s_bn;
-    // centroid accumulators: per (candidate, copy) two 64-bit words of three 20-bit-spaced fields each,
-    //   A = sum L | sum a << 20 | sum b << 40        B = sum (x - x0) | sum (y - y0) << 20 | count << 40
-    // so a pixel (or a whole column) costs two ds_add_u64 instead of six ds_add_u32.  No field can carry into its
-    // neighbour: a block has 2048 pixels, channels <= 255, x - x0 <= 63, y - y0 <= 93.
-    __shared__ unsigned long long s_acc[FUSE ? 64 * kBlkCopies * 2 : 1];
-    static_assert(R % 2 == 0, "rows are processed in pairs");
-    constexpr int BH = kWavesPerBlock * R;
-    static_assert(!FUSE || (BH * 64 * 255 < (1 << 20) && (BH - 1) * STRIDE * BH * 64 < (1 << 20)), "accumulator fields overflow");
-
-    f.select(blockIdx.z);
-    const uint32_t gen = f.generation();
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = (int)rfl((uint32_t)(tid >> 6));
-    const int W = f.W, S = f.S;
-    const int x0 = blockIdx.x * kTileW;
-    const int x = x0 + lane;
-    const int vrow_b0 = blockIdx.y * BH;
-    const int vrow_w0 = vrow_b0 + wave * R;
-    const bool okx = x < W;
-    const int nrows = max(0, min(R, Hv - vrow_w0));      // 0: this wavefront has no rows (bottom edge)
-    const int yw_lo = rem + vrow_w0 * STRIDE;
-#if defined(FSLIC_LAB) && FSLIC_LAB == 4
-    const uint32_t asg_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
-    volatile uint32_t* const asg_w = f.lab_stamps + ((size_t)(f.gen_off - 1u) * 2048u + (size_t)(blockIdx.y * gridDim.x + blockIdx.x)) * 16u;
-    ASG_PUT(0, wave == 0, asg_t0);
-#endif
-
-    // 1. pixel loads: nothing depends on them until the argmin, but they are issued AFTER the loads the prologue waits
-    // for (bins, table).  Every wavefront of the chip starts at the same time; with the pixel loads first the few bytes on the
-    // critical path queued behind the whole frame's pixel traffic (prologue 4 us of a wavefront life of 8 us at 4K).
-    // Out-of-image lanes and rows re-read the last valid column / row instead of being masked off: no exec juggling
-    // around the loads (their results are never stored and never reach the centroid sums).
-    uint32_t pix[R];
-    auto load_pixels = [&]() {
-        const uint32_t xc = (uint32_t)min(x, W - 1);
-        const int nr1 = (int)rfl((uint32_t)(max(nrows, 1) - 1));      // a wavefront without rows (bottom edge) re-reads the image's last visited row
-        const int ybase = (int)rfl((uint32_t)(nrows > 0 ? yw_lo : rem + (Hv - 1) * STRIDE));   // (both wave-uniform: stated, the scalar offsets below must be SGPRs)
-        // buffer loads: the row goes into the instruction's scalar offset, the column into ONE shared vector offset, so a
-        // row costs no vector instruction beyond the load itself (a 64-bit address per row was 6 scalar + 1 vector)
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(f.lab), 0, (int)((uint32_t)f.N * 4u), kRawBuffer);
-        const uint32_t pitch = (uint32_t)(STRIDE * W) * 4u, soff0 = (uint32_t)ybase * (uint32_t)W * 4u;
-        const int vo = (int)(xc * 4u);
-#pragma unroll
-        for (int r = 0; r < R; ++r) pix[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (int)(soff0 + (uint32_t)min(r, nr1) * pitch), 0);
-    };
-
-    // The list is built by ONE wavefront while the other three stage the table.  A block's wavefront i runs on SIMD i, so
-    // with a fixed choice the list builders of all resident blocks of a CU would share one SIMD (measured: their ~800
-    // instructions then take 3-6 us, with the other three SIMDs idle at the barrier); the choice rotates with the block.
-    const int gwave = (int)((blockIdx.x + blockIdx.y + blockIdx.z) & 3u);
-    if (wave == gwave) {
-        // 2a. the block's candidate list
-        const uint32_t novf = *f.ovf_cnt[0];
-        const int sh = f.cs_shift;
-        const ClusterRec* __restrict__ citems = f.cell_items[0];
-        const ClusterRec* __restrict__ oitems = f.ovf_items[0];
-        TileWindow win;
-        const int vlast = min(vrow_b0 + BH - 1, Hv - 1);
-        win.wy_lo = rem + vrow_b0 * STRIDE - S; win.wy_hi = rem + vlast * STRIDE + S;
-        win.wx_lo = x0 - S;                     win.wx_hi = min(x0 + kTileW - 1, W - 1) + S;
-        const int cxa = max(win.wx_lo, 0) >> sh, cxb = min(win.wx_hi, W - 1) >> sh;
-        const int cya = max(win.wy_lo, 0) >> sh, cyb = min(win.wy_hi, f.H - 1) >> sh;
-        const int ncxr = cxb - cxa + 1;
-        int cnt = 0;
-        // branch-free: a record that is not kept goes to a scratch entry (64 + lane), one past 64 kept to entry 63 (the block
-        // then bails out anyway)
-        auto visit = [&](const ClusterRec& rec, bool keep) {
-            const unsigned long long m = __ballot(keep);
-            const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)cnt));
-            const int idx = keep ? min(pos, 63) : 64 + lane;
-            s_braw[idx] = rec.yx; s_braw[128 + idx] = rec.lab; s_braw[256 + idx] = rec.tag;
-            cnt += __popcll(m);
-        };
-        // lane -> (cell column, slot); a cell row of up to 8 cells is one 16-byte load per lane, six cell rows in flight.
-        // The first trip (the only one unless the block sees more than 8 x 6 cells) is issued ahead of the pixel loads.
-        const char* const cbase = reinterpret_cast<const char*>(citems);
-        const uint32_t cpitch = (uint32_t)f.ncx * (uint32_t)(kCellCap * sizeof(ClusterRec));      // bytes per cell row (32-bit byte offsets)
-        auto issue = [&](int cx0, int cy0, ClusterRec (&rr)[6], bool (&okr)[6]) {
-            const int cxi = cx0 + (lane >> 3);
-            const bool colok = cxi < ncxr;
-            const uint32_t vo = ((uint32_t)(cxa + min(cxi, ncxr - 1)) * kCellCap + (uint32_t)(lane & 7)) * (uint32_t)sizeof(ClusterRec) + (uint32_t)cy0 * cpitch;
-#pragma unroll
-            for (int u = 0; u < 6; ++u) {      // unconditional loads (rows past the range re-read the last one)
-                okr[u] = colok && (cy0 + u) <= cyb;
-                rr[u] = *reinterpret_cast<const ClusterRec*>(cbase + (vo + (uint32_t)min(u, cyb - cy0) * cpitch));
-            }
-        };
-        auto consume = [&](int cy0, const ClusterRec (&rr)[6], const bool (&okr)[6]) {
-#pragma unroll
-            for (int u = 0; u < 6; ++u)
-                if (cy0 + u <= cyb) visit(rr[u], okr[u] && rr[u].pad == gen && in_window(rr[u], win));     // uniform
-        };
-        {
-            ClusterRec rr[6];
-            bool okr[6];
-            issue(0, cya, rr, okr);
-            load_pixels();
-            consume(cya, rr, okr);
-        }
-        for (int cx0 = 0; cx0 < ncxr; cx0 += 8)
-            for (int cy0 = cx0 == 0 ? cya + 6 : cya; cy0 <= cyb; cy0 += 6) {
-                ClusterRec rr[6];
-                bool okr[6];
-                issue(cx0, cy0, rr, okr);
-                consume(cy0, rr, okr);
-            }
-        for (uint32_t i0 = 0; i0 < novf; i0 += 64) {
-            const uint32_t i = i0 + lane;
-            ClusterRec rec;
-            rec.yx = 0; rec.lab = 0; rec.tag = 0; rec.pad = 0;
-            if (i < novf) rec = oitems[i];
-            visit(rec, i < novf && in_window(rec, win));
-        }
-        __builtin_amdgcn_wave_barrier();
-        // rank by (phase, k): list order == visit order of the reference's scatter (src/context.cpp:214-242)
-        const int bn = cnt;
-        if (bn <= 64) {
-            const bool act = lane < bn;
-            const uint32_t yx_j = act ? s_braw[lane] : 0u;
-            const uint32_t lab_j = act ? s_braw[128 + lane] : 0u;
-            const uint32_t tag_j = act ? s_braw[256 + lane] : 0xFFFFFFFFu;
-            int rank = 0;             // four at a time (independent readlanes); lanes >= bn hold 0xffffffff, which is never smaller
-            for (int i = 0; i < bn; i += 4)
-                rank += (int)(__builtin_amdgcn_readlane(tag_j, i) < tag_j) + (int)(__builtin_amdgcn_readlane(tag_j, i + 1) < tag_j) +
-                        (int)(__builtin_amdgcn_readlane(tag_j, i + 2) < tag_j) + (int)(__builtin_amdgcn_readlane(tag_j, i + 3) < tag_j);
-            uint32_t entry = kNoSlot;
-            if (FUSE) {
-                const uint32_t k = tag_j & 0xFFFFu;
-                const SlotGeom g = slot_geom((int)(yx_j >> 16), (int)(yx_j & 0xFFFFu), S, f.H, W, rem, STRIDE, BH, Hv);
-                const int by = (int)blockIdx.y, bx = (int)blockIdx.x;
-                if (g.any && by >= g.by0 && by <= g.by1)
-                    entry = (k * (uint32_t)f.cpart_ns + (uint32_t)((by - g.by0) * f.nbx + (bx - g.bx0))) * 6u;
-            }
-            if (act) {
-                s_list[rank] = make_uint4(yx_j, lab_j, tag_j & 0xFFFFu, entry);
-                const uint16_t k16 = (uint16_t)(tag_j & 0xFFFFu);
-                s_k16[rank] = k16; s_k16[64 + rank] = k16; s_k16[128 + rank] = k16; s_k16[192 + rank] = k16;
-            }
-        }
-        if (lane == 0) s_bn = (uint32_t)bn;
-        ASG_STAMP(1, true);
-    } else {
-        // 2b. spatial table -> LDS, four 16-byte loads in flight per thread; centroid accumulators <- 0
-        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(f.tab);
-        uint4* dst = reinterpret_cast<uint4*>(s_dyn);
-        const int nq = f.tab_words >> 2;
-        const int t = ((wave - gwave - 1) & 3) * 64 + lane;      // 0..191 over the three staging wavefronts
-        {                                              // first trip (the whole table unless it exceeds 12 KB), ahead of the pixel loads
-            uint4 q[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) q[u] = src[min(u * 192 + t, nq - 1)];
-            load_pixels();
-#pragma unroll
-            for (int u = 0; u < 4; ++u) dst[min(u * 192 + t, nq - 1)] = q[u];
-        }
-        for (int b0 = 4 * 192; b0 < nq; b0 += 4 * 192) {     // indices past the end are clamped: the last quad is rewritten, no masking
-            uint4 q[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) q[u] = src[min(b0 + u * 192 + t, nq - 1)];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) dst[min(b0 + u * 192 + t, nq - 1)] = q[u];
-        }
-        if (FUSE) {
-#pragma unroll
-            for (int i = 0; i < (64 * kBlkCopies * 2 + 191) / 192; ++i) s_acc[min(i * 192 + t, 64 * kBlkCopies * 2 - 1)] = 0ull;
-        }
-        ASG_STAMP(2, wave == ((gwave + 1) & 3));
-    }
-    __syncthreads();
-    ASG_STAMP(3, wave == 0);
-    const int bn = (int)rfl(s_bn);
-    if (bn > 64) {                            // more live candidates than idx bits: the host redoes the frame generically
-        if (tid == 0) *f.err_flag = 1u;
-        return;
-    }
-
-    // 3. the block list in registers: lane j = candidate j; candidates whose window reaches this wavefront's rows
-    const uint4 mine = s_list[min(lane, 63)];
-    const uint32_t yx_j = mine.x, lab_j = mine.y;
-    const int yw_hi = yw_lo + (nrows - 1) * STRIDE;
-    unsigned long long todo;
-    {
-        const int cyj = (int)(yx_j >> 16);
-        todo = __ballot(lane < bn && nrows > 0 && cyj + S >= yw_lo && cyj - S <= yw_hi);
-    }
-
-    // 4. the argmin, two rows per instruction
-    us2 best[R / 2];
-#pragma unroll
-    for (int q = 0; q < R / 2; ++q) best[q] = (us2){0xFFFF, 0xFFFF};
-    const uint32_t nrpad = (uint32_t)f.tab_nrpad;
-    const int dyoff = f.tab_dyoff;
-    if (VT) {
-        const int Cc = f.tab_dyoff;                 // centre index of the V table
-        const uint32_t xout = (uint32_t)f.tab_xout;
-        constexpr int BIAS = 32768;                 // makes the numerators of the row-range divisions positive
-        constexpr uint32_t full = (1u << R) - 1u;
-        // Per-candidate row ranges, computed ONCE in the vector unit with lane j = candidate j (the scalar unit is
-        // shared by the whole CU and issues about as many instructions per clock as the four SIMDs together).
-        //   rows r with dy_r = dy0 + r*STRIDE: above the centre r < rs, inside the window ra <= r <= rb
-        uint32_t vab_j;                             // rows above (low half) | rows at/below (high half) that are in the window
-        {
-            const int dy0 = yw_lo - (int)(yx_j >> 16);
-            const int rs = min(max((-dy0 + STRIDE * BIAS + STRIDE - 1) / STRIDE - BIAS, 0), R);
-            const int ra = min(max((-S - dy0 + STRIDE * BIAS + STRIDE - 1) / STRIDE - BIAS, 0), R);
-            const int rb = min(max((S - dy0 + STRIDE * BIAS) / STRIDE - BIAS, -1), R - 1);
-            const uint32_t upto_rs = (1u << rs) - 1u;
-            const uint32_t in_win = rb < 0 ? 0u : (((2u << rb) - 1u) & ~((1u << ra) - 1u) & full);
-            vab_j = (in_win & upto_rs) | ((in_win & ~upto_rs) << 16);
-        }
-        // row-vector table: entry t = (V[t], V[t+STRIDE], .. V[t+7*STRIDE]) as one 16-byte word, so the spatial terms of
-        // eight rows are ONE 16-byte-ALIGNED ds_read_b128 (a 2-byte-aligned b128 read costs 64 clk of the CU's LDS pipe
-        // instead of 8, scripts/microbench/lds_unaligned.hip)
-        const uint4* const s_rv = reinterpret_cast<const uint4*>(s_dyn);
-        auto pass = [&](uint32_t clab, uint32_t base, uint32_t idx01, const uint32_t* mq) {
-            uint32_t spw[R / 2];
-            {
-                const uint4 e0 = s_rv[base];
-                spw[0] = e0.x; spw[1] = e0.y; spw[2] = e0.z; spw[3] = e0.w;
-                if (R == 16) {
-                    const uint4 e1 = s_rv[base + 8 * STRIDE];
-                    spw[R / 2 - 4] = e1.x; spw[R / 2 - 3] = e1.y; spw[R / 2 - 2] = e1.z; spw[R / 2 - 1] = e1.w;
-                }
-            }
-            // sweeps over the row pairs instead of one chain per pair: a packed op that consumes the result of the
-            // packed op issued just before it costs a wait state (s_nop) on this target
-            uint32_t t[R / 2];
-#pragma unroll
-            for (int q = 0; q < R / 2; ++q) {
-                const uint32_t s0 = __builtin_amdgcn_sad_u8(pix[2 * q], clab, spw[q]);          // spatial pair + colour distance of row 2q
-                t[q] = __builtin_amdgcn_sad_hi_u8(pix[2 * q + 1], clab, s0);                     // + colour distance of row 2q+1 in the high half
-            }
-            us2 key[R / 2];
-#pragma unroll
-            for (int q = 0; q < R / 2; ++q) key[q] = key_pair(t[q], mq ? (mq[q] | idx01) : idx01);
-#pragma unroll
-            for (int q = 0; q < R / 2; ++q) min_in_place(best[q], key[q]);
-        };
-        // Four loops, each with ONE straight-line form of the pass (the order of the candidates is irrelevant: the key
-        // carries idx).  With the forms as branches of one loop body the compiler linearised them into guarded blocks,
-        // kept the running minima in two register sets and copied between them: 8-16 v_mov per candidate.
-        //   whole : every row inside the window and on one side of the centre (above: index k0 - |dx|, below: k0 + |dx|): no masks
-        //   above : some rows above the centre, masked          below : some rows at/below the centre, masked
-        // (a candidate whose centre row lies inside this wavefront's rows is in both masked loops)
-        const bool mine_todo = (todo >> lane) & 1ull;
-        const uint32_t va_j = vab_j & 0xFFFFu, vb_j = vab_j >> 16;
-        unsigned long long todo_wa = __ballot(mine_todo && va_j == full);      // whole, above the centre
-        unsigned long long todo_wb = __ballot(mine_todo && vb_j == full);      // whole, at/below
-        unsigned long long todo_above = __ballot(mine_todo && va_j != 0u && va_j != full);
-        unsigned long long todo_below = __ballot(mine_todo && vb_j != 0u && vb_j != full);
-        // CLAMP: lanes outside the x window get |dx| = xout (every row then reads the marker); !CLAMP: the caller runs the pass
-        // under `if (uxc <= S)` instead, i.e. with those lanes switched off (one vector instruction less per candidate)
-        auto fetch = [&](int c, uint32_t& clab, uint32_t& uxc, uint32_t& k0, uint32_t& idx01, auto clamp_tag) {
-            constexpr bool CLAMP = decltype(clamp_tag)::value;
-            const uint32_t cyx = __builtin_amdgcn_readlane(yx_j, c);
-            clab = __builtin_amdgcn_readlane(lab_j, c);
-            const int cy = (int)(cyx >> 16), cx = (int)(cyx & 0xFFFFu);
-            const uint32_t ux = __builtin_amdgcn_sad_u16((uint32_t)x, (uint32_t)cx, 0u);      // |x - cx|
-            uxc = CLAMP ? (ux <= (uint32_t)S ? ux : xout) : ux;
-            k0 = (uint32_t)(Cc + yw_lo - cy);                                                  // wave-uniform
-            idx01 = (uint32_t)c | ((uint32_t)c << 16);
-        };
-#pragma unroll 1
-        while (todo_wa) {
-            const int c = __builtin_ctzll(todo_wa);
-            todo_wa &= todo_wa - 1ull;
-            uint32_t clab, uxc, k0, idx01;
-            fetch(c, clab, uxc, k0, idx01, std::false_type{});
-            if (uxc <= (uint32_t)S) pass(clab, k0 - uxc, idx01, nullptr);
-        }
-#pragma unroll 1
-        while (todo_wb) {
-            const int c = __builtin_ctzll(todo_wb);
-            todo_wb &= todo_wb - 1ull;
-            uint32_t clab, uxc, k0, idx01;
-            fetch(c, clab, uxc, k0, idx01, std::false_type{});
-            if (uxc <= (uint32_t)S) pass(clab, k0 + uxc, idx01, nullptr);
-        }
-#pragma unroll 1
-        while (todo_above) {
-            const int c = __builtin_ctzll(todo_above);
-            todo_above &= todo_above - 1ull;
-            uint32_t clab, uxc, k0, idx01, mq[R / 2];
-            fetch(c, clab, uxc, k0, idx01, std::true_type{});
-            row_masks<R>(~__builtin_amdgcn_readlane(va_j, c) & full, mq);
-            pass(clab, k0 - uxc, idx01, mq);
-        }
-#pragma unroll 1
-        while (todo_below) {
-            const int c = __builtin_ctzll(todo_below);
-            todo_below &= todo_below - 1ull;
-            uint32_t clab, uxc, k0, idx01, mq[R / 2];
-            fetch(c, clab, uxc, k0, idx01, std::true_type{});
-            row_masks<R>(~__builtin_amdgcn_readlane(vb_j, c) & full, mq);
-            pass(clab, k0 + uxc, idx01, mq);
-        }
-    } else {
-#pragma unroll 1
-    while (todo) {
-        const int c = __builtin_ctzll(todo);
-        todo &= todo - 1ull;
-        const uint32_t cyx = __builtin_amdgcn_readlane(yx_j, c);
-        const uint32_t clab = __builtin_amdgcn_readlane(lab_j, c);
-        const int cy = (int)(cyx >> 16), cx = (int)(cyx & 0xFFFFu);
-        const uint32_t ux = __builtin_amdgcn_sad_u16((uint32_t)x, (uint32_t)cx, 0u);      // |x - cx|
-        const uint32_t uxc = min(ux, (uint32_t)(S + 1));
-        const uint32_t a0 = __umul24(uxc, nrpad) + (uint32_t)(yw_lo - cy + dyoff);        // dword index of the pair (row 0, row 1)
-        const uint32_t idx01 = (uint32_t)c | ((uint32_t)c << 16);
-#pragma unroll
-        for (int q = 0; q < R / 2; ++q) {
-            const uint32_t sp = s_dyn[a0 + (2 * q) * STRIDE];                                 // one aligned ds_read_b32 per row pair
-            const uint32_t s0 = __builtin_amdgcn_sad_u8(pix[2 * q], clab, sp);
-            const uint32_t s01 = __builtin_amdgcn_sad_hi_u8(pix[2 * q + 1], clab, s0);
-            min_in_place(best[q], key_pair(s01, idx01));
-        }
-    }
-    }
-
-    ASG_STAMP(4, wave == 0);
-    ASG_PUT(9, wave == 0, __popcll(todo));
-    ASG_PUT(10, wave == 0, bn);
-    // 5. write labels (+ fused centroid sums)
-    uint32_t slot[R];
-    {
-        uint32_t kk[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t key = (r & 1) ? (uint32_t)best[r / 2].y : (uint32_t)best[r / 2].x;
-            kk[r] = s_k16[key & 255u];                              // entry 255 when not found: read, never used
-        }
-        uint16_t* rowp = f.labels + (size_t)yw_lo * W;
-        const uint32_t xo = (uint32_t)x;
-        // Interior wavefront with every pixel assigned (the rule, by far): straight-line stores under one column mask.
-        // Otherwise (bottom rows missing, or a pixel no window reached: it keeps its label and still takes part in the
-        // update) row by row with the full rules.
-        us2 worst = best[0];
-#pragma unroll
-        for (int q = 1; q < R / 2; ++q) worst = __builtin_elementwise_max(worst, best[q]);
-        const bool all_found = __ballot(worst.x == 0xFFFF || worst.y == 0xFFFF) == 0ull;
-        if (all_found && nrows == R) {
-            if (okx) {      // written through (sc1, see st_stream), row in the scalar offset, column in one shared vector offset
-                const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(f.labels, 0, (int)((uint32_t)f.N * 2u), kRawBuffer);
-                const uint32_t so0 = (uint32_t)yw_lo * (uint32_t)W * 2u, pitch2 = (uint32_t)(STRIDE * W) * 2u;
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-                    __builtin_amdgcn_raw_buffer_store_b16((uint16_t)kk[r], ws, (int)(xo * 2u), (int)(so0 + (uint32_t)r * pitch2), kAuxSc1);
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t key = (r & 1) ? (uint32_t)best[r / 2].y : (uint32_t)best[r / 2].x;
-                slot[r] = (FUSE && okx) ? (key & 63u) : kNoSlot;
-            }
-        } else {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const bool ok = okx && r < nrows;
-            const uint32_t key = (r & 1) ? (uint32_t)best[r / 2].y : (uint32_t)best[r / 2].x;
-            const bool found = key != 0xFFFFu;
-            slot[r] = kNoSlot;
-            if (ok && found) st_stream(rowp + xo, (uint16_t)kk[r]);
-            if (FUSE && ok) {
-                if (found) slot[r] = key & 63u;
-                else {
-                    const uint32_t old = rowp[xo];     // stale label still takes part in update()
-                    if (old != 0xFFFFu) global_accumulate(f.sums[0], old, (uint32_t)(yw_lo + r * STRIDE), xo, pix[r]);
-                }
-            }
-            rowp += (size_t)STRIDE * W;
-        }
-    }
-    }
-    ASG_STAMP(5, wave == 0);
-    if (FUSE) {
-        {
-            // A column's rows fall into one or two runs of equal slot (a superpixel is taller than a wavefront's rows), so the
-            // sums are kept in registers per run and flushed when the slot changes: 2 LDS atomics per run instead of 2 per
-            // pixel (the 64-bit words as two 32-bit halves: no field carries across bit 32, see s_acc).
-            const uint32_t copy = (uint32_t)lane & (kBlkCopies - 1);
-            const uint32_t dyw = (uint32_t)(wave * R * STRIDE);            // first row of this wavefront relative to the block's
-            uint32_t cur = slot[0], a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0;
-            auto flush = [&]() {
-                if (cur != kNoSlot) {
-                    unsigned long long* a = s_acc + (cur * kBlkCopies + copy) * 2;
-                    atomicAdd(a, (unsigned long long)a_lo | ((unsigned long long)a_hi << 32));
-                    atomicAdd(a + 1, (unsigned long long)b_lo | ((unsigned long long)b_hi << 32));
-                }
-            };
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (r > 0 && slot[r] != cur) {
-                    flush();
-                    cur = slot[r]; a_lo = 0; a_hi = 0; b_lo = 0; b_hi = 0;
-                }
-                const uint32_t p = pix[r];
-                a_lo += (p & 255u) | ((p & 0xFF00u) << 12);                // sum L | sum a << 20
-                a_hi += (p >> 8) & 0xFF00u;                               // sum b << 40
-                b_lo += (uint32_t)lane | ((dyw + (uint32_t)(r * STRIDE)) << 20);   // sum (x - x0) | sum (y - y0) << 20
-                b_hi += 256u;                                             // count << 40
-            }
-            flush();
-        }
-        ASG_STAMP(6, wave == 0);
-        __syncthreads();
-        ASG_STAMP(7, wave == 0);
-        // one plain store per (candidate, quantity): entry reserved for (cluster, this block), zeros included
-        const uint32_t yb0 = (uint32_t)(rem + vrow_b0 * STRIDE);
-        for (int i = tid; i < bn * 6; i += 256) {
-            const int c = i / 6, q = i - c * 6;
-            const uint32_t entry = s_list[c].w;
-            if (entry != kNoSlot) {
-                unsigned long long A = 0, B = 0;
-#pragma unroll
-                for (int cpy = 0; cpy < kBlkCopies; ++cpy) { A += s_acc[(c * kBlkCopies + cpy) * 2]; B += s_acc[(c * kBlkCopies + cpy) * 2 + 1]; }
-                const uint32_t cnt = (uint32_t)(B >> 40);
-                uint32_t v;
-                if (q == 0) v = cnt;
-                else if (q == 1) v = ((uint32_t)(B >> 20) & 0xFFFFFu) + yb0 * cnt;
-                else if (q == 2) v = ((uint32_t)B & 0xFFFFFu) + (uint32_t)x0 * cnt;
-                else if (q == 3) v = (uint32_t)A & 0xFFFFFu;
-                else if (q == 4) v = (uint32_t)(A >> 20) & 0xFFFFFu;
-                else v = (uint32_t)(A >> 40);
-                f.cpart[(size_t)entry + (uint32_t)q] = v;
-            }
-        }
-    }
-    ASG_STAMP(8, wave == 0);
-}
-
 // =============================================================================================
-// Block assign kernel, second form (round 3).  Same tile, same argmin loops, same fused sums as assign_blk_body above; what
-// changed is everything around them, which the phase stamps of lab build 4 (profiles/r03_lab_assign_phases_*.txt) showed to be
-// a third of a block's life as one wavefront's serial work:
+// The block assign kernel's body (second form, round 3; the first form -- one wavefront builds and sorts the list while three
+// stage the table through registers -- is in the history and in profiles/r02_*).  The phase stamps of lab build 4
+// (profiles/r03_lab_assign_phases.txt) showed the prologue to be a third of a block's life as one wavefront's serial work:
 //   * the candidate list is gathered by ALL four wavefronts (one 16-byte bin slot per thread and trip, ballot compaction into
 //     per-wavefront parts of an LDS array: no atomics, no serial walk over six cell rows by one wavefront)
 //   * the (phase, k) ranks are counted in four partial sums, one per wavefront, and meet in LDS (second barrier); the list stays
@@ -1448,25 +1007,9 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
     ASG_STAMP(8, wave == 0);
 }
 
-// The kernels proper.  Register budgets are part of the design: left to itself the compiler schedules these bodies into
-// 82 - 90 VGPRs (5 - 6 wavefronts per SIMD); what it needs without spilling is 52 (16 rows per wavefront, no centroid sums:
-// 8 wavefronts per SIMD), 66 - 68 (8 rows: 7 per SIMD) and 74 - 80 (16 rows with centroid sums: 6 per SIMD).  At 3840x2160 the difference is 51 vs 60 us per fused launch
-// of eight frames and 69 vs 81 us for the full assignment (the round-1 kernels happened to get the small allocation because
-// their debug stamps cut the body into pieces; removing the stamps lost it until the budgets were stated).
-template <int R, bool FUSE, int STRIDE, bool VT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(7, 8))) void k_assign_blk(FrameDev f, int rem, int Hv) {
-    assign_blk_body<R, FUSE, STRIDE, VT>(f, rem, Hv);
-}
-template <int R, bool FUSE, int STRIDE, bool VT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void k_assign_blk_w8(FrameDev f, int rem, int Hv) {
-    assign_blk_body<R, FUSE, STRIDE, VT>(f, rem, Hv);
-}
-
-template <int R, bool FUSE, int STRIDE, bool VT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(6, 8))) void k_assign_blk_w6(FrameDev f, int rem, int Hv) {
-    assign_blk_body<R, FUSE, STRIDE, VT>(f, rem, Hv);
-}
-
+// The kernels proper.  Register budgets are part of the design (amdgpu_waves_per_eu): the bodies need 24 - 48 VGPRs with 8 rows per
+// wavefront (8 wavefronts per SIMD), 38 - 40 for the 16-row full pass (8) and 74 for the 16-row fused pass (6); left to itself the
+// compiler schedules them into more (at 3840x2160 that cost 17 % with the first form: 51 vs 60 us per fused launch of eight frames).
 template <int R, bool FUSE, int STRIDE, bool VT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(7, 8))) void k_assign_blk2(FrameDev f, int rem, int Hv, BlkMap bm) {
     assign_blk2_body<R, FUSE, STRIDE, VT>(f, rem, Hv, bm);
@@ -1491,36 +1034,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_wav
 
 // FSLIC_R16=0 (read once): fused passes never take 16 rows per wavefront (A/B measurements)
 static const bool g_fused_r16 = [] { const char* v = getenv("FSLIC_R16"); return !(v && atoi(v) == 0); }();
-// FSLIC_ASSIGN=1 (read once): the first form of the block kernel (round 2), kept for A/B measurements
-static const bool g_assign_v1 = [] { const char* v = getenv("FSLIC_ASSIGN"); return v && atoi(v) == 1; }();
 
 template <int R, bool FUSE, int STRIDE>
 static void launch_assign_blk_t(const FrameDev& f_, int nframes, int rem, int Hv, hipStream_t st) {
     FrameDev f = f_;
     if (FUSE) { f.tab = f.tabs; f.tab_words = f.tabs_words; f.tab_dyoff = f.tabs_dyoff; f.tab_nrpad = f.tabs_nrpad; }   // table of the subsampled stride
     dim3 grid((f.W + kTileW - 1) / kTileW, (Hv + kWavesPerBlock * R - 1) / (kWavesPerBlock * R), nframes);
-    if (!g_assign_v1) {
-        const size_t lds2 = ((size_t)f.tab_words * sizeof(uint32_t) + 1023) / 1024 * 1024;       // whole KB: what the LDS-DMA pieces fill
-        if constexpr (R == 16 && !FUSE) {
-            if (f.tab_vmode) launch((k_assign_blk2_w8<R, FUSE, STRIDE, true>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
-            else launch((k_assign_blk2_w8<R, FUSE, STRIDE, false>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
-        } else if constexpr (R == 16 && FUSE) {
-            launch((k_assign_blk2_w6<R, FUSE, STRIDE, true>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
-        } else {
-            if (f.tab_vmode) launch((k_assign_blk2<R, FUSE, STRIDE, true>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
-            else launch((k_assign_blk2<R, FUSE, STRIDE, false>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
-        }
-        return;
-    }
-    const size_t lds = (size_t)f.tab_words * sizeof(uint32_t);
+    const size_t lds2 = ((size_t)f.tab_words * sizeof(uint32_t) + 1023) / 1024 * 1024;       // whole KB: what the LDS-DMA pieces fill
     if constexpr (R == 16 && !FUSE) {
-        if (f.tab_vmode) launch((k_assign_blk_w8<R, FUSE, STRIDE, true>), grid, dim3(256), lds, st, f, rem, Hv);
-        else launch((k_assign_blk_w8<R, FUSE, STRIDE, false>), grid, dim3(256), lds, st, f, rem, Hv);
-    } else if constexpr (R == 16 && FUSE) {          // only launched with the row-vector table (launch_assign)
-        launch((k_assign_blk_w6<R, FUSE, STRIDE, true>), grid, dim3(256), lds, st, f, rem, Hv);
+        if (f.tab_vmode) launch((k_assign_blk2_w8<R, FUSE, STRIDE, true>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
+        else launch((k_assign_blk2_w8<R, FUSE, STRIDE, false>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
+    } else if constexpr (R == 16 && FUSE) {
+        launch((k_assign_blk2_w6<R, FUSE, STRIDE, true>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
     } else {
-        if (f.tab_vmode) launch((k_assign_blk<R, FUSE, STRIDE, true>), grid, dim3(256), lds, st, f, rem, Hv);
-        else launch((k_assign_blk<R, FUSE, STRIDE, false>), grid, dim3(256), lds, st, f, rem, Hv);
+        if (f.tab_vmode) launch((k_assign_blk2<R, FUSE, STRIDE, true>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
+        else launch((k_assign_blk2<R, FUSE, STRIDE, false>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
     }
 }
 
@@ -1542,7 +1070,7 @@ static bool blk_kernel_applies(const FrameDev& f, int stride) {
     return f.tab_words > 0 && stride >= 1 && stride <= 3 && (unsigned long long)f.N * 4ull < 0x7FFFFFFFull;
 }
 
-bool assign_fuses_cluster_pass(const FrameDev& f, int stride) { return !g_assign_v1 && blk_kernel_applies(f, stride); }
+bool assign_fuses_cluster_pass(const FrameDev& f, int stride) { return blk_kernel_applies(f, stride); }
 
 void launch_assign_fused_bin(const FrameDev& f_, int nframes, int rem, int stride, int it, hipStream_t st) {
     const FrameDev f = rotated(f_, it & 1, it & 1, it % 3);

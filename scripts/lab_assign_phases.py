@@ -21,7 +21,7 @@ p = make_params(10, 10.0, 0.25, 3)
 for i in range(3):
     e.iterate_batch([t.data_ptr() for t in d], [c.copy() for c in cl0], [t.data_ptr() for t in l], H, W, p, True)
 lib.fslic_hip_debug_cand_area_head.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
-names = (["list built (builder wave)", "table staged (a stager wave)", "barrier passed"] if os.environ.get("FSLIC_ASSIGN") == "1" else ["records kept (wave 0)", "first barrier", "ranks known"]) + ["argmin done", "labels stored", "sums flushed", "barrier before the flush", "end"]
+names = ["records kept (wave 0)", "first barrier", "ranks known", "argmin done", "labels stored", "sums flushed", "barrier before the flush", "end"]
 S = int(np.sqrt(H * W // K))
 for ps in passes:
     fused = ps < 10
