@@ -224,7 +224,9 @@ struct fslic_engine {
     fslic::LabTables tables{};
     // slot ownership and the completion of asynchronous groups
     std::mutex mu;
-    std::condition_variable cv;
+    std::condition_variable cv;        // callers: a slot has become free, a group is complete, the queue has room, everything has drained
+    std::condition_variable cv_work;   // the slot threads: a job has been handed over, the queue has work, a slot may serve the queue again, quit
+                                       // (two variables so that a submission does not wake the callers and a completion does not wake the idle slot threads)
     // the submit / drain pipeline (fslic_hip_pipeline_*): first error of a collected group, totals since the last drain
     int pipe_rc = 0;
     std::string pipe_err;

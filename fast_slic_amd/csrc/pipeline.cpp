@@ -94,7 +94,7 @@ void release_slot(fslic_engine* e, int slot) {
         std::lock_guard<std::mutex> lk(e->mu);
         e->slots[slot].busy = false;
     }
-    e->cv.notify_all();
+    e->cv.notify_all(); e->cv_work.notify_all();      // callers waiting for a slot; the slot's own thread may serve the queue again
 }
 
 void release_all_slots(fslic_engine* e) {
@@ -102,7 +102,7 @@ void release_all_slots(fslic_engine* e) {
         std::lock_guard<std::mutex> lk(e->mu);
         for (Slot& s : e->slots) s.busy = false;
     }
-    e->cv.notify_all();
+    e->cv.notify_all(); e->cv_work.notify_all();
 }
 
 // ---- the slot's host thread: one group at a time, begin + finish ---------------------------------------------------
@@ -130,7 +130,7 @@ void slot_worker(fslic_engine* e, Slot* s) {
         bool took = false;
         {
             std::unique_lock<std::mutex> lk(e->mu);
-            e->cv.wait(lk, [&] { return a.has_job || a.quit || (!e->pipe_q.empty() && !e->pipe_gathering && !s->busy && !s->pending); });
+            e->cv_work.wait(lk, [&] { return a.has_job || a.quit || (!e->pipe_q.empty() && !e->pipe_gathering && !s->busy && !s->pending); });
             if (a.quit) return;
             if (!a.has_job) {
                 // the submit queue's head, plus -- with batching on -- the submissions behind it that ask for the same work,
@@ -159,7 +159,7 @@ void slot_worker(fslic_engine* e, Slot* s) {
                 // meanwhile), so that the first groups of a burst are as full as the later ones.
                 if (a.n + unit <= limit && e->pipe_q.empty() && !e->pipe_gathering) {
                     e->pipe_gathering = true;
-                    e->cv.wait_for(lk, std::chrono::microseconds(100), [&] { return !e->pipe_q.empty() || a.quit; });
+                    e->cv_work.wait_for(lk, std::chrono::microseconds(100), [&] { return !e->pipe_q.empty() || a.quit; });
                     e->pipe_gathering = false;
                     gather();
                 }
@@ -168,7 +168,7 @@ void slot_worker(fslic_engine* e, Slot* s) {
                 took = true;
             }
         }
-        if (took) e->cv.notify_all();            // room in the queue
+        if (took) { e->cv.notify_all(); e->cv_work.notify_all(); }      // room in the queue (callers); the gathering wait is over (the other slot threads)
         int rc = group_begin(e, *s, &a.p, a.H, a.W, a.K, a.n, a.d_rgb, a.clusters, a.d_out);
         if (rc == FSLIC_OK) rc = group_finish(e, *s);
         if (rc != FSLIC_OK) {        // nothing may still run against the caller's buffers once the group is reported done
@@ -233,7 +233,7 @@ void stop_slot_thread(fslic_engine* e, Slot& s) {
         std::lock_guard<std::mutex> lk(e->mu);
         s.async->quit = true;
     }
-    e->cv.notify_all();
+    e->cv_work.notify_all();
     if (s.async->worker.joinable()) s.async->worker.join();
     s.async.reset();
 }
@@ -261,7 +261,7 @@ int fslic_hip_submit_group(fslic_engine* e, int slot, const fslic_params* p, int
         }
         hand_over(e, s, p, H, W, K, n_frames, d_rgb, clusters, d_labels);
     }
-    e->cv.notify_all();
+    e->cv_work.notify_all();          // the slot's thread
     return FSLIC_OK;
 }
 
@@ -280,7 +280,7 @@ int fslic_hip_wait_group(fslic_engine* e, int slot) {
         s.pending = false;
         if (rc == FSLIC_OK) set_thread_timing_report(make_timing_report(s));
     }
-    e->cv.notify_all();
+    e->cv.notify_all(); e->cv_work.notify_all();      // the slot is free again: callers, and its own thread (the queue)
     return rc;
 }
 
@@ -309,7 +309,7 @@ int fslic_hip_pipeline_submit(fslic_engine* e, const fslic_params* p, int H, int
         j.p = *p; j.H = H; j.W = W; j.K = K; j.n = n_frames;
         for (int i = 0; i < n_frames; i++) { j.d_rgb[i] = d_rgb[i]; j.clusters[i] = clusters[i]; j.d_out[i] = d_labels[i]; }
     }
-    e->cv.notify_all();
+    e->cv_work.notify_all();          // the slot threads (and the one waiting for a companion)
     return FSLIC_OK;
 }
 
