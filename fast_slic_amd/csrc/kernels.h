@@ -176,7 +176,6 @@ struct CcaDev {
 constexpr int kLscFeat = 10;        // l1, l2, a1, a2, b1, b2, x1, x2, y1, y2 (src/lsc.h:12)
 constexpr int kLscCfPitch = 16;     // floats per centroid record (10 features, padded to 64 bytes)
 constexpr int kLscExPitch = 12;     // int64 per cluster of the stale-pixel accumulators (10 features, weight, pad)
-constexpr float kLscFixScale = 1048576.0f;   // fixed point of those accumulators (order-independent sums)
 struct LscDev {
     size_t frame_bytes;
     float* feat;         // [10][N] planar: features already divided by the pixel weight (src/lsc.cpp:152-162)

@@ -119,9 +119,13 @@ __global__ __launch_bounds__(256) void k_lsc_features(FrameDev f, LscDev l) {
 }
 
 static __device__ __forceinline__ float wave_sum(float v) { return wave_reduce_add(v); }
-// fixed point of the fused update's accumulators: a wavefront's partial sum (256 pixels) of w*F stays below 256 * 51 and
-// one of w below 256 * 23000, so these scales keep the rounded partials inside 32 bits; the accumulators themselves are 64-bit
-constexpr float kLscFixF = 65536.0f, kLscFixW = 128.0f;
+// fixed point of the fused update's accumulators: a lane's partial sum (its column of kLscRows pixels) of w*F stays below
+// 4 * 51 and one of w below 4 * 23000, so these scales keep the rounded partials inside 32 bits; the accumulators themselves
+// are 64-bit (a cluster that owned a whole 4K frame would reach 4.4e14 and 7.8e14)
+constexpr float kLscFixF = 1048576.0f, kLscFixW = 4096.0f;
+constexpr int kLscCopies = 4;                             // privatised copies of a block's accumulators (lane & 3)
+constexpr int kLscAccW = kLscFeat + 1 + 2;                // 64-bit words per (candidate, copy): 10 x sum w*F, sum w, two packed integer words
+constexpr uint32_t kLscNoSlot = 0xFFFFFFFFu;
 
 // Seed centroids: unweighted mean of the features over the (2*(S/4)+1)^2 window around the centre, clipped to the
 // image (src/lsc.cpp:165-195).  One wavefront per cluster.
@@ -166,62 +170,6 @@ __global__ __launch_bounds__(256) void k_lsc_seed(FrameDev f, LscDev l) {
     }
 }
 
-// ---- cross-lane fold of the fused update ----------------------------------------------------
-// A halving butterfly: at each level two values are folded across one lane bit into ONE register, the lanes with the bit
-// clear keeping the first value's partial sum and the lanes with the bit set the second's (v_permlane32_swap / v_permlane16_swap
-// across the halves and the 16-lane rows, DPP moves under bank masks below that).  The order of the additions is fixed.
-typedef unsigned int lsc_u2 __attribute__((ext_vector_type(2)));
-static __device__ __forceinline__ float lsc_add(float a, float b) { return a + b; }
-static __device__ __forceinline__ uint32_t lsc_add(uint32_t a, uint32_t b) { return a + b; }
-static __device__ __forceinline__ uint32_t lsc_bits(float a) { return __float_as_uint(a); }
-static __device__ __forceinline__ uint32_t lsc_bits(uint32_t a) { return a; }
-template <typename T> static __device__ __forceinline__ T lsc_from(uint32_t a);
-template <> __device__ __forceinline__ float lsc_from<float>(uint32_t a) { return __uint_as_float(a); }
-template <> __device__ __forceinline__ uint32_t lsc_from<uint32_t>(uint32_t a) { return a; }
-template <typename T> static __device__ __forceinline__ T fold32(T a, T b) {     // lanes 0..31: a[l] + a[l+32]; lanes 32..63: b[l-32] + b[l]
-    const lsc_u2 r = __builtin_amdgcn_permlane32_swap(lsc_bits(a), lsc_bits(b), false, false);
-    return lsc_add(lsc_from<T>(r[0]), lsc_from<T>(r[1]));
-}
-template <typename T> static __device__ __forceinline__ T fold16(T a, T b) {     // even rows: a[row] + a[row+1]; odd rows: b[row-1] + b[row]
-    const lsc_u2 r = __builtin_amdgcn_permlane16_swap(lsc_bits(a), lsc_bits(b), false, false);
-    return lsc_add(lsc_from<T>(r[0]), lsc_from<T>(r[1]));
-}
-template <int CTRL, int BANKS_A, typename T> static __device__ __forceinline__ T fold_dpp(T a, T b) {   // banks A: a + a', the others: b + b'
-    const uint32_t m1 = __builtin_amdgcn_update_dpp(lsc_bits(b), lsc_bits(a), CTRL, 0xF, BANKS_A, false);
-    const uint32_t m2 = __builtin_amdgcn_update_dpp(lsc_bits(a), lsc_bits(b), CTRL, 0xF, 0xF ^ BANKS_A, false);
-    return lsc_add(lsc_from<T>(m1), lsc_from<T>(m2));
-}
-template <int CTRL, typename T> static __device__ __forceinline__ T sum_dpp(T a) {
-    return lsc_add(a, lsc_from<T>(__builtin_amdgcn_update_dpp(0u, lsc_bits(a), CTRL, 0xF, 0xF, true)));
-}
-constexpr int kDppRor8 = 0x128, kDppHalfMirror = 0x141, kDppQuadSwap1 = 0xB1, kDppQuadSwap2 = 0x4E;
-// 12 floats -> the total of v[q] in every lane of the quads with slot_f == q (see the slot arithmetic in the assign kernel)
-static __device__ __forceinline__ float lsc_fold12(const float* v) {
-    float g[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) g[i] = fold32(v[2 * i], v[2 * i + 1]);
-    float h[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) h[i] = fold16(g[2 * i], g[2 * i + 1]);
-    const float m0 = fold_dpp<kDppRor8, 0x3>(h[0], h[1]);
-    const float m1 = sum_dpp<kDppRor8>(h[2]);
-    float t = fold_dpp<kDppHalfMirror, 0x5>(m0, m1);
-    t = sum_dpp<kDppQuadSwap1>(t);
-    return sum_dpp<kDppQuadSwap2>(t);
-}
-// 6 integers -> the total of v[q] in every lane of the octets with slot_u == q
-static __device__ __forceinline__ uint32_t lsc_fold6(const uint32_t* v) {
-    uint32_t g[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) g[i] = fold32(v[2 * i], v[2 * i + 1]);
-    const uint32_t h0 = fold16(g[0], g[1]);
-    const uint32_t h1 = fold16(g[2], 0u);
-    uint32_t t = fold_dpp<kDppRor8, 0x3>(h0, h1);
-    t = sum_dpp<kDppHalfMirror>(t);
-    t = sum_dpp<kDppQuadSwap1>(t);
-    return sum_dpp<kDppQuadSwap2>(t);
-}
-
 // ---- assignment -----------------------------------------------------------------------------
 // Block = 64 columns x (4 wavefronts x kLscRows visited rows).  Wavefront 0 collects the clusters whose window can
 // reach the block from the coarse bins, orders them by the reference's visit order (phase, k) and stages their
@@ -237,17 +185,18 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
     __shared__ uint32_t s_yx[64], s_k[64];
     __shared__ __attribute__((aligned(16))) float s_cf[64 * 12];
     __shared__ int s_cnt;
-    // block-level accumulators of the fused update: per candidate of the block's list 11 feature sums (2^-20 fixed point)
-    // and 6 integer sums, 64-bit words (LDS atomics; flushed with ONE set of global atomics per (block, cluster))
-    constexpr int kAccW = kLscFeat + 1 + 6;
-    __shared__ unsigned long long s_accx[64 * kAccW];
+    // block-level accumulators of the fused update: per candidate of the block's list (and privatised copy) 11 feature sums
+    // in fixed point and the 6 integer sums packed into two words (sum L | sum a << 20 | sum b << 40 and sum (x - x0) |
+    // sum (y - y0) << 20 | count << 40, as the SLIC block kernel packs them: 1024 pixels per block, no field reaches 2^20);
+    // LDS atomics, flushed with ONE set of global atomics per (block, cluster)
+    __shared__ unsigned long long s_accx[stale_sums ? 64 * kLscCopies * kLscAccW : 1];
     const int wave = threadIdx.x >> 6, lane = LANE();
     const int S = f.S, W = f.W;
     const size_t N = (size_t)f.N;
     const int x0 = blockIdx.x * 64;
     const int v0 = blockIdx.y * kLscBH;
     if (stale_sums)
-        for (int i = threadIdx.x; i < 64 * kAccW; i += 256) s_accx[i] = 0ull;
+        for (int i = threadIdx.x; i < 64 * kLscCopies * kLscAccW; i += 256) s_accx[i] = 0ull;
     if (wave == 0) {
         const int v_last = min(v0 + kLscBH, Hv) - 1;
         TileWindow win;
@@ -318,7 +267,7 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
             const float4* src = reinterpret_cast<const float4*>(s_cf + c * 12);
             const float4 c0 = src[0], c1 = src[1], c2 = src[2];
             const float cf[kLscFeat] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y};
-            consider(cy, cx, rfl(s_k[c]), cf);
+            consider(cy, cx, (uint32_t)c, cf);
         }
     } else {
         // visit order of the reference (phase, then k) over every cluster
@@ -346,30 +295,33 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
     }
     // labels out; with an update following (stale_sums), also the label each visited pixel carries into update(): the new one,
     // or the one it keeps when nothing accepted it (src/lsc.cpp:217-220 never touches such a pixel; 0xFFFF: none yet)
-    uint32_t lbl[kLscRows];
+    const bool listed = cnt <= 64;                 // bk = position in the block's list (else the cluster itself)
+    uint32_t lbl[kLscRows], slot[kLscRows];
 #pragma unroll
     for (int r = 0; r < kLscRows; ++r) {
         lbl[r] = 0xFFFFu;
+        slot[r] = kLscNoSlot;
         if (!xok || vw + r >= Hv) continue;
         const size_t p = (size_t)yr[r] * W + x;
         if (best[r >> 1][r & 1] < FLT_MAX) {
-            st_stream(f.labels + p, (uint16_t)bk[r]);
-            lbl[r] = bk[r];
+            lbl[r] = listed ? s_k[bk[r]] : bk[r];
+            st_stream(f.labels + p, (uint16_t)lbl[r]);
+            if (listed) slot[r] = bk[r];
         } else if (stale_sums) {
             lbl[r] = f.labels[p];
         }
     }
     if (!stale_sums) return;
     // ---- update(), fused: the sums of src/context.cpp:301-354 (count, y, x, L, a, b) and of src/lsc.cpp:256-269 (sum w*F per
-    // feature, sum w) over this wavefront's pixels, label by label: every lane folds its rows that carry the label (f32 FMA
-    // chain like the reference build; lanes without such a row contribute zeros), a halving butterfly (lsc_fold12 / lsc_fold6:
-    // 43 cross-lane operations for the 17 values, against 102 for 17 full wave sums) leaves value q's total in the lanes of
-    // slot q, and ONE 64-bit LDS atomic instruction adds all 17 to the block's accumulators (the float sums in fixed point, so
-    // the totals do not depend on the order in which wavefronts arrive: run-to-run identical).  A wavefront of the 1280x720
-    // K=1600 fixture meets 8 labels on average.  (Measured alternatives per launch of 8 x 720p: lanes first folding their OWN
-    // label and the labels then served from those partial sums 75 us -- 17 butterflies per wavefront instead of 8 --, full wave
-    // sums instead of the butterfly 87 us, 16-lane row sums and LDS atomics from every row's first lane 172 us; this form 61 us.)
-    // This replaces a kernel that re-scanned every cluster's window for its members (64 of 100 us per iteration).
+    // feature, sum w) over this block's pixels.  A column's rows fall into one or two runs of equal label (a superpixel is
+    // taller than a wavefront's rows), so every lane sums its column run by run in registers (f32 FMA chain like the reference
+    // build) and adds a finished run to the block's accumulators with 13 LDS atomics: the float sums in fixed point, so the
+    // totals do not depend on the order in which lanes and wavefronts arrive (run-to-run identical), the six integer sums
+    // packed into two words.  Lanes of a run of columns with one label meet on the same words: kLscCopies privatised copies.
+    // (Measured per launch of 8 x 1280x720 K=1600, the forms this replaces: a loop over the wavefront's labels with a
+    // halving butterfly over the lanes per label 61 us -- 8 labels x (44 masked FMAs + 43 cross-lane operations + 17 LDS
+    // atomics) per wavefront --, lanes folding their own label first 75 us, full wave sums 87 us, 16-lane row sums 172 us;
+    // the kernel that re-scanned every cluster's window for its members 64 of 100 us per iteration.)
     float wgt[kLscRows];
     uint32_t pix[kLscRows];
 #pragma unroll
@@ -378,65 +330,84 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
         wgt[r] = l.weight[p];
         pix[r] = f.lab[p];
     }
-    uint32_t todo_rows = 0;                       // bit r: row r still has to be summed
+    // a pixel whose label is not on the block's list (it kept a label whose window has left it, or the block walks every
+    // cluster): straight to the global accumulators.  Rare.
 #pragma unroll
-    for (int r = 0; r < kLscRows; ++r) todo_rows |= (lbl[r] != 0xFFFFu ? 1u : 0u) << r;
-    const uint32_t my_k = lane < min(cnt, 64) && cnt <= 64 ? s_k[lane] : 0xFFFFFFFFu;      // the block's list: lane c = candidate c
-    // slot of this lane after the fold: the float sums end in the quads (lane bit 2 clear: slots 0..7, set: 8..10), the
-    // integer sums in the octets; one lane of each adds
-    const int b5 = (lane >> 5) & 1, b4 = (lane >> 4) & 1, b3 = (lane >> 3) & 1, b2 = (lane >> 2) & 1;
-    const int slot_f = b2 ? 8 + 2 * b4 + b5 : 4 * b3 + 2 * b4 + b5;
-    const int slot_u = b3 ? 4 + b5 : 2 * b4 + b5;
-    const bool adds_f = (lane & 3) == 0 && !(b2 && b3) && slot_f <= kLscFeat;
-    const bool adds_u = (lane & 7) == 1 && !(b3 && b4);
-    const int slot = adds_f ? slot_f : kLscFeat + 1 + slot_u;
-    const float fix = slot_f == kLscFeat ? kLscFixW : kLscFixF;
-    for (;;) {
-        uint32_t mine = 0xFFFFFFFFu;
+    for (int r = 0; r < kLscRows; ++r) {
+        if (lbl[r] == 0xFFFFu || slot[r] != kLscNoSlot) continue;
+        unsigned long long* e = reinterpret_cast<unsigned long long*>(l.extra + (size_t)lbl[r] * kLscExPitch);
 #pragma unroll
-        for (int r = 0; r < kLscRows; ++r) mine = ((todo_rows >> r) & 1u) ? lbl[r] : mine;
-        const unsigned long long pend = __ballot(mine != 0xFFFFFFFFu);
-        if (!pend) break;
-        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)mine, __builtin_ctzll(pend));
-        float fv[kLscFeat + 2];
-        uint32_t uv[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+        for (int q = 0; q < kLscFeat; ++q)
+            atomicAdd(e + q, (unsigned long long)(long long)(int)__builtin_rintf(__builtin_fmaf(wgt[r], F[r >> 1][q][r & 1], 0.0f) * kLscFixF));
+        atomicAdd(e + kLscFeat, (unsigned long long)(long long)(int)__builtin_rintf(wgt[r] * kLscFixW));
+        global_accumulate(f.sums[0], lbl[r], (uint32_t)yr[r], (uint32_t)x, pix[r]);
+    }
+    {
+        const uint32_t copy = (uint32_t)lane & (kLscCopies - 1);
+        uint32_t cur = slot[0], a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0;
+        float fv[kLscFeat + 1];
 #pragma unroll
-        for (int q = 0; q < kLscFeat + 2; ++q) fv[q] = 0.0f;
+        for (int q = 0; q <= kLscFeat; ++q) fv[q] = 0.0f;
+        auto flush = [&]() {
+            if (cur != kLscNoSlot) {
+                unsigned long long* a = s_accx + (cur * kLscCopies + copy) * kLscAccW;
+#pragma unroll
+                for (int q = 0; q < kLscFeat; ++q) atomicAdd(a + q, (unsigned long long)(long long)(int)__builtin_rintf(fv[q] * kLscFixF));
+                atomicAdd(a + kLscFeat, (unsigned long long)(long long)(int)__builtin_rintf(fv[kLscFeat] * kLscFixW));
+                atomicAdd(a + kLscFeat + 1, (unsigned long long)a_lo | ((unsigned long long)a_hi << 32));
+                atomicAdd(a + kLscFeat + 2, (unsigned long long)b_lo | ((unsigned long long)b_hi << 32));
+            }
+        };
 #pragma unroll
         for (int r = 0; r < kLscRows; ++r) {
-            const bool m = ((todo_rows >> r) & 1u) && lbl[r] == k0;
-            if (m) {
-                uv[0] += 1u; uv[1] += (uint32_t)yr[r]; uv[2] += (uint32_t)x;
-                uv[3] += pix[r] & 255u; uv[4] += (pix[r] >> 8) & 255u; uv[5] += (pix[r] >> 16) & 255u;
+            if (r > 0 && slot[r] != cur) {
+                flush();
+                cur = slot[r]; a_lo = 0; a_hi = 0; b_lo = 0; b_hi = 0;
 #pragma unroll
-                for (int q = 0; q < kLscFeat; ++q) fv[q] = __builtin_fmaf(wgt[r], F[r >> 1][q][r & 1], fv[q]);
-                fv[kLscFeat] += wgt[r];
-                todo_rows &= ~(1u << r);
+                for (int q = 0; q <= kLscFeat; ++q) fv[q] = 0.0f;
             }
+#pragma unroll
+            for (int q = 0; q < kLscFeat; ++q) fv[q] = __builtin_fmaf(wgt[r], F[r >> 1][q][r & 1], fv[q]);
+            fv[kLscFeat] += wgt[r];
+            const uint32_t p = pix[r];
+            a_lo += (p & 255u) | ((p & 0xFF00u) << 12);                      // sum L | sum a << 20
+            a_hi += (p >> 8) & 0xFF00u;                                     // sum b << 40
+            b_lo += (uint32_t)lane | (1u << 20);                            // sum (x - x0) | count << 20
+            b_hi += (uint32_t)(wave * kLscRows + r);                        // sum of the row's number inside the block << 32
         }
-        const float tf = lsc_fold12(fv);
-        const uint32_t tu = lsc_fold6(uv);
-        const unsigned long long v = adds_f ? (unsigned long long)(long long)(int)__builtin_rintf(tf * fix) : (unsigned long long)tu;
-        const unsigned long long hit = __ballot(my_k == k0);
-        if (adds_f || adds_u) {
-            if (hit) {
-                atomicAdd(&s_accx[__builtin_ctzll(hit) * kAccW + slot], v);
-            } else if (adds_f) {
-                atomicAdd(reinterpret_cast<unsigned long long*>(l.extra + (size_t)k0 * kLscExPitch) + slot_f, v);
-            } else {
-                atomicAdd(f.sums[0] + 6 * (size_t)k0 + slot_u, tu);
-            }
-        }
+        flush();
     }
     __syncthreads();
     // one set of global atomics per (block, cluster that received pixels here)
-    for (int i = threadIdx.x; i < min(cnt, 64) * kAccW && cnt <= 64; i += 256) {
-        const int c = i / kAccW, q = i - c * kAccW;
-        if (s_accx[c * kAccW + kLscFeat + 1] == 0ull) continue;          // count == 0: nothing for this cluster
-        const unsigned long long v = s_accx[i];
+    const uint32_t yb0 = (uint32_t)(rem + stride * v0);
+    for (int i = threadIdx.x; i < cnt * (kLscFeat + 1 + 6) && listed; i += 256) {
+        const int c = i / (kLscFeat + 1 + 6), q = i - c * (kLscFeat + 1 + 6);
+        const unsigned long long* a = s_accx + (size_t)c * kLscCopies * kLscAccW;
+        unsigned long long B = 0;
+#pragma unroll
+        for (int cpy = 0; cpy < kLscCopies; ++cpy) B += a[cpy * kLscAccW + kLscFeat + 2];
+        const uint32_t n = (uint32_t)(B >> 20) & 0xFFFu;
+        if (n == 0u) continue;                                              // nothing for this cluster
         const uint32_t k = s_k[c];
-        if (q <= kLscFeat) atomicAdd(reinterpret_cast<unsigned long long*>(l.extra + (size_t)k * kLscExPitch) + q, v);
-        else atomicAdd(f.sums[0] + 6 * (size_t)k + (q - kLscFeat - 1), (uint32_t)v);
+        if (q <= kLscFeat) {
+            unsigned long long v = 0;
+#pragma unroll
+            for (int cpy = 0; cpy < kLscCopies; ++cpy) v += a[cpy * kLscAccW + q];
+            atomicAdd(reinterpret_cast<unsigned long long*>(l.extra + (size_t)k * kLscExPitch) + q, v);
+        } else {
+            unsigned long long A = 0;
+#pragma unroll
+            for (int cpy = 0; cpy < kLscCopies; ++cpy) A += a[cpy * kLscAccW + kLscFeat + 1];
+            const int u = q - kLscFeat - 1;
+            uint32_t v;
+            if (u == 0) v = n;
+            else if (u == 1) v = yb0 * n + (uint32_t)stride * (uint32_t)(B >> 32);
+            else if (u == 2) v = (uint32_t)x0 * n + ((uint32_t)B & 0xFFFFFu);
+            else if (u == 3) v = (uint32_t)A & 0xFFFFFu;
+            else if (u == 4) v = (uint32_t)(A >> 20) & 0xFFFFFu;
+            else v = (uint32_t)(A >> 40);
+            atomicAdd(f.sums[0] + 6 * (size_t)k + u, v);
+        }
     }
 }
 
