@@ -190,11 +190,10 @@ int ensure_prepared(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G)
     return prepare(e, s, H, W, K, S, G);
 }
 
-// LSC variant: carve the feature arena for groups of up to G frames and (re)build the tables.  The tables follow
+// LSC variant: carve the arena (means, centroids, accumulators: no feature planes) for groups of up to G frames and (re)build the tables.  The tables follow
 // src/lsc.cpp:24-27,76-101 expression by expression (float vs double evaluation included) and use the host libm,
 // like the reference.
 int prepare_lsc(Slot& s, int H, int W, int K, int S, int G, float compactness) {
-    const size_t N = (size_t)H * W;
     const size_t lut_floats = 1024 + 2 * (size_t)W + 2 * (size_t)H;
     if (s.lsc_H != H || s.lsc_W != W || s.lsc_K != K || s.lsc_G < G) {
         G = std::max(G, (s.lsc_H == H && s.lsc_W == W && s.lsc_K == K) ? s.lsc_G : 0);
@@ -203,7 +202,6 @@ int prepare_lsc(Slot& s, int H, int W, int K, int S, int G, float compactness) {
         const size_t o_lut = take(lut_floats * 4);
         const size_t shared_bytes = off;
         off = 0;
-        const size_t o_feat = take(N * 4 * kLscFeat), o_w = take(N * 4);
         const size_t o_hist = take(768 * 4), o_extra = take((size_t)K * kLscExPitch * 8);
         const size_t zero_bytes = off - o_hist;
         const size_t o_means = take(64), o_cfeat = take((size_t)K * kLscCfPitch * 4);
@@ -222,7 +220,6 @@ int prepare_lsc(Slot& s, int H, int W, int K, int S, int G, float compactness) {
         char* b = s.lsc_arena + shared_bytes;
         LscDev& l = s.l;
         l.frame_bytes = frame_bytes;
-        l.feat = (float*)(b + o_feat); l.weight = (float*)(b + o_w);
         l.hist = (uint32_t*)(b + o_hist); l.extra = (long long*)(b + o_extra);
         l.means = (float*)(b + o_means); l.cfeat = (float*)(b + o_cfeat);
         const float* lut = (const float*)(s.lsc_arena + o_lut);

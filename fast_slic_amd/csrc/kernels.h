@@ -171,15 +171,14 @@ struct CcaDev {
     }
 };
 
-// Device state of the LSC variant (src/lsc.cpp): the 10-D feature map of every frame of the group and the feature-space
-// centroids.  Same per-frame sub-arena scheme as FrameDev (own arena, own frame stride).
+// Device state of the LSC variant (src/lsc.cpp): the feature means of every frame of the group, the feature-space centroids and
+// the tables the kernels rebuild a pixel's ten features from (no feature planes: lsc.hip).  Same per-frame sub-arena scheme as
+// FrameDev (own arena, own frame stride).
 constexpr int kLscFeat = 10;        // l1, l2, a1, a2, b1, b2, x1, x2, y1, y2 (src/lsc.h:12)
 constexpr int kLscCfPitch = 16;     // floats per centroid record (10 features, padded to 64 bytes)
 constexpr int kLscExPitch = 12;     // int64 per cluster of the stale-pixel accumulators (10 features, weight, pad)
 struct LscDev {
     size_t frame_bytes;
-    float* feat;         // [10][N] planar: features already divided by the pixel weight (src/lsc.cpp:152-162)
-    float* weight;       // [N]
     uint32_t* hist;      // 768: histograms of the L, a, b planes (feature means of the colour half, src/lsc.cpp:143-149)
     float* means;        // 16 (10 used)
     float* cfeat;        // K * kLscCfPitch
@@ -190,7 +189,7 @@ struct LscDev {
     const float* lut_y;       // [2][H]
     __host__ __device__ __forceinline__ void select(int z) {
         const size_t d = (size_t)z * frame_bytes;
-        FrameDev::adv(feat, d); FrameDev::adv(weight, d); FrameDev::adv(hist, d); FrameDev::adv(means, d);
+        FrameDev::adv(hist, d); FrameDev::adv(means, d);
         FrameDev::adv(cfeat, d); FrameDev::adv(extra, d);
     }
 };
@@ -226,7 +225,7 @@ PassGeom launch_assign(const FrameDev& f, int nframes, int rem, int stride, int 
 bool assign_fuses_cluster_pass(const FrameDev& f, int stride);
 void launch_assign_fused_bin(const FrameDev& f, int nframes, int rem, int stride, int it, hipStream_t st);
 void launch_assign_generic(const FrameDev& f, int nframes, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st);
-// LSC variant (lsc.hip).  prepare: feature map + seed centroids (src/lsc.cpp:12-15), after LAB and the mode-0 cluster pass.
+// LSC variant (lsc.hip).  prepare: feature means + seed centroids (src/lsc.cpp:12-15), after LAB and the mode-0 cluster pass.
 void launch_lsc_prepare(const FrameDev& f, const LscDev& l, int nframes, hipStream_t st);
 // 10-D assignment of rows == rem (mod stride) (src/lsc.cpp:197-224); stale_sums: an update follows
 void launch_lsc_assign(const FrameDev& f, const LscDev& l, int nframes, int rem, int stride, int buf, int sbuf, bool stale_sums, hipStream_t st);

@@ -89,33 +89,60 @@ __global__ __launch_bounds__(256) void k_lsc_means(FrameDev f, LscDev l) {
     }
 }
 
-// Per pixel: ten features from the tables, weight w = sum_f mean_f * F_f (FMA chain from zero, as the reference build
-// contracts src/lsc.cpp:156-158), features stored divided by w (src/lsc.cpp:309-316).
-__global__ __launch_bounds__(256) void k_lsc_features(FrameDev f, LscDev l) {
-    f.select(blockIdx.y);
-    l.select(blockIdx.y);
-    __shared__ float lc[1024];
-    __shared__ float mean[kLscFeat];
-    for (int i = threadIdx.x; i < 1024; i += 256) lc[i] = l.lut_color[i];
-    if (threadIdx.x < kLscFeat) mean[threadIdx.x] = l.means[threadIdx.x];
-    __syncthreads();
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)f.N) return;
-    const int y = (int)(i / (size_t)f.W), x = (int)(i - (size_t)y * f.W);
-    const uint32_t p = f.lab[i];
+// ---- features on the fly ----------------------------------------------------------------------
+// The reference materialises the ten features of every pixel, divided by the pixel's weight (src/lsc.cpp:103-162: 40 B of
+// feature planes + 4 B of weight per pixel).  They are table look-ups of the pixel's L, a, b bytes, its column and its row,
+// so the kernels below rebuild them from the 4-byte LAB word where they need them: weight w = sum_f mean_f * F_f (FMA chain
+// from zero, as the reference build contracts src/lsc.cpp:156-158) and the features times 1 / w (v_rcp_f32 + one Newton
+// step; the reference divides -- the quotients differ by at most an ulp, far below what the order of the reference's own f32
+// centroid sums moves them).  Measured against the materialised planes this path started with (8 x 1280x720 K=1600 per
+// launch, profiles/r03_lsc_recompute.txt): both numbers are in DESIGN.md.
+// Colour tables in LDS as (cos, sin) pairs: word pair v = L table, 256 + v = a/b table -- one ds_read_b64 per byte.
+static __device__ __forceinline__ void lsc_stage_lut(const LscDev& l, float* s_lut) {       // 256 threads
+    const int t = threadIdx.x;
+    reinterpret_cast<float2*>(s_lut)[t] = make_float2(l.lut_color[t], l.lut_color[256 + t]);
+    reinterpret_cast<float2*>(s_lut)[256 + t] = make_float2(l.lut_color[512 + t], l.lut_color[768 + t]);
+}
+// minimum over the 64 lanes (DPP steps inside the 16-lane rows, four readlanes across them)
+static __device__ __forceinline__ uint32_t lsc_wave_min(uint32_t v) {
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));      // quad_perm [1,0,3,2]
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));      // quad_perm [2,3,0,1]
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));     // row_half_mirror
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));     // row_mirror
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return min(min(r0, r1), min(r2, r3));
+}
+static __device__ __forceinline__ float lsc_uniform(float v) { return __uint_as_float(rfl(__float_as_uint(v))); }
+// two pixels of one column (LAB words p0, p1; rows with the y features y1, y2): features / weight - org as packed pairs, the weights
+static __device__ __forceinline__ void lsc_pair_features(const float* s_lut, uint32_t p0, uint32_t p1, float x1, float x2, f2 y1, f2 y2,
+                                                         const float* mean, const float* org, f2* G, f2& w) {
+    const float2* tl = reinterpret_cast<const float2*>(s_lut);
+    const float2 L0 = tl[p0 & 255u], L1 = tl[p1 & 255u];
+    const float2 A0 = tl[256u + ((p0 >> 8) & 255u)], A1 = tl[256u + ((p1 >> 8) & 255u)];
+    const float2 B0 = tl[256u + ((p0 >> 16) & 255u)], B1 = tl[256u + ((p1 >> 16) & 255u)];
+    const f2 F[kLscFeat] = {{L0.x, L1.x}, {L0.y, L1.y}, {A0.x, A1.x}, {A0.y, A1.y}, {B0.x, B1.x}, {B0.y, B1.y}, {x1, x1}, {x2, x2}, y1, y2};
+    f2 ww = {0.0f, 0.0f};
+#pragma unroll
+    for (int q = 0; q < kLscFeat; ++q) ww = __builtin_elementwise_fma((f2){mean[q], mean[q]}, F[q], ww);
+    f2 r = {__builtin_amdgcn_rcpf(ww[0]), __builtin_amdgcn_rcpf(ww[1])};
+    r = __builtin_elementwise_fma(__builtin_elementwise_fma(-ww, r, (f2){1.0f, 1.0f}), r, r);
+#pragma unroll
+    for (int q = 0; q < kLscFeat; ++q) G[q] = __builtin_elementwise_fma(F[q], r, (f2){-org[q], -org[q]});      // F / w - origin
+    w = ww;
+}
+// one pixel, tables read from global memory (the seed kernel: 169 pixels per cluster)
+static __device__ __forceinline__ void lsc_pixel_features(const LscDev& l, uint32_t p, int x, int y, int W, int H, const float* mean, float* G) {
     const uint32_t L = p & 255u, A = (p >> 8) & 255u, B = (p >> 16) & 255u;
-    float F[kLscFeat];
-    F[0] = lc[L]; F[1] = lc[256 + L];
-    F[2] = lc[512 + A]; F[3] = lc[768 + A];
-    F[4] = lc[512 + B]; F[5] = lc[768 + B];
-    F[6] = l.lut_x[x]; F[7] = l.lut_x[f.W + x];
-    F[8] = l.lut_y[y]; F[9] = l.lut_y[f.H + y];
+    const float F[kLscFeat] = {l.lut_color[L], l.lut_color[256 + L], l.lut_color[512 + A], l.lut_color[768 + A], l.lut_color[512 + B],
+                               l.lut_color[768 + B], l.lut_x[x], l.lut_x[W + x], l.lut_y[y], l.lut_y[H + y]};
     float w = 0.0f;
 #pragma unroll
     for (int q = 0; q < kLscFeat; ++q) w = __builtin_fmaf(mean[q], F[q], w);
-    st_stream(l.weight + i, w);
+    float r = __builtin_amdgcn_rcpf(w);
+    r = __builtin_fmaf(__builtin_fmaf(-w, r, 1.0f), r, r);
 #pragma unroll
-    for (int q = 0; q < kLscFeat; ++q) st_stream(l.feat + (size_t)q * f.N + i, F[q] / w);
+    for (int q = 0; q < kLscFeat; ++q) G[q] = F[q] * r;
 }
 
 static __device__ __forceinline__ float wave_sum(float v) { return wave_reduce_add(v); }
@@ -123,9 +150,10 @@ static __device__ __forceinline__ float wave_sum(float v) { return wave_reduce_a
 // 4 * 51 and one of w below 4 * 23000, so these scales keep the rounded partials inside 32 bits; the accumulators themselves
 // are 64-bit (a cluster that owned a whole 4K frame would reach 4.4e14 and 7.8e14)
 constexpr float kLscFixF = 1048576.0f, kLscFixW = 4096.0f;
-constexpr int kLscCopies = 4;                             // privatised copies of a block's accumulators (lane & 3)
+constexpr int kLscCopies = 2;                             // privatised copies of a block's accumulators (lane & 1)
 constexpr int kLscAccW = kLscFeat + 1 + 2;                // 64-bit words per (candidate, copy): 10 x sum w*F, sum w, two packed integer words
 constexpr uint32_t kLscNoSlot = 0xFFFFFFFFu;
+constexpr int kDppQuadSwap1 = 0xB1, kDppQuadSwap2 = 0x4E;     // quad_perm [1,0,3,2] and [2,3,0,1]
 
 // Seed centroids: unweighted mean of the features over the (2*(S/4)+1)^2 window around the centre, clipped to the
 // image (src/lsc.cpp:165-195).  One wavefront per cluster.
@@ -139,26 +167,18 @@ __global__ __launch_bounds__(256) void k_lsc_seed(FrameDev f, LscDev l) {
     const int y_lo = max(cy - q4, 0), y_hi = min(cy + q4 + 1, f.H);
     const int x_lo = max(cx - q4, 0), x_hi = min(cx + q4 + 1, f.W);
     const int nw = x_hi - x_lo, n = nw * (y_hi - y_lo);
+    float mean[kLscFeat];
+#pragma unroll
+    for (int q = 0; q < kLscFeat; ++q) mean[q] = lsc_uniform(l.means[q]);
     float acc[kLscFeat];
 #pragma unroll
     for (int q = 0; q < kLscFeat; ++q) acc[q] = 0.0f;
-    for (int t0 = lane; t0 - lane < n; t0 += 192) {
-        float v[3][kLscFeat];
+    for (int t = lane; t < n; t += 64) {
+        const int yy = y_lo + t / nw, xx = x_lo + t % nw;
+        float G[kLscFeat];
+        lsc_pixel_features(l, f.lab[(size_t)yy * f.W + xx], xx, yy, f.W, f.H, mean, G);
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {                   // loads of three steps in flight (clamped index, masked below)
-            const int t = min(t0 + 64 * u, n - 1);
-            const int yy = y_lo + t / nw, xx = x_lo + t % nw;
-            const size_t i = (size_t)yy * f.W + xx;
-#pragma unroll
-            for (int q = 0; q < kLscFeat; ++q) v[u][q] = l.feat[(size_t)q * f.N + i];
-        }
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            if (t0 + 64 * u < n) {
-#pragma unroll
-                for (int q = 0; q < kLscFeat; ++q) acc[q] += v[u][q];
-            }
-        }
+        for (int q = 0; q < kLscFeat; ++q) acc[q] += G[q];
     }
 #pragma unroll
     for (int q = 0; q < kLscFeat; ++q) acc[q] = wave_sum(acc[q]);
@@ -177,13 +197,20 @@ __global__ __launch_bounds__(256) void k_lsc_seed(FrameDev f, LscDev l) {
 // A pixel takes cluster k iff it lies in k's window and dist < best so far (strict, src/lsc.cpp:217; a NaN
 // centroid therefore never wins and +inf never beats the initial FLT_MAX).  More than 64 candidates (piled-up
 // clusters): the block walks all K clusters in visit order instead.
+#if defined(FSLIC_LAB) && FSLIC_LAB == 4      // lab build 4: phase time stamps (100 MHz ticks since the block's start), 16 words per (pass, block)
+#define LSC_STAMP(i_, cond_) do { if ((cond_) && lane == 0) { asm volatile("" ::: "memory"); lsc_w[(i_)] = (uint32_t)__builtin_amdgcn_s_memrealtime() - lsc_t0; asm volatile("" ::: "memory"); } } while (0)
+#else
+#define LSC_STAMP(i_, cond_) do { } while (0)
+#endif
 template <bool stale_sums>
 static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, int rem, int stride, int Hv) {
     f.select(blockIdx.z);
     l.select(blockIdx.z);
     __shared__ uint32_t s_raw[192];
     __shared__ uint32_t s_yx[64], s_k[64];
-    __shared__ __attribute__((aligned(16))) float s_cf[64 * 12];
+    __shared__ __attribute__((aligned(16))) float s_cf[64 * 12];      // per candidate: centroid - origin (10), its squared norm, pad
+    __shared__ __attribute__((aligned(16))) float s_org[12];          // the origin
+    __shared__ __attribute__((aligned(8))) float s_lut[1024];
     __shared__ int s_cnt;
     // block-level accumulators of the fused update: per candidate of the block's list (and privatised copy) 11 feature sums
     // in fixed point and the 6 integer sums packed into two words (sum L | sum a << 20 | sum b << 40 and sum (x - x0) |
@@ -192,11 +219,16 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
     __shared__ unsigned long long s_accx[stale_sums ? 64 * kLscCopies * kLscAccW : 1];
     const int wave = threadIdx.x >> 6, lane = LANE();
     const int S = f.S, W = f.W;
-    const size_t N = (size_t)f.N;
     const int x0 = blockIdx.x * 64;
     const int v0 = blockIdx.y * kLscBH;
+#if defined(FSLIC_LAB) && FSLIC_LAB == 4
+    const uint32_t lsc_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    volatile uint32_t* const lsc_w = f.lab_stamps + ((size_t)(f.gen_off - 1u) * 2048u + (size_t)(blockIdx.y * gridDim.x + blockIdx.x)) * 16u;
+    if (wave == 0 && lane == 0) lsc_w[0] = lsc_t0;
+#endif
     if (stale_sums)
         for (int i = threadIdx.x; i < 64 * kLscCopies * kLscAccW; i += 256) s_accx[i] = 0ull;
+    lsc_stage_lut(l, s_lut);
     if (wave == 0) {
         const int v_last = min(v0 + kLscBH, Hv) - 1;
         TileWindow win;
@@ -207,178 +239,263 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
         if (cnt <= 64) {
             const uint32_t mytag = lane < cnt ? s_raw[128 + lane] : 0xFFFFFFFFu;
             int rank = 0;
-            for (int j = 0; j < cnt; ++j) rank += s_raw[128 + j] < mytag ? 1 : 0;
+            for (int j = 0; j < cnt; ++j) rank += (uint32_t)__builtin_amdgcn_readlane((int)mytag, j) < mytag ? 1 : 0;
+            // The distance is evaluated as |C - O|^2 - 2 (G - O) . (C - O) (+ |G - O|^2, the same for every candidate of a pixel)
+            // around an origin O of the block's own neighbourhood -- the first finite centroid of the list -- instead of
+            // sum (G - C)^2 (src/lsc.cpp:212-215): 11 FMAs per candidate instead of 10 subtractions + 10 FMAs.  Around O every
+            // term is of the size of the distances themselves, so the rounding stays at a few f32 ulps of them (measured on the
+            // reference fixtures: the same agreement as the subtract-and-square form, profiles/r03_lsc_recompute.txt).
+            const uint32_t k = lane < cnt ? (mytag & 0xFFFFu) : 0u;
+            const float4* src = reinterpret_cast<const float4*>(l.cfeat + (size_t)k * kLscCfPitch);
+            const float4 q0 = src[0], q1 = src[1], q2 = src[2];
+            float cf[kLscFeat] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y};
+            float tot = 0.0f;
+#pragma unroll
+            for (int q = 0; q < kLscFeat; ++q) tot += cf[q];
+            // (the first in VISIT order: the lanes hold the list in the order the bin pass happened to insert it, which varies
+            // from run to run -- an origin picked by lane would move the rounding with it)
+            const bool finite = lane < cnt && (tot - tot) == 0.0f;                          // (NaN centroid of a memberless cluster: never the origin)
+            const uint32_t first = lsc_wave_min(finite ? (uint32_t)rank : 64u);
+            const unsigned long long fin = __ballot(finite && (uint32_t)rank == first);
+            const int o = fin ? __builtin_ctzll(fin) : 0;
+            float nrm = 0.0f;
+#pragma unroll
+            for (int q = 0; q < kLscFeat; ++q) {
+                const float org = fin ? __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(cf[q]), o)) : 0.0f;
+                if (lane == 0) s_org[q] = org;
+                cf[q] -= org;
+                nrm = __builtin_fmaf(cf[q], cf[q], nrm);
+            }
             if (lane < cnt) {
-                const uint32_t k = mytag & 0xFFFFu;
                 s_yx[rank] = s_raw[lane];
                 s_k[rank] = k;
-                const float4* src = reinterpret_cast<const float4*>(l.cfeat + (size_t)k * kLscCfPitch);
                 float4* dst = reinterpret_cast<float4*>(s_cf + rank * 12);
-                dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+                dst[0] = make_float4(cf[0], cf[1], cf[2], cf[3]); dst[1] = make_float4(cf[4], cf[5], cf[6], cf[7]);
+                dst[2] = make_float4(cf[8], cf[9], nrm, 0.0f);
             }
+        } else if (lane < 12) {
+            s_org[lane] = 0.0f;        // the walk over every cluster subtracts and squares, around no origin
         }
         if (lane == 0) s_cnt = cnt;
+        LSC_STAMP(1, true);                     // list built and staged (wave 0)
     }
-    // this wavefront's pixels: column x0 + lane of kLscRows visited rows (clamped addresses, masked results).  Rows are
-    // held in pairs (r, r+1) per feature: the distance chain then runs on packed f32 (v_pk_add_f32 / v_pk_fma_f32,
-    // two rows per instruction; each half is the same IEEE operation as the scalar form)
+    // this wavefront's pixels: column x0 + lane of kLscRows visited rows (clamped addresses, masked results), taken two rows
+    // (r, r+1) at a time: the feature and distance chains run on packed f32 (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, two
+    // rows per instruction; each half is the same IEEE operation as the scalar form), and a pair's twenty quotients are dead
+    // before the next pair's are formed -- all four rows at once cost 104 VGPRs (4 wavefronts per SIMD) with the sums below.
     const int x = x0 + lane;
     const bool xok = x < W;
     const int vw = (int)rfl((uint32_t)(v0 + wave * kLscRows));
-    f2 F[kLscRows / 2][kLscFeat];
     int yr[kLscRows];
+    uint32_t pix[kLscRows];
     const int xc = min(x, W - 1);
 #pragma unroll
     for (int r = 0; r < kLscRows; ++r) {
         yr[r] = rem + stride * min(vw + r, Hv - 1);
-        const size_t p = (size_t)yr[r] * W + xc;
-#pragma unroll
-        for (int q = 0; q < kLscFeat; ++q) F[r >> 1][q][r & 1] = l.feat[(size_t)q * N + p];
+        pix[r] = f.lab[(size_t)yr[r] * W + xc];
     }
+    const float xcos = l.lut_x[xc], xsin = l.lut_x[W + xc];
+    float mean[kLscFeat];
+#pragma unroll
+    for (int q = 0; q < kLscFeat; ++q) mean[q] = lsc_uniform(l.means[q]);
+    LSC_STAMP(2, wave == 1);                    // wave 1: its pixel loads issued
     __syncthreads();
+    LSC_STAMP(3, wave == 1);                    // barrier passed
     const int cnt = s_cnt;
-    f2 best[kLscRows / 2];
-    uint32_t bk[kLscRows];
-#pragma unroll
-    for (int r = 0; r < kLscRows; ++r) { best[r >> 1][r & 1] = FLT_MAX; bk[r] = 0xFFFFu; }
+    const bool listed = cnt <= 64;                 // a pixel's winner is kept as its position in the block's list (else: the cluster itself)
     const int y_top = yr[0], y_bot = yr[kLscRows - 1];
-    auto consider = [&](int cy, int cx, uint32_t k, const float* cf) {
-        const bool inx = abs(x - cx) <= S;
+    // the block's list across the lanes (lane j = candidate j): which candidates a pair of rows has to look at is one ballot,
+    // and the walk below meets only those -- no LDS round trip and scalar window tests per listed candidate
+    const uint32_t yx_j = (listed && lane < cnt) ? s_yx[lane] : 0u;
+    const int cy_j = (int)(yx_j >> 16), cx_j = (int)(yx_j & 0xFFFFu);
+    const bool col_j = listed && lane < cnt && !(cx_j + S < x0 || cx_j - S > x0 + 63);
+    const float2* const tl = reinterpret_cast<const float2*>(s_lut);
+    const uint32_t copy = (uint32_t)lane & (kLscCopies - 1);
 #pragma unroll
-        for (int h = 0; h < kLscRows / 2; ++h) {
-            const bool in0 = abs(yr[2 * h] - cy) <= S, in1 = abs(yr[2 * h + 1] - cy) <= S;   // uniform
-            if (!(in0 || in1)) continue;
+    for (int h = 0; h < kLscRows / 2; ++h) {
+        const int r0 = 2 * h, r1 = 2 * h + 1;
+        const f2 ycos = {lsc_uniform(l.lut_y[yr[r0]]), lsc_uniform(l.lut_y[yr[r1]])};
+        const f2 ysin = {lsc_uniform(l.lut_y[f.H + yr[r0]]), lsc_uniform(l.lut_y[f.H + yr[r1]])};
+        f2 G[kLscFeat], wv;
+        {
+            const float4* po = reinterpret_cast<const float4*>(s_org);
+            const float4 o0 = po[0], o1 = po[1], o2 = po[2];
+            const float org[kLscFeat] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w, o2.x, o2.y};
+            lsc_pair_features(s_lut, pix[r0], pix[r1], xcos, xsin, ycos, ysin, mean, org, G, wv);
+        }
+        f2 best = {FLT_MAX, FLT_MAX};
+        uint32_t bk0 = 0xFFFFu, bk1 = 0xFFFFu;
+        // cf: centroid - origin; nrm: its squared norm (listed candidates), or < 0: subtract and square
+        auto consider = [&](bool in0, bool in1, int cx, uint32_t id, const float* cf, float nrm, bool dot_form) {      // in0, in1: uniform
+            const bool inx = abs(x - cx) <= S;
             f2 d = {0.0f, 0.0f};
+            if (dot_form) {
 #pragma unroll
-            for (int q = 0; q < kLscFeat; ++q) {
-                const f2 c2 = {cf[q], cf[q]};
-                const f2 diff = F[h][q] - c2;
-                d = __builtin_elementwise_fma(diff, diff, d);
+                for (int q = 0; q < kLscFeat; ++q) d = __builtin_elementwise_fma(G[q], (f2){cf[q], cf[q]}, d);
+                d = __builtin_elementwise_fma(d, (f2){-2.0f, -2.0f}, (f2){nrm, nrm});
+            } else {
+#pragma unroll
+                for (int q = 0; q < kLscFeat; ++q) {
+                    const f2 c2 = {cf[q], cf[q]};
+                    const f2 diff = G[q] - c2;
+                    d = __builtin_elementwise_fma(diff, diff, d);
+                }
             }
-            if (in0 && inx && d[0] < best[h][0]) { best[h][0] = d[0]; bk[2 * h] = k; }
-            if (in1 && inx && d[1] < best[h][1]) { best[h][1] = d[1]; bk[2 * h + 1] = k; }
-        }
-    };
-    if (cnt <= 64) {
-        for (int c = 0; c < cnt; ++c) {
-            const uint32_t yx = rfl(s_yx[c]);
-            const int cy = (int)(yx >> 16), cx = (int)(yx & 0xFFFFu);
-            if (cx + S < x0 || cx - S > x0 + 63 || cy + S < y_top || cy - S > y_bot) continue;   // uniform
-            const float4* src = reinterpret_cast<const float4*>(s_cf + c * 12);
-            const float4 c0 = src[0], c1 = src[1], c2 = src[2];
-            const float cf[kLscFeat] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y};
-            consider(cy, cx, (uint32_t)c, cf);
-        }
-    } else {
-        // visit order of the reference (phase, then k) over every cluster
-        for (uint32_t ph = 0; ph < 4; ++ph) {
-            for (int k0 = 0; k0 < f.K; k0 += 64) {
-                const int k = k0 + lane;
-                const bool live = k < f.K;
-                const uint32_t yxl = live ? f.cl_yx[k] : 0u;
-                const uint32_t tg = live ? f.cl_tag[k] : 0xFFFFFFFFu;
-                const int cyl = (int)(yxl >> 16), cxl = (int)(yxl & 0xFFFFu);
-                const bool use = live && (tg >> 16) == ph && !(cxl + S < x0 || cxl - S > x0 + 63 || cyl + S < y_top || cyl - S > y_bot);
-                unsigned long long m = __ballot(use);
-                while (m) {
-                    const int c = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const uint32_t yx = (uint32_t)__builtin_amdgcn_readlane((int)yxl, c);
-                    const float* src = l.cfeat + (size_t)(k0 + c) * kLscCfPitch;
-                    float cf[kLscFeat];
+            if (in0 && inx && d[0] < best[0]) { best[0] = d[0]; bk0 = id; }
+            if (in1 && inx && d[1] < best[1]) { best[1] = d[1]; bk1 = id; }
+        };
+        if (listed) {
+            const unsigned long long m0 = __ballot(col_j && abs(yr[r0] - cy_j) <= S), m1 = __ballot(col_j && abs(yr[r1] - cy_j) <= S);
+            unsigned long long m = m0 | m1;
+            while (m) {                                  // ascending list position = the reference's visit order
+                const int c = __builtin_ctzll(m);
+                m &= m - 1;
+                const int cx = __builtin_amdgcn_readlane(cx_j, c);
+                const float4* src = reinterpret_cast<const float4*>(s_cf + c * 12);
+                const float4 c0 = src[0], c1 = src[1], c2 = src[2];
+                const float cf[kLscFeat] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y};
+                consider((m0 >> c) & 1ull, (m1 >> c) & 1ull, cx, (uint32_t)c, cf, c2.z, true);
+            }
+        } else {
+            // visit order of the reference (phase, then k) over every cluster
+            for (uint32_t ph = 0; ph < 4; ++ph) {
+                for (int k0 = 0; k0 < f.K; k0 += 64) {
+                    const int k = k0 + lane;
+                    const bool live = k < f.K;
+                    const uint32_t yxl = live ? f.cl_yx[k] : 0u;
+                    const uint32_t tg = live ? f.cl_tag[k] : 0xFFFFFFFFu;
+                    const int cyl = (int)(yxl >> 16), cxl = (int)(yxl & 0xFFFFu);
+                    const bool use = live && (tg >> 16) == ph && !(cxl + S < x0 || cxl - S > x0 + 63 || cyl + S < y_top || cyl - S > y_bot);
+                    unsigned long long m = __ballot(use);
+                    while (m) {
+                        const int c = __builtin_ctzll(m);
+                        m &= m - 1;
+                        const uint32_t yx = (uint32_t)__builtin_amdgcn_readlane((int)yxl, c);
+                        const float* src = l.cfeat + (size_t)(k0 + c) * kLscCfPitch;
+                        float cf[kLscFeat];
 #pragma unroll
-                    for (int q = 0; q < kLscFeat; ++q) cf[q] = src[q];
-                    consider((int)(yx >> 16), (int)(yx & 0xFFFFu), (uint32_t)(k0 + c), cf);
+                        for (int q = 0; q < kLscFeat; ++q) cf[q] = lsc_uniform(src[q]);      // (scalar registers: this rare path sets the kernel's VGPR peak)
+                        const int cy = (int)(yx >> 16);
+                        const bool in0 = abs(yr[r0] - cy) <= S, in1 = abs(yr[r1] - cy) <= S;
+                        if (in0 || in1) consider(in0, in1, (int)(yx & 0xFFFFu), (uint32_t)(k0 + c), cf, 0.0f, false);
+                    }
                 }
             }
         }
-    }
-    // labels out; with an update following (stale_sums), also the label each visited pixel carries into update(): the new one,
-    // or the one it keeps when nothing accepted it (src/lsc.cpp:217-220 never touches such a pixel; 0xFFFF: none yet)
-    const bool listed = cnt <= 64;                 // bk = position in the block's list (else the cluster itself)
-    uint32_t lbl[kLscRows], slot[kLscRows];
+        LSC_STAMP(4 + 2 * h, wave == 1);        // pair h: candidates walked
+        // labels out; with an update following (stale_sums), also the label each visited pixel carries into update(): the new
+        // one, or the one it keeps when nothing accepted it (src/lsc.cpp:217-220 never touches such a pixel; 0xFFFF: none yet)
+        uint32_t lbl[2], slot[2];
 #pragma unroll
-    for (int r = 0; r < kLscRows; ++r) {
-        lbl[r] = 0xFFFFu;
-        slot[r] = kLscNoSlot;
-        if (!xok || vw + r >= Hv) continue;
-        const size_t p = (size_t)yr[r] * W + x;
-        if (best[r >> 1][r & 1] < FLT_MAX) {
-            lbl[r] = listed ? s_k[bk[r]] : bk[r];
-            st_stream(f.labels + p, (uint16_t)lbl[r]);
-            if (listed) slot[r] = bk[r];
-        } else if (stale_sums) {
-            lbl[r] = f.labels[p];
+        for (int u = 0; u < 2; ++u) {
+            const int r = 2 * h + u;
+            lbl[u] = 0xFFFFu; slot[u] = kLscNoSlot;
+            if (!xok || vw + r >= Hv) continue;
+            const uint32_t bk = u ? bk1 : bk0;
+            const size_t p = (size_t)yr[r] * W + x;
+            if (best[u] < FLT_MAX) {
+                lbl[u] = listed ? s_k[bk] : bk;
+                st_stream(f.labels + p, (uint16_t)lbl[u]);
+                if (listed) slot[u] = bk;
+            } else if (stale_sums) {
+                lbl[u] = f.labels[p];
+            }
         }
+        if (stale_sums) {
+            // ---- update(), fused: the sums of src/context.cpp:301-354 (count, y, x, L, a, b) and of src/lsc.cpp:256-269 (sum
+            // w*F per feature, sum w) over this block's pixels.  Every lane adds its two pixels of the pair to the block's
+            // accumulators with 13 LDS atomics -- together when they carry the same label (a superpixel is taller than two
+            // rows: nearly always), one after the other otherwise: the float sums in fixed point, so the totals do not depend
+            // on the order in which lanes and wavefronts arrive (run-to-run identical), the six integer sums packed into two
+            // words.  Lanes of a run of columns with one label meet on the same words: kLscCopies privatised copies.
+            // The reference adds w * (F / w) per pixel and feature (src/lsc.cpp:262-264), which is the table value F up to an
+            // ulp: the sums take F itself.  Nothing of the sums is live while the candidates are walked (keeping a lane's runs
+            // in registers across the pairs saved a third of the atomics, which cost nothing, and held 16 registers).
+            // (Measured per launch of 8 x 1280x720 K=1600 on the materialised planes, the forms this replaces: a loop over the
+            // wavefront's labels with a halving butterfly over the lanes per label 61 us -- 8 labels x (44 masked FMAs + 43
+            // cross-lane operations + 17 LDS atomics) per wavefront --, lanes folding their own label first 75 us, full wave sums
+            // 87 us, 16-lane row sums 172 us; the kernel that re-scanned every cluster's window for its members 64 of 100 us per
+            // iteration.  Column runs + LDS atomics: 49 us, profiles/r03_lsc_sums_ablation.txt.)
+            float Fr[2][kLscFeat + 1];
+            uint32_t ia[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = 2 * h + u;
+                const uint32_t px = pix[r];
+                const float2 Lr = tl[px & 255u], Ar = tl[256u + ((px >> 8) & 255u)], Br = tl[256u + ((px >> 16) & 255u)];
+                Fr[u][0] = Lr.x; Fr[u][1] = Lr.y; Fr[u][2] = Ar.x; Fr[u][3] = Ar.y; Fr[u][4] = Br.x; Fr[u][5] = Br.y;
+                Fr[u][6] = xcos; Fr[u][7] = xsin; Fr[u][8] = ycos[u]; Fr[u][9] = ysin[u]; Fr[u][kLscFeat] = wv[u];
+                ia[u][0] = (px & 255u) | ((px & 0xFF00u) << 12);                 // L | a << 20
+                ia[u][1] = (px >> 8) & 0xFF00u;                                 // b << 40
+                ia[u][2] = (uint32_t)lane | (1u << 20);                         // x - x0 | count << 20
+                ia[u][3] = (uint32_t)(wave * kLscRows + r);                     // the row's number inside the block << 32
+                if (lbl[u] != 0xFFFFu && slot[u] == kLscNoSlot) {
+                    // its label is not on the block's list (it kept a label whose window has left it, or the block walks
+                    // every cluster): straight to the global accumulators.  Rare.
+                    unsigned long long* e = reinterpret_cast<unsigned long long*>(l.extra + (size_t)lbl[u] * kLscExPitch);
+#pragma unroll
+                    for (int q = 0; q < kLscFeat; ++q) atomicAdd(e + q, (unsigned long long)(long long)(int)__builtin_rintf(Fr[u][q] * kLscFixF));
+                    atomicAdd(e + kLscFeat, (unsigned long long)(long long)(int)__builtin_rintf(Fr[u][kLscFeat] * kLscFixW));
+                    global_accumulate(f.sums[0], lbl[u], (uint32_t)yr[r], (uint32_t)x, px);
+                }
+            }
+            const bool both = slot[0] == slot[1];
+            if (both) {
+#pragma unroll
+                for (int q = 0; q <= kLscFeat; ++q) Fr[0][q] += Fr[1][q];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ia[0][q] += ia[1][q];
+            }
+            // Lanes of one label hit the same words, and same-address LDS atomics are served one lane after the other (a
+            // 24-column superpixel: a dozen lanes per copy).  Four neighbouring columns mostly agree, so a quad whose lanes all
+            // hold one label for both rows adds ONE set of values (two DPP additions per value, fixed order) from its first
+            // lane; the other quads -- a label boundary runs through them -- add lane by lane.
+            const uint32_t sa = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)slot[0], kDppQuadSwap1, 0xF, 0xF, true);
+            const uint32_t sb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)slot[0], kDppQuadSwap2, 0xF, 0xF, true);
+            const uint32_t sc = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sa, kDppQuadSwap2, 0xF, 0xF, true);
+            const unsigned long long bq = __ballot(both);
+            const bool quad = ((bq >> (lane & ~3)) & 0xFull) == 0xFull && slot[0] == sa && slot[0] == sb && slot[0] == sc && slot[0] != kLscNoSlot;
+            if (__ballot(quad)) {                     // uniform
+                float t[kLscFeat + 1];
+                uint32_t it[4];
+#pragma unroll
+                for (int q = 0; q <= kLscFeat; ++q) {
+                    t[q] = Fr[0][q] + __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(Fr[0][q]), kDppQuadSwap1, 0xF, 0xF, true));
+                    t[q] = t[q] + __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(t[q]), kDppQuadSwap2, 0xF, 0xF, true));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    it[q] = ia[0][q] + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ia[0][q], kDppQuadSwap1, 0xF, 0xF, true);
+                    it[q] = it[q] + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)it[q], kDppQuadSwap2, 0xF, 0xF, true);
+                }
+                if (quad) {
+#pragma unroll
+                    for (int q = 0; q <= kLscFeat; ++q) Fr[0][q] = t[q];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ia[0][q] = it[q];
+                    if (lane & 3) slot[0] = kLscNoSlot;          // the quad's first lane speaks for it
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (slot[u] == kLscNoSlot || (u == 1 && both)) continue;
+                unsigned long long* a = s_accx + (slot[u] * kLscCopies + copy) * kLscAccW;
+#pragma unroll
+                for (int q = 0; q < kLscFeat; ++q) atomicAdd(a + q, (unsigned long long)(long long)(int)__builtin_rintf(Fr[u][q] * kLscFixF));
+                atomicAdd(a + kLscFeat, (unsigned long long)(long long)(int)__builtin_rintf(Fr[u][kLscFeat] * kLscFixW));
+                atomicAdd(a + kLscFeat + 1, (unsigned long long)ia[u][0] | ((unsigned long long)ia[u][1] << 32));
+                atomicAdd(a + kLscFeat + 2, (unsigned long long)ia[u][2] | ((unsigned long long)ia[u][3] << 32));
+            }
+        }
+        LSC_STAMP(5 + 2 * h, wave == 1);        // pair h: labels stored, runs summed
     }
     if (!stale_sums) return;
-    // ---- update(), fused: the sums of src/context.cpp:301-354 (count, y, x, L, a, b) and of src/lsc.cpp:256-269 (sum w*F per
-    // feature, sum w) over this block's pixels.  A column's rows fall into one or two runs of equal label (a superpixel is
-    // taller than a wavefront's rows), so every lane sums its column run by run in registers (f32 FMA chain like the reference
-    // build) and adds a finished run to the block's accumulators with 13 LDS atomics: the float sums in fixed point, so the
-    // totals do not depend on the order in which lanes and wavefronts arrive (run-to-run identical), the six integer sums
-    // packed into two words.  Lanes of a run of columns with one label meet on the same words: kLscCopies privatised copies.
-    // (Measured per launch of 8 x 1280x720 K=1600, the forms this replaces: a loop over the wavefront's labels with a
-    // halving butterfly over the lanes per label 61 us -- 8 labels x (44 masked FMAs + 43 cross-lane operations + 17 LDS
-    // atomics) per wavefront --, lanes folding their own label first 75 us, full wave sums 87 us, 16-lane row sums 172 us;
-    // the kernel that re-scanned every cluster's window for its members 64 of 100 us per iteration.)
-    float wgt[kLscRows];
-    uint32_t pix[kLscRows];
-#pragma unroll
-    for (int r = 0; r < kLscRows; ++r) {
-        const size_t p = (size_t)yr[r] * W + xc;
-        wgt[r] = l.weight[p];
-        pix[r] = f.lab[p];
-    }
-    // a pixel whose label is not on the block's list (it kept a label whose window has left it, or the block walks every
-    // cluster): straight to the global accumulators.  Rare.
-#pragma unroll
-    for (int r = 0; r < kLscRows; ++r) {
-        if (lbl[r] == 0xFFFFu || slot[r] != kLscNoSlot) continue;
-        unsigned long long* e = reinterpret_cast<unsigned long long*>(l.extra + (size_t)lbl[r] * kLscExPitch);
-#pragma unroll
-        for (int q = 0; q < kLscFeat; ++q)
-            atomicAdd(e + q, (unsigned long long)(long long)(int)__builtin_rintf(__builtin_fmaf(wgt[r], F[r >> 1][q][r & 1], 0.0f) * kLscFixF));
-        atomicAdd(e + kLscFeat, (unsigned long long)(long long)(int)__builtin_rintf(wgt[r] * kLscFixW));
-        global_accumulate(f.sums[0], lbl[r], (uint32_t)yr[r], (uint32_t)x, pix[r]);
-    }
-    {
-        const uint32_t copy = (uint32_t)lane & (kLscCopies - 1);
-        uint32_t cur = slot[0], a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0;
-        float fv[kLscFeat + 1];
-#pragma unroll
-        for (int q = 0; q <= kLscFeat; ++q) fv[q] = 0.0f;
-        auto flush = [&]() {
-            if (cur != kLscNoSlot) {
-                unsigned long long* a = s_accx + (cur * kLscCopies + copy) * kLscAccW;
-#pragma unroll
-                for (int q = 0; q < kLscFeat; ++q) atomicAdd(a + q, (unsigned long long)(long long)(int)__builtin_rintf(fv[q] * kLscFixF));
-                atomicAdd(a + kLscFeat, (unsigned long long)(long long)(int)__builtin_rintf(fv[kLscFeat] * kLscFixW));
-                atomicAdd(a + kLscFeat + 1, (unsigned long long)a_lo | ((unsigned long long)a_hi << 32));
-                atomicAdd(a + kLscFeat + 2, (unsigned long long)b_lo | ((unsigned long long)b_hi << 32));
-            }
-        };
-#pragma unroll
-        for (int r = 0; r < kLscRows; ++r) {
-            if (r > 0 && slot[r] != cur) {
-                flush();
-                cur = slot[r]; a_lo = 0; a_hi = 0; b_lo = 0; b_hi = 0;
-#pragma unroll
-                for (int q = 0; q <= kLscFeat; ++q) fv[q] = 0.0f;
-            }
-#pragma unroll
-            for (int q = 0; q < kLscFeat; ++q) fv[q] = __builtin_fmaf(wgt[r], F[r >> 1][q][r & 1], fv[q]);
-            fv[kLscFeat] += wgt[r];
-            const uint32_t p = pix[r];
-            a_lo += (p & 255u) | ((p & 0xFF00u) << 12);                      // sum L | sum a << 20
-            a_hi += (p >> 8) & 0xFF00u;                                     // sum b << 40
-            b_lo += (uint32_t)lane | (1u << 20);                            // sum (x - x0) | count << 20
-            b_hi += (uint32_t)(wave * kLscRows + r);                        // sum of the row's number inside the block << 32
-        }
-        flush();
-    }
+    LSC_STAMP(8, wave == 1);
     __syncthreads();
-    // one set of global atomics per (block, cluster that received pixels here)
+    LSC_STAMP(9, wave == 1);
+    // one set of global atomics per (block, cluster that received pixels here).  (Plain stores into per-(cluster, block) entries
+    // summed by k_lsc_update, as the SLIC block kernel delivers its sums, were built and measured: 48.6 against 47.1 us per launch
+    // of 8 x 1280x720 -- the window arithmetic in the prologue costs what the atomics cost at the end.)
     const uint32_t yb0 = (uint32_t)(rem + stride * v0);
     for (int i = threadIdx.x; i < cnt * (kLscFeat + 1 + 6) && listed; i += 256) {
         const int c = i / (kLscFeat + 1 + 6), q = i - c * (kLscFeat + 1 + 6);
@@ -409,14 +526,19 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
             atomicAdd(f.sums[0] + 6 * (size_t)k + u, v);
         }
     }
+    LSC_STAMP(10, wave == 1);
+#if defined(FSLIC_LAB) && FSLIC_LAB == 4
+    if (wave == 1 && lane == 0) lsc_w[11] = (uint32_t)cnt;
+#endif
 }
 
-// Two kernels over one body: the pass that is followed by an update carries the fused sums and needs 90 VGPRs (5 wavefronts per SIMD); the
-// final pass does not and fits 7 wavefronts per SIMD.  (Forcing the first to 80 VGPRs spills 7 registers: 66 instead of 60 us.)
+// Two kernels over one body: the pass that is followed by an update carries the fused sums and takes 81 VGPRs left to itself (5
+// wavefronts per SIMD); held to 80 it spills nothing and runs 6 (50.0 against 51.9 us per launch of 8 x 1280x720; 7 at 72 VGPRs: 49.9).
+// The final pass needs 53 (8 wavefronts per SIMD).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_lsc_assign(FrameDev f, LscDev l, int rem, int stride, int Hv) {
     lsc_assign_body<false>(f, l, rem, stride, Hv);
 }
-__global__ __launch_bounds__(256) void k_lsc_assign_sums(FrameDev f, LscDev l, int rem, int stride, int Hv) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_lsc_assign_sums(FrameDev f, LscDev l, int rem, int stride, int Hv) {
     lsc_assign_body<true>(f, l, rem, stride, Hv);
 }
 
@@ -445,7 +567,6 @@ void launch_lsc_prepare(const FrameDev& f, const LscDev& l, int nframes, hipStre
     const unsigned N = (unsigned)f.N;
     launch(k_lsc_hist, dim3((N + 4095) / 4096, nframes), dim3(256), 0, st, f, l);
     launch(k_lsc_means, dim3(nframes), dim3(256), 0, st, f, l);
-    launch(k_lsc_features, dim3((N + 255) / 256, nframes), dim3(256), 0, st, f, l);
     launch(k_lsc_seed, dim3((f.K + 3) / 4, nframes), dim3(256), 0, st, f, l);
 }
 
