@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 ASSIGN_BYTES_PER_PX = 6.0      # 4 B LAB read + 2 B label write per visited pixel
-LSC_ASSIGN_BYTES_PER_PX = 46.0 # 40 B features + 4 B weight + 2 B label (materialised features)
+LSC_ASSIGN_BYTES_PER_PX = 6.0  # 4 B LAB word + 2 B label: the features are rebuilt from the LAB word (SURVEY.md 8d's recompute design; the materialised one moved 46 B)
 PROFILE_TAG = "r03"
 
 WORKLOADS = {
@@ -694,11 +694,12 @@ def main():
                 if bad:
                     out["c3_k6000"]["parity_failures"] = bad[:8]
             del w6
-            # BASELINE configs[4]: LSC variant at 1280x720 K=1600 (f32 path; 46 B per visited pixel-assignment)
+            # BASELINE configs[4]: LSC variant at 1280x720 K=1600 (f32 path; 6 B per visited pixel-assignment, not its bound)
             wlsc = Workload(eng, 720, 1280, 1600, list(range(8)), variant_id=1)
             tl = wlsc.timed_groups(4, bytes_per_px=LSC_ASSIGN_BYTES_PER_PX)
             out["lsc_c5"] = {"workload": "1280x720 LSC variant, K=1600, 8 frames/GPU (configs[4])", "megapixels_per_sec": wlsc.throughput(100)[0],
-                             "dominant_kernel": "k_lsc_assign_sums (10-D distance + the fused update sums; priced at 46 B per visited pixel, it also reads the 4 B LAB word)",
+                             "dominant_kernel": "k_lsc_assign_sums (features rebuilt from the 4 B LAB word, 10-D distance, the fused update sums; priced at 6 B per visited pixel)",
+                             "bound": "instruction issue, not HBM: vector ALU busy 0.44 and LDS busy 0.40 of the launch (PMC, profiles/r03_lsc_pmc_instruction_mix.txt); the materialised-planes design (46 B per pixel) measured against this one in profiles/r03_lsc_recompute.txt",
                              "fused_assign_update": tl["fused_assign_update"],
                              "full_assign": tl["full_assign"], "device_ms_per_frame": tl["device_ms_per_frame"]}
             if not args.no_parity:      # tolerance-based (f32 path): fixture floor of the unmodified reference + run-to-run identity

@@ -4,9 +4,11 @@
 // Unlike the integer SLIC path this one is f32 and cannot be bit-identical to the reference: the reference's feature
 // means and centroid sums are sequential f32 accumulations in raster order (src/lsc.cpp:143-149, 256-269) whose
 // rounding depends on that order.  What is mirrored exactly: the tables (built on the host with the reference's own
-// expressions), the FMA contraction of the reference build in the weight and distance chains, IEEE division, the
-// visit order (phase, k) with a strict comparison, NaN centroids of memberless clusters, and the integer centroid
-// update.  Everything here is deterministic (fixed reduction trees, order-independent fixed point on the rare path).
+// expressions), the FMA contraction of the reference build in the weight chain, the visit order (phase, k) with a strict
+// comparison, NaN centroids of memberless clusters, and the integer centroid update.  Evaluated differently, inside the
+// same tolerance (the fixture agreement did not move, profiles/r03_lsc_recompute.txt): features times the reciprocal of the
+// weight instead of divided by it, the distance around a block origin instead of subtract-and-square, sum F for sum w * (F / w).
+// Everything here is deterministic (fixed reduction trees, order-independent fixed point for every sum).
 #include "device_common.h"
 #include <cfloat>
 
@@ -310,7 +312,7 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
     const int cy_j = (int)(yx_j >> 16), cx_j = (int)(yx_j & 0xFFFFu);
     const bool col_j = listed && lane < cnt && !(cx_j + S < x0 || cx_j - S > x0 + 63);
     const float2* const tl = reinterpret_cast<const float2*>(s_lut);
-    const uint32_t copy = (uint32_t)lane & (kLscCopies - 1);
+    const uint32_t copy = ((uint32_t)lane >> 2) & (kLscCopies - 1);      // by quad: mostly a quad's first lane adds for the four (below)
 #pragma unroll
     for (int h = 0; h < kLscRows / 2; ++h) {
         const int r0 = 2 * h, r1 = 2 * h + 1;
