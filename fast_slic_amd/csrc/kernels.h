@@ -187,6 +187,10 @@ struct LscDev {
     const float* lut_color;   // [4][256]: L cos, L sin, a/b cos, a/b sin
     const float* lut_x;       // [2][W]: cos, sin
     const float* lut_y;       // [2][H]
+    // fixed point of a block's accumulators in LDS (lsc.hip): the largest powers of two that keep 1024 pixels' sum of a feature
+    // inside 31 bits and of the weight inside 32; shifts from there to the 2^-20 / 2^-12 of the global accumulators
+    float blk_fix_f, blk_fix_w;
+    int blk_shift_f, blk_shift_w;
     __host__ __device__ __forceinline__ void select(int z) {
         const size_t d = (size_t)z * frame_bytes;
         FrameDev::adv(hist, d); FrameDev::adv(means, d);

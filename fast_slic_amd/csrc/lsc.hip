@@ -152,8 +152,18 @@ static __device__ __forceinline__ float wave_sum(float v) { return wave_reduce_a
 // 4 * 51 and one of w below 4 * 23000, so these scales keep the rounded partials inside 32 bits; the accumulators themselves
 // are 64-bit (a cluster that owned a whole 4K frame would reach 4.4e14 and 7.8e14)
 constexpr float kLscFixF = 1048576.0f, kLscFixW = 4096.0f;
-constexpr int kLscCopies = 2;                             // privatised copies of a block's accumulators (lane & 1)
-constexpr int kLscAccW = kLscFeat + 1 + 2;                // 64-bit words per (candidate, copy): 10 x sum w*F, sum w, two packed integer words
+// 4 privatised copies of every accumulator (by quad): lanes of a run of columns with one label meet on the same words, and
+// same-address LDS atomics are served one lane after the other (2 copies 45.5, 4 copies 44.1 us per launch of 8 x 1280x720; 8 copies
+// for lists of up to 32 candidates, chosen at run time: 45.4)
+constexpr int kLscCopyShift = 2;
+constexpr int kLscAccEntries = 64 << kLscCopyShift;
+// A block's accumulators (LDS), per (candidate, copy) eight 64-bit words: the eleven float sums in a coarser fixed point that keeps a
+// block's total (1024 pixels) inside 32 bits (LscDev::blk_fix_*: 2^-15 and 2^-6 for the default constants), two to a word -- the low
+// half always one of the colour features or the weight, which are never negative, so no borrow crosses into the high half, where
+// the spatial features (cos / sin of any angle) wrap in two's complement -- and the two packed integer words.  8 LDS atomics per
+// flush instead of 13.
+//   word 0..3: F0..F3 | F6..F9 << 32      word 4: F4 | F5 << 32      word 5: w      word 6, 7: integers
+constexpr int kLscAccW = 8;
 constexpr uint32_t kLscNoSlot = 0xFFFFFFFFu;
 constexpr int kDppQuadSwap1 = 0xB1, kDppQuadSwap2 = 0x4E;     // quad_perm [1,0,3,2] and [2,3,0,1]
 
@@ -218,7 +228,7 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
     // in fixed point and the 6 integer sums packed into two words (sum L | sum a << 20 | sum b << 40 and sum (x - x0) |
     // sum (y - y0) << 20 | count << 40, as the SLIC block kernel packs them: 1024 pixels per block, no field reaches 2^20);
     // LDS atomics, flushed with ONE set of global atomics per (block, cluster)
-    __shared__ unsigned long long s_accx[stale_sums ? 64 * kLscCopies * kLscAccW : 1];
+    __shared__ unsigned long long s_accx[stale_sums ? kLscAccEntries * kLscAccW : 1];
     const int wave = threadIdx.x >> 6, lane = LANE();
     const int S = f.S, W = f.W;
     const int x0 = blockIdx.x * 64;
@@ -229,7 +239,7 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
     if (wave == 0 && lane == 0) lsc_w[0] = lsc_t0;
 #endif
     if (stale_sums)
-        for (int i = threadIdx.x; i < 64 * kLscCopies * kLscAccW; i += 256) s_accx[i] = 0ull;
+        for (int i = threadIdx.x; i < kLscAccEntries * kLscAccW; i += 256) s_accx[i] = 0ull;
     lsc_stage_lut(l, s_lut);
     if (wave == 0) {
         const int v_last = min(v0 + kLscBH, Hv) - 1;
@@ -312,7 +322,8 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
     const int cy_j = (int)(yx_j >> 16), cx_j = (int)(yx_j & 0xFFFFu);
     const bool col_j = listed && lane < cnt && !(cx_j + S < x0 || cx_j - S > x0 + 63);
     const float2* const tl = reinterpret_cast<const float2*>(s_lut);
-    const uint32_t copy = ((uint32_t)lane >> 2) & (kLscCopies - 1);      // by quad: mostly a quad's first lane adds for the four (below)
+    constexpr int cshift = kLscCopyShift;
+    const uint32_t copy = ((uint32_t)lane >> 2) & ((1u << cshift) - 1u);  // by quad: mostly a quad's first lane adds for the four (below)
 #pragma unroll
     for (int h = 0; h < kLscRows / 2; ++h) {
         const int r0 = 2 * h, r1 = 2 * h + 1;
@@ -409,7 +420,7 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
             // accumulators with 13 LDS atomics -- together when they carry the same label (a superpixel is taller than two
             // rows: nearly always), one after the other otherwise: the float sums in fixed point, so the totals do not depend
             // on the order in which lanes and wavefronts arrive (run-to-run identical), the six integer sums packed into two
-            // words.  Lanes of a run of columns with one label meet on the same words: kLscCopies privatised copies.
+            // words.  Lanes of a run of columns with one label meet on the same words: privatised copies (kLscAccEntries).
             // The reference adds w * (F / w) per pixel and feature (src/lsc.cpp:262-264), which is the table value F up to an
             // ulp: the sums take F itself.  Nothing of the sums is live while the candidates are walked (keeping a lane's runs
             // in registers across the pairs saved a third of the atomics, which cost nothing, and held 16 registers).
@@ -481,12 +492,14 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 if (slot[u] == kLscNoSlot || (u == 1 && both)) continue;
-                unsigned long long* a = s_accx + (slot[u] * kLscCopies + copy) * kLscAccW;
+                unsigned long long* a = s_accx + ((slot[u] << cshift) + copy) * kLscAccW;
+                auto fixed = [&](int q) { return (uint32_t)(int)__builtin_rintf(Fr[u][q] * l.blk_fix_f); };
 #pragma unroll
-                for (int q = 0; q < kLscFeat; ++q) atomicAdd(a + q, (unsigned long long)(long long)(int)__builtin_rintf(Fr[u][q] * kLscFixF));
-                atomicAdd(a + kLscFeat, (unsigned long long)(long long)(int)__builtin_rintf(Fr[u][kLscFeat] * kLscFixW));
-                atomicAdd(a + kLscFeat + 1, (unsigned long long)ia[u][0] | ((unsigned long long)ia[u][1] << 32));
-                atomicAdd(a + kLscFeat + 2, (unsigned long long)ia[u][2] | ((unsigned long long)ia[u][3] << 32));
+                for (int q = 0; q < 4; ++q) atomicAdd(a + q, (unsigned long long)fixed(q) | ((unsigned long long)fixed(6 + q) << 32));
+                atomicAdd(a + 4, (unsigned long long)fixed(4) | ((unsigned long long)fixed(5) << 32));
+                atomicAdd(a + 5, (unsigned long long)(uint32_t)(int)__builtin_rintf(Fr[u][kLscFeat] * l.blk_fix_w));
+                atomicAdd(a + 6, (unsigned long long)ia[u][0] | ((unsigned long long)ia[u][1] << 32));
+                atomicAdd(a + 7, (unsigned long long)ia[u][2] | ((unsigned long long)ia[u][3] << 32));
             }
         }
         LSC_STAMP(5 + 2 * h, wave == 1);        // pair h: labels stored, runs summed
@@ -501,22 +514,24 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
     const uint32_t yb0 = (uint32_t)(rem + stride * v0);
     for (int i = threadIdx.x; i < cnt * (kLscFeat + 1 + 6) && listed; i += 256) {
         const int c = i / (kLscFeat + 1 + 6), q = i - c * (kLscFeat + 1 + 6);
-        const unsigned long long* a = s_accx + (size_t)c * kLscCopies * kLscAccW;
+        const unsigned long long* a = s_accx + ((size_t)c << cshift) * kLscAccW;
         unsigned long long B = 0;
-#pragma unroll
-        for (int cpy = 0; cpy < kLscCopies; ++cpy) B += a[cpy * kLscAccW + kLscFeat + 2];
+        for (int cpy = 0; cpy < (1 << cshift); ++cpy) B += a[cpy * kLscAccW + 7];
         const uint32_t n = (uint32_t)(B >> 20) & 0xFFFu;
         if (n == 0u) continue;                                              // nothing for this cluster
         const uint32_t k = s_k[c];
         if (q <= kLscFeat) {
-            unsigned long long v = 0;
-#pragma unroll
-            for (int cpy = 0; cpy < kLscCopies; ++cpy) v += a[cpy * kLscAccW + q];
-            atomicAdd(reinterpret_cast<unsigned long long*>(l.extra + (size_t)k * kLscExPitch) + q, v);
+            // the value's half of its word (the copies' words add up without a carry between the halves: a block's total fits its half)
+            const int word = q < 4 ? q : q < 6 ? 4 : q < kLscFeat ? q - 6 : 5;
+            const bool high = q == 5 || (q >= 6 && q < kLscFeat);
+            unsigned long long w = 0;
+            for (int cpy = 0; cpy < (1 << cshift); ++cpy) w += a[cpy * kLscAccW + word];
+            const long long field = high ? (long long)(int)(uint32_t)(w >> 32) : (long long)(uint32_t)w;
+            const long long v = field << (q < kLscFeat ? l.blk_shift_f : l.blk_shift_w);      // to the fixed point of the global accumulators
+            atomicAdd(reinterpret_cast<unsigned long long*>(l.extra + (size_t)k * kLscExPitch) + q, (unsigned long long)v);
         } else {
             unsigned long long A = 0;
-#pragma unroll
-            for (int cpy = 0; cpy < kLscCopies; ++cpy) A += a[cpy * kLscAccW + kLscFeat + 1];
+            for (int cpy = 0; cpy < (1 << cshift); ++cpy) A += a[cpy * kLscAccW + 6];
             const int u = q - kLscFeat - 1;
             uint32_t v;
             if (u == 0) v = n;
