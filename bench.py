@@ -699,7 +699,7 @@ def main():
             tl = wlsc.timed_groups(4, bytes_per_px=LSC_ASSIGN_BYTES_PER_PX)
             out["lsc_c5"] = {"workload": "1280x720 LSC variant, K=1600, 8 frames/GPU (configs[4])", "megapixels_per_sec": wlsc.throughput(100)[0],
                              "dominant_kernel": "k_lsc_assign_sums (features rebuilt from the 4 B LAB word, 10-D distance, the fused update sums; priced at 6 B per visited pixel)",
-                             "bound": "instruction issue, not HBM: vector ALU busy 0.44 and LDS busy 0.40 of the launch (PMC, profiles/r03_lsc_pmc_instruction_mix.txt); the materialised-planes design (46 B per pixel) measured against this one in profiles/r03_lsc_recompute.txt",
+                             "bound": "instruction issue, not HBM: vector ALU busy 0.46 and LDS busy 0.44 of the launch (PMC, profiles/r03_lsc_pmc_instruction_mix.txt); the materialised-planes design (46 B per pixel) measured against this one in profiles/r03_lsc_recompute.txt",
                              "fused_assign_update": tl["fused_assign_update"],
                              "full_assign": tl["full_assign"], "device_ms_per_frame": tl["device_ms_per_frame"]}
             if not args.no_parity:      # tolerance-based (f32 path): fixture floor of the unmodified reference + run-to-run identity
