@@ -148,9 +148,8 @@ static __device__ __forceinline__ void lsc_pixel_features(const LscDev& l, uint3
 }
 
 static __device__ __forceinline__ float wave_sum(float v) { return wave_reduce_add(v); }
-// fixed point of the fused update's accumulators: a lane's partial sum (its column of kLscRows pixels) of w*F stays below
-// 4 * 51 and one of w below 4 * 23000, so these scales keep the rounded partials inside 32 bits; the accumulators themselves
-// are 64-bit (a cluster that owned a whole 4K frame would reach 4.4e14 and 7.8e14)
+// fixed point of the global accumulators of the fused update (LscDev::extra, 64-bit: a cluster that owned a whole 4K frame
+// would reach 4.4e14 in a feature sum and 7.8e14 in the weight sum)
 constexpr float kLscFixF = 1048576.0f, kLscFixW = 4096.0f;
 // 4 privatised copies of every accumulator (by quad): lanes of a run of columns with one label meet on the same words, and
 // same-address LDS atomics are served one lane after the other (2 copies 45.5, 4 copies 44.1 us per launch of 8 x 1280x720; 8 copies
@@ -158,7 +157,7 @@ constexpr float kLscFixF = 1048576.0f, kLscFixW = 4096.0f;
 constexpr int kLscCopyShift = 2;
 constexpr int kLscAccEntries = 64 << kLscCopyShift;
 // A block's accumulators (LDS), per (candidate, copy) eight 64-bit words: the eleven float sums in a coarser fixed point that keeps a
-// block's total (1024 pixels) inside 32 bits (LscDev::blk_fix_*: 2^-15 and 2^-6 for the default constants), two to a word -- the low
+// block's total (1024 pixels) inside 32 bits (LscDev::blk_fix_*: 2^-15 and 2^-8 for the default constants), two to a word -- the low
 // half always one of the colour features or the weight, which are never negative, so no borrow crosses into the high half, where
 // the spatial features (cos / sin of any angle) wrap in two's complement -- and the two packed integer words.  8 LDS atomics per
 // flush instead of 13.
@@ -417,13 +416,13 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
         if (stale_sums) {
             // ---- update(), fused: the sums of src/context.cpp:301-354 (count, y, x, L, a, b) and of src/lsc.cpp:256-269 (sum
             // w*F per feature, sum w) over this block's pixels.  Every lane adds its two pixels of the pair to the block's
-            // accumulators with 13 LDS atomics -- together when they carry the same label (a superpixel is taller than two
+            // accumulators with 8 LDS atomics (kLscAccW) -- together when they carry the same label (a superpixel is taller than two
             // rows: nearly always), one after the other otherwise: the float sums in fixed point, so the totals do not depend
             // on the order in which lanes and wavefronts arrive (run-to-run identical), the six integer sums packed into two
             // words.  Lanes of a run of columns with one label meet on the same words: privatised copies (kLscAccEntries).
             // The reference adds w * (F / w) per pixel and feature (src/lsc.cpp:262-264), which is the table value F up to an
             // ulp: the sums take F itself.  Nothing of the sums is live while the candidates are walked (keeping a lane's runs
-            // in registers across the pairs saved a third of the atomics, which cost nothing, and held 16 registers).
+            // in registers across the pairs saved a third of the atomics and held 16 registers: 5 wavefronts per SIMD instead of 6).
             // (Measured per launch of 8 x 1280x720 K=1600 on the materialised planes, the forms this replaces: a loop over the
             // wavefront's labels with a halving butterfly over the lanes per label 61 us -- 8 labels x (44 masked FMAs + 43
             // cross-lane operations + 17 LDS atomics) per wavefront --, lanes folding their own label first 75 us, full wave sums
