@@ -494,6 +494,7 @@ static __device__ __forceinline__ void select_pass(const uint32_t* s_area, uint3
 // The heap is two arrays moved in tandem (candidate index, its area): one LDS round trip per level instead of two.
 // ---------------------------------------------------------------------------------------------
 typedef unsigned long long heap_t;      // area << 32 | candidate index: one LDS access moves an entry, comp looks at the high half
+constexpr int kTieWaveLevels = 4;       // __make_heap: parents of depth <= this are sifted by a wavefront each (tie_wave_sift)
 static __device__ __forceinline__ heap_t hp_ld(heap_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 static __device__ __forceinline__ void hp_st(heap_t* p, heap_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 static __device__ __forceinline__ uint32_t hp_area(heap_t e) { return (uint32_t)(e >> 32); }
@@ -529,51 +530,67 @@ static __device__ __forceinline__ void tie_adjust_heap(heap_t* h, int hole, int 
     if (writer) hp_st(h + cur, value);
 }
 
-// __pop_heap(first, middle, i) of the __heap_select loop = the sift above started at the root, executed by ONE wavefront.
-// The walk's choices do not depend on the new value, only on the heap, and a dependent LDS read per level is what a
-// sequential walk costs (most of the 11 levels at K = 1600: the candidates past the K-th leader are ordinary, large
-// components that sink to the leaves).  Here the wavefront fetches a whole sub-tree at once -- lane j (1..63) reads the node
-// with heap number j relative to the current node: five levels below it in ONE LDS round trip -- and resolves those
-// five levels with cross-lane reads (v_readlane, scalar compares); lane 0 stores the moves.  Nodes past the heap's end read as
-// area 0xffffffff, which reproduces the walk's rules for the node with one child and for leaves.  All lanes of the
-// wavefront must be active; control flow is uniform.
-static __device__ __forceinline__ void tie_replace_root(heap_t* h, int len, heap_t value, int lane) {
+// The same sift executed by ONE wavefront (all 64 lanes active, control flow uniform): __pop_heap(first, middle, i) of the
+// __heap_select loop (hole = the root, value = the candidate) and the upper levels of __make_heap (hole = a parent, value = its
+// own entry).  The walk's choices do not depend on the value, only on the heap, and a dependent LDS read per level is what a
+// sequential walk costs (most of the 11 levels at K = 1600: the candidates past the K-th leader are ordinary, large components
+// that sink to the leaves).  Here the wavefront fetches a whole sub-tree at once -- lane j (1..63) reads the node with heap
+// number j relative to the current node: five levels below it in ONE LDS round trip.  Which child a node prefers is then one
+// comparison per lane against its sibling's area (a quad swap: siblings 2j, 2j+1 share a quad) and one ballot; where the walk
+// stops (leaf, or a child larger than the value) another; the five steps are bit tests of those two masks on the scalar unit,
+// and every lane that lies on the path stores its entry at its parent's place in one LDS instruction.  Nodes past the heap's
+// end read as area 0xffffffff, which reproduces the walk's rules for the node with one child and for leaves.
+// (The first form of this routine resolved the five levels with three v_readlane per level and let lanes 0..4 store: a
+// replacement at the root took 0.93 us; profiles/r03_lab_select_stamps.txt has both.)
+// Returns the area of the entry that ends up at `hole`.
+static __device__ __forceinline__ uint32_t tie_wave_sift(heap_t* h, int len, int hole, heap_t value, int lane) {
     constexpr uint32_t kInf = 0xFFFFFFFFu;
     const uint32_t va = hp_area(value);
     const int t = 31 - __clz(lane | 1);                       // depth of relative node `lane` (lane 0: unused)
     const int off = lane - (1 << t);
-    int cur = 0;                                               // absolute index of the node the value may still end up at
+    int cur = hole;                                            // absolute index of the node the value may still end up at
+    uint32_t at_hole = va;
     for (;;) {
         const long long idx = (((long long)(cur + 1)) << t) + off - 1;
         const bool ok = lane >= 1 && idx < (long long)len;
         const heap_t e = ok ? hp_ld(h + idx) : ((heap_t)kInf << 32);
-        const uint32_t e_hi = (uint32_t)(e >> 32), e_lo = (uint32_t)e;
-        // five levels, straight-line (a taken scalar branch costs more than a level's arithmetic): lane s keeps step s's
-        // move (the node it fills and the child entry that moves up), lanes 0..5 the node reached before step s
-        int j = 1, node = cur;
+        const uint32_t a = (uint32_t)(e >> 32);
+        const uint32_t sib = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+        // even lanes (left children): comp(first[right], first[left]) = area[right] > area[left] -> the left one is taken
+        const unsigned long long left_pref = __ballot(sib > a);
+        const unsigned long long stop_at = __ballot(a == kInf || a > va);     // leaf, or __push_heap would bring the value back up to here
+        // five steps down the preferred children, straight-line on the scalar unit (a taken branch costs more than a step's
+        // arithmetic); the steps before the first stop are the moves that really happen
+        int c[5];
         uint32_t stops = 0;
-        int w_pos = 0;
-        uint32_t w_hi = 0, w_lo = 0;
+        {
+            int jj = 1;
+#pragma unroll
+            for (int s5 = 0; s5 < 5; ++s5) {
+                const int cl = 2 * jj;
+                c[s5] = cl + (int)(((left_pref >> cl) & 1ull) ^ 1ull);
+                stops |= (uint32_t)((stop_at >> c[s5]) & 1ull) << s5;
+                jj = c[s5];
+            }
+        }
+        const int nmove = __builtin_ctz(stops | 32u);
+        const bool stopped = nmove < 5;
+        unsigned long long path = 0;                           // relative nodes whose entries move up one place
+        int j = 1;
 #pragma unroll
         for (int s5 = 0; s5 < 5; ++s5) {
-            const int jl = (2 * j) & 63, jr = (2 * j + 1) & 63;
-            const uint32_t al = (uint32_t)__builtin_amdgcn_readlane((int)e_hi, jl), ar = (uint32_t)__builtin_amdgcn_readlane((int)e_hi, jr);
-            const bool left = ar > al;                         // comp(first[right], first[left]): the smaller area, the right child on a tie
-            const int jc = left ? jl : jr;
-            const uint32_t ac = left ? al : ar;
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)e_lo, jc);
-            stops |= (uint32_t)(ac == kInf || ac > va) << s5;  // leaf, or __push_heap would bring the value back up to here
-            if (lane == s5) { w_pos = node; w_hi = ac; w_lo = lo; }
-            node = 2 * node + (left ? 1 : 2);
-            j = jc;
+            path |= s5 < nmove ? 1ull << c[s5] : 0ull;
+            j = s5 < nmove ? c[s5] : j;
         }
-        if (lane == 5) w_pos = node;
-        const int nmove = stops ? __builtin_ctz(stops) : 5;    // moves of this round that really happen
-        if (lane < nmove) hp_st(h + w_pos, ((heap_t)w_hi << 32) | w_lo);
-        cur = __builtin_amdgcn_readlane(w_pos, nmove);
-        if (stops) break;
+        const long long pidx = (((long long)(cur + 1)) << max(t - 1, 0)) + (off >> 1) - 1;      // the parent of relative node `lane` (t >= 1 where used)
+        if ((path >> lane) & 1ull) hp_st(h + pidx, e);
+        if (cur == hole && (path & 0xCull)) at_hole = (uint32_t)__builtin_amdgcn_readlane((int)a, (path & 4ull) ? 2 : 3);   // the child that moved into the hole
+        const int tj = 31 - __clz(j);
+        cur = (int)((((long long)(cur + 1)) << tj) + (j - (1 << tj)) - 1);                 // absolute index of relative node j
+        if (stopped || 2 * cur + 1 >= len) break;                                           // (a leaf: no round trip to find that out)
     }
     if (lane == 0) hp_st(h + cur, value);
+    return at_hole;
 }
 
 #if defined(FSLIC_LAB) && FSLIC_LAB == 1      // lab build only (make LAB=1): 100 MHz time stamps of the select kernel in the unused status words 8..15
@@ -642,8 +659,15 @@ static __device__ __forceinline__ void tie_heap_select(const CcaDev& c, uint32_t
         while (((2 << d) - 1) <= last_parent) d++;           // depth of the deepest parent
         for (; d >= 0; --d) {
             const int lo = (1 << d) - 1, hi = min((2 << d) - 2, last_parent);
-            for (int p = lo + tid; p <= hi; p += 1024)
-                tie_adjust_heap(heap, p, len, hp_ld(heap + p), true);
+            if (d > kTieWaveLevels) {
+                // deep parents: many of them, short walks -- one thread each
+                for (int p = lo + tid; p <= hi; p += 1024)
+                    tie_adjust_heap(heap, p, len, hp_ld(heap + p), true);
+            } else {
+                // the upper levels: at most one parent per wavefront, walks of seven to eleven levels -- five levels per LDS round trip
+                for (int p = lo + (int)rfl((uint32_t)(tid >> 6)); p <= hi; p += 16)
+                    tie_wave_sift(heap, len, p, hp_ld(heap + p), lane);
+            }
             __syncthreads();
         }
     }
@@ -660,8 +684,7 @@ static __device__ __forceinline__ void tie_heap_select(const CcaDev& c, uint32_t
                 m &= m - 1ull;
                 const uint32_t aj = (uint32_t)__builtin_amdgcn_readlane((int)a, j);
                 if (aj > top_area) {
-                    tie_replace_root(heap, len, ((heap_t)aj << 32) | (heap_t)(base + (uint32_t)j), lane);
-                    top_area = hp_area(hp_ld(heap));
+                    top_area = tie_wave_sift(heap, len, 0, ((heap_t)aj << 32) | (heap_t)(base + (uint32_t)j), lane);
                 }
             }
         }
