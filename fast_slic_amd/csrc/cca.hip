@@ -486,12 +486,13 @@ static __device__ __forceinline__ void select_pass(const uint32_t* s_area, uint3
 //   1. rank every candidate by leader (bucket ranking), permute (leader, area) into that order
 //   2. __make_heap over the first K: level by level from the deepest parents up.  __adjust_heap(p) touches only p's
 //      subtree and the sequential loop visits parents in descending index order, i.e. deeper levels first; parents of one
-//      level have disjoint subtrees, so a level can run in parallel (one thread per parent) with identical results
+//      level have disjoint subtrees, so a level can run in parallel with identical results (the deep, populous levels one
+//      thread per parent; levels 0..4, whose walks are long, one wavefront per parent: tie_wave_sift)
 //   3. the __heap_select loop over candidates K..M-1 is sequential: one wavefront scans 64 candidates at a time for
 //      area > area[top] (the top's area never decreases, so a candidate rejected once stays rejected) and replays
-//      __pop_heap for the survivors in index order (all lanes walk the same path, lane 0 stores)
+//      __pop_heap for the survivors in index order (tie_wave_sift from the root: five levels per LDS round trip)
 //   4. the heap's K entries are the kept set: label = rank among the kept in leader order (src/cca.cpp:229-237)
-// The heap is two arrays moved in tandem (candidate index, its area): one LDS round trip per level instead of two.
+// A heap entry is one 64-bit word (area << 32 | candidate index): one LDS access moves it.
 // ---------------------------------------------------------------------------------------------
 typedef unsigned long long heap_t;      // area << 32 | candidate index: one LDS access moves an entry, comp looks at the high half
 constexpr int kTieWaveLevels = 4;       // __make_heap: parents of depth <= this are sifted by a wavefront each (tie_wave_sift)
