@@ -32,7 +32,7 @@ class Params(C.Structure):
         ("subsample_stride", C.c_int32), ("convert_to_lab", C.c_int32),
         ("manhattan_spatial_dist", C.c_int32), ("preemptive", C.c_int32),
         ("preemptive_thres", C.c_float), ("num_threads", C.c_int32), ("debug_mode", C.c_int32),
-        ("variant", C.c_int32), ("reserved", C.c_int32 * 5),
+        ("abi", C.c_int32), ("variant", C.c_int32), ("reserved", C.c_int32 * 4),
     ]
 
 
@@ -362,6 +362,7 @@ def make_params(max_iter, compactness, min_size_factor, subsample_stride, conver
                 manhattan_spatial_dist=True, preemptive=False, preemptive_thres=0.05, num_threads=-1,
                 debug_mode=False, variant=0):
     p = Params()
+    p.abi = PARAMS_ABI
     p.variant = int(variant)        # 0: Slic (Context), 1: LSC (ContextLSC)
     p.max_iter = int(max_iter)
     p.compactness = float(compactness)
@@ -376,6 +377,7 @@ def make_params(max_iter, compactness, min_size_factor, subsample_stride, conver
     return p
 
 
+PARAMS_ABI = 0x46533033         # FSLIC_PARAMS_ABI, include/fslic_hip.h
 VARIANT_SLIC, VARIANT_LSC, VARIANT_REALDIST, VARIANT_REALDIST_L2, VARIANT_REALDIST_NOQ = 0, 1, 2, 3, 4     # fslic_params.variant
 _REAL_DIST_VARIANTS = {"standard": VARIANT_REALDIST, "l2": VARIANT_REALDIST_L2, "noq": VARIANT_REALDIST_NOQ, "lsc": VARIANT_LSC}
 

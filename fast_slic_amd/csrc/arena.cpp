@@ -30,8 +30,6 @@ void free_slot(Slot& s) {
     if (s.h_patch) hipHostFree(s.h_patch);
     if (s.h_cand_leader) hipHostFree(s.h_cand_leader);
     if (s.h_cand_area) hipHostFree(s.h_cand_area);
-    if (s.h_rgb_pin) hipHostFree(s.h_rgb_pin);
-    if (s.h_out_pin) hipHostFree(s.h_out_pin);
     for (auto& e : s.ev) if (e) hipEventDestroy(e);
     for (auto& e : s.ev_it) if (e) hipEventDestroy(e);
     if (s.st) hipStreamDestroy(s.st);
@@ -267,19 +265,6 @@ int prepare_lsc(Slot& s, int H, int W, int K, int S, int G, float compactness) {
         s.l.blk_shift_f = 20 - bits_f; s.l.blk_shift_w = 12 - bits_w;
         s.lsc_S = S; s.lsc_compactness = compactness;
     }
-    return FSLIC_OK;
-}
-
-// Pinned staging of the host-memory entry points: `frames` frames of `px` pixels (RGB in, labels out).
-int ensure_pinned_staging(Slot& s, size_t px, int frames) {
-    if (s.pin_px >= px && s.pin_frames >= frames && s.pin_px * (size_t)s.pin_frames >= px * (size_t)frames) return FSLIC_OK;
-    HIPCHK(hipStreamSynchronize(s.st));
-    if (s.h_rgb_pin) { hipHostFree(s.h_rgb_pin); s.h_rgb_pin = nullptr; }
-    if (s.h_out_pin) { hipHostFree(s.h_out_pin); s.h_out_pin = nullptr; }
-    s.pin_px = 0; s.pin_frames = 0;
-    HIPCHK(hipHostMalloc((void**)&s.h_rgb_pin, px * 3 * (size_t)frames));
-    HIPCHK(hipHostMalloc((void**)&s.h_out_pin, px * 2 * (size_t)frames));
-    s.pin_px = px; s.pin_frames = frames;
     return FSLIC_OK;
 }
 

@@ -348,6 +348,11 @@ typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 // Algorithmic traffic: 4 B read + 2 B written per visited pixel.
 // =============================================================================================
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+// (Experiment builds -- make VAR=<name> DEFS=-DFSLIC_EXP=<bits>, kernels.h -- carry A/B forms of this kernel while they are being
+// measured, scripts/gpu_exp.sh; what round 4 measured is in profiles/r04_assign_experiments.txt.)
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release of GLOBAL memory too, which on
+// this target is s_waitcnt vmcnt(0): every pixel load (prologue) or label store (epilogue) still in flight would have to land first.
+static __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 constexpr int kRawBuffer = 0x00020000;     // 4th dword of a raw (stride 0) buffer descriptor on gfx9-family targets: DATA_FORMAT = 32
 constexpr int kAuxSc1 = 16;                // cache policy bit of the buffer builtins: sc1 (write through at agent scope)
 
@@ -378,7 +383,15 @@ static __device__ __forceinline__ void min_in_place(us2& best, us2 key) {
 
 template <int R>
 static __device__ __forceinline__ void row_masks(uint32_t inv, uint32_t (&m)[R / 2]) {
-    static_assert(R == 8 || R == 16, "row masks are built for 8 or 16 rows");
+    static_assert(R == 8 || R == 16 || R == 32, "row masks are built for 8, 16 or 32 rows");
+    if constexpr (R == 32) {
+        uint32_t lo[8], hi[8];
+        row_masks<16>(inv & 0xFFFFu, lo);
+        row_masks<16>(inv >> 16, hi);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { m[q] = lo[q]; m[8 + q] = hi[q]; }
+        return;
+    }
     const unsigned long long r1 = sbitrep(inv);                 // x2
     const unsigned long long r2 = sbitrep((uint32_t)r1);        // x4  (R <= 16: 32 significant bits of r1)
     if (R == 8) {
@@ -499,46 +512,29 @@ static __device__ __forceinline__ void fused_finalize(const FrameDev& f, uint32_
     }
 }
 
-// Blocks -> tiles, XCD-aware.  The hardware hands consecutive workgroups (x fastest) to the eight XCDs in turn, and every XCD has
-// its own L2: with the natural (tile column, tile row, frame) grid the eight neighbours that share a frame's bins and table
-// rows sit on eight different L2s (measured: 1.32 x the algorithmic bytes at 1280x720).  With FSLIC_XCD=1 the launch grid is
-// 8 * per workgroups in one dimension instead: workgroup b takes tile (b % 8) * per + b / 8, so that an XCD works through a
-// contiguous eighth of the tiles (whole frames).  Measured (profiles/r03_xcd_mapping.txt): the traffic of the fused launch at
-// 8 x 1280x720 falls to 1.15 x the algorithmic bytes, its duration does not (11.8 vs 11.5 us), and the HBM-bound 3840x2160
-// launches get SLOWER (fused 55.1 vs 46.7 us, full assignment 74.4 vs 67.6): tiles that run at the same time then lie in
-// eight different frames instead of next to each other in memory.  Off by default.
-struct BlkMap { uint32_t gx, gy, total, per; };
-static const bool g_xcd_chunks = [] { const char* v = getenv("FSLIC_XCD"); return v && atoi(v) == 1; }();
-static inline BlkMap blk_map(dim3 g) {
-    BlkMap m; m.gx = g.x; m.gy = g.y; m.total = g.x * g.y * g.z; m.per = g_xcd_chunks ? (m.total + 7u) / 8u : 0u;
-    return m;
-}
-static inline dim3 blk_grid(dim3 g) { return g_xcd_chunks ? dim3(8 * blk_map(g).per) : g; }
-static __device__ __forceinline__ void div_rem(uint32_t x, uint32_t n, uint32_t& q, uint32_t& rest) {     // x < 2^31, n >= 1
-    q = __umulhi(x, 0xFFFFFFFFu / n);
-    rest = x - q * n;
-    if (rest >= n) { q++; rest -= n; }
-    if (rest >= n) { q++; rest -= n; }
-}
+// Blocks -> tiles: the natural grid (tile column, tile row, frame).  The hardware hands consecutive workgroups (x fastest) to the
+// eight XCDs in turn, each with its own L2, so the eight neighbours that share a frame's bins and table rows sit on eight L2s
+// (1.32 x the algorithmic bytes at 1280x720).  An XCD-chunked order (an XCD works through a contiguous eighth of the tiles) was
+// built and measured in round 3 (profiles/r03_xcd_mapping.txt): traffic of the fused 8 x 1280x720 launch 1.15 x, its duration
+// unchanged (11.8 vs 11.5 us), the HBM-bound 3840x2160 launches 10 - 18 % SLOWER (tiles that run together then lie in eight
+// frames instead of side by side in memory).  Removed.
+struct BlkMap { uint32_t gx, gy; };
+static inline BlkMap blk_map(dim3 g) { BlkMap m; m.gx = g.x; m.gy = g.y; return m; }
+static inline dim3 blk_grid(dim3 g) { return g; }
 
 template <int R, bool FUSE, int STRIDE, bool VT, bool FBIN = false>
 static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, int Hv, const BlkMap& bm) {
     static_assert(!FBIN || FUSE, "the cluster pass rides on the fused centroid sums");
-    uint32_t bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;      // per == 0: the natural grid (tile column, tile row, frame)
-    if (bm.per != 0u) {
-        const uint32_t t = (blockIdx.x & 7u) * bm.per + (blockIdx.x >> 3);
-        if (t >= bm.total) return;                  // (up to seven workgroups of the last row have no tile)
-        uint32_t rest;
-        div_rem(t, bm.gx * bm.gy, bzi, rest);
-        div_rem(rest, bm.gx, byi, bxi);
-    }
-    bxi = rfl(bxi); byi = rfl(byi); bzi = rfl(bzi);      // wave-uniform: keep them (and everything derived) in scalar registers
+    const uint32_t bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;      // (tile column, tile row, frame)
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];   // spatial table (u16), whole KB (LDS-DMA lands 1 KB per wavefront instruction); 16-byte aligned: the row-vector reads are ds_read_b128
     __shared__ __attribute__((aligned(16))) uint4 s_raw[kWavesPerBlock][64];       // every wavefront's kept records {yx, lab, tag, -}
     __shared__ __attribute__((aligned(16))) uint32_t s_part[64][4];                // partial ranks: [candidate][wavefront]
     __shared__ __attribute__((aligned(16))) uint32_t s_wcnt[4];                    // kept records per wavefront
-    __shared__ __attribute__((aligned(16))) uint16_t s_k16[kWavesPerBlock][64];    // per wavefront (no barrier lies between its writes and the epilogue's reads): cluster number by rank
     __shared__ __attribute__((aligned(16))) uint32_t s_entry[FUSE ? 64 : 4];       // cpart entry by rank | kNoSlot
+    // cluster number by the LOW BYTE of a pixel's key (rank | two distance bits << 6, i.e. four copies): the byte comes out of the
+    // packed minima with one SDWA shift, no mask.  Every wavefront writes the same values (no barrier between these stores and the
+    // epilogue's reads: a wavefront's own stores precede its reads, and what the others store is identical).
+    __shared__ __attribute__((aligned(16))) uint16_t s_k256[256];
     // centroid accumulators: per (candidate, copy) two 64-bit words of three 20-bit-spaced fields each,
     //   A = sum L | sum a << 20 | sum b << 40        B = sum (x - x0) | sum (y - y0) << 20 | count << 40
     __shared__ __attribute__((aligned(16))) unsigned long long s_acc[FUSE ? 64 * kBlkCopies * 2 : 2];
@@ -628,8 +624,11 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
         for (int i = wave; i < nkb; i += kWavesPerBlock)
             lds_dma_16(reinterpret_cast<const uint4*>(f.tab) + min(i * 64 + lane, nq - 1), lds0 + (uint32_t)i * 1024u);
     }
-    if (FUSE) reinterpret_cast<uint4*>(s_acc)[tid] = make_uint4(0u, 0u, 0u, 0u);    // 64 * kBlkCopies * 2 * 8 bytes = 256 threads x 16
-    static_assert(64 * kBlkCopies * 2 * 8 == 256 * 16, "one 16-byte store per thread clears the accumulators");
+    if (FUSE) {
+#pragma unroll
+        for (int i = 0; i < kBlkCopies / 4; ++i) reinterpret_cast<uint4*>(s_acc)[tid + 256 * i] = make_uint4(0u, 0u, 0u, 0u);    // 64 * kBlkCopies * 2 * 8 bytes = 256 threads x 16 x (copies / 4)
+    }
+    static_assert(kBlkCopies % 4 == 0 && 64 * kBlkCopies * 2 * 8 == 256 * 16 * (kBlkCopies / 4), "16-byte stores of all threads clear the accumulators");
     load_pixels();
     {
         int cnt = 0;
@@ -659,8 +658,11 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
         if (lane == 0) s_wcnt[wave] = (uint32_t)cnt;
     }
     ASG_STAMP(1, wave == 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the table has landed (the compiler's counters do not include the LDS-DMA loads)
-    __syncthreads();
+    // The table has landed once at most R loads are outstanding (the compiler's counters do not include the LDS-DMA pieces): the R pixel
+    // loads were issued after them and loads return in order; whatever the gather issued later has been waited for by the compiler at
+    // its use.  The pixels themselves stay in flight across both barriers of the prologue (LDS-only barriers, see lds_barrier).
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(R) : "memory");
+    lds_barrier();
     ASG_STAMP(2, wave == 0);
     // lane j = candidate j of the block (raw order: wavefront 0's records, then wavefront 1's, ...)
     int bn;
@@ -686,13 +688,16 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
         for (int i = wave; i < bn; i += kWavesPerBlock) part += (uint32_t)(__builtin_amdgcn_readlane(tag_j, i) < tag_j);
         s_part[lane][wave] = part;
     }
-    __syncthreads();
+    lds_barrier();
     uint32_t rank_j;
     {
         const uint4 pr = *reinterpret_cast<const uint4*>(s_part[lane]);
         rank_j = pr.x + pr.y + pr.z + pr.w;
     }
-    if (lane < bn) s_k16[wave][rank_j] = (uint16_t)(mine.z & 0xFFFFu);
+    if (lane < bn) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) s_k256[d * 64 + (int)rank_j] = (uint16_t)(mine.z & 0xFFFFu);
+    }
     uint32_t fin_nx = 0, fin_ny = 0;             // FBIN, wavefront 0, lane j: blocks that deliver sums of candidate j (0: not this block)
     if (FUSE && wave == 0) {
         uint32_t entry = kNoSlot;
@@ -726,19 +731,21 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
         const int Cc = f.tab_dyoff;                 // centre index of the V table
         const uint32_t xout = (uint32_t)f.tab_xout;
         constexpr int BIAS = 32768;                 // makes the numerators of the row-range divisions positive
-        constexpr uint32_t full = (1u << R) - 1u;
+        constexpr uint32_t full = R >= 32 ? 0xFFFFFFFFu : (1u << (R & 31)) - 1u;
+        auto low_bits = [](int n) -> uint32_t { return n >= 32 ? 0xFFFFFFFFu : (1u << n) - 1u; };      // n in [0, 32]
         // Per-candidate row ranges, computed ONCE in the vector unit with lane j = candidate j (the scalar unit is
         // shared by the whole CU and issues about as many instructions per clock as the four SIMDs together).
         //   rows r with dy_r = dy0 + r*STRIDE: above the centre r < rs, inside the window ra <= r <= rb
-        uint32_t vab_j;                             // rows above (low half) | rows at/below (high half) that are in the window
+        uint32_t va_j, vb_j;                        // rows above / rows at or below the centre that are in the window
         {
             const int dy0 = yw_lo - (int)(yx_j >> 16);
             const int rs = min(max((-dy0 + STRIDE * BIAS + STRIDE - 1) / STRIDE - BIAS, 0), R);
             const int ra = min(max((-S - dy0 + STRIDE * BIAS + STRIDE - 1) / STRIDE - BIAS, 0), R);
             const int rb = min(max((S - dy0 + STRIDE * BIAS) / STRIDE - BIAS, -1), R - 1);
-            const uint32_t upto_rs = (1u << rs) - 1u;
-            const uint32_t in_win = rb < 0 ? 0u : (((2u << rb) - 1u) & ~((1u << ra) - 1u) & full);
-            vab_j = (in_win & upto_rs) | ((in_win & ~upto_rs) << 16);
+            const uint32_t upto_rs = low_bits(rs);
+            const uint32_t in_win = rb < 0 ? 0u : (low_bits(rb + 1) & ~low_bits(ra) & full);
+            va_j = in_win & upto_rs;
+            vb_j = in_win & ~upto_rs;
         }
         // row-vector table: entry t = (V[t], V[t+STRIDE], .. V[t+7*STRIDE]) as one 16-byte word, so the spatial terms of
         // eight rows are ONE 16-byte-ALIGNED ds_read_b128 (a 2-byte-aligned b128 read costs 64 clk of the CU's LDS pipe
@@ -749,9 +756,10 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
             {
                 const uint4 e0 = s_rv[base];
                 spw[0] = e0.x; spw[1] = e0.y; spw[2] = e0.z; spw[3] = e0.w;
-                if (R == 16) {
-                    const uint4 e1 = s_rv[base + 8 * STRIDE];
-                    spw[R / 2 - 4] = e1.x; spw[R / 2 - 3] = e1.y; spw[R / 2 - 2] = e1.z; spw[R / 2 - 1] = e1.w;
+#pragma unroll
+                for (int h = 1; h < R / 8; ++h) {
+                    const uint4 e1 = s_rv[base + 8 * h * STRIDE];
+                    spw[4 * h] = e1.x; spw[4 * h + 1] = e1.y; spw[4 * h + 2] = e1.z; spw[4 * h + 3] = e1.w;
                 }
             }
             // sweeps over the row pairs instead of one chain per pair: a packed op that consumes the result of the
@@ -775,7 +783,6 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
         //   above : some rows above the centre, masked          below : some rows at/below the centre, masked
         // (a candidate whose centre row lies inside this wavefront's rows is in both masked loops)
         const bool mine_todo = (todo >> lane) & 1ull;
-        const uint32_t va_j = vab_j & 0xFFFFu, vb_j = vab_j >> 16;
         unsigned long long todo_wa = __ballot(mine_todo && va_j == full);      // whole, above the centre
         unsigned long long todo_wb = __ballot(mine_todo && vb_j == full);      // whole, at/below
         unsigned long long todo_above = __ballot(mine_todo && va_j != 0u && va_j != full);
@@ -885,45 +892,100 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
     ASG_STAMP(4, wave == 0);
     ASG_PUT(9, wave == 0, __popcll(todo));
     ASG_PUT(10, wave == 0, bn);
+    // vmcnt(0), stated where the compiler sees it: the pixels are in registers from here on.  Without it the compiler (the loops above may
+    // run zero times) keeps "pixel load pending" marks on pix[] and places s_waitcnt vmcnt(R-1) .. vmcnt(0) in front of the sums of row
+    // 0 .. R-1 -- which, with R label stores issued in between, made every row's sums wait for a store's acknowledgement.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     // 5. write labels (+ fused centroid sums)
-    uint32_t slot[R];
+    bool epilogue_done = false;
     {
-        uint32_t kk[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t key = (r & 1) ? (uint32_t)best[r / 2].y : (uint32_t)best[r / 2].x;
-            kk[r] = s_k16[wave][key & 63u];                         // entry 63 when not found: read, never used
-        }
-        uint16_t* rowp = f.labels + (size_t)yw_lo * W;
-        const uint32_t xo = (uint32_t)x;
-        // Interior wavefront with every pixel assigned (the rule, by far): straight-line stores under one column mask.
-        // Otherwise (bottom rows missing, or a pixel no window reached: it keeps its label and still takes part in the
-        // update) row by row with the full rules.
         us2 worst = best[0];
 #pragma unroll
         for (int q = 1; q < R / 2; ++q) worst = __builtin_elementwise_max(worst, best[q]);
         const bool all_found = __ballot(worst.x == 0xFFFF || worst.y == 0xFFFF) == 0ull;
-        if (all_found && nrows == R) {
-            if (okx) {      // written through (sc1, see st_stream), row in the scalar offset, column in one shared vector offset
+        if (all_found && nrows == R) {          // interior wavefront with every pixel assigned: the rule, by far
+            epilogue_done = true;
+            if (okx) {
+                uint32_t kk[R];
+                const char* const ktab = reinterpret_cast<const char*>(s_k256);
+#pragma unroll
+                for (int q = 0; q < R / 2; ++q) {
+                    const uint32_t b = __builtin_bit_cast(uint32_t, best[q]);
+                    kk[2 * q] = *reinterpret_cast<const uint16_t*>(ktab + ((b & 0xFFu) << 1));
+                    kk[2 * q + 1] = *reinterpret_cast<const uint16_t*>(ktab + (((b >> 16) & 0xFFu) << 1));
+                }
                 const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(f.labels, 0, (int)((uint32_t)f.N * 2u), kRawBuffer);
                 const uint32_t so0 = (uint32_t)yw_lo * (uint32_t)W * 2u, pitch2 = (uint32_t)(STRIDE * W) * 2u;
 #pragma unroll
                 for (int r = 0; r < R; ++r)
-                    __builtin_amdgcn_raw_buffer_store_b16((uint16_t)kk[r], ws, (int)(xo * 2u), (int)(so0 + (uint32_t)r * pitch2), kAuxSc1);
-            }
+                    __builtin_amdgcn_raw_buffer_store_b16((uint16_t)kk[r], ws, (int)((uint32_t)x * 2u), (int)(so0 + (uint32_t)r * pitch2), kAuxSc1);
+                ASG_STAMP(5, wave == 0);
+                if (FUSE) {
+                    // Sums of update() (src/context.cpp:301-354), second form.  A lane keeps the PREFIX sums of its column (three
+                    // v_dot4 per row, nothing else: count, sum x and sum y of a prefix are constants of the row number).  Where the
+                    // label changes between rows r and r+1 the prefix goes to the upper run's accumulator with + and to the lower
+                    // run's with -, the whole column at the end to the last run's with +: every run receives (prefix at its end) -
+                    // (prefix at its start) in two pieces, and the 64-bit words (three 20-bit-spaced fields each, see s_acc) are added
+                    // modulo 2^64, so the transient negative pieces cost nothing.  No per-run state, no resets, no comparisons of
+                    // accumulated values: 4.5 vector instructions per row plus 9 per row gap in which some lane changes its label.
+                    const uint32_t copy16 = ((uint32_t)lane & (kBlkCopies - 1)) * 16u;
+                    const uint32_t dyw = (uint32_t)(wave * R * STRIDE);
+                    char* const accb = reinterpret_cast<char*>(s_acc);
+                    uint32_t sL = 0, sa = 0, sb = 0;
+                    uint32_t wq[R / 2];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t key = (r & 1) ? (uint32_t)best[r / 2].y : (uint32_t)best[r / 2].x;
-                slot[r] = (FUSE && okx) ? (key & 63u) : kNoSlot;
+                    for (int q = 0; q < R / 2; ++q) wq[q] = __builtin_bit_cast(uint32_t, best[q]) & 0x003F003Fu;
+                    auto words = [&](int cnt, unsigned long long& A, unsigned long long& B) {      // the column's first cnt rows
+                        const uint32_t a_lo = sL | (sa << 20), a_hi = (sa >> 12) | (sb << 8);
+                        const uint32_t ys = (uint32_t)cnt * dyw + (uint32_t)(STRIDE * (cnt * (cnt - 1) / 2));     // sum (y - y0) < 4096 (see the static_assert on BH)
+                        const uint32_t b_lo = __umul24((uint32_t)lane, (uint32_t)cnt) + (ys << 20), b_hi = (uint32_t)cnt << 8;
+                        A = (unsigned long long)a_lo | ((unsigned long long)a_hi << 32);
+                        B = (unsigned long long)b_lo | ((unsigned long long)b_hi << 32);
+                    };
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const uint32_t p = pix[r];
+                        sL = __builtin_amdgcn_udot4(p, 0x00000001u, sL, false);
+                        sa = __builtin_amdgcn_udot4(p, 0x00000100u, sa, false);
+                        sb = __builtin_amdgcn_udot4(p, 0x00010000u, sb, false);
+                        if (r == R - 1) break;
+                        const uint32_t cur = (r & 1) ? (wq[r / 2] >> 16) : (wq[r / 2] & 0xFFFFu);
+                        const uint32_t nxt = (r & 1) ? (wq[r / 2 + 1] & 0xFFFFu) : (wq[r / 2] >> 16);
+                        if (cur != nxt) {
+                            unsigned long long A, B;
+                            words(r + 1, A, B);
+                            unsigned long long* const up = reinterpret_cast<unsigned long long*>(accb + (cur * (uint32_t)(kBlkCopies * 16) + copy16));
+                            unsigned long long* const dn = reinterpret_cast<unsigned long long*>(accb + (nxt * (uint32_t)(kBlkCopies * 16) + copy16));
+                            atomicAdd(up, A);
+                            atomicAdd(up + 1, B);
+                            __hip_atomic_fetch_sub(dn, A, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_sub(dn + 1, B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                    {
+                        unsigned long long A, B;
+                        words(R, A, B);
+                        unsigned long long* const last = reinterpret_cast<unsigned long long*>(accb + ((wq[R / 2 - 1] >> 16) * (uint32_t)(kBlkCopies * 16) + copy16));
+                        atomicAdd(last, A);
+                        atomicAdd(last + 1, B);
+                    }
+                }
             }
-        } else {
+        }
+    }
+    if (!epilogue_done) {
+        // The exception: bottom rows missing, or a pixel no window reached (it keeps its label and still takes part in the update,
+        // src/context.cpp:138-145): row by row with the full rules, sums per run of equal slot.
+        uint32_t slot[R];
+        uint16_t* rowp = f.labels + (size_t)yw_lo * W;
+        const uint32_t xo = (uint32_t)x;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const bool ok = okx && r < nrows;
             const uint32_t key = (r & 1) ? (uint32_t)best[r / 2].y : (uint32_t)best[r / 2].x;
             const bool found = key != 0xFFFFu;
             slot[r] = kNoSlot;
-            if (ok && found) st_stream(rowp + xo, (uint16_t)kk[r]);
+            if (ok && found) st_stream(rowp + xo, s_k256[key & 63u]);
             if (FUSE && ok) {
                 if (found) slot[r] = key & 63u;
                 else {
@@ -938,14 +1000,8 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
             }
             rowp += (size_t)STRIDE * W;
         }
-    }
-    }
-    ASG_STAMP(5, wave == 0);
-    if (FUSE) {
-        {
-            // A column's rows fall into one or two runs of equal slot (a superpixel is taller than a wavefront's rows), so the
-            // sums are kept in registers per run and flushed when the slot changes: 2 LDS atomics per run instead of 2 per
-            // pixel (the 64-bit words as two 32-bit halves: no field carries across bit 32, see s_acc).
+        ASG_STAMP(5, wave == 0);
+        if (FUSE) {
             const uint32_t copy = (uint32_t)lane & (kBlkCopies - 1);
             const uint32_t dyw = (uint32_t)(wave * R * STRIDE);            // first row of this wavefront relative to the block's
             uint32_t cur = slot[0], a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0;
@@ -970,8 +1026,10 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
             }
             flush();
         }
+    }
+    if (FUSE) {
         ASG_STAMP(6, wave == 0);
-        __syncthreads();
+        lds_barrier();
         ASG_STAMP(7, wave == 0);
         // one plain store per (candidate, quantity): entry reserved for (cluster, this block), zeros included
         const uint32_t yb0 = (uint32_t)(rem + vrow_b0 * STRIDE);
@@ -1032,16 +1090,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_wav
     assign_blk2_body<R, true, STRIDE, VT, true>(f, rem, Hv, bm);
 }
 
-// FSLIC_R16=0 (read once): fused passes never take 16 rows per wavefront (A/B measurements)
-static const bool g_fused_r16 = [] { const char* v = getenv("FSLIC_R16"); return !(v && atoi(v) == 0); }();
-
 template <int R, bool FUSE, int STRIDE>
 static void launch_assign_blk_t(const FrameDev& f_, int nframes, int rem, int Hv, hipStream_t st) {
     FrameDev f = f_;
     if (FUSE) { f.tab = f.tabs; f.tab_words = f.tabs_words; f.tab_dyoff = f.tabs_dyoff; f.tab_nrpad = f.tabs_nrpad; }   // table of the subsampled stride
     dim3 grid((f.W + kTileW - 1) / kTileW, (Hv + kWavesPerBlock * R - 1) / (kWavesPerBlock * R), nframes);
     const size_t lds2 = ((size_t)f.tab_words * sizeof(uint32_t) + 1023) / 1024 * 1024;       // whole KB: what the LDS-DMA pieces fill
-    if constexpr (R == 16 && !FUSE) {
+    if constexpr (R == 32) {
+        static_assert(!FUSE, "32 rows per wavefront: full pass only");
+        launch((k_assign_blk2_w6<R, FUSE, STRIDE, true>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
+    } else if constexpr (R == 16 && !FUSE) {
         if (f.tab_vmode) launch((k_assign_blk2_w8<R, FUSE, STRIDE, true>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
         else launch((k_assign_blk2_w8<R, FUSE, STRIDE, false>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
     } else if constexpr (R == 16 && FUSE) {
@@ -1077,7 +1135,7 @@ void launch_assign_fused_bin(const FrameDev& f_, int nframes, int rem, int strid
     const int Hv = (f.H - rem + stride - 1) / stride;
     if (Hv <= 0) return;
     const int tiles_x = (f.W + kTileW - 1) / kTileW;
-    const bool r16 = g_fused_r16 && f.tab_vmode && nframes * tiles_x * ((Hv + kWavesPerBlock * 8 - 1) / (kWavesPerBlock * 8)) > 3072;      // as launch_assign
+    const bool r16 = f.tab_vmode && nframes * tiles_x * ((Hv + kWavesPerBlock * 8 - 1) / (kWavesPerBlock * 8)) > 3072;      // as launch_assign
     if (r16) {
         if (stride == 1) launch_assign_bin_t<16, 1>(f, nframes, rem, Hv, st);
         else if (stride == 2) launch_assign_bin_t<16, 2>(f, nframes, rem, Hv, st);
@@ -1092,6 +1150,9 @@ void launch_assign_fused_bin(const FrameDev& f_, int nframes, int rem, int strid
 static int assign_rows_per_wave(const FrameDev& f, int nframes, int Hv, bool fuse_update) {
     const int tiles_x = (f.W + kTileW - 1) / kTileW;
     const int blocks8 = nframes * tiles_x * ((Hv + kWavesPerBlock * 8 - 1) / (kWavesPerBlock * 8));
+    // 32 rows (row-vector table only): launches that keep the chip busy for three rounds of 16-row blocks and more -- the block
+    // prologue and the per-candidate fetch are then paid once per 8192 pixels instead of 4096
+    if (!fuse_update && f.tab_vmode && blocks8 > 4 * 6144) return 32;
     return (!fuse_update && blocks8 > 3072) ? 16 : 8;
 }
 
@@ -1116,7 +1177,9 @@ PassGeom launch_assign(const FrameDev& f_, int nframes, int rem, int stride, int
     if (Hv <= 0) return pg;
     if (f.tab_words > 0 && stride >= 1 && stride <= 3 && (unsigned long long)f.N * 4ull < 0x7FFFFFFFull) {       // block-level packed kernel (its buffer loads address a plane with 31-bit byte offsets; larger planes take the 32-bit kernel)
         if (!fuse_update && stride == 1) {
-            if (assign_rows_per_wave(f, nframes, Hv, false) == 16) launch_assign_blk_t<16, false, 1>(f, nframes, rem, Hv, st);
+            const int rpw = assign_rows_per_wave(f, nframes, Hv, false);
+            if (rpw == 32) launch_assign_blk_t<32, false, 1>(f, nframes, rem, Hv, st);
+            else if (rpw == 16) launch_assign_blk_t<16, false, 1>(f, nframes, rem, Hv, st);
             else launch_assign_blk_t<8, false, 1>(f, nframes, rem, Hv, st);
             return pg;
         }
@@ -1127,7 +1190,7 @@ PassGeom launch_assign(const FrameDev& f_, int nframes, int rem, int stride, int
             // 2048.  Small launches keep 8 rows (more, shorter-lived blocks fill the chip better); so does the 2-D table,
             // whose LDS footprint grows with the rows a wavefront spans.
             const int tiles_x = (f.W + kTileW - 1) / kTileW;
-            const bool r16 = g_fused_r16 && f.tab_vmode && nframes * tiles_x * ((Hv + kWavesPerBlock * 8 - 1) / (kWavesPerBlock * 8)) > 3072;
+            const bool r16 = f.tab_vmode && nframes * tiles_x * ((Hv + kWavesPerBlock * 8 - 1) / (kWavesPerBlock * 8)) > 3072;
             if (r16) {
                 pg.BH = kWavesPerBlock * 16;
                 if (stride == 1) launch_assign_blk_t<16, true, 1>(f, nframes, rem, Hv, st);
@@ -1141,7 +1204,7 @@ PassGeom launch_assign(const FrameDev& f_, int nframes, int rem, int stride, int
             return pg;
         }
     }
-    if (assign_rows_per_wave(f, nframes, Hv, fuse_update) == 16) launch_assign_r<16>(f, nframes, rem, stride, Hv, buf, sbuf, fuse_update, st);
+    if (assign_rows_per_wave(f, nframes, Hv, fuse_update) >= 16) launch_assign_r<16>(f, nframes, rem, stride, Hv, buf, sbuf, fuse_update, st);
     else launch_assign_r<8>(f, nframes, rem, stride, Hv, buf, sbuf, fuse_update, st);
     return pg;
 }

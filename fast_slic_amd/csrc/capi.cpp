@@ -12,33 +12,10 @@ using namespace fslic;
 
 static_assert(sizeof(fslic_cluster) == 32, "Cluster ABI (src/fast-slic-common.h:10-23)");
 
-namespace {
-// FSLIC_HOST_STAGING (read once): how the host-memory entry points move frames and label maps.  0 (default): pageable
-// hipMemcpyAsync on the slot's stream (the runtime's own staging).  1: the engine's copy pool + pinned staging that the LAB /
-// relabel kernels read and write in place.  2: copy pool + pinned staging + copy commands to / from the arena.  Measured
-// (profiles/r03_e2e_probe.txt, 1280x720 K=1600, one caller thread): 432 / 490 / 543 us per call -- kernels working on host memory
-// over PCIe take 84 us longer than on HBM, and the copy pool moves a frame no faster than the runtime does; 1 and 2 stay for
-// measurements.  FSLIC_COPY_THREADS: helper threads of the copy pool (default 3)
-int host_staging_mode() {
-    static const int mode = [] { const char* v = getenv("FSLIC_HOST_STAGING"); return v ? atoi(v) : 0; }();
-    return mode;
-}
-bool host_staging_enabled() { return host_staging_mode() != 0; }
-fslic::CopyPool* engine_copy_pool(fslic_engine* e) {
-    std::lock_guard<std::mutex> lk(e->mu);
-    if (!e->copy_pool) {
-        const char* v = getenv("FSLIC_COPY_THREADS");
-        const int n = v ? std::min(std::max(atoi(v), 0), 16) : 3;
-        e->copy_pool = copy_pool_create(n);
-    }
-    return e->copy_pool;
-}
-}  // namespace
-
 extern "C" {
 
 const char* fslic_hip_last_error(void) { return last_error().c_str(); }
-const char* fslic_hip_version(void) { return "fast_slic_amd 0.2 (gfx950)"; }
+const char* fslic_hip_version(void) { return "fast_slic_amd 0.3 (gfx950)"; }
 
 int fslic_hip_device_count(void) {
     int n = 0;
@@ -90,7 +67,6 @@ void fslic_hip_destroy(fslic_engine* e) {
     }
     if (e->d_gamma) hipFree(e->d_gamma);
     if (e->d_labtbl) hipFree(e->d_labtbl);
-    copy_pool_destroy(e->copy_pool);
     delete e;
 }
 
@@ -136,45 +112,30 @@ int fslic_hip_iterate(fslic_engine* e, const fslic_params* p, int H, int W, int 
     if (rc) return rc;
     const uint8_t* d_rgb = s.d_rgb_stage;
     uint16_t* d_out = s.d_out_stage;
-    const bool pinned_path = host_staging_enabled();
-    const bool dma = host_staging_mode() == 2;
+    // Pageable hipMemcpyAsync in and out on the slot's stream (the runtime's own staging).  Measured against it and not kept
+    // (profiles/r03_e2e_probe.txt, 1280x720 K=1600, one caller thread: 432 us per call like this): pinned staging read and written
+    // in place by the LAB / relabel kernels (490 us: kernels working over PCIe take 84 us longer than on HBM) and pinned staging
+    // filled by a pool of copy threads plus copy commands (543 us).
     const double t0 = knobs().host_timing ? now_us() : 0.0;
-    if (pinned_path) {
-        // the frame goes into pinned, device-accessible staging (the engine's copy pool: several threads) and the LAB kernel reads
-        // it from there; the relabel kernel writes the label map into pinned staging: no copy command on the stream either way
-        rc = ensure_pinned_staging(s, N, 1);
-        if (rc) return rc;
-        copy_pool_run(engine_copy_pool(e), s.h_rgb_pin, rgb, N * 3);
-        if (dma) {
-            HIPCHK(hipMemcpyAsync(s.d_rgb_stage, s.h_rgb_pin, N * 3, hipMemcpyHostToDevice, s.st));
-        } else {
-            d_rgb = s.h_rgb_pin;
-            d_out = s.h_out_pin;
-        }
-    } else {
-        HIPCHK(hipMemcpyAsync(s.d_rgb_stage, rgb, N * 3, hipMemcpyHostToDevice, s.st));
-    }
+    HIPCHK(hipMemcpyAsync(s.d_rgb_stage, rgb, N * 3, hipMemcpyHostToDevice, s.st));
     const double t1 = knobs().host_timing ? now_us() : 0.0;
     s.launch_timing = e->launch_timing;
     rc = group_begin(e, s, p, H, W, K, 1, &d_rgb, &clusters, &d_out);
-    if (rc) { (void)hipStreamSynchronize(s.st); return rc; }
     const double t2 = knobs().host_timing ? now_us() : 0.0;
-    rc = group_finish(e, s);
-    if (rc) return rc;
-    const double t3 = knobs().host_timing ? now_us() : 0.0;
-    if (pinned_path) {
-        if (dma) {
-            HIPCHK(hipMemcpyAsync(s.h_out_pin, s.d_out_stage, N * 2, hipMemcpyDeviceToHost, s.st));
-            HIPCHK(hipStreamSynchronize(s.st));
-        }
-        copy_pool_run(engine_copy_pool(e), labels, s.h_out_pin, N * 2);
-        if (knobs().host_timing)
-            fprintf(stderr, "[fslic host] iterate: frame in %.1f us, group begin %.1f, group finish (wait + write-back) %.1f, labels out %.1f (device %.1f us)\n",
-                    t1 - t0, t2 - t1, t3 - t2, now_us() - t3, s.total_ms * 1e3);
-    } else {
-        HIPCHK(hipMemcpyAsync(labels, s.d_out_stage, N * 2, hipMemcpyDeviceToHost, s.st));
-        HIPCHK(hipStreamSynchronize(s.st));
+    if (rc == FSLIC_OK) rc = group_finish(e, s);
+    if (rc != FSLIC_OK) {            // a failure after a partial enqueue: nothing may still run on the slot's stage buffers when the slot is released
+        const std::string msg = last_error();
+        (void)hipStreamSynchronize(s.st);
+        (void)hipGetLastError();
+        set_last_error(msg);
+        return rc;
     }
+    const double t3 = knobs().host_timing ? now_us() : 0.0;
+    HIPCHK(hipMemcpyAsync(labels, s.d_out_stage, N * 2, hipMemcpyDeviceToHost, s.st));
+    HIPCHK(hipStreamSynchronize(s.st));
+    if (knobs().host_timing)
+        fprintf(stderr, "[fslic host] iterate: frame in %.1f us, group begin %.1f, group finish (wait + write-back) %.1f, labels out %.1f (device %.1f us)\n",
+                t1 - t0, t2 - t1, t3 - t2, now_us() - t3, s.total_ms * 1e3);
     set_thread_timing_report(make_timing_report(s));
     return FSLIC_OK;
 }
@@ -205,9 +166,7 @@ int fslic_hip_iterate_batch(fslic_engine* e, const fslic_params* p, int H, int W
         Slot& s = e->slots[pd.slot];
         int r = group_finish(e, s);
         if (r) return r;
-        if (!device_ptrs && host_staging_enabled()) {
-            for (int i = 0; i < pd.n; i++) copy_pool_run(engine_copy_pool(e), labels[pd.first + i], s.h_out_pin + (size_t)i * N, N * 2);
-        } else if (!device_ptrs) {
+        if (!device_ptrs) {
             for (int i = 0; i < pd.n; i++)
                 HIPCHK(hipMemcpyAsync(labels[pd.first + i], s.at(s.d_out_stage, i), N * 2, hipMemcpyDeviceToHost, s.st));
             HIPCHK(hipStreamSynchronize(s.st));
@@ -241,16 +200,7 @@ int fslic_hip_iterate_batch(fslic_engine* e, const fslic_params* p, int H, int W
         Slot& s = e->slots[si];
         const uint8_t* d_rgb[kMaxGroup];
         uint16_t* d_out[kMaxGroup];
-        if (!device_ptrs && host_staging_enabled()) {
-            rc = ensure_prepared(e, s, H, W, K, S, n);
-            if (rc == FSLIC_OK) rc = ensure_pinned_staging(s, N, n);
-            if (rc) return bail(rc);
-            for (int i = 0; i < n; i++) {
-                copy_pool_run(engine_copy_pool(e), s.h_rgb_pin + (size_t)i * N * 3, rgb[first + i], N * 3);
-                d_rgb[i] = s.h_rgb_pin + (size_t)i * N * 3;
-                d_out[i] = s.h_out_pin + (size_t)i * N;
-            }
-        } else if (!device_ptrs) {
+        if (!device_ptrs) {
             rc = ensure_prepared(e, s, H, W, K, S, n);
             if (rc) return bail(rc);
             for (int i = 0; i < n; i++) {
@@ -345,7 +295,7 @@ int fslic_hip_last_host_topk_frames(fslic_engine* e, int slot) {
 
 int fslic_hip_separate_pass_redos(fslic_engine* e, int slot) {
     if (!e || slot < 0 || slot >= (int)e->slots.size()) return -1;
-    return e->slots[slot].n_separate_redo;
+    return __atomic_load_n(&e->slots[slot].n_separate_redo, __ATOMIC_RELAXED);
 }
 
 #ifdef FSLIC_LAB

@@ -97,13 +97,6 @@ struct Slot {
     uint32_t* d_yx_alt[2] = {nullptr, nullptr};   // the cluster pass's alternating position buffers (frame 0)
     uint8_t* d_rgb_stage = nullptr;
     uint16_t* d_out_stage = nullptr;
-    // host-memory entry points (fslic_hip_iterate, the reference's calling pattern): pinned, device-accessible staging of the
-    // caller's frames and label maps.  The LAB kernel reads the frame from it and the relabel kernel writes the label map into
-    // it over PCIe (no copy command, no separate D2H wait); the caller's pageable buffers are moved by the engine's copy pool.
-    uint8_t* h_rgb_pin = nullptr;    // pin_frames * pin_px * 3 bytes
-    uint16_t* h_out_pin = nullptr;   // pin_frames * pin_px * 2 bytes
-    size_t pin_px = 0;
-    int pin_frames = 0;
     int32_t* d_keep_leader = nullptr;
     uint16_t* d_keep_label = nullptr;
     // per-frame caller pointers of the current group: [0, kMaxGroup) inputs, [kMaxGroup, 2*kMaxGroup) outputs
@@ -159,7 +152,7 @@ struct Slot {
     float total_ms = 0, fa_ms = 0, lab_ms = 0, loop_ms = 0, cca_ms = 0;
     int last_path = 0;
     int n_host_topk = 0;             // frames of the last group whose top-K step ran on the host
-    int n_separate_redo = 0;         // frames (since the slot was created) redone with the separate cluster pass because of a stale pixel
+    int n_separate_redo = 0;         // (accessed with __atomic builtins) frames (since the slot was created) redone with the separate cluster pass because of a stale pixel
     bool have_pre = false;
     // Ownership (guarded by fslic_engine::mu): `busy` while a synchronous call or a stage utility runs on the slot,
     // `pending` from the submission of an asynchronous group until it has been collected.
@@ -213,7 +206,6 @@ struct Slot {
 
 }  // namespace fslic
 
-namespace fslic { struct CopyPool; }
 struct fslic_engine {
     int device = 0;
     int group_size = 8;              // frames per launch group of iterate_batch (FSLIC_GROUP)
@@ -247,7 +239,7 @@ struct fslic_engine {
     int pipe_batch_frames = 0;       // 0: one submission per group; otherwise the most frames a group may gather
     bool pipe_gathering = false;     // a slot thread is waiting briefly for a companion of the submission it took
     std::atomic<int> reserve_frames{0};   // arenas are carved for at least this many frames per group
-    fslic::CopyPool* copy_pool = nullptr;    // created on first use (host-memory entry points only)
+    int sync_waiters = 0;                    // (mu) synchronous callers waiting for a slot: the slot threads leave the submit queue alone meanwhile
     std::atomic<int> lab_force_generic{0};   // testing aid (fslic_hip_lab_force_generic): the brute-force gather kernels instead of the tiled ones
 };
 
@@ -256,14 +248,6 @@ struct fslic_engine {
 extern "C" int fslic_hip_lab_force_generic(fslic_engine* e, int on);
 
 namespace fslic {
-
-// ---- copypool.cpp ----
-// memcpy between the caller's pageable buffers and the slots' pinned staging, split over the engine's helper threads (one
-// thread moves 10 - 15 GB/s: 2.8 MB of a 1280x720 frame would cost as long as the whole device-side iterate()).
-struct CopyPool;
-CopyPool* copy_pool_create(int helpers);
-void copy_pool_destroy(CopyPool* p);
-void copy_pool_run(CopyPool* p, void* dst, const void* src, size_t bytes);      // returns when every byte has been copied; the caller takes part
 
 // ---- tables.cpp ----
 int configure_spatial(Slot& s, int S, const fslic_params* p);
@@ -275,7 +259,6 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G);
 int ensure_prepared(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G);
 int prepare_lsc(Slot& s, int H, int W, int K, int S, int G, float compactness);
 int ensure_cand_capacity(Slot& s, size_t M);
-int ensure_pinned_staging(Slot& s, size_t px, int frames);
 
 // ---- group.cpp ----
 int validate(const fslic_params* p, int H, int W, int K, int& S);

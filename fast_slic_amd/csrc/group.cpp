@@ -19,6 +19,8 @@ double now_us() {
 
 int validate(const fslic_params* p, int H, int W, int K, int& S) {
     if (!p) return fail(FSLIC_E_INVALID, "params is NULL");
+    static_assert(sizeof(fslic_params) == 64 && offsetof(fslic_params, abi) == 40 && offsetof(fslic_params, variant) == 44, "fslic_params layout (include/fslic_hip.h)");
+    if (p->abi != FSLIC_PARAMS_ABI) return fail(FSLIC_E_INVALID, "fslic_params.abi != FSLIC_PARAMS_ABI: the caller was built against another layout of the struct (include/fslic_hip.h)");
     if (H <= 0 || W <= 0) return fail(FSLIC_E_INVALID, "H and W must be positive");
     if (H > 32767 || W > 32767) return fail(FSLIC_E_INVALID, "H and W must fit int16 (src/context.cpp:262)");
     if ((long long)H * W >= (1ll << 31)) return fail(FSLIC_E_INVALID, "H*W must fit int32");
@@ -287,7 +289,13 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     // vector work a 1600-thread cluster pass does once.  So: fused where a launch does not fill the chip (latency-bound: the
     // reference's own one-frame-per-call pattern), separate where it does.  FSLIC_FUSEBIN=0 / 2: never / always.
     const int assign_blocks = n * ((s.W + kTileW - 1) / kTileW) * (((s.H + stride - 1) / stride + 31) / 32);
+#if defined(FSLIC_LAB) && FSLIC_LAB == 3
+    // lab build 3 turns st_stream into plain stores; the fused cluster pass hands partial sums from block to block through
+    // written-through (sc1) stores and agent-scope loads and would read stale lines of another XCD's L2: never fused there
+    const bool fuse_wanted = false;
+#else
     const bool fuse_wanted = knobs().fuse_bin == 2 || (knobs().fuse_bin == 1 && assign_blocks <= 640);
+#endif
     const bool fusebin = fuse_wanted && !separate_cluster_pass && !lsc && !rd && !generic && !pre && assign_fuses_cluster_pass(f, stride);
     int full_obuf = -1;
     for (int it = 0; fusebin && it < p->max_iter; it++) {
@@ -513,7 +521,7 @@ int group_finish(fslic_engine* e, Slot& s) {
                 if (s.h_misc[16 * (size_t)i + 2] != 0) return fail(FSLIC_E_INTERNAL, "generic path reported a candidate overflow");
                 s.last_path = 1;
             } else {
-                s.n_separate_redo++;
+                __atomic_fetch_add(&s.n_separate_redo, 1, __ATOMIC_RELAXED);      // (read by fslic_hip_separate_pass_redos without the engine lock)
             }
         }
         if (!s.generic && s.h_misc[16 * (size_t)i + 2] != 0) return fail(FSLIC_E_INTERNAL, "a redone frame still carries a kernel flag");

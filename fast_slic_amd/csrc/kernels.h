@@ -5,6 +5,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef FSLIC_EXP
+#define FSLIC_EXP 0      // experiment builds: make VAR=<name> DEFS=-DFSLIC_EXP=<bits> (assign.hip)
+#endif
+
 namespace fslic {
 
 // ---- compile-time geometry ---------------------------------------------------------------

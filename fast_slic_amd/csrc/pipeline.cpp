@@ -49,32 +49,50 @@ namespace {
 bool self_collecting(const Slot& s) { return s.pending && s.async && s.async->from_queue; }
 }  // namespace
 
+namespace {
+// wakes the slot threads when a caller that had been counted in sync_waiters leaves (declared BEFORE the lock: runs after it is released)
+struct WakeWorkers {
+    fslic_engine* e; bool armed = false;
+    explicit WakeWorkers(fslic_engine* e_) : e(e_) {}
+    ~WakeWorkers() { if (armed) e->cv_work.notify_all(); }
+};
+}  // namespace
+
 int acquire_slot(fslic_engine* e, int want, int& slot) {
+    WakeWorkers wake(e);
     std::unique_lock<std::mutex> lk(e->mu);
     const int ns = (int)e->slots.size();
     if (want >= ns) return fail(FSLIC_E_INVALID, "slot out of range");
+    // A caller that has to wait is counted (sync_waiters): while the count is non-zero the slot threads leave the submit queue alone,
+    // so the slot that frees next goes to the waiting caller instead of straight back to the queue (under a continuous
+    // pipeline_submit load a synchronous call could otherwise wait indefinitely).
+    auto got = [&](int i) { e->slots[i].busy = true; slot = i; return FSLIC_OK; };
     for (;;) {
         // A slot serving the submit / drain queue collects its group itself: it is busy for a while, not lost.  Only a
         // group submitted by slot number (collected by the caller's fslic_hip_wait_group) is a reason to refuse.
         if (want >= 0) {
             Slot& s = e->slots[want];
             if (s.pending && !self_collecting(s)) return fail(FSLIC_E_INVALID, "the slot still owns an unfinished group (call fslic_hip_wait_group first)");
-            if (!s.pending && !s.busy) { s.busy = true; slot = want; return FSLIC_OK; }
+            if (!s.pending && !s.busy) return got(want);
         } else {
             bool any_usable = false;
             for (int i = 0; i < ns; i++) {
                 Slot& s = e->slots[i];
                 if (s.pending) { any_usable = any_usable || self_collecting(s); continue; }
                 any_usable = true;
-                if (!s.busy) { s.busy = true; slot = i; return FSLIC_OK; }
+                if (!s.busy) return got(i);
             }
             if (!any_usable) return fail(FSLIC_E_INVALID, "every slot owns an unfinished asynchronous group");
         }
+        e->sync_waiters++;
         e->cv.wait(lk);
+        e->sync_waiters--;
+        wake.armed = true;
     }
 }
 
 int acquire_all_slots(fslic_engine* e) {
+    WakeWorkers wake(e);
     std::unique_lock<std::mutex> lk(e->mu);
     for (;;) {
         bool free_all = true;
@@ -83,7 +101,10 @@ int acquire_all_slots(fslic_engine* e) {
             free_all = free_all && !s.busy && !s.pending;
         }
         if (free_all) break;
+        e->sync_waiters++;
         e->cv.wait(lk);
+        e->sync_waiters--;
+        wake.armed = true;
     }
     for (Slot& s : e->slots) s.busy = true;
     return FSLIC_OK;
@@ -130,7 +151,7 @@ void slot_worker(fslic_engine* e, Slot* s) {
         bool took = false;
         {
             std::unique_lock<std::mutex> lk(e->mu);
-            e->cv_work.wait(lk, [&] { return a.has_job || a.quit || (!e->pipe_q.empty() && !e->pipe_gathering && !s->busy && !s->pending); });
+            e->cv_work.wait(lk, [&] { return a.has_job || a.quit || (!e->pipe_q.empty() && !e->pipe_gathering && !s->busy && !s->pending && e->sync_waiters == 0); });
             if (a.quit) return;
             if (!a.has_job) {
                 // the submit queue's head, plus -- with batching on -- the submissions behind it that ask for the same work,

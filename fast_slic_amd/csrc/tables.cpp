@@ -183,12 +183,12 @@ int configure_spatial(Slot& s, int S, const fslic_params* p) {
     f.tabs = s.d_tab + kTabMaxBytes / 2; f.tabs_words = 0; f.tabs_dyoff = 0;
     if (manhattan && tab2d_bytes > vtab_min && S >= 8 && max_sp + 765u < 1024u) {
         // Row-vector V tables (the Manhattan patch depends on |di| + |dj| only): one for the full pass (stride 1, up to
-        // 16 rows per wavefront) and one for the subsampled passes (stride_it, up to 16 rows per wavefront).
+        // 32 rows per wavefront) and one for the subsampled passes (stride_it, up to 16 rows per wavefront).
         const int xout = 2 * S + 1;
         auto build = [&](int stride, int rows, uint16_t* dst, int& words, int& cc) -> bool {
             const int pad = (rows - 1) * stride;
             const int Cc = xout + S + pad;
-            const int tlen = 2 * Cc + 1 + 8 * stride;            // entries that can be addressed: t0 + 8*stride for the upper half
+            const int tlen = 2 * Cc + 1 + (rows - 8) * stride;   // entries that can be addressed: t0 + 8*stride for every further eight rows
             if ((size_t)tlen * 16 > kTabMaxBytes) return false;
             auto V = [&](int t) -> uint16_t {
                 const int d = std::abs(t - Cc);
@@ -203,7 +203,7 @@ int configure_spatial(Slot& s, int S, const fslic_params* p) {
         };
         int w1 = 0, c1 = 0, ws = 0, cs = 0;
         const int st3 = std::min(stride_it, 3);
-        if (build(1, 16, s.h_tab, w1, c1) && build(st3, 16, s.h_tab + kTabMaxBytes / 2, ws, cs)) {
+        if (build(1, 32, s.h_tab, w1, c1) && build(st3, 16, s.h_tab + kTabMaxBytes / 2, ws, cs)) {
             f.tab_words = w1; f.tab_dyoff = c1; f.tab_vmode = 1; f.tab_xout = xout;
             f.tabs_words = ws; f.tabs_dyoff = cs;
             tiled_ok = true;

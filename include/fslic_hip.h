@@ -60,10 +60,14 @@ typedef struct fslic_params {
     float preemptive_thres;        /* src/context.h:33; ignored while preemptive == 0 */
     int32_t num_threads;           /* src/context.h:27; ignored on the GPU */
     int32_t debug_mode;            /* src/context.h:36; ignored (no recorder report) */
+    int32_t abi;                   /* must be FSLIC_PARAMS_ABI: the layout of this struct has changed between library versions (a testing
+                                    * flag lived in this slot in 0.2 and `variant` in the header of 0.2+); a caller built against
+                                    * another layout is refused with FSLIC_E_INVALID instead of being misread */
     int32_t variant;               /* FSLIC_VARIANT_SLIC: Context (src/context.h:127); FSLIC_VARIANT_LSC: ContextLSC
                                     * (src/lsc.h:6-26), picked by cfast_slic.pyx:199-216 from real_dist_type */
-    int32_t reserved[5];
+    int32_t reserved[4];           /* must be 0 */
 } fslic_params;
+#define FSLIC_PARAMS_ABI 0x46533033  /* "FS03" */
 
 enum {
     FSLIC_VARIANT_SLIC = 0,          /* Context, uint16 distances */
@@ -226,7 +230,10 @@ int fslic_hip_last_host_topk_frames(fslic_engine* e, int slot);
 /* Frames redone on `slot` since it was created because a visited pixel that no cluster window covered kept its label
  * (src/context.cpp:138-145 resets the assignment plane once per call, not per iteration) while the cluster pass
  * (src/context.cpp:356-373) ran fused into the assign kernel: such a frame is recomputed with the separate cluster pass,
- * the results are those of the reference either way.  Testing / diagnostics aid. */
+ * the results are those of the reference either way.  Cost: such a frame is computed TWICE (about 2 x the latency of that call);
+ * it only arises in groups small enough to take the fused cluster pass (one or two 1280x720 frames per call), with warm starts whose
+ * centres have drifted far enough apart to leave visited pixels uncovered.  A caller that sees this counter grow on a stream can set
+ * FSLIC_FUSEBIN=0 (the separate cluster pass everywhere: +8 % latency per one-frame call, no redo).  Diagnostics aid. */
 int fslic_hip_separate_pass_redos(fslic_engine* e, int slot);
 
 const char* fslic_hip_last_error(void);

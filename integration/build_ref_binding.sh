@@ -9,10 +9,17 @@ set -e
 HERE=$(cd "$(dirname "$0")" && pwd)
 ROOT=$(dirname "$HERE")
 REF=${REF:-/root/reference}
-if [ ! -d "$REF" ]; then echo "[integration] $REF absent: keeping the prebuilt integration/_build (if any)"; exit 0; fi
 B=$HERE/_build
 STAMP=$B/.stamp
 NEW=$(cat "$HERE/hip_arch.patch" "$ROOT/include/fslic_hip.h" "$0" | sha1sum | cut -c1-16)
+if [ ! -d "$REF" ]; then
+  # no reference here (the GPU box): the prebuilt module is used only if it was built from THIS header and patch -- a module built
+  # against another layout of fslic_params must not meet the new library
+  if [ -f "$STAMP" ] && [ "$(cat $STAMP)" = "$NEW" ]; then echo "[integration] $REF absent: keeping the prebuilt integration/_build"
+  elif [ -d "$B" ]; then echo "[integration] $REF absent and integration/_build is stale (header / patch changed since it was built): removed"; rm -rf "$B"
+  fi
+  exit 0
+fi
 if [ -f "$STAMP" ] && [ "$(cat $STAMP)" = "$NEW" ] && ls $B/cfast_slic*.so >/dev/null 2>&1 && [ -f $B/fast_slic/hip.pyc ]; then exit 0; fi
 rm -rf "$B"; mkdir -p "$B"
 T=$(mktemp -d /tmp/fslic_refbuild.XXXXXX)

@@ -37,6 +37,20 @@ def test_cluster_abi_is_32_bytes_with_reference_offsets():
     assert offs == dict(y=0, x=4, r=8, g=12, b=16, a=20, number=24, is_active=26, is_updatable=27, num_members=28)
 
 
+def test_params_struct_layout_and_abi_word():
+    """include/fslic_hip.h: 64 bytes, `abi` where a testing flag (0.2) and later `variant` used to live, `variant` behind it; the
+    ctypes mirror fills the ABI word the header defines (a caller built against another layout is refused by validate())."""
+    import ctypes as C
+    P = B.Params
+    assert C.sizeof(P) == 64
+    offs = {n: getattr(P, n).offset for n, _ in P._fields_}
+    assert offs["max_iter"] == 0 and offs["debug_mode"] == 36 and offs["abi"] == 40 and offs["variant"] == 44 and offs["reserved"] == 48
+    hdr = open(os.path.join(ROOT, "include", "fslic_hip.h")).read()
+    assert int(re.search(r"#define FSLIC_PARAMS_ABI (0x[0-9a-fA-F]+)", hdr).group(1), 16) == B.PARAMS_ABI
+    assert B.make_params(10, 10.0, 0.25, 3).abi == B.PARAMS_ABI
+    assert b"0.3" in B.load_library().fslic_hip_version()
+
+
 @pytest.mark.parametrize("H,W,K", [(480, 640, 200), (2160, 3840, 6000), (37, 53, 7), (10, 10, 100), (5, 300, 17)])
 def test_initialize_clusters_matches_oracle(H, W, K):
     img = variant("A", H, W)
@@ -78,3 +92,14 @@ def test_product_never_imports_the_oracle():
             if fn.endswith((".py", ".cpp", ".hip", ".h")):
                 text = open(os.path.join(dirpath, fn)).read()
                 assert "oracle" not in text.replace("no CPU fallback", ""), os.path.join(dirpath, fn)
+
+
+def test_the_library_reads_no_untested_switch():
+    """grep getenv over the library's sources == the switches tests/test_gpu_pipeline.py::test_parity_under_every_switch_the_library_reads (and FSLIC_FUSEBIN=2 next to it) runs."""
+    import glob
+    root = ROOT
+    found = set()
+    for fn in glob.glob(os.path.join(root, "fast_slic_amd", "csrc", "*")):
+        if os.path.isfile(fn):
+            found |= set(re.findall(r'getenv\("(\w+)"\)', open(fn).read()))
+    assert found == {"FSLIC_FUSEBIN", "FSLIC_GROUP", "FSLIC_GRAPH", "FSLIC_POISON", "FSLIC_HOST_TIMING"}, found

@@ -2,6 +2,7 @@
 (fast_slic_amd._binding -> libfslic_hip.so) and is compared bit-for-bit with the plain-C oracle on the
 same seeded inputs, and with the committed reference fixtures / digests."""
 import numpy as np
+from ctypes import byref as C_byref
 import pytest
 
 from oracle import oracle as orc
@@ -220,6 +221,17 @@ def test_errors_surface_like_the_reference():
         m.iterate(np.zeros([10, 10, 3], np.uint8), 10, 10.0, 0.25, 3)   # not initialised, pyx:151-152
     out = Slic(num_components=10, preemptive=True).iterate(np.zeros([64, 64, 3], np.uint8))      # preemptive mode exists (test_gpu_preemptive.py)
     assert out.shape == (64, 64)
+    # a caller built against another layout of fslic_params (no / another ABI word) is refused, not misread as "variant 0"
+    from fast_slic_amd import _binding as B
+    bad = B.make_params(10, 10.0, 0.25, 3, variant=B.VARIANT_LSC)
+    bad.abi = B.VARIANT_LSC               # what a binary built against the 0.2+ header stores at this offset
+    img = np.zeros([64, 64, 3], np.uint8)
+    cl = np.zeros(10, B.CLUSTER_DTYPE)
+    B.load_library().fslic_hip_initialize_clusters(64, 64, 10, img.ctypes.data, cl.ctypes.data)
+    lab = np.zeros((64, 64), np.uint16)
+    eng = B.default_engine()
+    rc = B.load_library().fslic_hip_iterate(eng._h, C_byref(bad), 64, 64, 10, img.ctypes.data, cl.ctypes.data, lab.ctypes.data)
+    assert rc == 1 and b"abi" in B.load_library().fslic_hip_last_error()
 
 
 # ---- device-resident and batched entry points ------------------------------------------------------

@@ -370,3 +370,24 @@ def test_parity_with_the_cluster_pass_always_fused():
                        cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
     tail = r.stdout.decode()[-2500:]
     assert r.returncode == 0 and " passed" in tail, tail
+
+
+@pytest.mark.parametrize("switch", ["FSLIC_FUSEBIN=0", "FSLIC_GROUP=1", "FSLIC_GROUP=16", "FSLIC_GRAPH=0", "FSLIC_POISON=1", "FSLIC_HOST_TIMING=1"])
+def test_parity_under_every_switch_the_library_reads(switch):
+    """Every environment switch of the shipping library (grep getenv fast_slic_amd/csrc: FSLIC_FUSEBIN, FSLIC_GROUP, FSLIC_GRAPH,
+    FSLIC_POISON, FSLIC_HOST_TIMING; read once when the library is loaded, hence a separate interpreter) against the oracle: the
+    BASELINE sizes (C2, C3, C3b), the batch entry points FSLIC_GROUP cuts into groups (64 frames of C4, device-resident and host
+    batches), a replayed pipeline, and the overflow / redo paths on a poisoned arena."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    name, value = switch.split("=")
+    env = dict(os.environ, **{name: value})
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"),
+                        os.path.join(root, "tests", "test_gpu_pipeline.py"), "-k",
+                        "baseline_sizes or config4 or group_of_eight_frames or device_resident_and_batch or poisoned or pipeline_of_replayed or stale_pixels"],
+                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
+    tail = r.stdout.decode()[-2500:]
+    assert r.returncode == 0 and " passed" in tail, tail
+
