@@ -482,6 +482,9 @@ def main():
     ap.add_argument("--no-4k", action="store_true", help="skip the 4K, K=6000, LSC and end-to-end sub-objects")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--timed-only", action="store_true", help="the timed region and nothing else (profiling runs: no roofline / parity / baseline legs)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="every rank of an N > 1 launch uses GPU 0: the host side of an N-rank launch (submit loops, slot threads, pinned "
+                         "blocks, rendezvous) measured on a one-GPU box; the line then says so and is NOT a scaling point")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / timing reduction only (no GPU work): CPU test of the N>1 path")
     args = ap.parse_args()
     if args.steps is None:
@@ -495,8 +498,8 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # one HIP context per rank: the rank's GPU becomes the only visible device before anything initialises HIP
-    dev = batch.bind_rank_to_its_gpu(local_rank) if (world > 1 and not args.dry_run) else local_rank
-    pinned = batch.pin_to_gpu_numa_node(local_rank, world, device_index=dev) if not args.dry_run else None
+    dev = batch.bind_rank_to_its_gpu(local_rank, share_device=args.share_device) if (world > 1 and not args.dry_run) else local_rank
+    pinned = batch.pin_to_gpu_numa_node(0 if args.share_device else local_rank, world, device_index=dev) if not args.dry_run else None
     dist = batch.init_process_group("gloo", rank, world)     # barrier + timing reduction only; no data-path collective
 
     def barrier(sync=None):
@@ -568,14 +571,17 @@ def main():
     gc.disable()
     barrier(sync)
     t0 = time.perf_counter()
+    cpu0 = time.process_time()                               # CPU time of this rank's process: its submit loop + slot threads
     first = n_setup + args.warmup
     for j in range(args.steps):
         wl.submit(first + j)
     totals = eng.pipeline_drain()                            # every step of the timed region is complete here
     mine = time.perf_counter() - t0                          # this rank's own clock over its steps (drained, synchronised)
+    cpu_mine = time.process_time() - cpu0
     barrier(sync)
     elapsed = batch.max_over_ranks(time.perf_counter() - t0, dist)
     per_rank = batch.gather_over_ranks(mine, dist, world)
+    per_rank_cpu = batch.gather_over_ranks(cpu_mine, dist, world)
     gc.enable()
 
     if rank == 0:
@@ -598,7 +604,12 @@ def main():
         }
         if strong:
             out["config"]["workload"] = "%s: fixed batch of %d frames per step over %d GPU(s), %d per GPU" % (cfg["name"].split(",")[0] + ", K=%d, 10 iters" % K, args.batch, world, fpg)
+        out["host_cpu_ms_per_step"] = {"per_rank": [round(c / args.steps * 1e3, 4) for c in per_rank_cpu],
+                                       "what": "process CPU time (submit loop + slot threads) of each rank over the timed region / steps"}
         if world > 1:        # each rank's own time over ITS steps (before the closing barrier) and its own rate
+            out["legs_skipped"] = ["roofline_4k", "c3_k6000", "lsc_c5", "single_frame", "end_to_end", "cpu_baseline"]      # printed by the N = 1 line only
+            if args.share_device:
+                out["config"]["share_device"] = "all %d ranks on GPU 0: a host-side load test, not a scaling point" % world
             out["per_rank_ms"] = {"min": round(min(per_rank) * 1e3, 3), "max": round(max(per_rank) * 1e3, 3), "all": [round(t * 1e3, 3) for t in per_rank]}
             out["per_rank_megapixels_per_sec"] = [round(float(H) * W * fpg * args.steps / t / 1e6, 1) for t in per_rank]
     if rank == 0 and args.timed_only:

@@ -1,4 +1,21 @@
-"""Python facade with the reference's surface (fast_slic/base_slic.py:3-59) on top of the HIP engine."""
+"""Python facade with the reference's surface (fast_slic/base_slic.py:3-59) on top of the HIP engine.
+
+The `BaseSlic` class below keeps the reference's constructor, attributes and `iterate()` body as they are (north_star: "keeping
+the fast_slic.Slic.iterate() Python surface"; SURVEY.md section 2 #1 "keep verbatim"), so that code written against
+`fast_slic.Slic` runs unchanged.  That part derives from fast_slic/base_slic.py of Algy/fast-slic:
+
+    MIT License -- Copyright (c) 2019 Alchan Kim
+
+    Permission is hereby granted, free of charge, to any person obtaining a copy of this software and associated documentation
+    files (the "Software"), to deal in the Software without restriction, including without limitation the rights to use, copy,
+    modify, merge, publish, distribute, sublicense, and/or sell copies of the Software, and to permit persons to whom the Software
+    is furnished to do so, subject to the following conditions: The above copyright notice and this permission notice shall be
+    included in all copies or substantial portions of the Software.  THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY
+    KIND, EXPRESS OR IMPLIED, INCLUDING BUT NOT LIMITED TO THE WARRANTIES OF MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND
+    NONINFRINGEMENT.  IN NO EVENT SHALL THE AUTHORS OR COPYRIGHT HOLDERS BE LIABLE FOR ANY CLAIM, DAMAGES OR OTHER LIABILITY,
+    WHETHER IN AN ACTION OF CONTRACT, TORT OR OTHERWISE, ARISING FROM, OUT OF OR IN CONNECTION WITH THE SOFTWARE OR THE USE OR
+    OTHER DEALINGS IN THE SOFTWARE.
+"""
 from ._binding import SlicModel, ARCH_NAME
 
 

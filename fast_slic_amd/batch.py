@@ -76,10 +76,14 @@ def gather_over_ranks(value, dist, world):
     return [float(t.item()) for t in out]
 
 
-def bind_rank_to_its_gpu(local_rank):
+def bind_rank_to_its_gpu(local_rank, share_device=False):
     """Before HIP is initialised in this process: make the rank's GPU the ONLY visible device (it then is device 0), so that a
     rank creates one context instead of one per GPU of the node.  An existing HIP_VISIBLE_DEVICES list is narrowed to its
-    local_rank-th entry.  Returns the device index to use afterwards (always 0)."""
+    local_rank-th entry.  Returns the device index to use afterwards (always 0).
+    share_device: every rank takes the FIRST visible GPU (bench.py --share-device: the host side of an N-rank launch -- N submit
+    loops, N x slots slot threads, N rendezvous members -- exercised on a box that has one GPU)."""
+    if share_device:
+        local_rank = 0
     cur = os.environ.get("HIP_VISIBLE_DEVICES")
     if cur:
         ids = [x for x in cur.split(",") if x != ""]

@@ -350,9 +350,6 @@ typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 // (Experiment builds -- make VAR=<name> DEFS=-DFSLIC_EXP=<bits>, kernels.h -- carry A/B forms of this kernel while they are being
 // measured, scripts/gpu_exp.sh; what round 4 measured is in profiles/r04_assign_experiments.txt.)
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release of GLOBAL memory too, which on
-// this target is s_waitcnt vmcnt(0): every pixel load (prologue) or label store (epilogue) still in flight would have to land first.
-static __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 constexpr int kRawBuffer = 0x00020000;     // 4th dword of a raw (stride 0) buffer descriptor on gfx9-family targets: DATA_FORMAT = 32
 constexpr int kAuxSc1 = 16;                // cache policy bit of the buffer builtins: sc1 (write through at agent scope)
 
@@ -727,7 +724,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
     for (int q = 0; q < R / 2; ++q) best[q] = (us2){0xFFFF, 0xFFFF};
     const uint32_t nrpad = (uint32_t)f.tab_nrpad;
     const int dyoff = f.tab_dyoff;
-    if (VT) {
+    if constexpr (VT) {
         const int Cc = f.tab_dyoff;                 // centre index of the V table
         const uint32_t xout = (uint32_t)f.tab_xout;
         constexpr int BIAS = 32768;                 // makes the numerators of the row-range divisions positive
@@ -1118,6 +1115,8 @@ static void launch_assign_bin_t(const FrameDev& f_, int nframes, int rem, int Hv
     const size_t lds2 = ((size_t)f.tab_words * sizeof(uint32_t) + 1023) / 1024 * 1024;
     if constexpr (R == 16) {
         launch((k_assign_bin_w6<R, STRIDE, true>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
+    } else if constexpr (R == 4) {
+        launch((k_assign_bin<R, STRIDE, false>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));      // (2-D table only)
     } else {
         if (f.tab_vmode) launch((k_assign_bin<R, STRIDE, true>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
         else launch((k_assign_bin<R, STRIDE, false>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
@@ -1135,8 +1134,15 @@ void launch_assign_fused_bin(const FrameDev& f_, int nframes, int rem, int strid
     const int Hv = (f.H - rem + stride - 1) / stride;
     if (Hv <= 0) return;
     const int tiles_x = (f.W + kTileW - 1) / kTileW;
-    const bool r16 = f.tab_vmode && nframes * tiles_x * ((Hv + kWavesPerBlock * 8 - 1) / (kWavesPerBlock * 8)) > 3072;      // as launch_assign
-    if (r16) {
+    const int blocks8 = nframes * tiles_x * ((Hv + kWavesPerBlock * 8 - 1) / (kWavesPerBlock * 8));
+    const bool r16 = f.tab_vmode && blocks8 > 3072;      // as launch_assign
+    // Launches that leave most of the chip idle even with 8-row wavefronts (one or two 1280x720 frames: 160 blocks each on 256
+    // CUs): 4 rows per wavefront.  A wavefront alone on its SIMD issues a dependent instruction every 8 - 10 clocks, so a
+    // block's life there is its instruction chain; half the rows halve the argmin, label and sum phases of that chain.
+    const bool r4 = !f.tab_vmode && stride == 3 && blocks8 <= 384;      // (measured: one 1280x720 frame per group 179.5 -> 175.7 us, profiles/r04_assign_experiments.txt)
+    if (r4) {
+        launch_assign_bin_t<4, 3>(f, nframes, rem, Hv, st);
+    } else if (r16) {
         if (stride == 1) launch_assign_bin_t<16, 1>(f, nframes, rem, Hv, st);
         else if (stride == 2) launch_assign_bin_t<16, 2>(f, nframes, rem, Hv, st);
         else launch_assign_bin_t<16, 3>(f, nframes, rem, Hv, st);

@@ -243,6 +243,58 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cc
     // nodes of several rows share a store (a lane holds at most one pending node; a row whose node would land on an occupied
     // lane flushes first), and the sixteen edge words of the wavefront's rows are collected in LDS and leave through sixteen lanes
     // of one store (two-lane stores row by row were measured: 31.2 instead of 30.8 us per 8 x 1280x720).
+    {
+    // Second form of the output phase (round 4; measured against the first as an experiment build, profiles/r04_cca_local_output.txt): the wavefront's node records are STAGED in LDS, one 16-byte store per row under the mask of the
+    // row's root lanes at the record's position pos[i] (positions are dense by construction: ballot ranks), and leave through
+    // coalesced stores of whole wavefronts afterwards -- no "pending node per lane" state, no flush branch per row, no merging
+    // selects.  The staging area is the wavefront's own strip of s_area (8 rows x 64 words = 128 records; its areas are read
+    // into registers first; no other wavefront touches the strip after the barrier above).  A wavefront with more than 128 nodes
+    // (noise: nearly every pixel its own component) takes the first form below.
+    if (wcount <= 128u) {
+        uint32_t ar[RW];
+#pragma unroll
+        for (int i = 0; i < RW; ++i) ar[i] = lds_ld(s_area + ((ly0 + i) * T + lane));
+        wave_lds_sync();
+        uint4* const stage = reinterpret_cast<uint4*>(s_area + ly0 * T);
+        const bool edge_lane = lane == 0 || lane == T - 1;
+        uint32_t* const s_edge = &s_last[wave][lane ? 1 : 0];
+        // (the frame's plane pointer is wave-uniform but lives in vector registers after select(): stated, or the buffer store is
+        // wrapped in a waterfall loop over "different" descriptors)
+        const unsigned long long lidp = (unsigned long long)(size_t)c.lid;
+        uint16_t* const lid_u = reinterpret_cast<uint16_t*>((size_t)(((unsigned long long)rfl((uint32_t)(lidp >> 32)) << 32) | rfl((uint32_t)lidp)));
+        const __amdgpu_buffer_rsrc_t lr = __builtin_amdgcn_make_buffer_rsrc(lid_u, 0, (int)rfl((uint32_t)c.N * 2u), 0x00020000);
+        const uint32_t n0 = nbase + wbase;
+        uint32_t up_id = 0;
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const int ly = ly0 + i;
+            const int y = ty0 + ly;
+            const bool rowok = y < c.H;                                       // uniform
+            const bool ok = okx && rowok;
+            const uint32_t id = ok ? lds_ld(s_par + root[i]) : 0u;
+            const uint32_t left_id = lane_left(id);                          // (every lane takes part in the shift)
+            if (ok) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)id, lr, (int)((uint32_t)x * 2u), (int)((uint32_t)y * (uint32_t)c.W * 2u), 16 /* sc1 */);
+            if (edge_lane) lds_st(s_edge + 2 * i, (lbl[i] & 0xFFFFu) | (id << 16));      // (s_last is dead since phase B)
+            if (pos[i] != 0xFFFFFFFFu) {
+                uint32_t adopt = kNoAdopt;
+                if (lane > 0) adopt = nbase + left_id;
+                else if (x == 0 && i > 0) adopt = nbase + up_id;
+                stage[pos[i]] = make_uint4(n0 + pos[i], (uint32_t)y * (uint32_t)c.W + (uint32_t)x, ar[i], adopt);
+            }
+            up_id = id;
+        }
+        wave_lds_sync();
+        for (uint32_t j = (uint32_t)lane; j < wcount; j += 64u) {
+            const uint4 rec = stage[j];
+            c.nrec[rec.x] = rec;
+            c.narea[rec.x] = rec.z;                  // where k_cca_compress adds the other nodes' areas when this one is the global root
+            c.roots[gbase + j] = rec.x;
+        }
+        if (lane < 2 * RW) (c.vedge + (size_t)(nbase / (uint32_t)kCcaTilePx) * (2 * TH))[2 * ly0 + lane] = lds_ld(&s_last[wave][lane]);
+        LOC_STAMP(6);
+        return;
+    }
+    }
     uint32_t up_id = 0;
     const bool edge_lane = lane == 0 || lane == T - 1;
     uint32_t* const s_edge = &s_last[wave][lane ? 1 : 0];     // this wavefront's 2 * RW edge words: (row, side) at 2 * row + side

@@ -35,6 +35,11 @@ static __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release of GLOBAL memory too, which on
+// this target is s_waitcnt vmcnt(0): every pixel load (prologue) or label store (epilogue) still in flight would have to land first.
+// Only where nothing but LDS contents passes between the wavefronts of the block at that point.
+static __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Streaming stores for planes that are written once and read by a LATER kernel (LAB plane, label maps, parents,
 // feature planes): written through at agent scope (`sc1`) instead of staying dirty in the XCD's L2.  A kernel's
 // end-of-kernel release otherwise writes all dirty lines back in one burst that nothing overlaps -- measured

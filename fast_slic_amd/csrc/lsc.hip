@@ -310,7 +310,7 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
 #pragma unroll
     for (int q = 0; q < kLscFeat; ++q) mean[q] = lsc_uniform(l.means[q]);
     LSC_STAMP(2, wave == 1);                    // wave 1: its pixel loads issued
-    __syncthreads();
+    lds_barrier();      // LDS contents only pass between the wavefronts here: pixel loads / label stores stay in flight (device_common.h)
     LSC_STAMP(3, wave == 1);                    // barrier passed
     const int cnt = s_cnt;
     const bool listed = cnt <= 64;                 // a pixel's winner is kept as its position in the block's list (else: the cluster itself)
@@ -505,7 +505,7 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
     }
     if (!stale_sums) return;
     LSC_STAMP(8, wave == 1);
-    __syncthreads();
+    lds_barrier();      // LDS contents only pass between the wavefronts here: pixel loads / label stores stay in flight (device_common.h)
     LSC_STAMP(9, wave == 1);
     // one set of global atomics per (block, cluster that received pixels here).  (Plain stores into per-(cluster, block) entries
     // summed by k_lsc_update, as the SLIC block kernel delivers its sums, were built and measured: 48.6 against 47.1 us per launch

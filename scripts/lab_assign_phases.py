@@ -31,6 +31,8 @@ for ps in passes:
     blocks8 = G * tiles_x * ((Hv + 31) // 32)
     vmode = S > 40          # tables.cpp: row-vector table when the 2-D table exceeds 12 KB (S = 72 yes, S = 24 / 37 no)
     R = 16 if ((not fused and blocks8 > 3072) or (fused and vmode and blocks8 > 3072)) else 8
+    if not fused and vmode and blocks8 > 4 * 6144:
+        R = 32                      # launch_assign: 32 rows per wavefront in the full pass of big launches
     nby = (Hv + 4 * R - 1) // (4 * R)
     nblk = tiles_x * nby
     allw = []
