@@ -449,14 +449,6 @@ static __device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return 
 static __device__ __forceinline__ unsigned long long ld_agent64(const void* p) {
     return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// floor(x / n) for x < 2^31, n >= 1, through the reciprocal r = floor((2^32 - 1) / n): the estimate is at most one short
-static __device__ __forceinline__ uint32_t div_by(uint32_t x, uint32_t n, uint32_t r) {
-    uint32_t q = __umulhi(x, r);
-    uint32_t rest = x - q * n;
-    if (rest >= n) { q++; rest -= n; }
-    if (rest >= n) q++;
-    return q;
-}
 static __device__ __forceinline__ void bin_insert_next(const FrameDev& f, uint32_t k, uint32_t yx, uint32_t lab) {
     const int y = (int)(yx >> 16), x = (int)(yx & 0xFFFFu);
     const uint32_t phase = (uint32_t)(2 * ((y / f.T) & 1) + ((x / f.T) & 1));      // visit order of the reference scatter: phase, then k

@@ -100,17 +100,18 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg, c
         const int32_t n = (int32_t)s[0];
         f.cl_n[k] = (uint32_t)n;
         if (n != 0) {
-            const int32_t h = n / 2;
-            y = ((int32_t)s[1] + h) / n;
-            x = ((int32_t)s[2] + h) / n;
+            // (sums of non-negative terms below 2^31: the unsigned quotients through one reciprocal are the reference's signed ones)
+            const uint32_t h = (uint32_t)n >> 1, rcp = 0xFFFFFFFFu / (uint32_t)n;
+            y = (int)div_by(s[1] + h, (uint32_t)n, rcp);
+            x = (int)div_by(s[2] + h, (uint32_t)n, rcp);
             // A centroid of in-image pixels is in the image, so this is a no-op on valid sums.  It only matters for a
             // frame whose tiled attempt overflowed a candidate list (some partial sums were then never written and
             // the frame is about to be redone by the generic path): positions must stay addressable meanwhile.
             y = min(max(y, 0), f.H - 1);
             x = min(max(x, 0), f.W - 1);
-            const int32_t L = ((int32_t)s[3] + h) / n;
-            const int32_t a = ((int32_t)s[4] + h) / n;
-            const int32_t b = ((int32_t)s[5] + h) / n;
+            const int32_t L = (int32_t)div_by(s[3] + h, (uint32_t)n, rcp);
+            const int32_t a = (int32_t)div_by(s[4] + h, (uint32_t)n, rcp);
+            const int32_t b = (int32_t)div_by(s[5] + h, (uint32_t)n, rcp);
             if (f.cl_f) {
                 // centroid_quantization_enabled() == false (src/context.cpp:449-452): (float)sum / n per component
                 // (src/context.cpp:374-380); bins, phases and windows use the integer parts (src/context.cpp:214-217)

@@ -86,6 +86,16 @@ static __device__ __forceinline__ uint32_t lane_left(uint32_t v) {
 
 static __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// floor(x / n) for x < 2^31, n >= 1, through the reciprocal r = floor((2^32 - 1) / n): the estimate is at most one short
+// (the five round_int means of a cluster, src/fast-slic-common.h:62-65, cost one division instead of five)
+static __device__ __forceinline__ uint32_t div_by(uint32_t x, uint32_t n, uint32_t r) {
+    uint32_t q = __umulhi(x, r);
+    uint32_t rest = x - q * n;
+    if (rest >= n) { q++; rest -= n; }
+    if (rest >= n) q++;
+    return q;
+}
+
 // Which assign blocks (64 px x BH visited rows) can hold pixels of a cluster centred at (cy, cx): the blocks its
 // (2S+1)^2 window overlaps, in block columns [bx0, bx1] and block rows [by0, by1] (any == false: no visited row).
 // The block kernel and the cluster pass evaluate this identically, which is what pairs writer and reader of

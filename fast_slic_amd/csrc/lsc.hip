@@ -309,6 +309,15 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
     float mean[kLscFeat];
 #pragma unroll
     for (int q = 0; q < kLscFeat; ++q) mean[q] = lsc_uniform(l.means[q]);
+    // the rows' y features, all of them now: fetched pair by pair inside the loop below, the second pair's loads sat behind the first
+    // pair's label stores in the vector-memory queue and their s_waitcnt exposed the stores' (written-through) acknowledgements
+    // (through LDS: eight more scalar registers spill, eight vector registers cost a wavefront per SIMD)
+    __shared__ __attribute__((aligned(16))) float s_yf[4][2 * kLscRows];      // per wavefront and row pair: cos r0, cos r1, sin r0, sin r1
+    static_assert(kLscRows == 4, "two row pairs per wavefront");
+    if (lane < 2 * kLscRows) {
+        const int r = (lane >> 2) * 2 + (lane & 1);
+        s_yf[wave][lane] = l.lut_y[((lane >> 1) & 1) * f.H + rem + stride * min(vw + r, Hv - 1)];
+    }
     LSC_STAMP(2, wave == 1);                    // wave 1: its pixel loads issued
     lds_barrier();      // LDS contents only pass between the wavefronts here: pixel loads / label stores stay in flight (device_common.h)
     LSC_STAMP(3, wave == 1);                    // barrier passed
@@ -326,8 +335,9 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
 #pragma unroll
     for (int h = 0; h < kLscRows / 2; ++h) {
         const int r0 = 2 * h, r1 = 2 * h + 1;
-        const f2 ycos = {lsc_uniform(l.lut_y[yr[r0]]), lsc_uniform(l.lut_y[yr[r1]])};
-        const f2 ysin = {lsc_uniform(l.lut_y[f.H + yr[r0]]), lsc_uniform(l.lut_y[f.H + yr[r1]])};
+        const float4 yv = *reinterpret_cast<const float4*>(&s_yf[wave][4 * h]);
+        const f2 ycos = {lsc_uniform(yv.x), lsc_uniform(yv.y)};
+        const f2 ysin = {lsc_uniform(yv.z), lsc_uniform(yv.w)};
         f2 G[kLscFeat], wv;
         {
             const float4* po = reinterpret_cast<const float4*>(s_org);
@@ -411,6 +421,10 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
                 if (listed) slot[u] = bk;
             } else if (stale_sums) {
                 lbl[u] = f.labels[p];
+                // waited for HERE, inside the rare branch: left to the compiler the wait lands behind the merge of the two branches,
+                // where it also holds every wavefront that took the other one until its label store (written through) is
+                // acknowledged -- four store round trips per wavefront and pass
+                __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
             }
         }
         if (stale_sums) {

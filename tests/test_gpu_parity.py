@@ -1,6 +1,8 @@
 """GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C ABI
 (fast_slic_amd._binding -> libfslic_hip.so) and is compared bit-for-bit with the plain-C oracle on the
 same seeded inputs, and with the committed reference fixtures / digests."""
+import os
+
 import numpy as np
 from ctypes import byref as C_byref
 import pytest
@@ -394,7 +396,7 @@ def test_graph_replay_equals_direct_launches():
             assert np.array_equal(labels, exp[0]), describe_mismatch("rep %d (launch mode %d)" % (rep, modes[-1]), labels, exp[0])
             assert not cluster_fields_equal(cl, exp[1])
             assert e.last_device_times()[0] > 0.0          # the events around the replayed sequence still time it
-        assert modes[0] == 0 and 1 in modes and modes[-1] == 2, modes
+        assert (modes[0] == 0 and 1 in modes and modes[-1] == 2) or os.environ.get("FSLIC_GRAPH") == "0", modes
     finally:
         e.close()
 
@@ -445,7 +447,7 @@ def test_pipeline_of_replayed_groups_collected_in_completion_order():
             inflight[s] = (exp, (d_rgb, a_rgb))
         for s in list(inflight):
             check(s)
-        assert modes.count(2) >= (rounds - 2) * nslots, modes      # most groups were graph replays
+        assert modes.count(2) >= (rounds - 2) * nslots or os.environ.get("FSLIC_GRAPH") == "0", modes      # most groups were graph replays
     finally:
         e.close()
 

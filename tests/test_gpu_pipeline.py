@@ -9,6 +9,7 @@
 * four Python threads drive four models through the process-wide engine at once (the reference allows that:
   cfast_slic.pyx:188-193 releases the GIL, per-call Context) and every result is bit-equal to the oracle
 """
+import os
 import threading
 
 import numpy as np
@@ -74,7 +75,7 @@ def _run_pipeline(H, W, K, seeds, group, nslots, rounds, expect_replay=True, min
                 assert cls[j].tobytes() == exp[i][1].tobytes(), "round %d seed %d: %s" % (r, seeds[i], "; ".join(cluster_fields_equal(cls[j], exp[i][1])))
         if expect_replay:
             modes = [e.last_launch_mode(s) for s in range(nslots)]
-            assert 2 in modes, modes                        # slots that served more than two groups replay their graph
+            assert 2 in modes or os.environ.get("FSLIC_GRAPH") == "0", modes      # slots that served more than two groups replay their graph (unless graphs are switched off)
     finally:
         if engine is None: e.close()
 
