@@ -310,16 +310,18 @@ def parity_of(wl, j):
     return bad
 
 
-def lsc_parity_of(wl, j, j_other):
+def lsc_parity_of(wl, j, j_other, measured=None):
     """LSC (f32 path, tolerance-based parity): the label maps of submission j against the committed fixture of
     the unmodified reference (tests/golden/lsc_cases.npz, frame seed 0 of this workload: agreement >= 0.99 as in
     tests/test_gpu_lsc.py) and against submission j_other of the same inputs (run-to-run identity: the sums are fixed point)."""
     bad = []
+    measured = {} if measured is None else measured
     try:
         fx = np.load(os.path.join(ROOT, "tests", "golden", "lsc_cases.npz"), allow_pickle=False)
         want = fx["A_%dx%d_k%d/labels" % (wl.H, wl.W, wl.K)]
+        want_cl = fx["A_%dx%d_k%d/clusters" % (wl.H, wl.W, wl.K)]
     except (OSError, KeyError):
-        want = None
+        want = want_cl = None
     a = [t.cpu().numpy().view(np.uint16) for t in wl.sets[j][0]]
     b = [t.cpu().numpy().view(np.uint16) for t in wl.sets[j_other][0]]
 
@@ -332,8 +334,15 @@ def lsc_parity_of(wl, j, j_other):
         return float(best.sum()) / p.size
     if want is not None:
         agree = min(best_overlap(a[0], want), best_overlap(want, a[0]))
+        cl = wl.sets[j][1][0]
+        measured["best_overlap_both_ways_min"] = round(agree, 5)
+        measured["mean_centre_shift_px"] = round(float(np.mean(np.hypot(cl["y"] - want_cl["y"], cl["x"] - want_cl["x"]))), 4)
+        measured["max_centre_shift_px"] = round(float(np.max(np.hypot(cl["y"] - want_cl["y"], cl["x"] - want_cl["x"]))), 3)
+        measured["against"] = "tests/golden/lsc_cases.npz (unmodified fast_slic.LSC, 1 thread), frame 0 of the timed region's last submission"
         if agree < 0.99:
             bad.append("frame 0: best overlap with the reference fixture %.4f (< 0.99)" % agree)
+        if measured["mean_centre_shift_px"] > 0.1:
+            bad.append("frame 0: mean centre shift %.4f px (> 0.1, the floor of tests/test_gpu_lsc.py)" % measured["mean_centre_shift_px"])
     else:
         bad.append("fixture A_%dx%d_k%d missing" % (wl.H, wl.W, wl.K))
     for i in range(wl.n):
@@ -714,9 +723,11 @@ def main():
                              "fused_assign_update": tl["fused_assign_update"],
                              "full_assign": tl["full_assign"], "device_ms_per_frame": tl["device_ms_per_frame"]}
             if not args.no_parity:      # tolerance-based (f32 path): fixture floor of the unmodified reference + run-to-run identity
-                bad = lsc_parity_of(wlsc, wlsc.last_timed, wlsc.last_timed - 3)
+                measured = {}
+                bad = lsc_parity_of(wlsc, wlsc.last_timed, wlsc.last_timed - 3, measured)
                 out["lsc_c5"]["parity"] = not bad
-                out["lsc_c5"]["parity_rule"] = "best overlap (both ways) >= 0.99 with tests/golden/lsc_cases.npz (fast_slic.LSC, 1 thread) on frame 0, as tests/test_gpu_lsc.py; every frame and Cluster byte identical between two submissions"
+                out["lsc_c5"]["measured"] = measured
+                out["lsc_c5"]["parity_rule"] = "best overlap (both ways) >= 0.99 and mean centre shift <= 0.1 px against tests/golden/lsc_cases.npz (fast_slic.LSC, 1 thread) on frame 0, as tests/test_gpu_lsc.py (north_star's 1e-3 on centroids holds for the integer paths, where they are exact; this f32 path differs from the reference in the order of its sums); every frame and Cluster byte identical between two submissions"
                 if bad:
                     out["lsc_c5"]["parity_failures"] = bad[:8]
             del wlsc
