@@ -61,7 +61,7 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     }
     if (!s.h_misc) HIPCHK(hipHostMalloc((void**)&s.h_misc, 64 * kMaxGroup));
     if (!s.h_lut) HIPCHK(hipHostMalloc((void**)&s.h_lut, kLutMaxWords * 4));
-    if (!s.h_tab) HIPCHK(hipHostMalloc((void**)&s.h_tab, 2 * kTabMaxBytes));
+    if (!s.h_tab) HIPCHK(hipHostMalloc((void**)&s.h_tab, 3 * kTabMaxBytes));
     if (s.h_patchf_cap < P * P) {
         if (s.h_patchf) hipHostFree(s.h_patchf);
         s.h_patchf = nullptr; s.h_patchf_cap = 0;
@@ -80,7 +80,7 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_patch = take(P * P * 2);
     const size_t o_lut = take(kLutMaxWords * 4);
-    const size_t o_tab = take(2 * kTabMaxBytes);
+    const size_t o_tab = take(3 * kTabMaxBytes);
     const size_t o_patchf = take(P * P * 4);
     const size_t shared_bytes = off;
     off = 0;

@@ -1021,6 +1021,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
         lds_barrier();
         ASG_STAMP(7, wave == 0);
         // one plain store per (candidate, quantity): entry reserved for (cluster, this block), zeros included
+        // (three threads per candidate with one 8-byte store each: measured, no difference -- profiles/r04_assign_experiments.txt)
         const uint32_t yb0 = (uint32_t)(rem + vrow_b0 * STRIDE);
         for (int i = tid; i < bn * 6; i += 256) {
             const int c = i / 6, q = i - c * 6;
@@ -1083,6 +1084,7 @@ template <int R, bool FUSE, int STRIDE>
 static void launch_assign_blk_t(const FrameDev& f_, int nframes, int rem, int Hv, hipStream_t st) {
     FrameDev f = f_;
     if (FUSE) { f.tab = f.tabs; f.tab_words = f.tabs_words; f.tab_dyoff = f.tabs_dyoff; f.tab_nrpad = f.tabs_nrpad; }   // table of the subsampled stride
+    if (FUSE && R == 16 && !f.tab_vmode) { f.tab = f.tabs16; f.tab_words = f.tabs16_words; f.tab_dyoff = f.tabs16_dyoff; f.tab_nrpad = f.tabs16_nrpad; }
     dim3 grid((f.W + kTileW - 1) / kTileW, (Hv + kWavesPerBlock * R - 1) / (kWavesPerBlock * R), nframes);
     const size_t lds2 = ((size_t)f.tab_words * sizeof(uint32_t) + 1023) / 1024 * 1024;       // whole KB: what the LDS-DMA pieces fill
     if constexpr (R == 32) {
@@ -1092,7 +1094,8 @@ static void launch_assign_blk_t(const FrameDev& f_, int nframes, int rem, int Hv
         if (f.tab_vmode) launch((k_assign_blk2_w8<R, FUSE, STRIDE, true>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
         else launch((k_assign_blk2_w8<R, FUSE, STRIDE, false>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
     } else if constexpr (R == 16 && FUSE) {
-        launch((k_assign_blk2_w6<R, FUSE, STRIDE, true>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
+        if (f.tab_vmode) launch((k_assign_blk2_w6<R, FUSE, STRIDE, true>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
+        else launch((k_assign_blk2_w6<R, FUSE, STRIDE, false>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
     } else {
         if (f.tab_vmode) launch((k_assign_blk2<R, FUSE, STRIDE, true>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
         else launch((k_assign_blk2<R, FUSE, STRIDE, false>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
@@ -1188,7 +1191,9 @@ PassGeom launch_assign(const FrameDev& f_, int nframes, int rem, int stride, int
             // 2048.  Small launches keep 8 rows (more, shorter-lived blocks fill the chip better); so does the 2-D table,
             // whose LDS footprint grows with the rows a wavefront spans.
             const int tiles_x = (f.W + kTileW - 1) / kTileW;
-            const bool r16 = f.tab_vmode && nframes * tiles_x * ((Hv + kWavesPerBlock * 8 - 1) / (kWavesPerBlock * 8)) > 3072;
+            const int fblocks8 = nframes * tiles_x * ((Hv + kWavesPerBlock * 8 - 1) / (kWavesPerBlock * 8));
+            // (2-D table: 16 rows from 2048 eight-row blocks on -- the launch then is one round of blocks instead of one and a bit)
+            const bool r16 = (f.tab_vmode && fblocks8 > 3072) || (!f.tab_vmode && f.tabs16_words > 0 && fblocks8 > 2048);
             if (r16) {
                 pg.BH = kWavesPerBlock * 16;
                 if (stride == 1) launch_assign_blk_t<16, true, 1>(f, nframes, rem, Hv, st);

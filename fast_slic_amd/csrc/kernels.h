@@ -101,6 +101,10 @@ struct FrameDev {
                                // |dx| = tab_xout.  `tab` serves the full (stride 1) pass, `tabs` the subsampled passes
     const uint16_t* tabs;
     int tabs_words, tabs_dyoff, tabs_nrpad;
+    // tab_vmode == 0 only: the subsampled stride's 2-D table built for 16 rows per wavefront (tabs16_words == 0: too large to keep six
+    // blocks per CU resident, the 16-row fused pass is then not used)
+    const uint16_t* tabs16;
+    int tabs16_words, tabs16_dyoff, tabs16_nrpad;
     // tab_vmode == 0: pair-packed column-major patch copy, dword [ux'][j] = (e(j), e(j+stride)) with e = patch or kTabOut
     // outside the window, row pitch tab_nrpad dwords, j = dy + tab_dyoff
     // generic-path tables

@@ -181,6 +181,7 @@ int configure_spatial(Slot& s, int S, const fslic_params* p) {
     const size_t tab2d_bytes = (size_t)(S + 2) * (2 * (S + std::max(7 * std::min(stride_it, 3), 15)) + 1) * 2;
     constexpr size_t vtab_min = 12288;
     f.tabs = s.d_tab + kTabMaxBytes / 2; f.tabs_words = 0; f.tabs_dyoff = 0;
+    f.tabs16 = s.d_tab + kTabMaxBytes; f.tabs16_words = 0; f.tabs16_dyoff = 0; f.tabs16_nrpad = 0;
     if (manhattan && tab2d_bytes > vtab_min && S >= 8 && max_sp + 765u < 1024u) {
         // Row-vector V tables (the Manhattan patch depends on |di| + |dj| only): one for the full pass (stride 1, up to
         // 32 rows per wavefront) and one for the subsampled passes (stride_it, up to 16 rows per wavefront).
@@ -238,6 +239,12 @@ int configure_spatial(Slot& s, int S, const fslic_params* p) {
             f.tab_words = w1; f.tab_nrpad = n1; f.tab_dyoff = d1;
             f.tabs_words = ws; f.tabs_nrpad = ns; f.tabs_dyoff = ds;
             tiled_ok = true;
+            // the same for 16 rows per wavefront, kept only while a block (10 KB of lists and accumulators + the table) leaves six
+            // blocks per CU resident
+            int w16 = 0, n16 = 0, d16 = 0;
+            if (build2d(st3, 16, reinterpret_cast<uint32_t*>(s.h_tab + kTabMaxBytes), w16, n16, d16) && (size_t)w16 * 4 <= 16384) {
+                f.tabs16_words = w16; f.tabs16_nrpad = n16; f.tabs16_dyoff = d16;
+            }
         }
     }
     if (stride_it > 3 && !have_mc && f.lut_words == 0) tiled_ok = false;   // strides the packed kernel does not take need the 32-bit kernel
@@ -247,6 +254,8 @@ int configure_spatial(Slot& s, int S, const fslic_params* p) {
         HIPCHK(hipMemcpyAsync(s.d_tab, s.h_tab, (size_t)f.tab_words * 4, hipMemcpyHostToDevice, s.st));
     if (f.tabs_words > 0)
         HIPCHK(hipMemcpyAsync(const_cast<uint16_t*>(f.tabs), s.h_tab + kTabMaxBytes / 2, (size_t)f.tabs_words * 4, hipMemcpyHostToDevice, s.st));
+    if (f.tabs16_words > 0)
+        HIPCHK(hipMemcpyAsync(const_cast<uint16_t*>(f.tabs16), s.h_tab + kTabMaxBytes, (size_t)f.tabs16_words * 4, hipMemcpyHostToDevice, s.st));
     if (f.lut_words > 0)
         HIPCHK(hipMemcpyAsync(s.d_lut, s.h_lut, (size_t)f.lut_words * 4, hipMemcpyHostToDevice, s.st));
     s.sp_tiled_ok = tiled_ok;

@@ -21,6 +21,10 @@ for lib in $LIBS; do
   grep -E "^==|k_assign|k_cca_local|k_bin" $OUT/kstats$tag.txt | cut -c1-150
   cd $R
   timeout 300 python bench.py --timed-only --steps ${EXP_STEPS:-400} 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('720p pipelined', d['value'], 'MP/s', d['ms_per_step'], 'ms/step')" | tee $OUT/bench$tag.txt
+  if [ "${EXP_NOBATCH:-0}" = "1" ]; then
+    timeout 300 python bench.py --timed-only --no-batching --steps ${EXP_STEPS:-400} 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('720p pipelined, one submission per group', d['value'], 'MP/s')" | tee -a $OUT/bench$tag.txt
+    for rep in 1 2 3; do timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --timed-only 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('driver command line (20 steps)', d['value'], 'MP/s')" | tee -a $OUT/bench$tag.txt; done
+  fi
   if [[ " ${EXP_4K:-} " == *" $lib "* ]]; then
     timeout 300 python bench.py --workload 4k --timed-only --steps 100 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('4K pipelined', d['value'], 'MP/s', d['ms_per_step'], 'ms/step')" | tee -a $OUT/bench$tag.txt
   fi
