@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 ASSIGN_BYTES_PER_PX = 6.0      # 4 B LAB read + 2 B label write per visited pixel
 LSC_ASSIGN_BYTES_PER_PX = 6.0  # 4 B LAB word + 2 B label: the features are rebuilt from the LAB word (SURVEY.md 8d's recompute design; the materialised one moved 46 B)
-PROFILE_TAG = "r03"
+PROFILE_TAG = "r04"
 
 WORKLOADS = {
     "720p": dict(H=720, W=1280, K=1600, fpg=8, name="1280x720 RGB, K=1600, 10 iters (configs[1]), 8 frames/GPU"),
@@ -76,7 +76,7 @@ def measured_copy_bandwidth():
 def pmc_traffic(key):
     """HBM bytes per launch of the assign kernels from the committed rocprofv3 --pmc passes of this workload
     (profiles/<round>_pmc_assign_traffic.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE); None when absent."""
-    for tag in (PROFILE_TAG, "r02", "r01"):
+    for tag in (PROFILE_TAG, "r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", "%s_pmc_assign_traffic.json" % tag)) as f:
                 return json.load(f)[key], "profiles/%s_pmc_assign_traffic.json" % tag
@@ -85,13 +85,13 @@ def pmc_traffic(key):
     return None, None
 
 
-def rocprof_avg_us(csv_name, needle):
-    """Average duration (us) of the first kernel whose name contains `needle` in a committed rocprofv3 summary
+def rocprof_avg_us(csv_name, *needles):
+    """Average duration (us) of the first kernel whose name contains every one of `needles` in a committed rocprofv3 summary
     (profiles/<round>_kernel_stats_*.csv, written by scripts/gpu_profiles.sh from a --kernel-trace run); None when absent."""
     try:
         with open(os.path.join(ROOT, "profiles", "%s_%s" % (PROFILE_TAG, csv_name))) as f:
             for line in f:
-                if needle in line:
+                if all(n in line for n in needles):
                     return float(line.rsplit('",', 1)[1].split(",")[2])
     except (OSError, ValueError, IndexError):
         pass
@@ -638,7 +638,7 @@ def main():
         pmc, pmc_src = pmc_traffic("720p_x%d" % per_launch_frames) if args.workload == "720p" else (None, None)
         fu = big["fused_assign_update"]
         out["roofline"] = {
-            "kernel": "k_assign_blk2<8,true,3,*> (fused assign + centroid sums; %d launches per group, %dx%d x %d frames per launch: "
+            "kernel": "k_assign_blk2<R,true,3,false> (R = 16 rows per wavefront in launches of more than 2048 eight-row blocks, else 8; fused assign + centroid sums; %d launches per group, %dx%d x %d frames per launch: "
                       "%s), GPU to itself" % (fu["launches_per_group"], W, H, per_launch_frames,
                                               "two submissions per group, as the pipelined region runs them" if merged_max > 1 else "one submission per group"),
             "bound": "hbm", "achieved": fu["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fu["frac"],
@@ -655,7 +655,7 @@ def main():
         out["roofline"]["frac_of_measured_copy"] = round(fu["achieved"] / copy_gbs, 4) if copy_gbs else None
         # the same launch by rocprofv3's kernel duration (committed summary of `scripts/frames.py 720 1280 1600 6 slic 8` under
         # --kernel-trace): events on the stream also see the launch gap of the directly enqueued (timed) group
-        rp = rocprof_avg_us("kernel_stats_1280x720_k1600_slic_x%d.csv" % per_launch_frames, "k_assign_blk2<8, true, 3") if args.workload == "720p" else None
+        rp = rocprof_avg_us("kernel_stats_1280x720_k1600_slic_x%d.csv" % per_launch_frames, "k_assign_blk2", ", true, 3, ") if args.workload == "720p" else None      # <8,..> for 8-frame launches, _w6<16,..> for 16
         if rp:
             out["roofline"]["by_rocprofv3_kernel_duration"] = {
                 "avg_launch_us": rp, "achieved": round(gbs(fu["bytes_per_launch"], rp * 1e-3), 2),
