@@ -989,6 +989,15 @@ __global__ __launch_bounds__(256) void k_cca_chain(CcaDev c) {
 
 // The last kernel of a group also carries the group's results to the host: blocks past the relabel grid copy the
 // cluster state and the frame's status words into the engine's pinned blocks (ExportDev; K == 0: nothing to export).
+// largest value of the wavefront's 64 lanes (DPP row steps, then the four rows through v_readlane)
+static __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#define FSLIC_DPP_MAX(ctrl) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, 0xF, 0xF, false))
+    FSLIC_DPP_MAX(0xB1); FSLIC_DPP_MAX(0x4E); FSLIC_DPP_MAX(0x141); FSLIC_DPP_MAX(0x140);
+#undef FSLIC_DPP_MAX
+    return max(max((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
+               max((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
+}
+
 __global__ __launch_bounds__(256) void k_cca_relabel(CcaDev c, ExportDev ex, int relabel_blocks) {
     const int z = blockIdx.y;
     if ((int)blockIdx.x >= relabel_blocks) {
@@ -1009,28 +1018,45 @@ __global__ __launch_bounds__(256) void k_cca_relabel(CcaDev c, ExportDev ex, int
     const int tiles_x = c.tiles_x, tiles_y = (c.H + TH - 1) / TH;
     const int ntiles = tiles_x * tiles_y;
     const bool vec = (c.W & 3) == 0;
+    // The tile's table of final labels goes into LDS first -- as much of it as the tile's pixels refer to (the largest component number
+    // among them, found by a block-wide maximum: a few hundred entries), with coalesced 16-byte loads.  Read straight from memory every
+    // pixel's look-up was a 64-address gather through the vector-memory path (eight per thread), which bounded the pass (65 us per
+    // 8 x 3840x2160 = 4 TB/s of its 4 B per pixel).
+    __shared__ __attribute__((aligned(16))) uint16_t s_fin[kCcaTilePx];
+    __shared__ uint32_t s_max;
     for (int tile = blockIdx.x; tile < ntiles; tile += relabel_blocks) {
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-        const uint16_t* __restrict__ fin = c.nfinal + (size_t)tile * kCcaTilePx;
+        const uint16_t* __restrict__ gfin = c.nfinal + (size_t)tile * kCcaTilePx;
         const int x0 = tx * T + 4 * (int)(threadIdx.x & 15);
         const int r0 = (int)(threadIdx.x >> 4);                 // rows r0 and r0 + 16 of the tile
+        if (tile != (int)blockIdx.x) __syncthreads();           // (a block that takes several tiles: the previous tile's look-ups are done)
+        if (threadIdx.x == 0) s_max = 0u;
+        __syncthreads();
         if (vec) {
             uint2 v[2];
             bool ok[2];
+            uint32_t mx = 0;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int y = ty * TH + r0 + 16 * h;
                 ok[h] = y < c.H && x0 < c.W;
                 v[h] = make_uint2(0u, 0u);
                 if (ok[h]) v[h] = *reinterpret_cast<const uint2*>(c.lid + (size_t)y * c.W + x0);
+                mx = max(max(mx, max(v[h].x & 0xFFFFu, v[h].x >> 16)), max(v[h].y & 0xFFFFu, v[h].y >> 16));
             }
+            mx = wave_max_u32(mx);
+            if ((threadIdx.x & 63) == 0) atomicMax(&s_max, mx);
+            __syncthreads();
+            const uint32_t cnt = min(s_max + 1u, (uint32_t)kCcaTilePx);
+            for (uint32_t i = threadIdx.x; i * 8u < cnt; i += 256u) reinterpret_cast<uint4*>(s_fin)[i] = reinterpret_cast<const uint4*>(gfin)[i];
+            __syncthreads();
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 if (!ok[h]) continue;
                 const int y = ty * TH + r0 + 16 * h;
                 uint2 o;
-                o.x = (uint32_t)fin[v[h].x & 0xFFFFu] | ((uint32_t)fin[v[h].x >> 16] << 16);
-                o.y = (uint32_t)fin[v[h].y & 0xFFFFu] | ((uint32_t)fin[v[h].y >> 16] << 16);
+                o.x = (uint32_t)s_fin[v[h].x & 0xFFFFu] | ((uint32_t)s_fin[v[h].x >> 16] << 16);
+                o.y = (uint32_t)s_fin[v[h].y & 0xFFFFu] | ((uint32_t)s_fin[v[h].y >> 16] << 16);
                 st_stream(reinterpret_cast<uint2*>(c.out + (size_t)y * c.W + x0), o);
             }
         } else {
@@ -1040,7 +1066,7 @@ __global__ __launch_bounds__(256) void k_cca_relabel(CcaDev c, ExportDev ex, int
                 if (y >= c.H) continue;
                 for (int q = 0; q < 4; ++q) {
                     const int x = x0 + q;
-                    if (x < c.W) st_stream(c.out + (size_t)y * c.W + x, fin[c.lid[(size_t)y * c.W + x]]);
+                    if (x < c.W) st_stream(c.out + (size_t)y * c.W + x, gfin[c.lid[(size_t)y * c.W + x]]);
                 }
             }
         }
