@@ -123,7 +123,8 @@ def load_library():
         lib.fslic_hip_last_group_frames.argtypes = [vp, i32]
         lib.fslic_hip_last_path.argtypes = [vp, i32]
         lib.fslic_hip_last_launch_mode.argtypes = [vp, i32]
-        lib.fslic_hip_lab_force_generic.argtypes = [vp, i32]      # testing aid, not in include/fslic_hip.h
+        if hasattr(lib, "fslic_hip_lab_force_generic"):           # testing aid, not in include/fslic_hip.h: a library given through
+            lib.fslic_hip_lab_force_generic.argtypes = [vp, i32]  # FSLIC_LIB may lack it (only the tests that use it then fail)
         lib.fslic_hip_last_error.restype = C.c_char_p
         lib.fslic_hip_version.restype = C.c_char_p
         lib.fslic_hip_get_connectivity.argtypes = [vp, i32, i32, i32, vp, vp, vp]

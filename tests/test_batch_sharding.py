@@ -107,10 +107,13 @@ def test_rank_binds_to_its_own_gpu():
     code = ("import os, sys; sys.path.insert(0, %r); from fast_slic_amd import batch\n"
             "os.environ.pop('HIP_VISIBLE_DEVICES', None); d = batch.bind_rank_to_its_gpu(5); print(d, os.environ['HIP_VISIBLE_DEVICES'])\n"
             "os.environ['HIP_VISIBLE_DEVICES'] = '4,5,6,7'; d = batch.bind_rank_to_its_gpu(2); print(d, os.environ['HIP_VISIBLE_DEVICES'])\n"
-            "os.environ['HIP_VISIBLE_DEVICES'] = '3'; d = batch.bind_rank_to_its_gpu(0); print(d, os.environ['HIP_VISIBLE_DEVICES'])" % ROOT)
+            "os.environ['HIP_VISIBLE_DEVICES'] = '3'; d = batch.bind_rank_to_its_gpu(0); print(d, os.environ['HIP_VISIBLE_DEVICES'])\n"
+            # bench.py --share-device: every rank takes the first visible GPU (the host side of an N-rank launch on a one-GPU box)
+            "os.environ.pop('HIP_VISIBLE_DEVICES', None); d = batch.bind_rank_to_its_gpu(5, share_device=True); print(d, os.environ['HIP_VISIBLE_DEVICES'])\n"
+            "os.environ['HIP_VISIBLE_DEVICES'] = '4,5,6,7'; d = batch.bind_rank_to_its_gpu(2, share_device=True); print(d, os.environ['HIP_VISIBLE_DEVICES'])" % ROOT)
     r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert r.returncode == 0, r.stderr.decode()
-    assert r.stdout.decode().split() == ["0", "5", "0", "6", "0", "3"]
+    assert r.stdout.decode().split() == ["0", "5", "0", "6", "0", "3", "0", "0", "0", "4"]
 
 
 def test_torchrun_environment_is_respected():
