@@ -392,3 +392,34 @@ def test_parity_under_every_switch_the_library_reads(switch):
     tail = r.stdout.decode()[-2500:]
     assert r.returncode == 0 and " passed" in tail, tail
 
+
+
+@pytest.mark.parametrize("stride,n", [(1, 8), (2, 12), (3, 16)])
+def test_sixteen_row_fused_pass_on_the_2d_table_at_every_stride(stride, n):
+    """Launches of more than 2048 eight-row blocks with the 2-D spatial table (S <= 40) take the fused passes with 16 rows per wavefront
+    (launch_assign, assign.hip; its own table `tabs16`): 8 / 12 / 16 frames of 1280x720 K=1600 in ONE group reach that at subsample_stride
+    1 / 2 / 3 (3680 / 2880 / 2560 blocks), the bench only at 3.  Every frame against the oracle, twice (the second group replays)."""
+    import torch
+    H, W, K = 720, 1280, 1600
+    frames = [variant("A", H, W, seed=40 + i) for i in range(n)]
+    p = make_params(10, 10.0, 0.25, stride)
+    exp = [orc.slic_iterate(f, orc.initialize_clusters(f, K), subsample_stride=stride) for f in frames]
+    e = Engine(0, 1)
+    try:
+        d_rgb = [torch.from_numpy(f).cuda() for f in frames]
+        d_lab = [torch.empty((H, W), dtype=torch.int16, device="cuda") for _ in frames]
+        torch.cuda.synchronize()
+        a_rgb = e.pointer_array([t.data_ptr() for t in d_rgb])
+        a_lab = e.pointer_array([t.data_ptr() for t in d_lab])
+        for rep in range(3):
+            cls = [orc.initialize_clusters(f, K) for f in frames]
+            a_cls = e.pointer_array([c.ctypes.data for c in cls])
+            e.submit_group(0, a_rgb, a_cls, a_lab, n, H, W, K, p)
+            e.wait_group(0)
+            assert e.last_group_frames(0) == n
+            for i in range(n):
+                got = d_lab[i].cpu().numpy().view(np.uint16)
+                assert np.array_equal(got, exp[i][0]), describe_mismatch("stride %d rep %d frame %d" % (stride, rep, i), got, exp[i][0])
+                assert cls[i].tobytes() == exp[i][1].tobytes(), (stride, rep, i)
+    finally:
+        e.close()
