@@ -501,7 +501,7 @@ static __device__ __forceinline__ void fused_finalize(const FrameDev& f, uint32_
     }
 }
 
-// Blocks -> tiles: the natural grid (tile column, tile row, frame).  The hardware hands consecutive workgroups (x fastest) to the
+// Blocks -> tiles: no remapping inside a frame.  The hardware hands consecutive workgroups (x fastest) to the
 // eight XCDs in turn, each with its own L2, so the eight neighbours that share a frame's bins and table rows sit on eight L2s
 // (1.32 x the algorithmic bytes at 1280x720).  An XCD-chunked order (an XCD works through a contiguous eighth of the tiles) was
 // built and measured in round 3 (profiles/r03_xcd_mapping.txt): traffic of the fused 8 x 1280x720 launch 1.15 x, its duration
@@ -509,12 +509,17 @@ static __device__ __forceinline__ void fused_finalize(const FrameDev& f, uint32_
 // frames instead of side by side in memory).  Removed.
 struct BlkMap { uint32_t gx, gy; };
 static inline BlkMap blk_map(dim3 g) { BlkMap m; m.gx = g.x; m.gy = g.y; return m; }
-static inline dim3 blk_grid(dim3 g) { return g; }
+// The launch grid is (tile columns, FRAMES, tile rows): workgroups are handed out x fastest, so tile row r of every frame of the group
+// runs before row r + 1 of any, and the partial last rows (a frame's visited rows are rarely a multiple of the block height: one
+// wavefront of four at 3840x2160) come last, where the launch drains.  Measured against (columns, rows, frames) in round 4
+// (profiles/r04_assign_experiments.txt): fused 8 x 4K 45.1 -> 44.3 us, 8 x 1280x720 11.9 -> 11.6, full pass 8 x 1280x720 15.0 -> 13.5 us;
+// pipelined rates unchanged.
+static inline dim3 blk_grid(dim3 g) { return dim3(g.x, g.z, g.y); }
 
 template <int R, bool FUSE, int STRIDE, bool VT, bool FBIN = false>
 static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, int Hv, const BlkMap& bm) {
     static_assert(!FBIN || FUSE, "the cluster pass rides on the fused centroid sums");
-    const uint32_t bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;      // (tile column, tile row, frame)
+    const uint32_t bxi = blockIdx.x, byi = blockIdx.z, bzi = blockIdx.y;      // (tile column, tile row, frame): see blk_grid
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];   // spatial table (u16), whole KB (LDS-DMA lands 1 KB per wavefront instruction); 16-byte aligned: the row-vector reads are ds_read_b128
     __shared__ __attribute__((aligned(16))) uint4 s_raw[kWavesPerBlock][64];       // every wavefront's kept records {yx, lab, tag, -}
     __shared__ __attribute__((aligned(16))) uint32_t s_part[64][4];                // partial ranks: [candidate][wavefront]
