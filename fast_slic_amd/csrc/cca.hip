@@ -72,147 +72,190 @@ static __device__ __forceinline__ uint32_t lds_find_ro(uint32_t* par, uint32_t x
     return x;
 }
 
-// One block = one 64x64 tile = 4 wavefronts x 16 rows.  Lane = column.
-//  A  each wavefront resolves its own 16-row strip top-down: horizontal runs by ballot, one LDS union per
-//     horizontal overlap with the row above; the (possibly stale) root of the pixel above travels in a VGPR,
-//     so a row costs a handful of dependent LDS operations instead of chain walks
+// ---- wavefront-mask helpers of the tile kernel.  A lane predicate that every lane computes from ONE comparison is a 64-bit mask in
+// scalar registers (v_cmp writes it), mask logic is scalar-ALU work, and a mask becomes a lane predicate again at no cost
+// (inverse ballot: the mask is the condition register).  Written with bools the same logic goes through the vector ALU: a
+// v_cndmask + v_cmp pair per ballot, DPP shifts of predicates, 64-bit find-first-set per lane (round 3: 921 vector instructions per
+// wavefront of 512 pixels, the second consumer of vector issue slots in a group).
+typedef unsigned long long u64;
+static __device__ __forceinline__ u64 ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+static __device__ __forceinline__ bool lanes(u64 m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+// value of the lane to the left; lane 0 reads 0 / keeps `old`
+static __device__ __forceinline__ uint32_t lane_left0(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, true); }
+static __device__ __forceinline__ uint32_t lane_left_or(uint32_t old, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x138, 0xF, 0xF, false); }
+// number of set bits of m below this lane
+static __device__ __forceinline__ uint32_t rank_in(u64 m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+// LDS word at a BYTE offset (the tile kernel's union-find names its nodes by byte offset: no shift per dependent look-up)
+static __device__ __forceinline__ uint32_t* lds_at(uint32_t* base, uint32_t off) { return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(base) + off); }
+static __device__ __forceinline__ uint32_t ldsb_find(uint32_t* par, uint32_t x) {
+    for (;;) {
+        const uint32_t p = lds_ld(lds_at(par, x));
+        if (p == x) return x;
+        const uint32_t gp = lds_ld(lds_at(par, p));
+        if (gp == p) return p;
+        lds_st(lds_at(par, x), gp);
+        x = gp;
+    }
+}
+static __device__ __forceinline__ void ldsb_union(uint32_t* par, uint32_t a, uint32_t b) {
+    for (;;) {
+        a = ldsb_find(par, a);
+        b = ldsb_find(par, b);
+        if (a == b) return;
+        if (a < b) { const uint32_t t = a; a = b; b = t; }
+        const uint32_t old = atomicMin(lds_at(par, a), b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+// One block = one 64x32 tile = 4 wavefronts x 8 rows.  Lane = column.  The nodes of the tile's union-find are the horizontal RUNS:
+// run j of tile row r is node r * 64 + j (named by its byte offset, (r * 64 + j) * 4), so a smaller name means an earlier first
+// pixel in raster order and the root of a component (minimum by atomicMin hooks) is the run that holds its first pixel.
+//  A  each wavefront resolves its own strip top-down: runs by ONE comparison per row (a pixel outside the image carries a
+//     label no neighbour has, so validity never enters the predicates), the run index by mbcnt, one non-returning ds_min per
+//     distinct (run, root above) pair; the (possibly stale) root of the pixel above travels in a VGPR, so a row costs one LDS
+//     round trip
 //  B  the three strip seams inside the tile are merged in LDS
-//  C  flatten: every pixel -> tile-local root (min raster index), run lengths added
-//     to the root's area
+//  C  flatten: every run -> tile-local root, run lengths added to the root's area (one LDS atomic per run end: + position of the
+//     last pixel + 1 at the end, - position of the first at the start), the roots ranked by ballot
 //  D  the tile-local roots become the tile's nodes (numbered, appended to the frame's node list: one returning global atomic per
 //     tile), every pixel gets its root's number
 #if defined(FSLIC_LAB) && FSLIC_LAB == 2      // lab build 2: time stamps of the tile kernel (100 MHz ticks since the block's start), 8 words per block at the end of the (idle) candidate array
-#define LOC_STAMP(i_) do { __syncthreads(); if (threadIdx.x == 0) c.cand_leader[(size_t)c.N - 8 * (size_t)(blockIdx.y * (gridDim.x / nframes) + tile_x + 1) + (i_)] = (int32_t)((uint32_t)__builtin_amdgcn_s_memrealtime() - loc_t); } while (0)
+#define LOC_STAMP(i_) do { __syncthreads(); if (threadIdx.x == 0) c.cand_leader[(size_t)c.N - 8 * (size_t)(blockIdx.z * gridDim.y + blockIdx.y + 1) + (i_)] = (int32_t)((uint32_t)__builtin_amdgcn_s_memrealtime() - loc_t); } while (0)
 #else
 #define LOC_STAMP(i_) do { } while (0)
 #endif
 // (at most 80 SGPRs: with the ~105 the compiler takes by itself only six wavefronts fit a SIMD's scalar register file
 // instead of eight -- measured with per-block time stamps: 1500 blocks resident instead of 2048, 39 us instead of 2 rounds;
 // 88 and 96 were measured too: 35 instead of 33.7 us per 8 x 1280x720, although they spill fewer scalars)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cca_local(CcaDev c, int nframes) {
-    // The frame is the FASTEST-varying part of the block index: blocks that start together then reserve their root ranges on
-    // different frames' counters (with the frame slowest, the first 1800 blocks of a 4K group all hit frame 0's counter at
-    // once: 7 us instead of 0.8 us per block for that atomic, profiles/r02_lab_tile_ccl_phases_4k.txt)
-    const int frame = (int)(blockIdx.x % (unsigned)nframes), tile_x = (int)(blockIdx.x / (unsigned)nframes);
-    c.select(frame);
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cca_local(CcaDev c) {
+    // Grid (frames, tile columns, tile rows): the frame is the FASTEST-varying part of the dispatch order: blocks that start
+    // together then reserve their root ranges on different frames' counters (with the frame slowest, the first 1800 blocks of a 4K
+    // group all hit frame 0's counter at once: 7 us instead of 0.8 us per block for that atomic,
+    // profiles/r02_lab_tile_ccl_phases_4k.txt)
+    const int tile_x = (int)blockIdx.y, tile_y = (int)blockIdx.z;
+    c.select((int)blockIdx.x);
 #if defined(FSLIC_LAB) && FSLIC_LAB == 2
     const uint32_t loc_t = (uint32_t)__builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0) c.cand_leader[(size_t)c.N - 8 * (size_t)(blockIdx.y * (gridDim.x / nframes) + tile_x + 1) + 7] = (int32_t)loc_t;      // absolute start
+    if (threadIdx.x == 0) c.cand_leader[(size_t)c.N - 8 * (size_t)(blockIdx.z * gridDim.y + blockIdx.y + 1) + 7] = (int32_t)loc_t;      // absolute start
 #endif
     constexpr int T = kCcaTile;
     constexpr int TH = kCcaTileH;
     constexpr int RW = TH / 4;
-    __shared__ uint32_t s_last[4][T];       // labels of every strip's last row (all the seam merge of phase B reads)
+    static_assert(T == 64 && RW == 8, "lane = column, eight rows per wavefront");
+    __shared__ uint32_t s_last[4][T];       // (label | node << 17) of every strip's last row (the seam merge of phase B reads it); the edge words afterwards
     __shared__ uint32_t s_par[T * TH];
     __shared__ uint32_t s_area[T * TH];
     __shared__ uint32_t s_nroots, s_base;
     if (threadIdx.x == 0) s_nroots = 0;        // (three barriers lie between this and its first use)
     const int lane = LANE();
     const int wave = (int)rfl((uint32_t)(threadIdx.x >> 6));
-    const int tx0 = tile_x * T, ty0 = blockIdx.y * TH;
-    const int x = tx0 + lane;
-    const bool okx = x < c.W;
+    const int tx0 = tile_x * T, ty0 = tile_y * TH;
     const int ly0 = wave * RW;
-    const unsigned long long lowmask = (2ull << lane) - 1ull;
+    // the part of the wavefront's 64 x 8 strip inside the image: the first `ncols` lanes of the first `nrows` rows
+    const int ncols = min(c.W - tx0, T), nrows = min(max(c.H - (ty0 + ly0), 0), RW);
+    const u64 colmask = ncols >= 64 ? ~0ull : ((1ull << ncols) - 1ull);
+#define ROW_MASK(i_) ((i_) < nrows ? colmask : 0ull)
 
+    // A pixel outside the image gets a label that differs from its left and upper neighbours' (and from every real label), so it
+    // is a run, a node and a component of its own that nothing ever joins; the masks above keep it out of the outputs.
+    const uint16_t* const rowp = c.in + ((size_t)(ty0 + ly0) * c.W + tx0);
     uint32_t lbl[RW];
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
-        const int y = ty0 + ly0 + i;
-        lbl[i] = (okx && y < c.H) ? (uint32_t)c.in[(size_t)y * c.W + x] : 0x10000u;
+        lbl[i] = 0x10000u | (uint32_t)((i & 1) << 6) | (uint32_t)lane;
+        if (lanes(ROW_MASK(i))) lbl[i] = (uint32_t)rowp[(size_t)i * c.W + lane];
     }
     LOC_STAMP(0);
     // ---- A ----
-    // Per row: every pixel whose upper neighbour has the same label folds the (possibly stale) root carried in
-    // its VGPR into its run's node with a non-returning ds_min; one dependent ds_read then yields the run's
-    // root.  Only where a run joins two so-far distinct components (U shapes) is a real union needed.
-    // Where a run joins two so-far distinct components, the union (two finds and a returning atomic: four or more dependent LDS
-    // round trips, and one lane that needs it holds up the whole wavefront) is not done on the spot: the lane keeps the pair and
-    // the wavefront executes the pending pairs together -- when a lane would need to keep a second one, and after the last row.
-    // The order of the unions does not matter for the result (the next row only needs SOME root of the pixel above, possibly a
-    // stale one, exactly as before).  Row loop: one round trip per row instead of five (4.5 -> 2 us of a 13 us block life).
+    // Per row: the pixels whose upper neighbour has the same label fold the (possibly stale) root carried in the VGPR into their
+    // run's node with a non-returning ds_min; one dependent ds_read then yields the run's root.  One lane speaks for its
+    // neighbours: consecutive pixels of a run that carry the same root above would all hit the same LDS word (same-address
+    // atomics of a wavefront are served one lane after the other: a 40-pixel run was 40 serial operations on the CU's one LDS
+    // pipe, which every resident block shares).
+    // Where a run joins two so-far distinct components (U shapes), the union (two finds and a returning atomic: four or more
+    // dependent LDS round trips, and one lane that needs it holds up the whole wavefront) is not done on the spot: the lane keeps
+    // the pair and the wavefront executes the pending pairs together -- when a lane would need to keep a second one, and after
+    // the last row.  The order of the unions does not matter for the result (the next row only needs SOME root of the pixel
+    // above, possibly a stale one).  Row loop: one round trip per row instead of five (4.5 -> 2 us of a 13 us block life).
+    uint32_t nodev[RW];
     uint32_t up_root = 0, pend_a = 0, pend_b = 0;
-    bool pending = false;
+    u64 pending = 0;
     auto run_pending = [&]() {
-        if (pending) lds_union(s_par, pend_a, pend_b);
-        pending = false;
+        if (lanes(pending)) ldsb_union(s_par, pend_a, pend_b);
+        pending = 0;
     };
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
-        const int ly = ly0 + i;
-        const bool ok = okx && (ty0 + ly) < c.H;
-        const int p = ly * T + lane;
         const uint32_t l = lbl[i];
-        const uint32_t left = lane_left(l);
-        const bool start = (lane == 0) || (l != left) || !ok;
-        const unsigned long long m = __ballot(start);
-        const uint32_t node = (uint32_t)(ly * T + (63 - __clzll(m & lowmask)));
-        if (i == RW - 1) s_last[wave][lane] = l;
-        s_area[p] = 0u;
-        s_par[p] = node;
+        const u64 m = ballot(l != lane_left0(l)) | 1ull;                        // first pixels of the row's runs
+        const uint32_t node = ((uint32_t)(ly0 + i) << 8) + (rank_in(m >> 1) << 2);    // (starts in lanes 1..lane = the run's index)
+        nodev[i] = node;
+        if (lanes(m)) { *lds_at(s_par, node) = node; *lds_at(s_area, node) = 0u; }
+        if (i == RW - 1) s_last[wave][lane] = l | (node << 17);
         uint32_t cur_root = node;
         if (i > 0) {
-            const bool up_same = ok && (lbl[i - 1] == l);
-            // one lane speaks for its neighbours: consecutive pixels of a run that carry the same root above would all hit
-            // the same LDS word (same-address atomics of a wavefront are served one lane after the other: a 40-pixel run was
-            // 40 serial operations on the CU's one LDS pipe, which every resident block shares)
-            // (the lane shifts are evaluated by every lane, outside the short-circuit expression: a DPP shift returns the
-            // lane's own value when its source lane is masked off)
-            const uint32_t left_root = lane_left(up_root), left_same = lane_left((uint32_t)up_same);
-            const bool rep = up_same && (start || left_root != up_root || left_same == 0u);
-            if (rep) __hip_atomic_fetch_min(s_par + node, up_root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (ok) cur_root = lds_ld(s_par + node);
-            const bool need = rep && up_root != cur_root;
-            if (__ballot(need && pending)) run_pending();                 // uniform
-            if (need) { pend_a = up_root; pend_b = cur_root; pending = true; }
+            const u64 same = ballot(lbl[i - 1] == l);                           // same label above
+            const u64 other = ballot(lane_left0(up_root) != up_root);           // the left neighbour carries another root
+            const u64 rep = same & (m | other | ~(same << 1));
+            if (lanes(rep)) __hip_atomic_fetch_min(lds_at(s_par, node), up_root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            cur_root = lds_ld(lds_at(s_par, node));
+            const u64 need = rep & ballot(up_root != cur_root);
+            if (need & pending) run_pending();
+            const bool nd = lanes(need);
+            pend_a = nd ? up_root : pend_a;
+            pend_b = nd ? cur_root : pend_b;
+            pending |= need;
         }
         up_root = cur_root;
     }
     run_pending();
-    __syncthreads();
+    lds_barrier();
     LOC_STAMP(1);
     // ---- B ----
     if (wave > 0) {
-        const int p = ly0 * T + lane;
-        const bool ok = okx && (ty0 + ly0) < c.H;
         const uint32_t l = lbl[0];
-        const uint32_t left = lane_left(l);
-        if (ok && s_last[wave - 1][lane] == l) {
-            const bool first = (lane == 0) || (left != l) || (s_last[wave - 1][max(lane - 1, 0)] != l);
-            if (first) lds_union(s_par, (uint32_t)p, (uint32_t)(p - T));
-        }
+        const uint32_t prev = s_last[wave - 1][lane];
+        const u64 m = ballot(l != lane_left0(l)) | 1ull;
+        const u64 same = ballot((prev & 0x1FFFFu) == l);
+        const u64 first = same & (m | ~(same << 1));                            // one lane per (run, run above) contact
+        if (lanes(first)) ldsb_union(s_par, nodev[0], prev >> 17);
     }
-    __syncthreads();
+    lds_barrier();
     LOC_STAMP(2);
     // ---- C ----
+    // every pixel's tile-local root: two unconditional steps (their loads are independent across the rows), then steps for
+    // all rows together until none moves
     uint32_t root[RW];
 #pragma unroll
-    for (int i = 0; i < RW; ++i) root[i] = s_par[(ly0 + i) * T + lane];
+    for (int i = 0; i < RW; ++i) root[i] = lds_ld(lds_at(s_par, nodev[i]));
 #pragma unroll
-    for (int i = 0; i < RW; ++i) root[i] = s_par[root[i]];
+    for (int i = 0; i < RW; ++i) root[i] = lds_ld(lds_at(s_par, root[i]));
+    for (;;) {
+        uint32_t nx[RW];
 #pragma unroll
-    for (int i = 0; i < RW; ++i) root[i] = lds_find_ro(s_par, root[i]);
+        for (int i = 0; i < RW; ++i) nx[i] = lds_ld(lds_at(s_par, root[i]));
+        u64 moved = 0;
+#pragma unroll
+        for (int i = 0; i < RW; ++i) { moved |= ballot(nx[i] != root[i]); root[i] = nx[i]; }
+        if (!moved) break;
+    }
     // run lengths -> the root's area; and, in the same sweep, this wavefront's tile-local roots: their positions inside the
     // wavefront's share of the root list come from ballots alone (running count in a scalar register)
     uint32_t pos[RW];
     uint32_t wcount = 0;
+    const uint32_t lane_p1 = (uint32_t)lane + 1u;
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
-        const int ly = ly0 + i;
-        const int y = ty0 + ly;
-        const bool ok = okx && y < c.H;
-        const uint32_t r = ok ? root[i] : 0xFFFFFFFFu;
-        const uint32_t rl = lane_left(r);
-        const bool start = (lane == 0) || (r != rl) || !ok;
-        const unsigned long long m = __ballot(start);
-        if (ok && start) {
-            const unsigned long long higher = (lane == 63) ? 0ull : (m >> (lane + 1));
-            const int len = higher ? __ffsll((long long)higher) : (64 - lane);
-            atomicAdd(&s_area[r], (uint32_t)len);
-        }
-        const bool isroot = ok && root[i] == (uint32_t)(ly * T + lane);
-        const unsigned long long mr = __ballot(isroot);
-        pos[i] = isroot ? wcount + (uint32_t)__popcll(mr & ((1ull << lane) - 1ull)) : 0xFFFFFFFFu;
+        const u64 ok = ROW_MASK(i);
+        const uint32_t l = lbl[i];
+        const u64 m = ballot(l != lane_left0(l)) | 1ull;                        // (as in A: two instructions, cheaper than keeping eight masks)
+        const u64 e = (m >> 1) | (1ull << 63);                                  // last pixels of the runs
+        const uint32_t len_part = (lanes(e) ? lane_p1 : 0u) - (lanes(m) ? (uint32_t)lane : 0u);
+        if (lanes((m | e) & ok)) atomicAdd(lds_at(s_area, root[i]), len_part);
+        const u64 mr = m & ok & ballot(root[i] == nodev[i]);                    // the first pixel of a root run
+        pos[i] = lanes(mr) ? wcount + rank_in(mr) : 0xFFFFFFFFu;
         wcount += (uint32_t)__popcll(mr);
     }
     LOC_STAMP(3);
@@ -224,120 +267,69 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cc
     // 25 us block life.  A dense list lets the passes over the roots run as flat, evenly loaded grids.
     uint32_t wbase = 0;
     if (lane == 0 && wcount) wbase = atomicAdd(&s_nroots, wcount);
-    wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
-    __syncthreads();                              // every wavefront's share of s_nroots and every run's area are in
+    wbase = rfl(wbase);
+    lds_barrier();                                // every wavefront's share of s_nroots and every run's area are in
     LOC_STAMP(4);
     if (threadIdx.x == 0) s_base = s_nroots ? atomicAdd(&c.counters[0], s_nroots) : 0u;
     // the component numbers inside the tile: a root publishes its number where the pixels of its component look for
     // their root (s_par is dead: every wavefront has flattened, barrier above)
 #pragma unroll
     for (int i = 0; i < RW; ++i)
-        if (pos[i] != 0xFFFFFFFFu) lds_st(s_par + ((ly0 + i) * T + lane), wbase + pos[i]);
-    __syncthreads();
+        if (pos[i] != 0xFFFFFFFFu) lds_st(lds_at(s_par, root[i]), wbase + pos[i]);
+    lds_barrier();
     LOC_STAMP(5);
-    const uint32_t nbase = (uint32_t)(blockIdx.y * (gridDim.x / (unsigned)nframes) + (unsigned)tile_x) * (uint32_t)kCcaTilePx;
+    const uint32_t nbase = (uint32_t)(tile_y * (int)gridDim.y + tile_x) * (uint32_t)kCcaTilePx;
     const uint32_t gbase = s_base + wbase;
-    // The kernel is bound by vector-ALU instructions (about 810 per wavefront of 512 pixels; the SIMDs are 65 % busy issuing them at
-    // eight wavefronts each: SQ counters) and every memory instruction of a wavefront occupies the CU's address path however few
-    // lanes are active, so the outputs are organised for few instructions of either kind: a node is ONE 16-byte record, the
-    // nodes of several rows share a store (a lane holds at most one pending node; a row whose node would land on an occupied
-    // lane flushes first), and the sixteen edge words of the wavefront's rows are collected in LDS and leave through sixteen lanes
-    // of one store (two-lane stores row by row were measured: 31.2 instead of 30.8 us per 8 x 1280x720).
-    {
-    // Second form of the output phase (round 4; measured against the first as an experiment build, profiles/r04_cca_local_output.txt): the wavefront's node records are STAGED in LDS, one 16-byte store per row under the mask of the
-    // row's root lanes at the record's position pos[i] (positions are dense by construction: ballot ranks), and leave through
-    // coalesced stores of whole wavefronts afterwards -- no "pending node per lane" state, no flush branch per row, no merging
-    // selects.  The staging area is the wavefront's own strip of s_area (8 rows x 64 words = 128 records; its areas are read
-    // into registers first; no other wavefront touches the strip after the barrier above).  A wavefront with more than 128 nodes
-    // (noise: nearly every pixel its own component) takes the first form below.
-    if (wcount <= 128u) {
-        uint32_t ar[RW];
+    // The outputs are organised for few instructions: a node is ONE 16-byte record; the wavefront's records are STAGED in LDS (one
+    // 16-byte store per row under the mask of the row's root lanes, at the record's position: positions are dense by
+    // construction) and leave through coalesced stores of whole wavefronts; the sixteen edge words of the wavefront's rows are
+    // collected in LDS and leave through sixteen lanes of one store (two-lane stores row by row were measured: 31.2 instead of
+    // 30.8 us per 8 x 1280x720).  The staging area is the wavefront's own strip of s_area (8 rows x 64 words = 128 records; the
+    // areas of its roots are read into registers first; no other wavefront's roots live in the strip).
+    uint32_t ar[RW];
 #pragma unroll
-        for (int i = 0; i < RW; ++i) ar[i] = lds_ld(s_area + ((ly0 + i) * T + lane));
-        wave_lds_sync();
-        uint4* const stage = reinterpret_cast<uint4*>(s_area + ly0 * T);
-        const bool edge_lane = lane == 0 || lane == T - 1;
-        uint32_t* const s_edge = &s_last[wave][lane ? 1 : 0];
-        // (the frame's plane pointer is wave-uniform but lives in vector registers after select(): stated, or the buffer store is
-        // wrapped in a waterfall loop over "different" descriptors)
-        const unsigned long long lidp = (unsigned long long)(size_t)c.lid;
-        uint16_t* const lid_u = reinterpret_cast<uint16_t*>((size_t)(((unsigned long long)rfl((uint32_t)(lidp >> 32)) << 32) | rfl((uint32_t)lidp)));
-        const __amdgpu_buffer_rsrc_t lr = __builtin_amdgcn_make_buffer_rsrc(lid_u, 0, (int)rfl((uint32_t)c.N * 2u), 0x00020000);
-        const uint32_t n0 = nbase + wbase;
-        uint32_t up_id = 0;
+    for (int i = 0; i < RW; ++i) ar[i] = lds_ld(lds_at(s_area, root[i]));     // (a root lane's root is its own run)
+    wave_lds_sync();
+    uint4* const stage = reinterpret_cast<uint4*>(s_area + ly0 * T);
+    uint32_t* const s_edge = &s_last[wave][lane ? 1 : 0];     // this wavefront's 2 * RW edge words: (row, side) at 2 * row + side (s_last is dead since phase B)
+    const __amdgpu_buffer_rsrc_t lr = __builtin_amdgcn_make_buffer_rsrc(c.lid, 0, (int)((uint32_t)c.N * 2u), 0x00020000);
+    const uint32_t n0 = nbase + wbase;
+    // adopt: the node of the pixel left of a node's first pixel (in image column 0: above it), where that pixel lies in this tile
+    // and this wavefront's rows: what k_cca_chain follows (src/cca.cpp:243-248) without a look-up by pixel.  Lane 0 has no left
+    // neighbour in the tile: the DPP shift leaves it `old`, which is the number above (image column 0) or what makes kNoAdopt.
+    const uint32_t no_adopt = kNoAdopt - nbase;
+    uint32_t up_id = no_adopt;
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const uint32_t y = (uint32_t)(ty0 + ly0 + i);
+        const uint32_t id = lds_ld(lds_at(s_par, root[i]));
+        const uint32_t left_id = lane_left_or(tile_x == 0 ? up_id : no_adopt, id);
+        if (lanes(ROW_MASK(i))) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)id, lr, lane * 2, (int)((y * (uint32_t)c.W + (uint32_t)tx0) * 2u), 16 /* sc1 */);
+        // the tile's first and last column, row by row: what the pass over the vertical tile seams reads (a column of the
+        // label plane is one 64-byte sector per pixel)
+        if (lanes(0x8000000000000001ull)) lds_st(s_edge + 2 * i, lbl[i] | (id << 16));
+        root[i] = nbase + left_id;           // (the root's name is not needed any more: the register holds the row's adopt values)
+        up_id = id;
+    }
+    for (uint32_t b = 0; b < wcount; b += 128u) {      // (one trip unless nearly every pixel is its own component)
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
-            const int ly = ly0 + i;
-            const int y = ty0 + ly;
-            const bool rowok = y < c.H;                                       // uniform
-            const bool ok = okx && rowok;
-            const uint32_t id = ok ? lds_ld(s_par + root[i]) : 0u;
-            const uint32_t left_id = lane_left(id);                          // (every lane takes part in the shift)
-            if (ok) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)id, lr, (int)((uint32_t)x * 2u), (int)((uint32_t)y * (uint32_t)c.W * 2u), 16 /* sc1 */);
-            if (edge_lane) lds_st(s_edge + 2 * i, (lbl[i] & 0xFFFFu) | (id << 16));      // (s_last is dead since phase B)
-            if (pos[i] != 0xFFFFFFFFu) {
-                uint32_t adopt = kNoAdopt;
-                if (lane > 0) adopt = nbase + left_id;
-                else if (x == 0 && i > 0) adopt = nbase + up_id;
-                stage[pos[i]] = make_uint4(n0 + pos[i], (uint32_t)y * (uint32_t)c.W + (uint32_t)x, ar[i], adopt);
-            }
-            up_id = id;
+            const uint32_t q = pos[i] - b;
+            if (q < 128u) stage[q] = make_uint4(n0 + pos[i], (uint32_t)(ty0 + ly0 + i) * (uint32_t)c.W + (uint32_t)tx0 + (uint32_t)lane, ar[i], root[i]);
         }
         wave_lds_sync();
-        for (uint32_t j = (uint32_t)lane; j < wcount; j += 64u) {
+        const uint32_t cnt = min(wcount - b, 128u);
+        for (uint32_t j = (uint32_t)lane; j < cnt; j += 64u) {
             const uint4 rec = stage[j];
             c.nrec[rec.x] = rec;
             c.narea[rec.x] = rec.z;                  // where k_cca_compress adds the other nodes' areas when this one is the global root
-            c.roots[gbase + j] = rec.x;
+            c.roots[gbase + b + j] = rec.x;
         }
-        if (lane < 2 * RW) (c.vedge + (size_t)(nbase / (uint32_t)kCcaTilePx) * (2 * TH))[2 * ly0 + lane] = lds_ld(&s_last[wave][lane]);
-        LOC_STAMP(6);
-        return;
+        wave_lds_sync();
     }
-    }
-    uint32_t up_id = 0;
-    const bool edge_lane = lane == 0 || lane == T - 1;
-    uint32_t* const s_edge = &s_last[wave][lane ? 1 : 0];     // this wavefront's 2 * RW edge words: (row, side) at 2 * row + side
-    uint32_t h_pos = 0, h_adopt = 0, h_yx = 0;                // the lane's pending node: position, adopt, row
-    bool have = false;
-    auto flush = [&]() {
-        if (have) {
-            const int ly = (int)h_yx;
-            const uint32_t n = nbase + wbase + h_pos;
-            const uint32_t a = s_area[ly * T + lane];
-            c.nrec[n] = make_uint4(n, (uint32_t)((size_t)(ty0 + ly) * c.W + x), a, h_adopt);
-            c.narea[n] = a;                       // where k_cca_compress adds the other nodes' areas when this one is the global root
-            c.roots[gbase + h_pos] = n;
-        }
-        have = false;
-    };
-#pragma unroll
-    for (int i = 0; i < RW; ++i) {
-        const int ly = ly0 + i;
-        const int y = ty0 + ly;
-        const bool ok = okx && y < c.H;
-        const uint32_t id = ok ? lds_ld(s_par + root[i]) : 0u;
-        const uint32_t left_id = lane_left(id);                          // (every lane takes part in the shift)
-        if (ok) st_stream(c.lid + (size_t)y * c.W + x, (uint16_t)id);
-        // the tile's first and last column, row by row: what the pass over the vertical tile seams reads (a column of the
-        // label plane is one 64-byte sector per pixel)
-        if (edge_lane) lds_st(s_edge + 2 * i, (lbl[i] & 0xFFFFu) | (id << 16));      // (s_last is dead since phase B)
-        const bool isroot = pos[i] != 0xFFFFFFFFu;
-        if (__ballot(isroot && have)) flush();                           // uniform
-        if (isroot) {
-            // the node of the pixel left of this node's first pixel (in image column 0: above it), where that pixel lies in
-            // this tile and this wavefront's rows: what k_cca_chain follows (src/cca.cpp:243-248) without a look-up by pixel
-            uint32_t adopt = kNoAdopt;
-            if (lane > 0) adopt = nbase + left_id;
-            else if (x == 0 && i > 0) adopt = nbase + up_id;
-            h_pos = pos[i]; h_adopt = adopt; h_yx = (uint32_t)ly; have = true;
-        }
-        up_id = id;
-    }
-    flush();
-    __builtin_amdgcn_wave_barrier();
     if (lane < 2 * RW) (c.vedge + (size_t)(nbase / (uint32_t)kCcaTilePx) * (2 * TH))[2 * ly0 + lane] = lds_ld(&s_last[wave][lane]);
     LOC_STAMP(6);
+#undef ROW_MASK
 }
 
 static __device__ __forceinline__ uint32_t g_load(uint32_t* p) {
@@ -900,7 +892,7 @@ static int root_pass_blocks(const CcaDev& c) {
 void launch_cca_phase1(const CcaDev& c, int nframes, hipStream_t st) {
     constexpr int T = kCcaTile;
     const int tx = (c.W + T - 1) / T, ty = (c.H + kCcaTileH - 1) / kCcaTileH;
-    launch(k_cca_local, dim3(tx * nframes, ty), dim3(256), 0, st, c, nframes);
+    launch(k_cca_local, dim3(nframes, tx, ty), dim3(256), 0, st, c);
     const int nh = (ty - 1) * c.W, nv = (tx - 1) * c.H;
     if (nh + nv > 0)
         launch(k_cca_border, dim3((nh + nv + 255) / 256, nframes), dim3(256), 0, st, c, nh, nv);
