@@ -554,7 +554,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
     const int vrow_b0 = (int)byi * BH;
     const int vrow_w0 = vrow_b0 + wave * R;
     const bool okx = x < W;
-    const int nrows = max(0, min(R, Hv - vrow_w0));      // 0: this wavefront has no rows (bottom edge)
+    const int nrows = (int)rfl((uint32_t)max(0, min(R, Hv - vrow_w0)));      // 0: this wavefront has no rows (bottom edge); (stated uniform: the clamp is a v_med3, and what follows from it stays in the scalar unit)
     const int yw_lo = rem + vrow_w0 * STRIDE;
 #if defined(FSLIC_LAB) && FSLIC_LAB == 4
     const uint32_t asg_t0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
@@ -600,10 +600,12 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
     const char* const cbase = reinterpret_cast<const char*>(f.cell_items[0]);
     auto slot_ptr = [&](uint32_t e) -> const ClusterRec* {      // slot e of the block's cell range, cells row-major (slots past the end re-read slot 0..7 of the first cell)
         const uint32_t cell = e < nslots ? e >> 3 : 0u;
-        uint32_t cyi = (cell * inv) >> 16;
-        if (cyi * ncxr > cell) cyi--;
-        const uint32_t cxi = cell - cyi * ncxr;
-        const uint32_t off = (((uint32_t)cya + cyi) * (uint32_t)f.ncx + (uint32_t)cxa + cxi) * (uint32_t)(kCellCap * sizeof(ClusterRec)) + (e & 7u) * (uint32_t)sizeof(ClusterRec);
+        // (24-bit multiplies: every factor is a cell count or a reciprocal below 2^17, and a 32-bit v_mul_lo_u32 issues at a quarter of the rate)
+        uint32_t cyi = __umul24(cell, inv) >> 16;
+        const uint32_t back = __umul24(cyi, ncxr);
+        if (back > cell) cyi--;
+        const uint32_t cxi = cell - __umul24(cyi, ncxr);
+        const uint32_t off = (__umul24((uint32_t)cya + cyi, (uint32_t)f.ncx) + (uint32_t)cxa + cxi) * (uint32_t)(kCellCap * sizeof(ClusterRec)) + (e & 7u) * (uint32_t)sizeof(ClusterRec);
         return reinterpret_cast<const ClusterRec*>(cbase + off);
     };
     const ClusterRec rec0 = *slot_ptr((uint32_t)tid);
@@ -627,17 +629,21 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
     {
         int cnt = 0;
         uint4* const myraw = s_raw[wave];
-        auto visit = [&](const ClusterRec& rec, bool keep) {
-            const unsigned long long m = __ballot(keep);
+        // (the tests are single comparisons whose results are wavefront masks, combined by the scalar unit: device_common.h, ballot)
+        auto visit = [&](const ClusterRec& rec, unsigned long long among) {
+            const int cy = (int)(rec.yx >> 16), cx = (int)(rec.yx & 0xFFFFu);
+            const unsigned long long m = among & ballot(cy >= win.wy_lo) & ballot(cy <= win.wy_hi) & ballot(cx >= win.wx_lo) & ballot(cx <= win.wx_hi);
             const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)cnt));
-            if (keep && pos < 64) myraw[pos] = make_uint4(rec.yx, rec.lab, rec.tag, 0u);
+            if (lanes(m & ballot(pos < 64))) myraw[pos] = make_uint4(rec.yx, rec.lab, rec.tag, 0u);
             cnt += __popcll(m);
         };
-        visit(rec0, (uint32_t)tid < nslots && rec0.pad == gen && in_window(rec0, win));
-        if (nslots > 256u) visit(rec1, 256u + (uint32_t)tid < nslots && rec1.pad == gen && in_window(rec1, win));
+        auto first_lanes = [](int n) -> unsigned long long { return n >= 64 ? ~0ull : n <= 0 ? 0ull : (1ull << n) - 1ull; };
+        const int w64 = wave * 64;
+        visit(rec0, first_lanes((int)nslots - w64) & ballot(rec0.pad == gen));
+        if (nslots > 256u) visit(rec1, first_lanes((int)nslots - 256 - w64) & ballot(rec1.pad == gen));
         for (uint32_t e0 = 512u; e0 < nslots; e0 += 256u) {                        // (blocks that see more than 64 cells: S < 16)
             const ClusterRec rec = *slot_ptr(e0 + (uint32_t)tid);
-            visit(rec, e0 + (uint32_t)tid < nslots && rec.pad == gen && in_window(rec, win));
+            visit(rec, first_lanes((int)nslots - (int)e0 - w64) & ballot(rec.pad == gen));
         }
         if (wave == kWavesPerBlock - 1) {                                          // the spill list (cells with more than kCellCap centres)
             const ClusterRec* __restrict__ oitems = f.ovf_items[0];
@@ -646,7 +652,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
                 ClusterRec rec;
                 rec.yx = 0; rec.lab = 0; rec.tag = 0; rec.pad = 0;
                 if (i < novf) rec = oitems[i];
-                visit(rec, i < novf && in_window(rec, win));
+                visit(rec, first_lanes((int)novf - (int)i0));
             }
         }
         if (lane == 0) s_wcnt[wave] = (uint32_t)cnt;
@@ -698,7 +704,8 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
         const SlotGeom g = slot_geom((int)(mine.x >> 16), (int)(mine.x & 0xFFFFu), S, f.H, W, rem, STRIDE, BH, Hv);
         const int by = (int)byi, bx = (int)bxi;
         if (g.any && by >= g.by0 && by <= g.by1) {
-            entry = ((mine.z & 0xFFFFu) * (uint32_t)f.cpart_ns + (uint32_t)((by - g.by0) * f.nbx + (bx - g.bx0))) * 6u;
+            const uint32_t e1 = __umul24(mine.z & 0xFFFFu, (uint32_t)f.cpart_ns) + __umul24((uint32_t)(by - g.by0), (uint32_t)f.nbx) + (uint32_t)(bx - g.bx0);      // (24-bit factors, full-rate multiplies)
+            entry = (e1 << 2) + (e1 << 1);
             if (FBIN && lane < bn) { fin_nx = (uint32_t)(g.bx1 - g.bx0 + 1); fin_ny = (uint32_t)(g.by1 - g.by0 + 1); }
         }
         if (lane < bn) s_entry[rank_j] = entry;
@@ -712,7 +719,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
     unsigned long long todo;
     {
         const int cyj = (int)(yx_j >> 16);
-        todo = __ballot(lane < bn && nrows > 0 && cyj + S >= yw_lo && cyj - S <= yw_hi);
+        todo = nrows > 0 ? (bn >= 64 ? ~0ull : (1ull << bn) - 1ull) & ballot(cyj >= yw_lo - S) & ballot(cyj <= yw_hi + S) : 0ull;
     }
 
     // 4. the argmin, two rows per instruction
@@ -724,7 +731,13 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
     if constexpr (VT) {
         const int Cc = f.tab_dyoff;                 // centre index of the V table
         const uint32_t xout = (uint32_t)f.tab_xout;
-        constexpr int BIAS = 32768;                 // makes the numerators of the row-range divisions positive
+        // The row-range divisions: numerators made positive by BIAS rows, quotients through a 24-bit multiply (full rate; the 32-bit
+        // v_mul_hi_u32 the compiler takes for n / 3 issues at a quarter of it).  |dy0| <= S + BH * STRIDE for a candidate on the block's
+        // list and S <= 426 in this table mode (tables.cpp: tlen * 16 <= kTabMaxBytes), so 0 < numerator < 3 * 1024 + 1300, far inside
+        // the range where (n * 21846) >> 16 == n / 3 (n < 32768).
+        constexpr int BIAS = 1024;
+        static_assert(STRIDE >= 1 && STRIDE <= 3, "row-range divisions");
+        auto div_stride = [](int n) -> int { return STRIDE == 1 ? n : STRIDE == 2 ? (n >> 1) : (int)(__umul24((uint32_t)n, 21846u) >> 16); };
         constexpr uint32_t full = R >= 32 ? 0xFFFFFFFFu : (1u << (R & 31)) - 1u;
         auto low_bits = [](int n) -> uint32_t { return n >= 32 ? 0xFFFFFFFFu : (1u << n) - 1u; };      // n in [0, 32]
         // Per-candidate row ranges, computed ONCE in the vector unit with lane j = candidate j (the scalar unit is
@@ -733,9 +746,9 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
         uint32_t va_j, vb_j;                        // rows above / rows at or below the centre that are in the window
         {
             const int dy0 = yw_lo - (int)(yx_j >> 16);
-            const int rs = min(max((-dy0 + STRIDE * BIAS + STRIDE - 1) / STRIDE - BIAS, 0), R);
-            const int ra = min(max((-S - dy0 + STRIDE * BIAS + STRIDE - 1) / STRIDE - BIAS, 0), R);
-            const int rb = min(max((S - dy0 + STRIDE * BIAS) / STRIDE - BIAS, -1), R - 1);
+            const int rs = min(max(div_stride(-dy0 + STRIDE * BIAS + STRIDE - 1) - BIAS, 0), R);
+            const int ra = min(max(div_stride(-S - dy0 + STRIDE * BIAS + STRIDE - 1) - BIAS, 0), R);
+            const int rb = min(max(div_stride(S - dy0 + STRIDE * BIAS) - BIAS, -1), R - 1);
             const uint32_t upto_rs = low_bits(rs);
             const uint32_t in_win = rb < 0 ? 0u : (low_bits(rb + 1) & ~low_bits(ra) & full);
             va_j = in_win & upto_rs;
@@ -776,11 +789,10 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
         //   whole : every row inside the window and on one side of the centre (above: index k0 - |dx|, below: k0 + |dx|): no masks
         //   above : some rows above the centre, masked          below : some rows at/below the centre, masked
         // (a candidate whose centre row lies inside this wavefront's rows is in both masked loops)
-        const bool mine_todo = (todo >> lane) & 1ull;
-        unsigned long long todo_wa = __ballot(mine_todo && va_j == full);      // whole, above the centre
-        unsigned long long todo_wb = __ballot(mine_todo && vb_j == full);      // whole, at/below
-        unsigned long long todo_above = __ballot(mine_todo && va_j != 0u && va_j != full);
-        unsigned long long todo_below = __ballot(mine_todo && vb_j != 0u && vb_j != full);
+        unsigned long long todo_wa = todo & ballot(va_j == full);               // whole, above the centre
+        unsigned long long todo_wb = todo & ballot(vb_j == full);               // whole, at/below
+        unsigned long long todo_above = todo & ballot(va_j != 0u) & ~todo_wa;
+        unsigned long long todo_below = todo & ballot(vb_j != 0u) & ~todo_wb;
         // CLAMP: lanes outside the x window get |dx| = xout (every row then reads the marker); !CLAMP: the caller runs the pass
         // under `if (uxc <= S)` instead, i.e. with those lanes switched off (one vector instruction less per candidate)
         auto fetch = [&](int c, uint32_t& clab, uint32_t& uxc, uint32_t& k0, uint32_t& idx01, auto clamp_tag) {
@@ -838,12 +850,12 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
         {
             const int cyj = (int)(yx_j >> 16);
             const int yh = yw_lo + (R / 2) * STRIDE;     // first row of the lower half
-            const bool mine_todo = (todo >> lane) & 1ull;
-            const bool up = cyj + S >= yw_lo && cyj - S <= yw_lo + (R / 2 - 1) * STRIDE;
-            const bool lo = cyj + S >= yh && cyj - S <= yh + (R / 2 - 1) * STRIDE;
-            todo_b = __ballot(mine_todo && up && lo);
-            todo_u = __ballot(mine_todo && up && !lo);
-            todo_l = __ballot(mine_todo && !up && lo);
+            // (cyj + S >= yw_lo holds for every candidate on the list: `todo`)
+            const unsigned long long up = todo & ballot(cyj <= yw_lo + (R / 2 - 1) * STRIDE + S);
+            const unsigned long long lo = todo & ballot(cyj >= yh - S) & ballot(cyj <= yh + (R / 2 - 1) * STRIDE + S);
+            todo_b = up & lo;
+            todo_u = up & ~lo;
+            todo_l = lo & ~up;
         }
         // byte pitch of a table column in a VGPR: |dx| * pitch + row offset is then ONE v_mad_u32_u24 (two scalar operands would
         // not fit one VALU instruction) and the result is the LDS byte address itself (no shift)
@@ -896,7 +908,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
         us2 worst = best[0];
 #pragma unroll
         for (int q = 1; q < R / 2; ++q) worst = __builtin_elementwise_max(worst, best[q]);
-        const bool all_found = __ballot(worst.x == 0xFFFF || worst.y == 0xFFFF) == 0ull;
+        const bool all_found = (ballot(worst.x == 0xFFFF) | ballot(worst.y == 0xFFFF)) == 0ull;
         if (all_found && nrows == R) {          // interior wavefront with every pixel assigned: the rule, by far
             epilogue_done = true;
             if (okx) {
@@ -1025,26 +1037,25 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
         ASG_STAMP(6, wave == 0);
         lds_barrier();
         ASG_STAMP(7, wave == 0);
-        // one plain store per (candidate, quantity): entry reserved for (cluster, this block), zeros included
-        // (three threads per candidate with one 8-byte store each: measured, no difference -- profiles/r04_assign_experiments.txt)
-        const uint32_t yb0 = (uint32_t)(rem + vrow_b0 * STRIDE);
-        for (int i = tid; i < bn * 6; i += 256) {
-            const int c = i / 6, q = i - c * 6;
-            const uint32_t entry = s_entry[c];
+        // The block's sums leave through wavefront 0, lane j = candidate j: the 24-byte entry reserved for (cluster, this block) as
+        // three 8-byte stores, zeros included.  (One thread per (candidate, quantity) spread the stores over three wavefronts, but each
+        // of them paid an index division, the whole sum and a six-way select for one value: ~100 issue slots in three of the four
+        // wavefronts, a tenth of the kernel's vector work; three threads per candidate with one 8-byte store each had been measured
+        // by duration alone: no difference, profiles/r04_assign_experiments.txt.)
+        if (wave == 0 && lane < bn) {
+            const uint32_t entry = s_entry[lane];
             if (entry != kNoSlot) {
                 unsigned long long A = 0, B = 0;
 #pragma unroll
-                for (int cpy = 0; cpy < kBlkCopies; ++cpy) { A += s_acc[(c * kBlkCopies + cpy) * 2]; B += s_acc[(c * kBlkCopies + cpy) * 2 + 1]; }
-                const uint32_t cnt = (uint32_t)(B >> 40);
-                uint32_t v;
-                if (q == 0) v = cnt;
-                else if (q == 1) v = ((uint32_t)(B >> 20) & 0xFFFFFu) + yb0 * cnt;
-                else if (q == 2) v = ((uint32_t)B & 0xFFFFFu) + (uint32_t)x0 * cnt;
-                else if (q == 3) v = (uint32_t)A & 0xFFFFFu;
-                else if (q == 4) v = (uint32_t)(A >> 20) & 0xFFFFFu;
-                else v = (uint32_t)(A >> 40);
-                if (FBIN) st_stream(f.cpart + (size_t)entry + (uint32_t)q, v);      // written through: another block's lane reads it
-                else f.cpart[(size_t)entry + (uint32_t)q] = v;
+                for (int cpy = 0; cpy < kBlkCopies; ++cpy) { A += s_acc[(lane * kBlkCopies + cpy) * 2]; B += s_acc[(lane * kBlkCopies + cpy) * 2 + 1]; }
+                const uint32_t yb0 = (uint32_t)(rem + vrow_b0 * STRIDE);
+                const uint32_t cnt = (uint32_t)(B >> 40);                 // (at most 64 x BH pixels: the products below are 24-bit multiplies)
+                const uint2 q01 = make_uint2(cnt, ((uint32_t)(B >> 20) & 0xFFFFFu) + __umul24(yb0, cnt));
+                const uint2 q23 = make_uint2(((uint32_t)B & 0xFFFFFu) + __umul24((uint32_t)x0, cnt), (uint32_t)A & 0xFFFFFu);
+                const uint2 q45 = make_uint2((uint32_t)(A >> 20) & 0xFFFFFu, (uint32_t)(A >> 40));
+                uint2* const dst = reinterpret_cast<uint2*>(f.cpart + (size_t)entry);      // (entries are 24 bytes apart in an 8-byte aligned array)
+                if (FBIN) { st_stream(dst, q01); st_stream(dst + 1, q23); st_stream(dst + 2, q45); }      // written through: another block's lane reads it
+                else { dst[0] = q01; dst[1] = q23; dst[2] = q45; }
             }
         }
         if (FBIN) {

@@ -78,8 +78,6 @@ static __device__ __forceinline__ uint32_t lds_find_ro(uint32_t* par, uint32_t x
 // v_cndmask + v_cmp pair per ballot, DPP shifts of predicates, 64-bit find-first-set per lane (round 3: 921 vector instructions per
 // wavefront of 512 pixels, the second consumer of vector issue slots in a group).
 typedef unsigned long long u64;
-static __device__ __forceinline__ u64 ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
-static __device__ __forceinline__ bool lanes(u64 m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 // value of the lane to the left; lane 0 reads 0 / keeps `old`
 static __device__ __forceinline__ uint32_t lane_left0(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, true); }
 static __device__ __forceinline__ uint32_t lane_left_or(uint32_t old, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x138, 0xF, 0xF, false); }
@@ -265,12 +263,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cc
     // kernel come AFTER it: a wavefront waiting for the atomic's result would also wait for every store it has in flight
     // (the per-pixel plane is written through), and the other three wait for it at the barrier -- that wait was 8 - 14 us of a
     // 25 us block life.  A dense list lets the passes over the roots run as flat, evenly loaded grids.
+    // (both returning atomics of this phase are single-lane by construction and written as instructions: for an atomic with a
+    // wave-uniform operand the compiler emits its wavefront-reduction prologue -- mbcnt, first-lane test, multiply by the lane count,
+    // readfirstlane -- around them: twenty vector instructions for nothing)
     uint32_t wbase = 0;
-    if (lane == 0 && wcount) wbase = atomicAdd(&s_nroots, wcount);
+    if (wcount != 0u && lanes(1ull)) {
+        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(wbase) : "v"((uint32_t)(size_t)(__attribute__((address_space(3))) uint32_t*)&s_nroots), "v"(wcount) : "memory");
+    }
     wbase = rfl(wbase);
     lds_barrier();                                // every wavefront's share of s_nroots and every run's area are in
     LOC_STAMP(4);
-    if (threadIdx.x == 0) s_base = s_nroots ? atomicAdd(&c.counters[0], s_nroots) : 0u;
+    if (wave == 0 && lanes(1ull)) {
+        const uint32_t nr = lds_ld(&s_nroots);
+        uint32_t base = 0;
+        if (nr) asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(base) : "v"(c.counters), "v"(nr) : "memory");
+        lds_st(&s_base, base);
+    }
     // the component numbers inside the tile: a root publishes its number where the pixels of its component look for
     // their root (s_par is dead: every wavefront has flattened, barrier above)
 #pragma unroll
@@ -280,52 +288,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cc
     LOC_STAMP(5);
     const uint32_t nbase = (uint32_t)(tile_y * (int)gridDim.y + tile_x) * (uint32_t)kCcaTilePx;
     const uint32_t gbase = s_base + wbase;
-    // The outputs are organised for few instructions: a node is ONE 16-byte record; the wavefront's records are STAGED in LDS (one
-    // 16-byte store per row under the mask of the row's root lanes, at the record's position: positions are dense by
-    // construction) and leave through coalesced stores of whole wavefronts; the sixteen edge words of the wavefront's rows are
-    // collected in LDS and leave through sixteen lanes of one store (two-lane stores row by row were measured: 31.2 instead of
-    // 30.8 us per 8 x 1280x720).  The staging area is the wavefront's own strip of s_area (8 rows x 64 words = 128 records; the
-    // areas of its roots are read into registers first; no other wavefront's roots live in the strip).
+    // The outputs are organised for few instructions of either pipe: a node is ONE 16-byte record in memory; what a root lane knows
+    // about its node (row and lane of the first pixel, area, the neighbour to adopt from) is STAGED in LDS as one packed word at the
+    // node's position (positions are dense by construction), and whole wavefronts expand the words into records and store them
+    // coalesced.  (Staging the finished 16-byte records cost 13.7 clk of the CU's LDS pipe per ds_write_b128 however few lanes
+    // write -- scripts/microbench/lds_atomics.out --, a quarter of the kernel's LDS time; a 4-byte write costs a fifth of that.)
+    // The sixteen edge words of the wavefront's rows are collected in LDS and leave through sixteen lanes of one store (two-lane
+    // stores row by row were measured: 31.2 instead of 30.8 us per 8 x 1280x720).  The staging area is the wavefront's own strip
+    // of s_area (8 rows x 64 words: one word per pixel, so every node fits; the areas of its roots are read into registers first;
+    // no other wavefront's roots live in the strip).
+    //   staged word: bits 0-8 row * 64 + lane of the first pixel, 9-19 area - 1, 20-31 number of the node to adopt from (0xFFF: none)
     uint32_t ar[RW];
 #pragma unroll
     for (int i = 0; i < RW; ++i) ar[i] = lds_ld(lds_at(s_area, root[i]));     // (a root lane's root is its own run)
     wave_lds_sync();
-    uint4* const stage = reinterpret_cast<uint4*>(s_area + ly0 * T);
+    uint32_t* const stage = s_area + ly0 * T;
     uint32_t* const s_edge = &s_last[wave][lane ? 1 : 0];     // this wavefront's 2 * RW edge words: (row, side) at 2 * row + side (s_last is dead since phase B)
     const __amdgpu_buffer_rsrc_t lr = __builtin_amdgcn_make_buffer_rsrc(c.lid, 0, (int)((uint32_t)c.N * 2u), 0x00020000);
-    const uint32_t n0 = nbase + wbase;
     // adopt: the node of the pixel left of a node's first pixel (in image column 0: above it), where that pixel lies in this tile
     // and this wavefront's rows: what k_cca_chain follows (src/cca.cpp:243-248) without a look-up by pixel.  Lane 0 has no left
-    // neighbour in the tile: the DPP shift leaves it `old`, which is the number above (image column 0) or what makes kNoAdopt.
-    const uint32_t no_adopt = kNoAdopt - nbase;
-    uint32_t up_id = no_adopt;
+    // neighbour in the tile: the DPP shift leaves it `old`, which is the number above (image column 0) or the "none" mark.
+    uint32_t up_id = 0xFFFu;
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
         const uint32_t y = (uint32_t)(ty0 + ly0 + i);
         const uint32_t id = lds_ld(lds_at(s_par, root[i]));
-        const uint32_t left_id = lane_left_or(tile_x == 0 ? up_id : no_adopt, id);
+        const uint32_t left_id = lane_left_or(tile_x == 0 ? up_id : 0xFFFu, id);
         if (lanes(ROW_MASK(i))) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)id, lr, lane * 2, (int)((y * (uint32_t)c.W + (uint32_t)tx0) * 2u), 16 /* sc1 */);
         // the tile's first and last column, row by row: what the pass over the vertical tile seams reads (a column of the
         // label plane is one 64-byte sector per pixel)
         if (lanes(0x8000000000000001ull)) lds_st(s_edge + 2 * i, lbl[i] | (id << 16));
-        root[i] = nbase + left_id;           // (the root's name is not needed any more: the register holds the row's adopt values)
+        if (pos[i] != 0xFFFFFFFFu) lds_st(stage + pos[i], (uint32_t)(i * T + lane) | ((ar[i] - 1u) << 9) | (left_id << 20));
         up_id = id;
     }
-    for (uint32_t b = 0; b < wcount; b += 128u) {      // (one trip unless nearly every pixel is its own component)
-#pragma unroll
-        for (int i = 0; i < RW; ++i) {
-            const uint32_t q = pos[i] - b;
-            if (q < 128u) stage[q] = make_uint4(n0 + pos[i], (uint32_t)(ty0 + ly0 + i) * (uint32_t)c.W + (uint32_t)tx0 + (uint32_t)lane, ar[i], root[i]);
-        }
-        wave_lds_sync();
-        const uint32_t cnt = min(wcount - b, 128u);
-        for (uint32_t j = (uint32_t)lane; j < cnt; j += 64u) {
-            const uint4 rec = stage[j];
-            c.nrec[rec.x] = rec;
-            c.narea[rec.x] = rec.z;                  // where k_cca_compress adds the other nodes' areas when this one is the global root
-            c.roots[gbase + b + j] = rec.x;
-        }
-        wave_lds_sync();
+    wave_lds_sync();
+    const uint32_t n0 = nbase + wbase;
+    const uint32_t first_px = (uint32_t)(ty0 + ly0) * (uint32_t)c.W + (uint32_t)tx0;
+    for (uint32_t j = (uint32_t)lane; j < wcount; j += 64u) {
+        const uint32_t w = lds_ld(stage + j);
+        const uint32_t n = n0 + j, a = ((w >> 9) & 0x7FFu) + 1u, ad = w >> 20;
+        c.nrec[n] = make_uint4(n, first_px + __umul24((w >> 6) & 7u, (uint32_t)c.W) + (w & 63u), a, ad == 0xFFFu ? kNoAdopt : nbase + ad);
+        c.narea[n] = a;                          // where k_cca_compress adds the other nodes' areas when this one is the global root
+        c.roots[gbase + j] = n;
     }
     if (lane < 2 * RW) (c.vedge + (size_t)(nbase / (uint32_t)kCcaTilePx) * (2 * TH))[2 * ly0 + lane] = lds_ld(&s_last[wave][lane]);
     LOC_STAMP(6);

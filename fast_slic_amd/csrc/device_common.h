@@ -84,6 +84,13 @@ static __device__ __forceinline__ uint32_t lane_left(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
 }
 
+// A lane predicate that every lane computes from ONE comparison is a 64-bit mask in scalar registers (the v_cmp writes it); mask
+// logic is scalar-ALU work, and a mask becomes a lane predicate again at no cost (inverse ballot: the mask is the condition
+// register).  A ballot of a COMPOUND bool goes through the vector ALU instead (the booleans are and-ed as masks, materialised by
+// v_cndmask and compared again), and (mask >> lane) & 1 is a 64-bit vector shift: write ballot(a) & ballot(b) and lanes(mask).
+static __device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+static __device__ __forceinline__ bool lanes(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
 static __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // floor(x / n) for x < 2^31, n >= 1, through the reciprocal r = floor((2^32 - 1) / n): the estimate is at most one short
@@ -100,15 +107,21 @@ static __device__ __forceinline__ uint32_t div_by(uint32_t x, uint32_t n, uint32
 // (2S+1)^2 window overlaps, in block columns [bx0, bx1] and block rows [by0, by1] (any == false: no visited row).
 // The block kernel and the cluster pass evaluate this identically, which is what pairs writer and reader of
 // FrameDev::cpart.
+// n / d for 0 <= n < 65536 (image rows) and the subsampling strides in use: 1, 2, 3 without a division -- n / 3 as a 24-bit multiply
+// ((n * 43691) >> 17 is exact below 131072 and the product stays below 2^32); with a constant d the compiler would take
+// v_mul_hi_u32, which issues at a quarter of the rate, with a run-time d the whole division sequence.
+static __device__ __forceinline__ int div_rows(int n, int d) {
+    return d == 1 ? n : d == 2 ? (n >> 1) : d == 3 ? (int)(__umul24((uint32_t)n, 43691u) >> 17) : n / d;
+}
 struct SlotGeom { int bx0, bx1, by0, by1; bool any; };
 static __device__ __forceinline__ SlotGeom slot_geom(int cy, int cx, int S, int H, int W, int rem, int stride, int BH, int Hv) {
     SlotGeom g;
     g.bx0 = max(cx - S, 0) >> 6;
     g.bx1 = min(cx + S, W - 1) >> 6;
     const int t = max(cy - S, 0) - rem;
-    const int v0 = t <= 0 ? 0 : (t + stride - 1) / stride;
+    const int v0 = t <= 0 ? 0 : div_rows(t + stride - 1, stride);
     const int u = min(cy + S, H - 1) - rem;
-    const int v1 = u < 0 ? -1 : min(u / stride, Hv - 1);
+    const int v1 = u < 0 ? -1 : min(div_rows(u, stride), Hv - 1);
     g.any = v0 <= v1;
     g.by0 = v0 / BH;
     g.by1 = g.any ? v1 / BH : -1;
