@@ -486,6 +486,7 @@ def main():
                     help="strong scaling: a FIXED batch of this many frames per step split over the GPUs (BASELINE configs[3]: 64); "
                          "default 0 = weak scaling, --frames-per-gpu frames on every GPU")
     ap.add_argument("--slots", type=int, default=6, help="groups in flight per GPU (stream + host thread each)")
+    ap.add_argument("--launch-frames", type=int, default=16, help="most frames a launch group gathers from the submit queue (dynamic batching; the library's limit is 16)")
     ap.add_argument("--no-batching", action="store_true", help="one submission per launch group (no dynamic batching in the pipeline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-4k", action="store_true", help="skip the 4K, K=6000, LSC and end-to-end sub-objects")
@@ -555,7 +556,7 @@ def main():
     eng = Engine(dev, nslots)
     # Dynamic batching: a slot thread that finds two submissions waiting serves them as one group (16 frames per launch instead
     # of 8).  Results are per frame and do not change; the parity gate below checks a submission of the timed region.
-    merged_max = 1 if args.no_batching else max(1, min(2, 16 // fpg))
+    merged_max = 1 if args.no_batching else max(1, args.launch_frames // fpg)
     if merged_max > 1:
         eng.pipeline_batching(merged_max * fpg)
     Workload.merged_max = merged_max

@@ -23,7 +23,10 @@ constexpr uint32_t kHuge = 0x40000000u;   // out-of-window marker added to the d
 constexpr int kCcaTile = 64;        // connectivity tile width  (one wavefront of columns)
 constexpr int kCcaTileH = 32;       // connectivity tile height (4 wavefronts x 8 rows), one block of 256 threads
 constexpr int kCcaTilePx = kCcaTile * kCcaTileH;
-constexpr int kMaxGroup = 16;       // frames of one group share every launch (frame index = last grid dimension)
+#ifndef FSLIC_MAX_GROUP
+#define FSLIC_MAX_GROUP 16
+#endif
+constexpr int kMaxGroup = FSLIC_MAX_GROUP;       // frames of one group share every launch (frame index = a grid dimension)
 
 // One cluster as the kernels see it (16 B, one ds_read_b128 / global_load_dwordx4).
 //   yx  = y << 16 | x          (integer centre, src/context.cpp:262 casts to int16)
