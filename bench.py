@@ -688,7 +688,7 @@ def main():
             four, one = w4.timed_groups(5), w4.timed_groups(4, n=1)
             pmc4, pmc4_src = pmc_traffic("4k_k1600")
             fa = four["full_assign"]
-            out["roofline_4k"] = {"kernel": "k_assign_blk2_w8<16,false,1,true> (full_assign launch, 3840x2160, K=1600), 8 frames per launch",
+            out["roofline_4k"] = {"kernel": "k_assign_blk2_w6<32,false,1,true> (full_assign launch, 32 rows per wavefront, 3840x2160, K=1600), 8 frames per launch",
                                   "bound": "hbm", "achieved": fa["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fa["frac"],
                                   "traffic": pmc4["full_assign"]["bytes"] * 8 if pmc4 else None, "traffic_source": pmc4_src,
                                   "avg_launch_ms": fa["avg_launch_ms"], "fused_assign_update": four["fused_assign_update"],
