@@ -369,32 +369,101 @@ static __device__ __forceinline__ void g_union(const CcaDev& c, uint32_t a, uint
     }
 }
 
+// (parent, leader) of a node with ONE 8-byte load: a node's leader never changes, its parent only through the 32-bit CAS below
+static __device__ __forceinline__ uint2 g_load2(const CcaDev& c, uint32_t n) {
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<unsigned long long*>(c.nrec + n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+// x -> its root (path halving as in g_find), returns the root's leader
+static __device__ __forceinline__ uint32_t g_find_leader(const CcaDev& c, uint32_t& x, uint2 r) {      // r = g_load2(x), already fetched
+    for (;;) {
+        if (r.x == x) return r.y;
+        const uint2 g = g_load2(c, r.x);
+        if (g.x == r.x) { x = r.x; return g.y; }
+        __hip_atomic_store(n_parent(c, x), g.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x = g.x;
+        r = g_load2(c, x);
+    }
+}
+// g_union with the two first look-ups in flight together and the leaders arriving with the parents: a contact between two nodes
+// that are still roots (the rule: every node is, when this pass starts) costs one round trip for both records and one for the CAS
+static __device__ __forceinline__ void g_union2(const CcaDev& c, uint32_t a, uint32_t b) {
+    uint2 ra = g_load2(c, a), rb = g_load2(c, b);
+    for (;;) {
+        const uint32_t la = g_find_leader(c, a, ra), lb = g_find_leader(c, b, rb);
+        if (a == b) return;
+        if (la < lb) { const uint32_t t = a; a = b; b = t; }
+        if (atomicCAS(n_parent(c, a), a, b) == a) return;
+        ra = g_load2(c, a); rb = g_load2(c, b);
+    }
+}
+
+// The seams between tiles.  A thread takes kSeamPx consecutive pixels of a seam (along the seam) and has everything a contact needs
+// in flight at once: the labels on both sides, the left neighbours' (a contact is reported by the first pixel of a run of
+// contacts only), and -- speculatively -- the component numbers on both sides.  The pass is a chain of dependent round trips
+// per wavefront; it was labels -> numbers -> parents -> leaders -> CAS (57.7 us per 8 x 3840x2160, 10.8 per 8 x 1280x720, 7.6 for
+// one frame) and is labels + numbers -> records -> CAS: 46.7 / 9.4 / 6.3 us.  More pixels per thread (fewer, longer wavefronts)
+// were measured in the same trip (profiles/r04_assign_experiments.txt): 2: 46.0 / 11.9 / 9.7, 4: 48.4 / 16.3 / 14.2, 8: 53.5 / 23.3 / 21.9 --
+// a thread's contacts are served one after the other.  One pixel per thread.
+#ifndef FSLIC_SEAM_PX
+#define FSLIC_SEAM_PX 1
+#endif
+constexpr int kSeamPx = FSLIC_SEAM_PX;
 __global__ __launch_bounds__(256) void k_cca_border(CcaDev c, int nh, int nv) {
     c.select(blockIdx.y);
     constexpr int T = kCcaTile;
     constexpr int TH = kCcaTileH;
+    static_assert(TH % kSeamPx == 0 && T % kSeamPx == 0, "a thread's pixels lie in one tile");
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int W = c.W, H = c.H;
-    if (i < nh) {            // pixel on the first row of a tile row, merge with the pixel above
-        const int by = i / W + 1, x = i - (by - 1) * W;
-        const int p = by * TH * W + x;
-        const uint16_t lbl = c.in[p];
-        if (c.in[p - W] == lbl) {
-            const bool first = (x % T == 0) || c.in[p - 1] != lbl || c.in[p - W - 1] != lbl;
-            if (first) g_union(c, node_at(c, by * TH, x, (size_t)p), node_at(c, by * TH - 1, x, (size_t)(p - W)));
+    if (i < nh) {            // kSeamPx pixels on the first row of a tile row, merged with the pixels above
+        const int cw = (W + kSeamPx - 1) / kSeamPx;
+        const int sr = i / cw, x0 = (i - sr * cw) * kSeamPx;
+        const int y = (sr + 1) * TH;
+        const size_t p = (size_t)y * W + x0;
+        uint32_t cur[kSeamPx + 1], up[kSeamPx + 1], nc[kSeamPx], nu[kSeamPx];      // [0]: the left neighbours
+        const bool has_left = (x0 % T) != 0;
+        cur[0] = has_left ? (uint32_t)c.in[p - 1] : 0x10000u;
+        up[0] = has_left ? (uint32_t)c.in[p - W - 1] : 0x10000u;
+#pragma unroll
+        for (int q = 0; q < kSeamPx; ++q) {
+            const bool ok = x0 + q < W;
+            cur[q + 1] = ok ? (uint32_t)c.in[p + q] : 0x20000u;
+            up[q + 1] = ok ? (uint32_t)c.in[p - W + q] : 0x30000u;
+            nc[q] = ok ? (uint32_t)c.lid[p + q] : 0u;
+            nu[q] = ok ? (uint32_t)c.lid[p - W + q] : 0u;
         }
-    } else if (i < nh + nv) { // pixel on the first column of a tile column, merge with the pixel to the left
+        const uint32_t tile = (uint32_t)((sr + 1) * c.tiles_x + x0 / T) * (uint32_t)kCcaTilePx;
+#pragma unroll
+        for (int q = 0; q < kSeamPx; ++q) {
+            const uint32_t lbl = cur[q + 1];
+            if (up[q + 1] == lbl && (cur[q] != lbl || up[q] != lbl))
+                g_union2(c, tile + nc[q], tile - (uint32_t)c.tiles_x * (uint32_t)kCcaTilePx + nu[q]);
+        }
+    } else if (i < nh + nv) { // kSeamPx pixels on the first column of a tile column, merged with the pixels to the left
         const int j = i - nh;
-        const int bx = j / H + 1, y = j - (bx - 1) * H;
-        const int r = y % TH;
-        const uint32_t tile_r = (uint32_t)((y / TH) * c.tiles_x + bx), tile_l = tile_r - 1u;
-        const uint32_t* er = c.vedge + ((size_t)tile_r * TH + r) * 2;           // this pixel: first column of the right tile
-        const uint32_t* el = c.vedge + ((size_t)tile_l * TH + r) * 2 + 1;       // its left neighbour: last column of the left tile
-        const uint32_t a = er[0], b = el[0];
-        if (((a ^ b) & 0xFFFFu) == 0u) {
-            const uint32_t lbl = a & 0xFFFFu;
-            const bool first = (r == 0) || (er[-2] & 0xFFFFu) != lbl || (el[-2] & 0xFFFFu) != lbl;
-            if (first) g_union(c, tile_r * (uint32_t)kCcaTilePx + (a >> 16), tile_l * (uint32_t)kCcaTilePx + (b >> 16));
+        const int ch = (H + kSeamPx - 1) / kSeamPx;
+        const int bx = j / ch + 1, y0 = (j - (bx - 1) * ch) * kSeamPx;
+        const int r0 = y0 % TH;
+        const uint32_t tile_r = (uint32_t)((y0 / TH) * c.tiles_x + bx), tile_l = tile_r - 1u;
+        const uint32_t* er = c.vedge + ((size_t)tile_r * TH + r0) * 2;           // first column of the right tile, row by row (stride 2 words)
+        const uint32_t* el = c.vedge + ((size_t)tile_l * TH + r0) * 2 + 1;       // last column of the left tile
+        uint32_t a[kSeamPx + 1], b[kSeamPx + 1];                                // [0]: the pixels above
+        a[0] = r0 ? er[-2] : 0x10000u;
+        b[0] = r0 ? el[-2] : 0x20000u;
+#pragma unroll
+        for (int q = 0; q < kSeamPx; ++q) {
+            const bool ok = y0 + q < H;
+            a[q + 1] = ok ? er[2 * q] : 0x10000u;
+            b[q + 1] = ok ? el[2 * q] : 0x20000u;
+        }
+#pragma unroll
+        for (int q = 0; q < kSeamPx; ++q) {
+            const uint32_t lbl = a[q + 1] & 0xFFFFu;
+            const bool contact = y0 + q < H && ((a[q + 1] ^ b[q + 1]) & 0xFFFFu) == 0u;
+            const bool first = q + r0 == 0 || (a[q] & 0xFFFFu) != lbl || (b[q] & 0xFFFFu) != lbl;
+            if (contact && first)
+                g_union2(c, tile_r * (uint32_t)kCcaTilePx + (a[q + 1] >> 16), tile_l * (uint32_t)kCcaTilePx + (b[q + 1] >> 16));
         }
     }
 }
@@ -897,7 +966,7 @@ void launch_cca_phase1(const CcaDev& c, int nframes, hipStream_t st) {
     constexpr int T = kCcaTile;
     const int tx = (c.W + T - 1) / T, ty = (c.H + kCcaTileH - 1) / kCcaTileH;
     launch(k_cca_local, dim3(nframes, tx, ty), dim3(256), 0, st, c);
-    const int nh = (ty - 1) * c.W, nv = (tx - 1) * c.H;
+    const int nh = (ty - 1) * ((c.W + kSeamPx - 1) / kSeamPx), nv = (tx - 1) * ((c.H + kSeamPx - 1) / kSeamPx);      // threads: kSeamPx seam pixels each
     if (nh + nv > 0)
         launch(k_cca_border, dim3((nh + nv + 255) / 256, nframes), dim3(256), 0, st, c, nh, nv);
     launch(k_cca_compress, dim3(root_pass_blocks(c) * nframes), dim3(256), 0, st, c, nframes);
