@@ -484,9 +484,15 @@ __global__ __launch_bounds__(256) void k_cca_compress(CcaDev c, int nframes) {
     const int lane = LANE();
     const uint32_t gstride = nbx * blockDim.x;
     const int64_t thr = (int64_t)c.min_threshold;
-    // a wavefront's trips are uniform (the ballot below needs every lane)
-    for (uint32_t w0 = bx * blockDim.x + (threadIdx.x & ~63u); w0 < n; w0 += gstride) {
-        const uint32_t i = w0 + (uint32_t)lane;
+    // a BLOCK's trips are uniform: the candidate append below is one returning atomic per block and trip, not per wavefront.  Every
+    // append of a frame lands on the same counter, and same-address returning global atomics are served one after the other at about
+    // 8.5 ns each: with one per wavefront (about 800 per 1280x720 frame) the pass took 11.4 us for one frame and 15.3 for eight
+    // (eight counters in parallel); per block 6.6 and 9.0 (profiles/r04_assign_experiments.txt)
+    __shared__ uint32_t s_app[2];          // [0] candidates of the block in this trip, [1] their base in the list
+    for (uint32_t b0 = bx * blockDim.x; b0 < n; b0 += gstride) {
+        const uint32_t i = b0 + threadIdx.x;
+        if (threadIdx.x == 0) s_app[0] = 0u;
+        __syncthreads();
         const bool live = i < n;
         const uint32_t r = c.roots[min(i, n - 1)];
         const uint32_t a = n_local(c, r);
@@ -512,13 +518,13 @@ __global__ __launch_bounds__(256) void k_cca_compress(CcaDev c, int nframes) {
         }
         const int32_t leader = cand ? (int32_t)n_leader(c, g) : 0;
         const unsigned long long m = __ballot(cand);
-        if (m) {
-            const int first = __ffsll((long long)m) - 1;
-            uint32_t base = 0;
-            if (lane == first) base = atomicAdd(&c.counters[1], (uint32_t)__popcll(m));
-            base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
-            if (cand) c.cand_leader[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = leader;
-        }
+        uint32_t wbase = 0;
+        if (m && lane == 0) wbase = atomicAdd(&s_app[0], (uint32_t)__popcll(m));      // this wavefront's place among the block's candidates
+        wbase = rfl(wbase);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_app[0]) s_app[1] = atomicAdd(&c.counters[1], s_app[0]);
+        __syncthreads();
+        if (cand) c.cand_leader[s_app[1] + wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = leader;
     }
 }
 
