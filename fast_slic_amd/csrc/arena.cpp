@@ -122,7 +122,7 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     char* b = s.arena + shared_bytes;          // frame 0
     FrameDev& f = s.f;
     f.frame_bytes = frame_bytes;
-    f.H = H; f.W = W; f.N = (int)N; f.K = K; f.S = S; f.T = 2 * S + 32;
+    f.H = H; f.W = W; f.N = (int)N; f.K = K; f.S = S; f.T = 2 * S + 32; f.T_rcp = 0xFFFFFFFFu / (uint32_t)f.T;
     f.cs_shift = sh; f.ncx = ncx; f.ncy = ncy; f.ncell = (int)ncell;
     f.lab = (uint32_t*)(b + o_lab);
     f.labels = (uint16_t*)(b + o_labels);

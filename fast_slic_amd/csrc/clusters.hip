@@ -28,16 +28,21 @@ static __device__ __forceinline__ void gather_sums(const FrameDev& f, const Pass
     // per eight entries instead of one per entry: this pass is a chain of dependent loads on a handful of blocks, and
     // it sits on the critical path of every iteration)
     const int nx = g.bx1 - g.bx0 + 1, ne = nx * (g.by1 - g.by0 + 1);
+    // e / nx for the handful of entries of a cluster through a 16-bit reciprocal (guarded): eight general divisions per batch were a
+    // sixth of this kernel's instructions, and it sits on the critical path of every iteration
+    const uint32_t inv_nx = (uint32_t)(65536.0f * __builtin_amdgcn_rcpf((float)nx)) + 1u;
     constexpr int kBatch = 8;
     for (int e0 = 0; e0 < ne; e0 += kBatch) {
         uint2 v[kBatch][3];
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {
             const int e = e0 + u;
-            const int ey = e / nx, ex = e - ey * nx;
+            uint32_t ey = __umul24((uint32_t)e, inv_nx) >> 16;
+            if (__umul24(ey, (uint32_t)nx) > (uint32_t)e) ey--;
+            const uint32_t ex = (uint32_t)e - __umul24(ey, (uint32_t)nx);
             v[u][0] = v[u][1] = v[u][2] = make_uint2(0u, 0u);
             if (e < ne) {
-                const uint2* p = reinterpret_cast<const uint2*>(cp + (ey * f.nbx + ex) * 6);   // 24-byte entries
+                const uint2* p = reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(cp) + __umul24(__umul24(ey, (uint32_t)f.nbx) + ex, 24u));   // 24-byte entries
                 v[u][0] = p[0]; v[u][1] = p[1]; v[u][2] = p[2];
             }
         }
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg, c
         z0[0] = 0; z0[1] = 0; z0[2] = 0; z0[3] = 0; z0[4] = 0; z0[5] = 0;
     }
     // visit order of the reference scatter: phase = 2*((cy/T)&1) + ((cx/T)&1), then k
-    const uint32_t phase = (uint32_t)(2 * ((y / f.T) & 1) + ((x / f.T) & 1));
+    const uint32_t phase = 2u * (div_by((uint32_t)y, (uint32_t)f.T, f.T_rcp) & 1u) + (div_by((uint32_t)x, (uint32_t)f.T, f.T_rcp) & 1u);
     ClusterRec rec;
     rec.yx = yx; rec.lab = lab; rec.tag = (phase << 16) | (uint32_t)k; rec.pad = f.generation();
     f.cl_tag[k] = rec.tag;

@@ -123,8 +123,9 @@ static __device__ __forceinline__ SlotGeom slot_geom(int cy, int cx, int S, int 
     const int u = min(cy + S, H - 1) - rem;
     const int v1 = u < 0 ? -1 : min(div_rows(u, stride), Hv - 1);
     g.any = v0 <= v1;
-    g.by0 = v0 / BH;
-    g.by1 = g.any ? v1 / BH : -1;
+    const int bsh = 31 - __clz(BH);          // BH = 4 wavefronts x {4, 8, 16, 32} rows: a power of two (no division in the cluster pass)
+    g.by0 = v0 >> bsh;
+    g.by1 = g.any ? v1 >> bsh : -1;
     return g;
 }
 

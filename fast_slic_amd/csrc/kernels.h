@@ -50,6 +50,7 @@ struct FrameDev {
     // geometry
     int H, W, N, K, S;
     int T;               // 2S + 32, phase cell side (src/context.cpp:213)
+    uint32_t T_rcp;      // floor((2^32 - 1) / T): the cluster pass divides by T without a division (device_common.h, div_by)
     int cs_shift;        // coarse bin side = 1 << cs_shift
     int ncx, ncy, ncell;
     // Generation stamp of the bin pass that filled cell_items[buf] (ClusterRec::pad) = *gen_base + gen_off.  The base

@@ -14,10 +14,14 @@ struct LabConst { int cb[9]; };
 
 static __device__ __forceinline__ uint32_t lab_px(uint32_t R, uint32_t G, uint32_t B,
                                                   const uint16_t* sg, const uint16_t* sl, const LabConst& k) {
-    const int sr = sg[R], sgv = sg[G], sb = sg[B];
-    const int xr = (k.cb[0] * sr + k.cb[1] * sgv + k.cb[2] * sb) >> 16;
-    const int yr = (k.cb[3] * sr + k.cb[4] * sgv + k.cb[5] * sb) >> 16;
-    const int zr = (k.cb[6] * sr + k.cb[7] * sgv + k.cb[8] * sb) >> 16;
+    // (24-bit multiply-adds: the gamma values are below 2^14, the matrix coefficients below 2^16 and a row's sum below 2^30, so the
+    // results are the reference's ints; a 32-bit v_mul_lo_u32 issues at a quarter of the rate, and nine of them per pixel were more
+    // than half of this kernel's vector time)
+    const uint32_t sr = sg[R], sgv = sg[G], sb = sg[B];
+    auto row = [&](int i) -> int {
+        return (int)((__umul24((uint32_t)k.cb[i], sr) + __umul24((uint32_t)k.cb[i + 1], sgv) + __umul24((uint32_t)k.cb[i + 2], sb)) >> 16);
+    };
+    const int xr = row(0), yr = row(3), zr = row(6);
     const int fx = sl[xr], fy = sl[yr], fz = sl[zr];
     const int ciel = 116 * fy - (16 << 13);
     const int ciea = 500 * (fx - fy) + (128 << 13);
