@@ -544,10 +544,14 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
     __shared__ __attribute__((aligned(16))) uint32_t s_part[64][4];                // partial ranks: [candidate][wavefront]
     __shared__ __attribute__((aligned(16))) uint32_t s_wcnt[4];                    // kept records per wavefront
     __shared__ __attribute__((aligned(16))) uint32_t s_entry[FUSE ? 64 : 4];       // cpart entry by rank | kNoSlot
-    // cluster number by the LOW BYTE of a pixel's key (rank | two distance bits << 6, i.e. four copies): the byte comes out of the
-    // packed minima with one SDWA shift, no mask.  Every wavefront writes the same values (no barrier between these stores and the
-    // epilogue's reads: a wavefront's own stores precede its reads, and what the others store is identical).
-    __shared__ __attribute__((aligned(16))) uint16_t s_k256[256];
+    // cluster number by a pixel's rank (the low six bits of its key).  Every wavefront writes the same values (no barrier between
+    // these stores and the epilogue's reads: a wavefront's own stores precede its reads, and what the others store is identical).
+    // (Until the end of round 4 the table had 256 entries indexed by the key's whole low byte -- rank | two distance bits, four copies
+    // 128 bytes apart -- to save the mask: but 128 bytes is the period of the LDS banks, lanes of equal rank and different distance bits
+    // met on one bank at different addresses, and the sixteen look-ups of a wavefront cost 120 LDS cycles, 90 of them bank conflicts,
+    // and 8 % of the fused launch's duration: scripts/gpu_r04_knock.sh, profiles/r04_assign_experiments.txt.  The 64 entries are one
+    // pass over the banks: equal ranks read one address, different ranks different banks.)
+    __shared__ __attribute__((aligned(16))) uint16_t s_k256[64];
     // centroid accumulators: per (candidate, copy) two 64-bit words of three 20-bit-spaced fields each,
     //   A = sum L | sum a << 20 | sum b << 40        B = sum (x - x0) | sum (y - y0) << 20 | count << 40
     __shared__ __attribute__((aligned(16))) unsigned long long s_acc[FUSE ? 64 * kBlkCopies * 2 : 2];
@@ -713,10 +717,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
         const uint4 pr = *reinterpret_cast<const uint4*>(s_part[lane]);
         rank_j = pr.x + pr.y + pr.z + pr.w;
     }
-    if (lane < bn) {
-#pragma unroll
-        for (int d = 0; d < 4; ++d) s_k256[d * 64 + (int)rank_j] = (uint16_t)(mine.z & 0xFFFFu);
-    }
+    if (lane < bn) s_k256[(int)rank_j] = (uint16_t)(mine.z & 0xFFFFu);
     uint32_t fin_nx = 0, fin_ny = 0;             // FBIN, wavefront 0, lane j: blocks that deliver sums of candidate j (0: not this block)
     if (FUSE && wave == 0) {
         uint32_t entry = kNoSlot;
@@ -935,7 +936,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
                 const char* const ktab = reinterpret_cast<const char*>(s_k256);
 #pragma unroll
                 for (int q = 0; q < R / 2; ++q) {
-                    const uint32_t b = __builtin_bit_cast(uint32_t, best[q]);
+                    const uint32_t b = __builtin_bit_cast(uint32_t, best[q]) & 0x003F003Fu;       // (the fused sums below need the ranks alone as well)
                     kk[2 * q] = *reinterpret_cast<const uint16_t*>(ktab + ((b & 0xFFu) << 1));
                     kk[2 * q + 1] = *reinterpret_cast<const uint16_t*>(ktab + (((b >> 16) & 0xFFu) << 1));
                 }
