@@ -551,7 +551,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
     // met on one bank at different addresses, and the sixteen look-ups of a wavefront cost 120 LDS cycles, 90 of them bank conflicts,
     // and 8 % of the fused launch's duration: scripts/gpu_r04_knock.sh, profiles/r04_assign_experiments.txt.  The 64 entries are one
     // pass over the banks: equal ranks read one address, different ranks different banks.)
-    __shared__ __attribute__((aligned(16))) uint16_t s_k256[64];
+    __shared__ __attribute__((aligned(16))) uint16_t s_klab[64];
     // centroid accumulators: per (candidate, copy) two 64-bit words of three 20-bit-spaced fields each,
     //   A = sum L | sum a << 20 | sum b << 40        B = sum (x - x0) | sum (y - y0) << 20 | count << 40
     __shared__ __attribute__((aligned(16))) unsigned long long s_acc[FUSE ? 64 * kBlkCopies * 2 : 2];
@@ -717,7 +717,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
         const uint4 pr = *reinterpret_cast<const uint4*>(s_part[lane]);
         rank_j = pr.x + pr.y + pr.z + pr.w;
     }
-    if (lane < bn) s_k256[(int)rank_j] = (uint16_t)(mine.z & 0xFFFFu);
+    if (lane < bn) s_klab[(int)rank_j] = (uint16_t)(mine.z & 0xFFFFu);
     uint32_t fin_nx = 0, fin_ny = 0;             // FBIN, wavefront 0, lane j: blocks that deliver sums of candidate j (0: not this block)
     if (FUSE && wave == 0) {
         uint32_t entry = kNoSlot;
@@ -933,7 +933,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
             epilogue_done = true;
             if (okx) {
                 uint32_t kk[R];
-                const char* const ktab = reinterpret_cast<const char*>(s_k256);
+                const char* const ktab = reinterpret_cast<const char*>(s_klab);
 #pragma unroll
                 for (int q = 0; q < R / 2; ++q) {
                     const uint32_t b = __builtin_bit_cast(uint32_t, best[q]) & 0x003F003Fu;       // (the fused sums below need the ranks alone as well)
@@ -1011,7 +1011,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
             const uint32_t key = (r & 1) ? (uint32_t)best[r / 2].y : (uint32_t)best[r / 2].x;
             const bool found = key != 0xFFFFu;
             slot[r] = kNoSlot;
-            if (ok && found) st_stream(rowp + xo, s_k256[key & 63u]);
+            if (ok && found) st_stream(rowp + xo, s_klab[key & 63u]);
             if (FUSE && ok) {
                 if (found) slot[r] = key & 63u;
                 else {
