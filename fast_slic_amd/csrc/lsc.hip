@@ -507,12 +507,17 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
                 if (slot[u] == kLscNoSlot || (u == 1 && both)) continue;
                 unsigned long long* a = s_accx + ((slot[u] << cshift) + copy) * kLscAccW;
                 auto fixed = [&](int q) { return (uint32_t)(int)__builtin_rintf(Fr[u][q] * l.blk_fix_f); };
+#if !(FSLIC_EXP & 8)      // (knock-out build 8, scripts/gpu_r04_knock.sh: what the block accumulators' LDS atomics cost; results wrong on purpose)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) atomicAdd(a + q, (unsigned long long)fixed(q) | ((unsigned long long)fixed(6 + q) << 32));
                 atomicAdd(a + 4, (unsigned long long)fixed(4) | ((unsigned long long)fixed(5) << 32));
                 atomicAdd(a + 5, (unsigned long long)(uint32_t)(int)__builtin_rintf(Fr[u][kLscFeat] * l.blk_fix_w));
                 atomicAdd(a + 6, (unsigned long long)ia[u][0] | ((unsigned long long)ia[u][1] << 32));
                 atomicAdd(a + 7, (unsigned long long)ia[u][2] | ((unsigned long long)ia[u][3] << 32));
+#else
+                asm volatile("" :: "v"(a), "v"(fixed(0)), "v"(fixed(1)), "v"(fixed(2)), "v"(fixed(3)), "v"(fixed(4)), "v"(fixed(5)), "v"(fixed(6)), "v"(fixed(7)), "v"(fixed(8)), "v"(fixed(9)),
+                             "v"(ia[u][0]), "v"(ia[u][1]), "v"(ia[u][2]), "v"(ia[u][3]));
+#endif
             }
         }
         LSC_STAMP(5 + 2 * h, wave == 1);        // pair h: labels stored, runs summed

@@ -1,6 +1,9 @@
 #!/bin/bash
-# Round 4: knock-out builds of the fused assign kernel (results wrong on purpose; FSLIC_EXP 1: no LDS atomics in the fast epilogue, 2: no
-# whole-column atomics, 4: no label look-ups): duration and SQ counters of the fused launch at 8 x 3840x2160, to see what its LDS time is made of.
+# Round 4: knock-out builds (results wrong on purpose, only duration and SQ counters are read): what a kernel's LDS time is made of.
+# Fused assign kernel at 8 x 3840x2160: the guards were FSLIC_EXP 1 (no LDS atomics in the fast epilogue), 2 (no whole-column atomics), 4 (no
+# label look-ups); they found the label table's bank conflicts and were removed with the fix (profiles/r04_assign_experiments.txt; restore them
+# from commit 7126983's parent to repeat).  LSC: FSLIC_EXP 8 (no block-accumulator atomics in k_lsc_assign_sums) is in lsc.hip, not yet run:
+#   make -C fast_slic_amd/csrc VAR=k8 DEFS=-DFSLIC_EXP=8;  FSLIC_LIB=.../libfslic_hip_var_k8.so PMC_VAR=lsc bash scripts/gpu_pmc_group.sh
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 for lib in libfslic_hip.so libfslic_hip_var_k1.so libfslic_hip_var_k2.so libfslic_hip_var_k4.so; do
