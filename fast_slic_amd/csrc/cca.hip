@@ -616,6 +616,21 @@ static __device__ __forceinline__ void select_pass(const uint32_t* s_area, uint3
 //      __pop_heap for the survivors in index order (tie_wave_sift from the root: five levels per LDS round trip)
 //   4. the heap's K entries are the kept set: label = rank among the kept in leader order (src/cca.cpp:229-237)
 // A heap entry is one 64-bit word (area << 32 | candidate index): one LDS access moves it.
+//
+// Round 5: only the SMALL entries are replayed.  With a* the K-th largest area (known from the selection above), every
+// candidate with area > a* ("big") is kept whatever the heap does, and the heap is a min-heap on the area, so the small entries
+// (area <= a*: the ties at the cut and whatever lies below it, M - K + a handful) form a connected region around the root.  Where
+// a sift's walk leaves that region (both children big) nothing it does further down can change the position of a small entry ever
+// again: a child of a big entry is big (heap property), and a walk prefers a small child to a big one whichever big one it is.  So
+// every sift -- of __make_heap and of __pop_heap alike -- stops at the first preferred child whose area exceeds min(value, a*): the
+// positions and contents of the small entries stay exactly libstdc++'s, the big entries' arrangement does not (and is not read).
+// The kept set is then "big, or small and still in the heap", the latter as one bit per candidate (set for the first K, cleared
+// when an entry leaves through the root, set when a candidate enters).  tests/test_oracle.py pins this rule against the restated
+// library calls on 3000 inputs built to tie.  What it buys: a replacement walks the depth of the small region (five or six levels
+// for the ~50 small entries of a 1280x720 K=1600 frame) instead of the heap's eleven to thirteen, and during the sequential
+// __heap_select loop the top six levels of the heap live in the REGISTERS of the one wavefront that replays it (lane j = heap node
+// j - 1): a replacement that ends inside them -- nearly all -- is ballots, scalar bit tests and lane moves, no LDS round trip at all
+// (round 4: three round trips of ~0.3 us each, 21 of the 46 us this kernel took for a 1280x720 frame with a tie).
 // ---------------------------------------------------------------------------------------------
 typedef unsigned long long heap_t;      // area << 32 | candidate index: one LDS access moves an entry, comp looks at the high half
 constexpr int kTieWaveLevels = 4;       // __make_heap: parents of depth <= this are sifted by a wavefront each (tie_wave_sift)
@@ -631,7 +646,10 @@ static __device__ __forceinline__ uint32_t hp_area(heap_t e) { return (uint32_t)
 // of the path moved up one place and `value` stored at position h, h = the last path index whose area is <= value's.  That
 // is a top-down sift that stops at the first larger child -- identical results, a handful of levels instead of the whole
 // depth twice (pinned against the library's own heap calls in the tests, like the rest of the tie path).
-static __device__ __forceinline__ void tie_adjust_heap(heap_t* h, int hole, int len, heap_t value, bool writer) {
+// `astar` (the K-th largest area): the sparse rule of tie_heap_select -- a child larger than astar ends the walk like a child larger
+// than the value does.
+static __device__ __forceinline__ void tie_adjust_heap(heap_t* h, int hole, int len, heap_t value, bool writer, uint32_t astar) {
+    const uint32_t vlim = min(hp_area(value), astar);
     int cur = hole;
     for (;;) {
         int child;
@@ -647,7 +665,7 @@ static __device__ __forceinline__ void tie_adjust_heap(heap_t* h, int hole, int 
         } else {
             break;
         }
-        if (hp_area(em) > hp_area(value)) break;                              // __push_heap would bring it back here
+        if (hp_area(em) > vlim) break;                                        // __push_heap would bring it back here (or: the small region ends)
         if (writer) hp_st(h + cur, em);
         cur = child;
     }
@@ -667,9 +685,10 @@ static __device__ __forceinline__ void tie_adjust_heap(heap_t* h, int hole, int 
 // (The first form of this routine resolved the five levels with three v_readlane per level and let lanes 0..4 store: a
 // replacement at the root took 0.93 us; profiles/r03_lab_select_stamps.txt has both.)
 // Returns the area of the entry that ends up at `hole`.
-static __device__ __forceinline__ uint32_t tie_wave_sift(heap_t* h, int len, int hole, heap_t value, int lane) {
+static __device__ __forceinline__ uint32_t tie_wave_sift(heap_t* h, int len, int hole, heap_t value, int lane, uint32_t astar) {
     constexpr uint32_t kInf = 0xFFFFFFFFu;
     const uint32_t va = hp_area(value);
+    const uint32_t vlim = min(va, astar);                      // (sparse rule, see tie_heap_select: astar < kInf)
     const int t = 31 - __clz(lane | 1);                       // depth of relative node `lane` (lane 0: unused)
     const int off = lane - (1 << t);
     int cur = hole;                                            // absolute index of the node the value may still end up at
@@ -682,7 +701,7 @@ static __device__ __forceinline__ uint32_t tie_wave_sift(heap_t* h, int len, int
         const uint32_t sib = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
         // even lanes (left children): comp(first[right], first[left]) = area[right] > area[left] -> the left one is taken
         const unsigned long long left_pref = __ballot(sib > a);
-        const unsigned long long stop_at = __ballot(a == kInf || a > va);     // leaf, or __push_heap would bring the value back up to here
+        const unsigned long long stop_at = __ballot(a > vlim);                // leaf (kInf), __push_heap would bring the value back up to here, or the small region ends
         // five steps down the preferred children, straight-line on the scalar unit (a taken branch costs more than a step's
         // arithmetic); the steps before the first stop are the moves that really happen
         int c[5];
@@ -722,7 +741,7 @@ static __device__ __forceinline__ uint32_t tie_wave_sift(heap_t* h, int len, int
 #else
 #define SEL_STAMP(i_) do { } while (0)
 #endif
-static __device__ __forceinline__ void tie_heap_select(const CcaDev& c, uint32_t M, uint32_t K, uint32_t* s_area, uint32_t* s_lead, uint32_t* s_key,
+static __device__ __forceinline__ void tie_heap_select(const CcaDev& c, uint32_t M, uint32_t K, uint32_t astar, uint32_t* s_area, uint32_t* s_lead, uint32_t* s_key,
                                                        uint32_t* s_bcnt, uint32_t* s_bstart, uint32_t* s_bfill, uint32_t* s_w) {
     const int tid = threadIdx.x, lane = tid & 63;
     SEL_STAMP(2);
@@ -773,6 +792,13 @@ static __device__ __forceinline__ void tie_heap_select(const CcaDev& c, uint32_t
             s_area[r] = my_area[q];
             if (r < K) heap[r] = ((heap_t)my_area[q] << 32) | r;
         }
+    // "in the heap" bits, one per candidate (the ranking buckets are dead): the first K in leader order to begin with
+    uint32_t* const s_in = s_bcnt;
+    static_assert(kSelSortCap / 32 <= 3 * kSelBuckets, "one bit per candidate in the bucket arrays");
+    for (uint32_t w = (uint32_t)tid; w < (uint32_t)(kSelSortCap / 32); w += 1024u) {
+        const uint32_t lo = w * 32u;
+        s_in[w] = K >= lo + 32u ? 0xFFFFFFFFu : (K <= lo ? 0u : (1u << (K - lo)) - 1u);
+    }
     __syncthreads();
     SEL_STAMP(3);
     // 2. __make_heap(first, first + K)
@@ -786,11 +812,11 @@ static __device__ __forceinline__ void tie_heap_select(const CcaDev& c, uint32_t
             if (d > kTieWaveLevels) {
                 // deep parents: many of them, short walks -- one thread each
                 for (int p = lo + tid; p <= hi; p += 1024)
-                    tie_adjust_heap(heap, p, len, hp_ld(heap + p), true);
+                    tie_adjust_heap(heap, p, len, hp_ld(heap + p), true, astar);
             } else {
                 // the upper levels: at most one parent per wavefront, walks of seven to eleven levels -- five levels per LDS round trip
                 for (int p = lo + (int)rfl((uint32_t)(tid >> 6)); p <= hi; p += 16)
-                    tie_wave_sift(heap, len, p, hp_ld(heap + p), lane);
+                    tie_wave_sift(heap, len, p, hp_ld(heap + p), lane, astar);
             }
             __syncthreads();
         }
@@ -798,7 +824,11 @@ static __device__ __forceinline__ void tie_heap_select(const CcaDev& c, uint32_t
     SEL_STAMP(4);
     // 3. for (i = K; i < M; ++i) if (comp(*i, *first)) __pop_heap(first, middle, i)
     if (tid < 64) {
-        uint32_t top_area = hp_area(hp_ld(heap));
+        constexpr uint32_t kInf = 0xFFFFFFFFu;
+        // the top six levels of the heap in this wavefront's registers: lane j (1..63) = heap node j - 1 (absent nodes: area kInf)
+        uint32_t ea = kInf, ei = 0u;
+        if (lane >= 1 && lane - 1 < len) { const heap_t e = hp_ld(heap + (lane - 1)); ea = hp_area(e); ei = (uint32_t)e; }
+        uint32_t top_area = (uint32_t)__builtin_amdgcn_readlane((int)ea, 1);
         for (uint32_t base = K; base < M; base += 64) {
             const uint32_t i = base + (uint32_t)lane;
             const uint32_t a = i < M ? s_area[i] : 0u;
@@ -807,36 +837,64 @@ static __device__ __forceinline__ void tie_heap_select(const CcaDev& c, uint32_t
                 const int j = __builtin_ctzll(m);
                 m &= m - 1ull;
                 const uint32_t aj = (uint32_t)__builtin_amdgcn_readlane((int)a, j);
-                if (aj > top_area) {
-                    top_area = tie_wave_sift(heap, len, 0, ((heap_t)aj << 32) | (heap_t)(base + (uint32_t)j), lane);
+                if (aj <= top_area) continue;
+                const uint32_t vi = base + (uint32_t)j;
+                // the entry at the root leaves the heap, the candidate enters (the bit of a big candidate is never read)
+                const uint32_t ti = (uint32_t)__builtin_amdgcn_readlane((int)ei, 1);
+                if (lane == 0) { atomicAnd(&s_in[ti >> 5], ~(1u << (ti & 31u))); atomicOr(&s_in[vi >> 5], 1u << (vi & 31u)); }
+                const uint32_t vlim = min(aj, astar);
+                const uint32_t sib = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ea, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+                const unsigned long long left_pref = __ballot(sib > ea);       // (as tie_wave_sift)
+                const unsigned long long stop_at = __ballot(ea > vlim);
+                int cn[5];
+                uint32_t stops = 0;
+                {
+                    int jj = 1;
+#pragma unroll
+                    for (int s5 = 0; s5 < 5; ++s5) {
+                        const int cl = 2 * jj;
+                        cn[s5] = cl + (int)(((left_pref >> cl) & 1ull) ^ 1ull);
+                        stops |= (uint32_t)((stop_at >> cn[s5]) & 1ull) << s5;
+                        jj = cn[s5];
+                    }
                 }
+                const int nmove = __builtin_ctz(stops | 32u);
+                // the entries on the path move up one place, lane to lane
+                int dst = 1;
+#pragma unroll
+                for (int s5 = 0; s5 < 5; ++s5) {
+                    if (s5 < nmove) {
+                        const uint32_t ma = (uint32_t)__builtin_amdgcn_readlane((int)ea, cn[s5]), mi = (uint32_t)__builtin_amdgcn_readlane((int)ei, cn[s5]);
+                        ea = write_lane(ea, ma, dst);
+                        ei = write_lane(ei, mi, dst);
+                        dst = cn[s5];
+                    }
+                }
+                const int cur = dst - 1;                                       // heap index of the place the value may still end up at
+                if (nmove < 5 || 2 * cur + 1 >= len) {
+                    ea = write_lane(ea, aj, dst);
+                    ei = write_lane(ei, vi, dst);
+                } else {
+                    // the small region reaches below the sixth level here (rare): the rest of the walk on the heap in LDS, whose
+                    // entries from the seventh level down are current (nothing above has ever been written back, nothing above is
+                    // read: the sift reads the descendants of `cur` only), then this node's new entry back into its register
+                    (void)tie_wave_sift(heap, len, cur, ((heap_t)aj << 32) | (heap_t)vi, lane, astar);
+                    const heap_t e = hp_ld(heap + cur);
+                    if (lane == dst) { ea = hp_area(e); ei = (uint32_t)e; }
+                }
+                top_area = (uint32_t)__builtin_amdgcn_readlane((int)ea, 1);
             }
         }
     }
     __syncthreads();
     SEL_STAMP(5);
-    // 4. kept set = the heap's K entries; label = rank among the kept in leader order
-    // the kept flags reuse the heap's words (dead once its indices have been read): read all indices first
-    uint32_t kept_idx[PER];
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        const uint32_t t = (uint32_t)tid + (uint32_t)q * 1024u;
-        kept_idx[q] = t < K ? (uint32_t)heap[t] : 0xFFFFFFFFu;
-    }
-    __syncthreads();
-    uint32_t* const ha_ = s_lead;
-    for (uint32_t i = tid; i < M; i += 1024) ha_[i] = 0u;
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < PER; ++q)
-        if (kept_idx[q] != 0xFFFFFFFFu) ha_[kept_idx[q]] = 1u;
-    __syncthreads();
+    // 4. kept set = the big candidates and the small ones still in the heap; label = rank among the kept in leader order
     // exclusive scan of the flags: thread t owns candidates [PER * t, PER * t + PER)
     uint32_t fl[PER], cnt = 0;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         const uint32_t i = (uint32_t)tid * PER + (uint32_t)q;
-        fl[q] = i < M ? ha_[i] : 0u;
+        fl[q] = i < M ? (uint32_t)(s_area[i] > astar) | ((s_in[i >> 5] >> (i & 31u)) & 1u) : 0u;
         cnt += fl[q];
     }
     uint32_t total;
@@ -921,7 +979,7 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int cap) {
                 if (tid == 0) c.counters[3] = 2u;
                 return;
             }
-            tie_heap_select(c, M, (uint32_t)K, s_area, s_lead, s_key, s_bcnt, s_bstart, s_bfill, s_w);
+            tie_heap_select(c, M, (uint32_t)K, astar, s_area, s_lead, s_key, s_bcnt, s_bstart, s_bfill, s_w);
             if (tid == 0) c.counters[3] = 0u;
             return;
         }

@@ -93,6 +93,16 @@ static __device__ __forceinline__ bool lanes(unsigned long long m) { return __bu
 
 static __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// v with lane `lane` (wave-uniform) replaced by the wave-uniform `val`: v_writelane_b32.  With the value in a scalar register the lane
+// select has to come through M0 on this target (one scalar operand per vector instruction); M0 is saved and restored, as around the
+// LDS-DMA pieces of assign.hip.
+static __device__ __forceinline__ uint32_t write_lane(uint32_t v, uint32_t val, int lane) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                 : "+v"(v), "=&s"(keep) : "s"(val), "s"(lane));
+    return v;
+}
+
 // floor(x / n) for x < 2^31, n >= 1, through the reciprocal r = floor((2^32 - 1) / n): the estimate is at most one short
 // (the five round_int means of a cluster, src/fast-slic-common.h:62-65, cost one division instead of five)
 static __device__ __forceinline__ uint32_t div_by(uint32_t x, uint32_t n, uint32_t r) {

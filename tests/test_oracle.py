@@ -137,6 +137,67 @@ def test_topdown_sift_keeps_exactly_what_libstdcxx_heap_select_keeps():
         assert got == exp, (trial, M, K)
 
 
+def _sparse_heap_select(M, K, area):
+    """The rule the device replays since round 5 (fast_slic_amd/csrc/cca.hip, tie_heap_select): with a* the K-th largest area, a
+    sift -- of __make_heap and of __pop_heap alike -- stops at the first preferred child whose area exceeds min(value's area, a*),
+    and the kept set is "area > a*, or still in the heap" (one bit per candidate).  The arrangement of the entries above a* then
+    differs from libstdc++'s; the kept set must not."""
+    astar = int(np.sort(area)[::-1][K - 1])
+    h = list(range(K))
+    inheap = [i < K for i in range(M)]
+
+    def sift(hole, value):
+        cur, vlim = hole, min(int(area[value]), astar)
+        while True:
+            if cur < (K - 1) // 2:
+                r = 2 * (cur + 1)
+                child = r - 1 if area[h[r]] > area[h[r - 1]] else r
+            elif (K & 1) == 0 and cur == (K - 2) // 2:
+                child = 2 * cur + 1
+            else:
+                break
+            if area[h[child]] > vlim:
+                break
+            h[cur] = h[child]
+            cur = child
+        h[cur] = value
+
+    for p in range((K - 2) // 2, -1, -1) if K >= 2 else []:
+        sift(p, h[p])
+    for i in range(K, M):
+        if area[i] > area[h[0]]:
+            assert area[h[0]] <= astar          # the root is never an entry above a*: fewer than K of those exist
+            inheap[h[0]] = False
+            inheap[i] = True
+            sift(0, i)
+    return [i for i in range(M) if area[i] > astar or inheap[i]]
+
+
+def test_sparse_sift_keeps_exactly_what_libstdcxx_heap_select_keeps():
+    rng = np.random.RandomState(2)
+    for trial in range(3000):
+        M = int(rng.randint(2, 400))
+        K = int(rng.randint(1, M))
+        style = trial % 6
+        if style == 0:
+            area = rng.randint(1, 6, M)
+        elif style == 1:
+            area = rng.randint(1, 50, M)
+        elif style == 2:
+            area = np.sort(rng.randint(1, 20, M))
+        elif style == 3:
+            area = np.sort(rng.randint(1, 20, M))[::-1].copy()
+        elif style == 4:
+            area = rng.randint(1, 1000, M)
+        else:                                       # the bench frames' shape: M a little above K, most areas far above the cut
+            K = max(1, M - int(rng.randint(1, 40)))
+            area = np.where(rng.rand(M) < 0.15, rng.randint(1, 4, M), rng.randint(50, 60, M))
+        area = area.astype(np.int32)
+        got = _sparse_heap_select(M, K, area)
+        exp = sorted(orc.heap_select(np.arange(M, dtype=np.int32), K, area)[:K].tolist())
+        assert got == exp, (trial, M, K)
+
+
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built (no /root/reference here)")
 def test_oracle_equals_live_reference():
     rng = np.random.default_rng(3)
