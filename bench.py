@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 ASSIGN_BYTES_PER_PX = 6.0      # 4 B LAB read + 2 B label write per visited pixel
 LSC_ASSIGN_BYTES_PER_PX = 6.0  # 4 B LAB word + 2 B label: the features are rebuilt from the LAB word (SURVEY.md 8d's recompute design; the materialised one moved 46 B)
-PROFILE_TAG = "r04"
+PROFILE_TAG = "r05"
 
 WORKLOADS = {
     "720p": dict(H=720, W=1280, K=1600, fpg=8, name="1280x720 RGB, K=1600, 10 iters (configs[1]), 8 frames/GPU"),
@@ -52,31 +52,30 @@ def gbs(nbytes, ms):
     return nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
 
 
-def measured_copy_bandwidth():
-    """Empirical HBM bandwidth of this box (SURVEY.md 8d asks for fractions against the measured peak as well as the spec):
-    a device-to-device copy of 1 GiB (read 1 GiB + write 1 GiB, far beyond the 256 MB infinity cache), best of 5, HIP events."""
-    import torch
-    n = 1 << 30
-    a = torch.empty(n, dtype=torch.uint8, device="cuda").fill_(1)
-    b = torch.empty_like(a)
-    best = 0.0
-    for rep in range(6):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(4):
-            b.copy_(a)
-        e1.record()
-        torch.cuda.synchronize()
-        if rep:
-            best = max(best, gbs(2.0 * n * 4, e0.elapsed_time(e1)))
-    del a, b
-    return round(best, 1)
+def measured_copy_bandwidth(eng):
+    """Empirical HBM bandwidth of this box (SURVEY.md 8d asks for fractions against the measured peak as well as the spec): the
+    library's plain streaming copy kernel (16 bytes per lane and trip, csrc/graph.hip k_copy16 -- the form the MI355X guide quotes
+    6.29 TB/s for) over 1 GiB (read 1 GiB + write 1 GiB, far beyond the 256 MB infinity cache), best of 5, HIP events."""
+    try:
+        return round(eng.copy_bandwidth(1 << 30, 5), 1)
+    except (AttributeError, RuntimeError):      # an A/B library of an earlier round (FSLIC_LIB) has no such entry point
+        return None
+
+
+PATH_BYTES_PER_PX = 37.0       # SURVEY.md 8d: 7 N (LAB) + 10 x 6 N / 3 (fused assign + update) + 6 N (full assign) + 4 N (connectivity lower bound)
+
+
+def path_roofline(mp_per_s, what):
+    """Fraction of the HBM roofline of the WHOLE path at a measured rate (megapixels/s of one GPU): 37 N algorithmic bytes per frame."""
+    ach = mp_per_s * 1e6 * PATH_BYTES_PER_PX / 1e9
+    return {"what": what, "bytes_per_px": PATH_BYTES_PER_PX, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "ceiling_megapixels_per_sec": round(HBM_PEAK_GBS * 1e9 / PATH_BYTES_PER_PX / 1e6, 0)}
 
 
 def pmc_traffic(key):
     """HBM bytes per launch of the assign kernels from the committed rocprofv3 --pmc passes of this workload
     (profiles/<round>_pmc_assign_traffic.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE); None when absent."""
-    for tag in (PROFILE_TAG, "r03", "r02", "r01"):
+    for tag in (PROFILE_TAG, "r04", "r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", "%s_pmc_assign_traffic.json" % tag)) as f:
                 return json.load(f)[key], "profiles/%s_pmc_assign_traffic.json" % tag
@@ -88,14 +87,15 @@ def pmc_traffic(key):
 def rocprof_avg_us(csv_name, *needles):
     """Average duration (us) of the first kernel whose name contains every one of `needles` in a committed rocprofv3 summary
     (profiles/<round>_kernel_stats_*.csv, written by scripts/gpu_profiles.sh from a --kernel-trace run); None when absent."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "%s_%s" % (PROFILE_TAG, csv_name))) as f:
-            for line in f:
-                if all(n in line for n in needles):
-                    return float(line.rsplit('",', 1)[1].split(",")[2])
-    except (OSError, ValueError, IndexError):
-        pass
-    return None
+    for tag in (PROFILE_TAG, "r04"):
+        try:
+            with open(os.path.join(ROOT, "profiles", "%s_%s" % (tag, csv_name))) as f:
+                for line in f:
+                    if all(n in line for n in needles):
+                        return float(line.rsplit('",', 1)[1].split(",")[2]), tag
+        except (OSError, ValueError, IndexError):
+            continue
+    return None, None
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -486,7 +486,10 @@ def main():
                     help="strong scaling: a FIXED batch of this many frames per step split over the GPUs (BASELINE configs[3]: 64); "
                          "default 0 = weak scaling, --frames-per-gpu frames on every GPU")
     ap.add_argument("--slots", type=int, default=6, help="groups in flight per GPU (stream + host thread each)")
-    ap.add_argument("--launch-frames", type=int, default=16, help="most frames a launch group gathers from the submit queue (dynamic batching; the library's limit is 16)")
+    ap.add_argument("--launch-frames", type=int, default=None,
+                    help="most frames a launch group gathers from the submit queue (dynamic batching; the library's limit is 16).  Default: 16, and at "
+                         "most two submissions per group (every merged form is a buffer set and a recorded graph per slot: small --frames-per-gpu "
+                         "would otherwise multiply the setup); given explicitly, as many submissions as fit")
     ap.add_argument("--no-batching", action="store_true", help="one submission per launch group (no dynamic batching in the pipeline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-4k", action="store_true", help="skip the 4K, K=6000, LSC and end-to-end sub-objects")
@@ -499,6 +502,8 @@ def main():
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 1000 if args.workload == "720p" else 200
+    if args.launch_frames is not None and not 1 <= args.launch_frames <= 16:
+        ap.error("--launch-frames must be in 1..16 (the library's group limit, FSLIC_MAX_GROUP)")
 
     from fast_slic_amd import batch
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -556,7 +561,12 @@ def main():
     eng = Engine(dev, nslots)
     # Dynamic batching: a slot thread that finds two submissions waiting serves them as one group (16 frames per launch instead
     # of 8).  Results are per frame and do not change; the parity gate below checks a submission of the timed region.
-    merged_max = 1 if args.no_batching else max(1, args.launch_frames // fpg)
+    if args.no_batching:
+        merged_max = 1
+    elif args.launch_frames is None:
+        merged_max = max(1, min(2, 16 // fpg))
+    else:
+        merged_max = max(1, args.launch_frames // fpg)
     if merged_max > 1:
         eng.pipeline_batching(merged_max * fpg)
     Workload.merged_max = merged_max
@@ -612,6 +622,9 @@ def main():
             "device_ms_per_frame": round(totals["device_ms"] / max(totals["frames"], 1), 4),
             "host_topk_frames": totals["host_topk_frames"],
         }
+        # the whole path against its own ceiling: 37 N algorithmic bytes per frame (LAB 7N, ten fused passes 6N/3 each, full
+        # assign 6N, connectivity 4N) at the 8 TB/s of the specification = 216 GP/s per GPU
+        out["roofline_path"] = path_roofline(out["value"] / world, "value (whole job / n_gpus)")
         if strong:
             out["config"]["workload"] = "%s: fixed batch of %d frames per step over %d GPU(s), %d per GPU" % (cfg["name"].split(",")[0] + ", K=%d, 10 iters" % K, args.batch, world, fpg)
         out["host_cpu_ms_per_step"] = {"per_rank": [round(c / args.steps * 1e3, 4) for c in per_rank_cpu],
@@ -641,27 +654,28 @@ def main():
         out["roofline"] = {
             "kernel": "k_assign_blk2<R,true,3,false> (R = 16 rows per wavefront in launches of more than 2048 eight-row blocks, else 8; fused assign + centroid sums; %d launches per group, %dx%d x %d frames per launch: "
                       "%s), GPU to itself" % (fu["launches_per_group"], W, H, per_launch_frames,
-                                              "two submissions per group, as the pipelined region runs them" if merged_max > 1 else "one submission per group"),
+                                              "%d submissions per group, as the pipelined region runs them" % merged_max if merged_max > 1 else "one submission per group"),
             "bound": "hbm", "achieved": fu["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fu["frac"],
             "traffic": pmc["fused_assign_update"]["bytes"] if pmc else None, "traffic_source": pmc_src,
             "bytes_per_launch": fu["bytes_per_launch"], "avg_launch_ms": fu["avg_launch_ms"],
             "full_assign": big["full_assign"], "all_assign_launches": big["all_assign_launches"],
             "device_ms_per_frame": big["device_ms_per_frame"],
         }
+        out["roofline"]["path"] = out.pop("roofline_path")      # the fraction for `value` itself, next to the dominant kernel's
         if merged_max > 1:
             out["roofline"]["launch_of_one_submission"] = {"frames_per_launch": fpg, "fused_assign_update": alone["fused_assign_update"],
                                                            "full_assign": alone["full_assign"], "device_ms_per_frame": alone["device_ms_per_frame"]}
-        copy_gbs = measured_copy_bandwidth()
-        out["hbm_copy_measured"] = {"value": copy_gbs, "unit": "GB/s", "what": "device-to-device copy of 1 GiB (bytes read + bytes written), best of 5"}
+        copy_gbs = measured_copy_bandwidth(eng)
+        out["hbm_copy_measured"] = {"value": copy_gbs, "unit": "GB/s", "what": "streaming copy of 1 GiB by the library's k_copy16 (16 B per lane and trip; bytes read + bytes written), best of 5, HIP events"}
         out["roofline"]["frac_of_measured_copy"] = round(fu["achieved"] / copy_gbs, 4) if copy_gbs else None
         # the same launch by rocprofv3's kernel duration (committed summary of `scripts/frames.py 720 1280 1600 6 slic 8` under
         # --kernel-trace): events on the stream also see the launch gap of the directly enqueued (timed) group
-        rp = rocprof_avg_us("kernel_stats_1280x720_k1600_slic_x%d.csv" % per_launch_frames, "k_assign_blk2", ", true, 3, ") if args.workload == "720p" else None      # <8,..> for 8-frame launches, _w6<16,..> for 16
+        rp, rp_tag = rocprof_avg_us("kernel_stats_1280x720_k1600_slic_x%d.csv" % per_launch_frames, "k_assign_blk2", ", true, 3, ") if args.workload == "720p" else (None, None)      # <8,..> for 8-frame launches, _w6<16,..> for 16
         if rp:
             out["roofline"]["by_rocprofv3_kernel_duration"] = {
                 "avg_launch_us": rp, "achieved": round(gbs(fu["bytes_per_launch"], rp * 1e-3), 2),
                 "frac": round(gbs(fu["bytes_per_launch"], rp * 1e-3) / HBM_PEAK_GBS, 4),
-                "source": "profiles/%s_kernel_stats_1280x720_k1600_slic_x%d.csv" % (PROFILE_TAG, per_launch_frames)}
+                "source": "profiles/%s_kernel_stats_1280x720_k1600_slic_x%d.csv" % (rp_tag, per_launch_frames)}
         # contended: slot 0's groups carry per-launch events while the other slots keep the GPU busy
         base = len(wl.sets)
         wl.buffers(6 * nslots)
@@ -688,12 +702,13 @@ def main():
             four, one = w4.timed_groups(5), w4.timed_groups(4, n=1)
             pmc4, pmc4_src = pmc_traffic("4k_k1600")
             fa = four["full_assign"]
+            mp4 = w4.throughput(60)[0]
             out["roofline_4k"] = {"kernel": "k_assign_blk2_w6<32,false,1,true> (full_assign launch, 32 rows per wavefront, 3840x2160, K=1600), 8 frames per launch",
                                   "bound": "hbm", "achieved": fa["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fa["frac"],
                                   "traffic": pmc4["full_assign"]["bytes"] * 8 if pmc4 else None, "traffic_source": pmc4_src,
                                   "avg_launch_ms": fa["avg_launch_ms"], "fused_assign_update": four["fused_assign_update"],
                                   "all_assign_launches": four["all_assign_launches"], "device_ms_per_frame": four["device_ms_per_frame"],
-                                  "megapixels_per_sec_pipelined": w4.throughput(60)[0], "single_frame_launch": one,
+                                  "megapixels_per_sec_pipelined": mp4, "path": path_roofline(mp4, "megapixels_per_sec_pipelined"), "single_frame_launch": one,
                                   "frac_of_measured_copy": round(fa["achieved"] / copy_gbs, 4) if copy_gbs else None}
             if not args.no_parity:      # the last submission of that pipelined region (6 slots, batching, graph replay) against the oracle
                 bad = parity_of(w4, w4.last_timed)
@@ -705,7 +720,8 @@ def main():
             # BASELINE configs[2]: 3840x2160 K=6000 (centre pile-up, tie at the cut)
             w6 = Workload(eng, 2160, 3840, 6000, list(range(4)))
             t6 = w6.timed_groups(4)
-            out["c3_k6000"] = {"workload": WORKLOADS["4k6000"]["name"], "megapixels_per_sec": w6.throughput(60)[0],
+            mp6 = w6.throughput(60)[0]
+            out["c3_k6000"] = {"workload": WORKLOADS["4k6000"]["name"], "megapixels_per_sec": mp6, "path": path_roofline(mp6, "megapixels_per_sec"),
                                "dominant_kernel": "k_assign_blk fused assign+update", "fused_assign_update": t6["fused_assign_update"],
                                "full_assign": t6["full_assign"], "all_assign_launches": t6["all_assign_launches"],
                                "device_ms_per_frame": t6["device_ms_per_frame"]}

@@ -44,7 +44,7 @@ EXPORTS = [
     "fslic_hip_last_device_times", "fslic_hip_set_launch_timing", "fslic_hip_last_assign_loop", "fslic_hip_last_group_frames", "fslic_hip_last_path", "fslic_hip_last_launch_mode", "fslic_hip_group_done", "fslic_hip_last_error", "fslic_hip_version",
     "fslic_hip_get_connectivity", "fslic_hip_knn_connectivity", "fslic_hip_get_mask_density", "fslic_hip_cluster_density_to_mask",
     "fslic_hip_pipeline_submit", "fslic_hip_pipeline_drain", "fslic_hip_pipeline_batching", "fslic_hip_last_host_topk_frames",
-    "fslic_hip_separate_pass_redos",
+    "fslic_hip_separate_pass_redos", "fslic_hip_copy_bandwidth",
 ]
 
 _lib = None
@@ -111,6 +111,8 @@ def load_library():
         lib.fslic_hip_pipeline_batching.argtypes = [vp, i32]
         lib.fslic_hip_last_host_topk_frames.argtypes = [vp, i32]
         lib.fslic_hip_separate_pass_redos.argtypes = [vp, i32]
+        if hasattr(lib, "fslic_hip_copy_bandwidth"):      # (an A/B build of an earlier round, FSLIC_LIB, may lack it)
+            lib.fslic_hip_copy_bandwidth.argtypes = [vp, C.c_size_t, i32, C.POINTER(C.c_double)]
         lib.fslic_hip_group_done.argtypes = [vp, i32]
         lib.fslic_hip_rgb_to_lab.argtypes = [vp, i32, i32, vp, i32, vp]
         lib.fslic_hip_enforce_connectivity.argtypes = [vp, vp, i32, i32, i32, i32]
@@ -285,6 +287,12 @@ class Engine(object):
     def separate_pass_redos(self):
         """Frames (all slots, since the engine was created) redone with the separate cluster pass because of a stale pixel."""
         return sum(int(load_library().fslic_hip_separate_pass_redos(self._h, s)) for s in range(self.n_slots))
+
+    def copy_bandwidth(self, nbytes=1 << 30, reps=5):
+        """Measured HBM rate of this GPU in GB/s: bytes read + written per second of a plain streaming copy of `nbytes`."""
+        v = C.c_double()
+        _check(load_library().fslic_hip_copy_bandwidth(self._h, C.c_size_t(int(nbytes)), int(reps), C.byref(v)))
+        return v.value
 
     def group_done(self, slot):
         """True when wait_group(slot) would not block."""

@@ -625,8 +625,8 @@ static __device__ __forceinline__ void select_pass(const uint32_t* s_area, uint3
 // every sift -- of __make_heap and of __pop_heap alike -- stops at the first preferred child whose area exceeds min(value, a*): the
 // positions and contents of the small entries stay exactly libstdc++'s, the big entries' arrangement does not (and is not read).
 // The kept set is then "big, or small and still in the heap", the latter as one bit per candidate (set for the first K, cleared
-// when an entry leaves through the root, set when a candidate enters).  tests/test_oracle.py pins this rule against the restated
-// library calls on 3000 inputs built to tie.  What it buys: a replacement walks the depth of the small region (five or six levels
+// when an entry leaves through the root, set when a candidate enters).  The CPU suite pins this rule against the restated library
+// calls on 3000 inputs built to tie (tests/, test_sparse_sift_keeps_exactly_what_libstdcxx_heap_select_keeps).  What it buys: a replacement walks the depth of the small region (five or six levels
 // for the ~50 small entries of a 1280x720 K=1600 frame) instead of the heap's eleven to thirteen, and during the sequential
 // __heap_select loop the top six levels of the heap live in the REGISTERS of the one wavefront that replays it (lane j = heap node
 // j - 1): a replacement that ends inside them -- nearly all -- is ballots, scalar bit tests and lane moves, no LDS round trip at all

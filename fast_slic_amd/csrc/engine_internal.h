@@ -141,6 +141,10 @@ struct Slot {
     std::vector<GraphEntry> graphs;
     int last_launch_mode = 0;        // 0 direct, 1 recorded this call, 2 replayed
     bool launch_timing = false;      // the engine's flag as it stood when this slot's current group was submitted
+    // the slot's own host thread waits for a group by sleeping and polling instead of spinning (group.cpp, nap_wait)
+    bool nap_wait = false;           // set for groups served by the slot thread
+    double recent_wait_us[4] = {1e30, 1e30, 1e30, 1e30};   // its last four waits (1e30: none yet)
+    unsigned recent_wait_i = 0;
     // per-call state
     int H = 0, W = 0, K = 0, S = 0;
     int nframes = 0;

@@ -293,4 +293,38 @@ int fslic_hip_knn_connectivity(int H, int W, int K, const fslic_cluster* cluster
     return FSLIC_OK;
 }
 
+// Measurement aid of bench.py: the rate of a plain 16-bytes-per-lane streaming copy on this GPU (bytes read + bytes written per
+// second), best of `reps` launches after one warm-up, HIP events on a slot's stream.  Buffers are allocated for the call.
+int fslic_hip_copy_bandwidth(fslic_engine* e, size_t bytes, int reps, double* gb_per_s) {
+    if (!e || !gb_per_s) return fail(FSLIC_E_INVALID, "NULL pointer argument");
+    if (bytes < 16 || reps < 1) return fail(FSLIC_E_INVALID, "bytes and reps must be positive");
+    bytes &= ~(size_t)15;
+    SlotLease lease(e);
+    int rc = lease.take();
+    if (rc) return rc;
+    Slot& s = e->slots[lease.slot];
+    HIPCHK(hipSetDevice(e->device));
+    void *a = nullptr, *b = nullptr;
+    if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess) {
+        if (a) hipFree(a);
+        (void)hipGetLastError();
+        return fail(FSLIC_E_HIP, "hipMalloc failed for the copy probe");
+    }
+    hipError_t err = hipMemsetAsync(a, 1, bytes, s.st);
+    double best = 0.0;
+    for (int r = 0; r <= reps && err == hipSuccess; r++) {
+        err = hipEventRecord(s.ev[0], s.st);
+        launch_copy16(a, b, bytes, s.st);
+        if (err == hipSuccess) err = hipEventRecord(s.ev[1], s.st);
+        if (err == hipSuccess) err = hipStreamSynchronize(s.st);
+        float ms = 0.0f;
+        if (err == hipSuccess) err = hipEventElapsedTime(&ms, s.ev[0], s.ev[1]);
+        if (r > 0 && ms > 0.0f) best = std::max(best, 2.0 * (double)bytes / ((double)ms * 1e-3) / 1e9);
+    }
+    hipFree(a); hipFree(b);
+    if (err != hipSuccess) return fail(FSLIC_E_HIP, std::string("copy probe: ") + hipGetErrorString(err));
+    *gb_per_s = best;
+    return FSLIC_OK;
+}
+
 }  // extern "C"

@@ -287,4 +287,7 @@ void launch_density_to_mask(const uint16_t* labels, const uint8_t* dens, uint8_t
 void launch_adjacent_pairs(const uint16_t* labels, int H, int W, int K, uint32_t* tab_pair, unsigned long long* tab_key,
                            uint32_t cap, uint32_t* counters, hipStream_t st);
 
+// streaming copy of `bytes` (a multiple of 16) for the measured HBM rate bench.py prints (fslic_hip_copy_bandwidth)
+void launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t st);
+
 }  // namespace fslic

@@ -14,6 +14,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <sys/prctl.h>
+
 namespace fslic {
 
 namespace {
@@ -147,6 +149,7 @@ bool same_work(const fslic_engine::PipeJob& j, const Slot::Async& a) {
 void slot_worker(fslic_engine* e, Slot* s) {
     Slot::Async& a = *s->async;
     (void)hipSetDevice(e->device);
+    (void)prctl(PR_SET_TIMERSLACK, 1000UL);      // this thread's 10 us naps (group.cpp, nap_wait) are not rounded up to the default 50 us slack
     for (;;) {
         bool took = false;
         {
@@ -191,7 +194,9 @@ void slot_worker(fslic_engine* e, Slot* s) {
         }
         if (took) { e->cv.notify_all(); e->cv_work.notify_all(); }      // room in the queue (callers); the gathering wait is over (the other slot threads)
         int rc = group_begin(e, *s, &a.p, a.H, a.W, a.K, a.n, a.d_rgb, a.clusters, a.d_out);
+        s->nap_wait = true;
         if (rc == FSLIC_OK) rc = group_finish(e, *s);
+        s->nap_wait = false;
         if (rc != FSLIC_OK) {        // nothing may still run against the caller's buffers once the group is reported done
             const std::string msg = last_error();
             (void)hipStreamSynchronize(s->st);

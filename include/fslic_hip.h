@@ -236,6 +236,11 @@ int fslic_hip_last_host_topk_frames(fslic_engine* e, int slot);
  * FSLIC_FUSEBIN=0 (the separate cluster pass everywhere: +8 % latency per one-frame call, no redo).  Diagnostics aid. */
 int fslic_hip_separate_pass_redos(fslic_engine* e, int slot);
 
+/* Measurement aid (no counterpart in the reference): bytes read + written per second, in GB/s, of a plain streaming copy of
+ * `bytes` on the engine's GPU (best of `reps` launches, HIP events) -- the measured HBM rate that bench.py prints next to the 8 TB/s of
+ * the specification.  Allocates and frees 2 x `bytes` of device memory. */
+int fslic_hip_copy_bandwidth(fslic_engine* e, size_t bytes, int reps, double* gb_per_s);
+
 const char* fslic_hip_last_error(void);
 const char* fslic_hip_version(void);
 
