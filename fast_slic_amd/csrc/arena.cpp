@@ -91,7 +91,11 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
     const size_t o_pre = take(((size_t)K * 2 + (size_t)pre_cw * pre_ch + 16) * 4);         // is_updatable, is_active, active cells, flags
     // partial centroid sums of the block kernel: one entry per (cluster, assign block its window can overlap);
     // blocks are 64 px wide and at least 32 visited rows (stride >= 1) tall
-    const int nbx = 2 * S / 64 + 2, nby = 2 * S / 16 + 2;      // (the smallest assign block: 64 columns x 16 visited rows)
+    // (the smallest assign block: 64 columns x 16 visited rows).  Both counts are rounded up to powers of two: an entry is addressed by
+    // the block's coordinates modulo the grid (device_common.h, cpart_slot), so that the cluster pass can load a cluster's entries
+    // before it knows where the cluster is
+    auto pow2ceil = [](int v) { int p2 = 1; while (p2 < v) p2 <<= 1; return p2; };
+    const int nbx = pow2ceil(2 * S / 64 + 2), nby = pow2ceil(2 * S / 16 + 2);
     const size_t o_cpart = take((size_t)K * nbx * nby * 6 * 4);
     const size_t o_zero = off;
     const size_t o_sums = take((size_t)K * 6 * 4), o_sums1 = take((size_t)K * 6 * 4);

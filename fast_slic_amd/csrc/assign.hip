@@ -460,7 +460,7 @@ static __device__ __forceinline__ void bin_insert_next(const FrameDev& f, uint32
     if (slot < (uint32_t)kCellCap) f.cell_items[1][(size_t)cell * kCellCap + slot] = rec;
     else f.ovf_items[1][atomicAdd(f.ovf_cnt[1], 1u)] = rec;
 }
-static __device__ __forceinline__ void fused_finalize(const FrameDev& f, uint32_t k, uint32_t yx, uint32_t lab, uint32_t nx, uint32_t ny) {
+static __device__ __forceinline__ void fused_finalize(const FrameDev& f, uint32_t k, uint32_t yx, uint32_t lab, uint32_t nx, uint32_t ny, uint32_t b0, uint32_t ymask) {
     // the pass's sums of cluster k: what went through global atomics plus one entry per assign block its window overlaps
     uint32_t* const s0 = f.sums[0] + 6 * (size_t)k;
     uint32_t s[6];
@@ -482,7 +482,7 @@ static __device__ __forceinline__ void fused_finalize(const FrameDev& f, uint32_
             const uint32_t ex = e - __umul24(ey, nx);
             v[u][0] = v[u][1] = v[u][2] = 0ull;
             if (e < ne) {
-                const char* p = cp + __umul24(__umul24(ey, (uint32_t)f.nbx) + ex, 24u);             // 24-byte entries, 8-byte aligned
+                const char* p = cp + __umul24(cpart_slot((b0 >> 16) + ey, (b0 & 0xFFFFu) + ex, ymask, (uint32_t)f.nbx), 24u);      // 24-byte entries, 8-byte aligned
                 v[u][0] = ld_agent64(p); v[u][1] = ld_agent64(p + 8); v[u][2] = ld_agent64(p + 16);
             }
         }
@@ -718,15 +718,16 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
         rank_j = pr.x + pr.y + pr.z + pr.w;
     }
     if (lane < bn) s_klab[(int)rank_j] = (uint16_t)(mine.z & 0xFFFFu);
-    uint32_t fin_nx = 0, fin_ny = 0;             // FBIN, wavefront 0, lane j: blocks that deliver sums of candidate j (0: not this block)
+    uint32_t fin_nx = 0, fin_ny = 0, fin_b0 = 0; // FBIN, wavefront 0, lane j: blocks that deliver sums of candidate j (0: not this block), the first of them (row << 16 | column)
     if (FUSE && wave == 0) {
         uint32_t entry = kNoSlot;
         const SlotGeom g = slot_geom((int)(mine.x >> 16), (int)(mine.x & 0xFFFFu), S, f.H, W, rem, STRIDE, BH, Hv);
-        const int by = (int)byi, bx = (int)bxi;
+        const int by = (int)byi;
         if (g.any && by >= g.by0 && by <= g.by1) {
-            const uint32_t e1 = __umul24(mine.z & 0xFFFFu, (uint32_t)f.cpart_ns) + __umul24((uint32_t)(by - g.by0), (uint32_t)f.nbx) + (uint32_t)(bx - g.bx0);      // (24-bit factors, full-rate multiplies)
+            // (the entry by the block's own coordinates modulo the entry grid: the reader needs no geometry to find it; 24-bit factors, full-rate multiplies)
+            const uint32_t e1 = __umul24(mine.z & 0xFFFFu, (uint32_t)f.cpart_ns) + cpart_slot(byi, bxi, cpart_rows_mask(S, STRIDE, BH), (uint32_t)f.nbx);
             entry = (e1 << 2) + (e1 << 1);
-            if (FBIN && lane < bn) { fin_nx = (uint32_t)(g.bx1 - g.bx0 + 1); fin_ny = (uint32_t)(g.by1 - g.by0 + 1); }
+            if (FBIN && lane < bn) { fin_nx = (uint32_t)(g.bx1 - g.bx0 + 1); fin_ny = (uint32_t)(g.by1 - g.by0 + 1); fin_b0 = ((uint32_t)g.by0 << 16) | (uint32_t)g.bx0; }
         }
         if (lane < bn) s_entry[rank_j] = entry;
     }
@@ -1084,7 +1085,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
             if (wave == 0 && fin_nx != 0u) {
                 const uint32_t k = mine.z & 0xFFFFu;
                 const uint32_t before = __hip_atomic_fetch_add(f.cl_arrive + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (before + 1u == fin_nx * fin_ny) fused_finalize(f, k, mine.x, mine.y, fin_nx, fin_ny);
+                if (before + 1u == fin_nx * fin_ny) fused_finalize(f, k, mine.x, mine.y, fin_nx, fin_ny, fin_b0, cpart_rows_mask(S, STRIDE, BH));
             }
         }
     }

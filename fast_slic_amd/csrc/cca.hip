@@ -629,8 +629,9 @@ static __device__ __forceinline__ void select_pass(const uint32_t* s_area, uint3
 // calls on 3000 inputs built to tie (tests/, test_sparse_sift_keeps_exactly_what_libstdcxx_heap_select_keeps).  What it buys: a replacement walks the depth of the small region (five or six levels
 // for the ~50 small entries of a 1280x720 K=1600 frame) instead of the heap's eleven to thirteen, and during the sequential
 // __heap_select loop the top six levels of the heap live in the REGISTERS of the one wavefront that replays it (lane j = heap node
-// j - 1): a replacement that ends inside them -- nearly all -- is ballots, scalar bit tests and lane moves, no LDS round trip at all
-// (round 4: three round trips of ~0.3 us each, 21 of the 46 us this kernel took for a 1280x720 frame with a tie).
+// j - 1): a replacement that ends inside them -- nearly all -- is three comparisons, a handful of mask tests per lane and one lane
+// permutation for the entries that move up, no round trip through the heap in LDS at all (round 4: three round trips of ~0.3 us
+// each, 21 of the 46 us this kernel took for a 1280x720 frame with a tie).
 // ---------------------------------------------------------------------------------------------
 typedef unsigned long long heap_t;      // area << 32 | candidate index: one LDS access moves an entry, comp looks at the high half
 constexpr int kTieWaveLevels = 4;       // __make_heap: parents of depth <= this are sifted by a wavefront each (tie_wave_sift)
@@ -807,17 +808,31 @@ static __device__ __forceinline__ void tie_heap_select(const CcaDev& c, uint32_t
         const int last_parent = (len - 2) / 2;
         int d = 0;
         while (((2 << d) - 1) <= last_parent) d++;           // depth of the deepest parent
-        for (; d >= 0; --d) {
-            const int lo = (1 << d) - 1, hi = min((2 << d) - 2, last_parent);
-            if (d > kTieWaveLevels) {
-                // deep parents: many of them, short walks -- one thread each
-                for (int p = lo + tid; p <= hi; p += 1024)
-                    tie_adjust_heap(heap, p, len, hp_ld(heap + p), true, astar);
-            } else {
-                // the upper levels: at most one parent per wavefront, walks of seven to eleven levels -- five levels per LDS round trip
-                for (int p = lo + (int)rfl((uint32_t)(tid >> 6)); p <= hi; p += 16)
-                    tie_wave_sift(heap, len, p, hp_ld(heap + p), lane, astar);
+        // The deep levels (depth > kTieWaveLevels) subtree by subtree: the 2^(kTieWaveLevels+1) subtrees rooted one level below the
+        // wavefront-sifted levels are independent of each other, so a wavefront takes whole subtrees and walks their levels bottom-up
+        // with nothing but its own LDS ordering between two levels -- one thread per parent, as before, but no block barrier per level
+        // (a barrier among sixteen wavefronts plus the LDS round trips behind it was ~0.55 us per level, six to eight levels).
+        constexpr int DS = kTieWaveLevels + 1;                  // depth of the subtree roots
+        if (d >= DS) {
+            const int wave = (int)rfl((uint32_t)(tid >> 6));
+            for (int t = d - DS; t >= 0; --t) {                 // relative depth of the parents handled in this step
+                for (int sub = wave; sub < (1 << DS); sub += 16) {
+                    const int r = (1 << DS) - 1 + sub;          // the subtree's root
+                    for (int j = lane; j < (1 << t); j += 64) {
+                        const int p = ((r + 1) << t) - 1 + j;
+                        if (p <= last_parent) tie_adjust_heap(heap, p, len, hp_ld(heap + p), true, astar);
+                    }
+                }
+                wave_lds_sync();
             }
+            __syncthreads();
+            d = DS - 1;
+        }
+        for (; d >= 0; --d) {
+            // the upper levels: at most one parent per wavefront, walks of several levels -- five levels per LDS round trip
+            const int lo = (1 << d) - 1, hi = min((2 << d) - 2, last_parent);
+            for (int p = lo + (int)rfl((uint32_t)(tid >> 6)); p <= hi; p += 16)
+                tie_wave_sift(heap, len, p, hp_ld(heap + p), lane, astar);
             __syncthreads();
         }
     }
@@ -843,37 +858,27 @@ static __device__ __forceinline__ void tie_heap_select(const CcaDev& c, uint32_t
                 const uint32_t ti = (uint32_t)__builtin_amdgcn_readlane((int)ei, 1);
                 if (lane == 0) { atomicAnd(&s_in[ti >> 5], ~(1u << (ti & 31u))); atomicOr(&s_in[vi >> 5], 1u << (vi & 31u)); }
                 const uint32_t vlim = min(aj, astar);
+                // The walk, for all five levels at once and without a scalar step per level: lane j (>= 2) is the child its parent
+                // prefers when its sibling's area is larger (left children; the sibling shares the lane's quad) or not smaller (right
+                // children: libstdc++ takes the right one on a tie), and its entry moves up if the walk gets there and the entry is
+                // not beyond the value (or the small region).  The entries that move are the lanes for which that holds at
+                // themselves AND at every ancestor: five bit tests of one wavefront mask per lane.
                 const uint32_t sib = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ea, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
-                const unsigned long long left_pref = __ballot(sib > ea);       // (as tie_wave_sift)
-                const unsigned long long stop_at = __ballot(ea > vlim);
-                int cn[5];
-                uint32_t stops = 0;
-                {
-                    int jj = 1;
+                const unsigned long long pref = (ballot(sib > ea) & 0x5555555555555554ull) | (ballot(sib >= ea) & 0xAAAAAAAAAAAAAAA8ull);
+                const unsigned long long okm = (pref & ~ballot(ea > vlim)) | 3ull;      // (bits 0, 1: the ancestors "above the root" hold nobody up)
+                uint32_t on = 1u;
 #pragma unroll
-                    for (int s5 = 0; s5 < 5; ++s5) {
-                        const int cl = 2 * jj;
-                        cn[s5] = cl + (int)(((left_pref >> cl) & 1ull) ^ 1ull);
-                        stops |= (uint32_t)((stop_at >> cn[s5]) & 1ull) << s5;
-                        jj = cn[s5];
-                    }
-                }
-                const int nmove = __builtin_ctz(stops | 32u);
-                // the entries on the path move up one place, lane to lane
-                int dst = 1;
-#pragma unroll
-                for (int s5 = 0; s5 < 5; ++s5) {
-                    if (s5 < nmove) {
-                        const uint32_t ma = (uint32_t)__builtin_amdgcn_readlane((int)ea, cn[s5]), mi = (uint32_t)__builtin_amdgcn_readlane((int)ei, cn[s5]);
-                        ea = write_lane(ea, ma, dst);
-                        ei = write_lane(ei, mi, dst);
-                        dst = cn[s5];
-                    }
-                }
+                for (int s5 = 0; s5 < 5; ++s5) on &= (uint32_t)(okm >> (lane >> s5));
+                const unsigned long long moved = ballot((on & 1u) != 0u) & ~3ull;        // a chain from level 1 down: at most one lane per level
+                const int dst = moved ? 63 - __builtin_clzll(moved) : 1;                // where the value ends up (unless the walk goes on below the sixth level)
+                // every entry on the chain to its parent's lane, in one pull: the parent of a moved lane fetches it
+                const uint32_t kids = lane < 32 ? (uint32_t)(moved >> (2 * lane)) & 3u : 0u;
+                const int from = (kids ? 2 * lane + (int)(kids >> 1) : lane) << 2;
+                ea = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)ea);
+                ei = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)ei);
                 const int cur = dst - 1;                                       // heap index of the place the value may still end up at
-                if (nmove < 5 || 2 * cur + 1 >= len) {
-                    ea = write_lane(ea, aj, dst);
-                    ei = write_lane(ei, vi, dst);
+                if (dst < 32 || 2 * cur + 1 >= len) {
+                    if (lane == dst) { ea = aj; ei = vi; }
                 } else {
                     // the small region reaches below the sixth level here (rare): the rest of the walk on the heap in LDS, whose
                     // entries from the seventh level down are current (nothing above has ever been written back, nothing above is

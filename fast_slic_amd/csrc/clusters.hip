@@ -16,44 +16,36 @@ namespace fslic {
 // =============================================================================================
 // Sums of cluster k over the pass: the block kernel's partial sums (one entry per overlapping block) plus whatever
 // went through global atomics.  out[0..5] = count, sum y, sum x, sum L, sum a, sum b.
-static __device__ __forceinline__ void gather_sums(const FrameDev& f, const PassGeom& pg, int k, uint32_t yx, uint32_t* out) {
-    const uint32_t* s = f.sums[0] + 6 * (size_t)k;
+// The entries of a cluster sit at (block row mod NY, block column mod nbx) of its NY x nbx entry grid (kernels.h, FrameDev::nbx), so
+// their addresses do not depend on where the cluster is: they are requested TOGETHER with the cluster's position, colour and
+// neighbours -- one memory round trip for everything this pass reads -- and which of them are live (written by a block of this
+// pass) is decided from the position when both have arrived.  (Until round 5 the entries were addressed relative to the first
+// block the window overlaps: position -> geometry -> entries, a dependent round trip more on a launch that is nothing but a chain of
+// them and sits between every two assign passes.)
+template <int NB> struct EntryLoads { uint2 v[NB][3]; };
+template <int NB> static __device__ __forceinline__ void request_entries(const FrameDev& f, int k, uint32_t e0, uint32_t ne, EntryLoads<NB>& L) {
+    const char* cp = reinterpret_cast<const char*>(f.cpart + (size_t)k * f.cpart_ns * 6);
 #pragma unroll
-    for (int q = 0; q < 6; ++q) out[q] = s[q];
-    if (!pg.use_slots) return;
-    const SlotGeom g = slot_geom((int)(yx >> 16), (int)(yx & 0xFFFFu), f.S, f.H, f.W, pg.rem, pg.stride, pg.BH, pg.Hv);
-    if (!g.any) return;
-    const uint32_t* cp = f.cpart + (size_t)k * f.cpart_ns * 6;
-    // entries (by, bx) in [by0, by1] x [bx0, bx1], eight at a time with all their loads in flight (one memory round trip
-    // per eight entries instead of one per entry: this pass is a chain of dependent loads on a handful of blocks, and
-    // it sits on the critical path of every iteration)
-    const int nx = g.bx1 - g.bx0 + 1, ne = nx * (g.by1 - g.by0 + 1);
-    // e / nx for the handful of entries of a cluster through a 16-bit reciprocal (guarded): eight general divisions per batch were a
-    // sixth of this kernel's instructions, and it sits on the critical path of every iteration
-    const uint32_t inv_nx = (uint32_t)(65536.0f * __builtin_amdgcn_rcpf((float)nx)) + 1u;
-    constexpr int kBatch = 8;
-    for (int e0 = 0; e0 < ne; e0 += kBatch) {
-        uint2 v[kBatch][3];
+    for (int u = 0; u < NB; ++u) {
+        const uint32_t e = min(e0 + (uint32_t)u, ne - 1u);        // (past the grid: re-read its last entry, masked out below)
+        const uint2* p = reinterpret_cast<const uint2*>(cp + __umul24(e, 24u));
+        L.v[u][0] = p[0]; L.v[u][1] = p[1]; L.v[u][2] = p[2];
+    }
+}
+template <int NB> static __device__ __forceinline__ void add_live_entries(const FrameDev& f, const SlotGeom& g, bool take, uint32_t e0, uint32_t ne, uint32_t ymask, const EntryLoads<NB>& L, uint32_t* out) {
+    const uint32_t nbx = (uint32_t)f.nbx, xsh = 31u - (uint32_t)__clz((int)nbx);
+    const uint32_t dy = (uint32_t)(g.by1 - g.by0), dx = (uint32_t)(g.bx1 - g.bx0);
 #pragma unroll
-        for (int u = 0; u < kBatch; ++u) {
-            const int e = e0 + u;
-            uint32_t ey = __umul24((uint32_t)e, inv_nx) >> 16;
-            if (__umul24(ey, (uint32_t)nx) > (uint32_t)e) ey--;
-            const uint32_t ex = (uint32_t)e - __umul24(ey, (uint32_t)nx);
-            v[u][0] = v[u][1] = v[u][2] = make_uint2(0u, 0u);
-            if (e < ne) {
-                const uint2* p = reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(cp) + __umul24(__umul24(ey, (uint32_t)f.nbx) + ex, 24u));   // 24-byte entries
-                v[u][0] = p[0]; v[u][1] = p[1]; v[u][2] = p[2];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < kBatch; ++u) {
-            out[0] += v[u][0].x; out[1] += v[u][0].y; out[2] += v[u][1].x; out[3] += v[u][1].y; out[4] += v[u][2].x; out[5] += v[u][2].y;
-        }
+    for (int u = 0; u < NB; ++u) {
+        const uint32_t e = e0 + (uint32_t)u;
+        const uint32_t ry = ((e >> xsh) - (uint32_t)g.by0) & ymask, rx = (e - (uint32_t)g.bx0) & (nbx - 1u);     // offset of the entry's block from the window's first
+        const bool livee = take && e < ne && ry <= dy && rx <= dx;
+        out[0] += livee ? L.v[u][0].x : 0u; out[1] += livee ? L.v[u][0].y : 0u; out[2] += livee ? L.v[u][1].x : 0u;
+        out[3] += livee ? L.v[u][1].y : 0u; out[4] += livee ? L.v[u][2].x : 0u; out[5] += livee ? L.v[u][2].y : 0u;
     }
 }
 
-template <int MODE>
+template <int MODE, int NB = 8>
 __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg, const uint32_t* __restrict__ src_yx, size_t src_stride) {
     f.select(blockIdx.y);
     // mode 0: the centres of a group start are read where the host staged them (pinned memory), no upload command
@@ -88,12 +80,30 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg, c
         shadowed = !f.cl_f && k > 0 && yx_in[k - 1] == yx;
         f.cl_shadow[k] = shadowed ? 1u : 0u;
     } else {
-        // what the tail needs, requested before the gather so that it does not cost another round trip afterwards
-        const uint32_t lab_own = live ? f.cl_lab[k] : 0u;
-        const uint32_t yx_prev = (live && k > 0) ? yx_in[k - 1] : 0u, lab_prev = (live && k > 0) ? f.cl_lab[k - 1] : 0u;
-        // a shadowed cluster is in no candidate list: it received nothing and its cpart entries are stale
+        // everything the pass reads, requested in one go (see request_entries)
+        const int kc = min(max(k, 0), f.K - 1);              // (dead lanes re-read a valid cluster: no predicated loads)
+        const uint32_t lab_own = f.cl_lab[kc];
+        const uint32_t yx_prev = yx_in[max(kc - 1, 0)], lab_prev = f.cl_lab[max(kc - 1, 0)];
+        const uint32_t shadow_word = f.cl_shadow[kc];        // (loaded whatever the pass geometry: a load inside a branch is waited for at the branch's end)
+        const uint2* const sp = reinterpret_cast<const uint2*>(f.sums[0] + 6 * (size_t)kc);
+        const uint2 s01 = sp[0], s23 = sp[1], s45 = sp[2];
+        const uint32_t ymask = cpart_rows_mask(f.S, pg.stride, max(pg.BH, 1)), ne = pg.use_slots ? (ymask + 1u) * (uint32_t)f.nbx : 0u;
+        // (NB = entries per trip, chosen by the launcher: four for grids of four -- 1280x720 K=1600 --, else eight; larger grids --
+        // wide windows on 8-row blocks -- take further trips)
+        EntryLoads<NB> L;
+        if (pg.use_slots) request_entries<NB>(f, kc, 0u, ne, L);
+        // a shadowed cluster is in no candidate list: it received nothing and its entries are stale
+        const bool take = live && !(pg.use_slots && shadow_word);
         uint32_t s[6] = {0u, 0u, 0u, 0u, 0u, 0u};
-        if (live && !(pg.use_slots && f.cl_shadow[k])) gather_sums(f, pg, k, yx, s);
+        if (take) { s[0] = s01.x; s[1] = s01.y; s[2] = s23.x; s[3] = s23.y; s[4] = s45.x; s[5] = s45.y; }
+        if (pg.use_slots) {
+            const SlotGeom g = slot_geom((int)(yx >> 16), (int)(yx & 0xFFFFu), f.S, f.H, f.W, pg.rem, pg.stride, pg.BH, pg.Hv);
+            add_live_entries<NB>(f, g, take && g.any, 0u, ne, ymask, L, s);
+            for (uint32_t e0 = (uint32_t)NB; e0 < ne; e0 += (uint32_t)NB) {
+                request_entries<NB>(f, kc, e0, ne, L);
+                add_live_entries<NB>(f, g, take && g.any, e0, ne, ymask, L, s);
+            }
+        }
         // member count of cluster k-1 (needed below): the previous thread's
         __shared__ uint32_t s_n[256];
         s_n[threadIdx.x] = s[0];
@@ -101,6 +111,7 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg, c
         if (!live || threadIdx.x == 0) return;
         const uint32_t n_prev = s_n[threadIdx.x - 1];
         lab = lab_own;
+        const uint32_t yx_prev_k = k > 0 ? yx_prev : 0u, lab_prev_k = k > 0 ? lab_prev : 0u;
         uint32_t* z0 = f.sums[1] + 6 * (size_t)k;    // the next pass accumulates here (sums[0] is still being read by neighbours)
         const int32_t n = (int32_t)s[0];
         f.cl_n[k] = (uint32_t)n;
@@ -133,7 +144,7 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg, c
             f.cl_lab[k] = lab;
             f.cl_moved[k] = 1;
         } else if (!f.cl_f && k > 0 && n_prev == 0u) {
-            shadowed = yx_prev == yx && lab_prev == lab;
+            shadowed = yx_prev_k == yx && lab_prev_k == lab;
         }
         f.cl_yx_out[k] = yx;
         f.cl_shadow[k] = shadowed ? 1u : 0u;
@@ -160,10 +171,19 @@ void launch_bin_clusters(const FrameDev& f_, int nframes, int mode, int buf, int
     const FrameDev f = rotated(f_, buf, sbuf);
     if (mode == 0) {
         const int n = f.K > f.ncell ? f.K : f.ncell;
-        launch(k_bin_clusters<0>, dim3((n + 255) / 256, nframes), dim3(256), 0, st, f, pg, src_yx, src_stride);
+        launch((k_bin_clusters<0, 8>), dim3((n + 255) / 256, nframes), dim3(256), 0, st, f, pg, src_yx, src_stride);
     } else {
         const int bk = (f.K + 254) / 255, bc = (f.ncell + 255) / 256;    // 255 clusters per block (see the kernel)
-        launch(k_bin_clusters<1>, dim3(bk > bc ? bk : bc, nframes), dim3(256), 0, st, f, pg, nullptr, (size_t)0);
+        // entries per cluster in this pass's grid (device_common.h, cpart_rows_mask, on the host)
+        int ne = 0;
+        if (pg.use_slots) {
+            const int n = (2 * f.S / pg.stride) / pg.BH + 2;
+            int ny = 1;
+            while (ny < n) ny <<= 1;
+            ne = ny * f.nbx;
+        }
+        if (ne > 0 && ne <= 4) launch((k_bin_clusters<1, 4>), dim3(bk > bc ? bk : bc, nframes), dim3(256), 0, st, f, pg, nullptr, (size_t)0);
+        else launch((k_bin_clusters<1, 8>), dim3(bk > bc ? bk : bc, nframes), dim3(256), 0, st, f, pg, nullptr, (size_t)0);
     }
 }
 

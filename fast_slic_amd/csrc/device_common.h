@@ -93,16 +93,6 @@ static __device__ __forceinline__ bool lanes(unsigned long long m) { return __bu
 
 static __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// v with lane `lane` (wave-uniform) replaced by the wave-uniform `val`: v_writelane_b32.  With the value in a scalar register the lane
-// select has to come through M0 on this target (one scalar operand per vector instruction); M0 is saved and restored, as around the
-// LDS-DMA pieces of assign.hip.
-static __device__ __forceinline__ uint32_t write_lane(uint32_t v, uint32_t val, int lane) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
-                 : "+v"(v), "=&s"(keep) : "s"(val), "s"(lane));
-    return v;
-}
-
 // floor(x / n) for x < 2^31, n >= 1, through the reciprocal r = floor((2^32 - 1) / n): the estimate is at most one short
 // (the five round_int means of a cluster, src/fast-slic-common.h:62-65, cost one division instead of five)
 static __device__ __forceinline__ uint32_t div_by(uint32_t x, uint32_t n, uint32_t r) {
@@ -139,6 +129,16 @@ static __device__ __forceinline__ SlotGeom slot_geom(int cy, int cx, int S, int 
     return g;
 }
 
+// FrameDev::cpart addressing (see kernels.h, FrameDev::nbx).  NY - 1 for a pass of the given geometry: NY = the block rows a
+// (2S+1)-row window can overlap (its visited rows span at most 2S / stride indices, i.e. at most (2S / stride) / BH + 2 blocks of BH
+// visited rows), rounded up to a power of two.
+static __device__ __forceinline__ uint32_t cpart_rows_mask(int S, int stride, int BH) {
+    const int n = (div_rows(2 * S, stride) >> (31 - __clz(BH))) + 2;
+    return (1u << (32 - __clz(n - 1))) - 1u;
+}
+static __device__ __forceinline__ uint32_t cpart_slot(uint32_t by, uint32_t bx, uint32_t ymask, uint32_t nbx) {
+    return __umul24(by & ymask, nbx) + (bx & (nbx - 1u));
+}
 
 // integer centroid sums of one pixel through global atomics (generic kernels, stale-label pixels): count, y, x, L, a, b
 static __device__ __forceinline__ void global_accumulate(uint32_t* sums, uint32_t k, uint32_t y, uint32_t x, uint32_t pix) {

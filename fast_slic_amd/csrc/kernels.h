@@ -85,8 +85,11 @@ struct FrameDev {
                          // (global atomics: generic / 32-bit kernels, and stale-label pixels of the block kernel)
     uint32_t* cpart;     // K * cpart_ns * 6: per-(cluster, overlapping assign block) partial sums of the block
                          // kernel, written with plain stores (one writer per entry), gathered by the cluster pass
-    int cpart_ns;        // entries per cluster (allocation), >= NBX * NBY of every pass geometry
-    int nbx;             // assign blocks (64 px wide) a cluster window can overlap horizontally: 2S/64 + 2
+    int cpart_ns;        // entries per cluster (allocation): nbx x (a power of two >= the block rows a window overlaps in any pass geometry)
+    int nbx;             // assign blocks (64 px wide) a cluster window can overlap horizontally, 2S/64 + 2, rounded up to a power of two.
+                         // The entry of (cluster, block (by, bx)) is (by mod NY) * nbx + (bx mod nbx), NY = the pass's own power-of-two
+                         // row count (device_common.h, cpart_rows_mask): a window overlaps at most NY x nbx CONSECUTIVE blocks, so
+                         // the residues are distinct, and which entries are live follows from the cluster's position alone
     // coarse bins, double buffered by iteration parity
     uint32_t* cell_cnt[2];     // ncell
     ClusterRec* cell_items[2]; // ncell * kCellCap

@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 from fast_slic_amd import Engine, make_params, CLUSTER_DTYPE, _binding as B
 from fast_slic_amd.synth import variant
-H, W, K, G = 720, 1280, 1600, 8
+H, W, K, G = (int(v) for v in sys.argv[1:5]) if len(sys.argv) >= 5 else (720, 1280, 1600, 8)      # python scripts/lab_select_stamps.py [H W K G]
 e = Engine(0, 1)
 imgs = [variant("A", H, W, seed=g) for g in range(G)]
 d = [torch.from_numpy(im).cuda() for im in imgs]
