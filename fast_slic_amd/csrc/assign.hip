@@ -349,7 +349,7 @@ typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 // =============================================================================================
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 // (Experiment builds -- make VAR=<name> DEFS=-DFSLIC_EXP=<bits>, kernels.h -- carry A/B forms of this kernel while they are being
-// measured, scripts/gpu_exp.sh; what round 4 measured is in profiles/r04_assign_experiments.txt.)
+// measured, scripts/gpu_trip.sh; what round 4 measured is in profiles/r04_assign_experiments.txt.)
 constexpr int kRawBuffer = 0x00020000;     // 4th dword of a raw (stride 0) buffer descriptor on gfx9-family targets: DATA_FORMAT = 32
 constexpr int kAuxSc1 = 16;                // cache policy bit of the buffer builtins: sc1 (write through at agent scope)
 
@@ -549,7 +549,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
     // (Until the end of round 4 the table had 256 entries indexed by the key's whole low byte -- rank | two distance bits, four copies
     // 128 bytes apart -- to save the mask: but 128 bytes is the period of the LDS banks, lanes of equal rank and different distance bits
     // met on one bank at different addresses, and the sixteen look-ups of a wavefront cost 120 LDS cycles, 90 of them bank conflicts,
-    // and 8 % of the fused launch's duration: scripts/gpu_r04_knock.sh, profiles/r04_assign_experiments.txt.  The 64 entries are one
+    // and 8 % of the fused launch's duration: scripts/gpu_knock.sh, profiles/r04_assign_experiments.txt.  The 64 entries are one
     // pass over the banks: equal ranks read one address, different ranks different banks.)
     __shared__ __attribute__((aligned(16))) uint16_t s_klab[64];
     // centroid accumulators: per (candidate, copy) two 64-bit words of three 20-bit-spaced fields each,
@@ -590,6 +590,11 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
     // critical path queued behind the whole frame's pixel traffic (prologue 4 us of a wavefront life of 8 us at 4K).
     // Out-of-image lanes and rows re-read the last valid column / row instead of being masked off: no exec juggling
     // around the loads (their results are never stored and never reach the centroid sums).
+    // CONTRACT with the table wait below (s_waitcnt vmcnt(kPixelLoads)): load_pixels() issues EXACTLY kPixelLoads vector-memory loads,
+    // all of them unconditional, and nothing else may be issued to vector memory between the LDS-DMA pieces of the table and that
+    // wait -- the wait counts on "at most kPixelLoads operations outstanding" meaning "the pieces, which are older, have landed"
+    // (loads return in order).  A load added, removed or made conditional here changes the count the wait must state.
+    constexpr int kPixelLoads = R;
     uint32_t pix[R];
     auto load_pixels = [&]() {
         const uint32_t xc = (uint32_t)min(x, W - 1);
@@ -600,6 +605,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(f.lab), 0, (int)((uint32_t)f.N * 4u), kRawBuffer);
         const uint32_t pitch = (uint32_t)(STRIDE * W) * 4u, soff0 = (uint32_t)ybase * (uint32_t)W * 4u;
         const int vo = (int)(xc * 4u);
+        static_assert(kPixelLoads == R, "one buffer load per visited row: see the contract above");
 #pragma unroll
         for (int r = 0; r < R; ++r) pix[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (int)(soff0 + (uint32_t)min(r, nr1) * pitch), 0);
     };
@@ -684,7 +690,11 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
     // The table has landed once at most R loads are outstanding (the compiler's counters do not include the LDS-DMA pieces): the R pixel
     // loads were issued after them and loads return in order; whatever the gather issued later has been waited for by the compiler at
     // its use.  The pixels themselves stay in flight across both barriers of the prologue (LDS-only barriers, see lds_barrier).
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(R) : "memory");
+#if defined(FSLIC_LAB) && FSLIC_LAB == 5      // lab build 5: the conservative wait (everything landed); results must not differ from the product's
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kPixelLoads) : "memory");
+#endif
     lds_barrier();
     ASG_STAMP(2, wave == 0);
     // lane j = candidate j of the block (raw order: wavefront 0's records, then wavefront 1's, ...)
@@ -754,7 +764,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
         const uint32_t xout = (uint32_t)f.tab_xout;
         // The row-range divisions: numerators made positive by BIAS rows, quotients through a 24-bit multiply (full rate; the 32-bit
         // v_mul_hi_u32 the compiler takes for n / 3 issues at a quarter of it).  |dy0| <= S + BH * STRIDE for a candidate on the block's
-        // list and S <= 426 in this table mode (tables.cpp: tlen * 16 <= kTabMaxBytes), so 0 < numerator < 3 * 1024 + 1300, far inside
+        // list and S <= 419 in this table mode (tables.cpp: tlen * 16 <= kTabMaxBytes for the 16-row table), so 0 < numerator < 3 * 1024 + 1300, far inside
         // the range where (n * 21846) >> 16 == n / 3 (n < 32768).
         constexpr int BIAS = 1024;
         static_assert(STRIDE >= 1 && STRIDE <= 3, "row-range divisions");
@@ -1122,6 +1132,8 @@ static void launch_assign_blk_t(const FrameDev& f_, int nframes, int rem, int Hv
     FrameDev f = f_;
     if (FUSE) { f.tab = f.tabs; f.tab_words = f.tabs_words; f.tab_dyoff = f.tabs_dyoff; f.tab_nrpad = f.tabs_nrpad; }   // table of the subsampled stride
     if (FUSE && R == 16 && !f.tab_vmode) { f.tab = f.tabs16; f.tab_words = f.tabs16_words; f.tab_dyoff = f.tabs16_dyoff; f.tab_nrpad = f.tabs16_nrpad; }
+    // row-vector mode, full pass with at most 16 rows per wavefront: the shorter stride-1 table (48 entries = 768 bytes of LDS per block less)
+    if (!FUSE && R <= 16 && f.tab_vmode && f.tabv16_words > 0) { f.tab = f.tabv16; f.tab_words = f.tabv16_words; f.tab_dyoff = f.tabv16_dyoff; }
     dim3 grid((f.W + kTileW - 1) / kTileW, (Hv + kWavesPerBlock * R - 1) / (kWavesPerBlock * R), nframes);
     const size_t lds2 = ((size_t)f.tab_words * sizeof(uint32_t) + 1023) / 1024 * 1024;       // whole KB: what the LDS-DMA pieces fill
     if constexpr (R == 32) {
@@ -1190,7 +1202,7 @@ static int assign_rows_per_wave(const FrameDev& f, int nframes, int Hv, bool fus
     const int blocks8 = nframes * tiles_x * ((Hv + kWavesPerBlock * 8 - 1) / (kWavesPerBlock * 8));
     // 32 rows (row-vector table only): launches that keep the chip busy for three rounds of 16-row blocks and more -- the block
     // prologue and the per-candidate fetch are then paid once per 8192 pixels instead of 4096
-    if (!fuse_update && f.tab_vmode && blocks8 > 4 * 6144) return 32;
+    if (!fuse_update && f.tab_vmode && f.tab_rows32 && blocks8 > 4 * 6144) return 32;
     return (!fuse_update && blocks8 > 3072) ? 16 : 8;
 }
 

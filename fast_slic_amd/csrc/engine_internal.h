@@ -162,6 +162,7 @@ struct Slot {
     // `pending` from the submission of an asynchronous group until it has been collected.
     bool busy = false;
     bool pending = false;
+    int wanted = 0;                  // synchronous callers waiting for THIS slot (fslic_hip_iterate_device with a slot number): its thread leaves the submit queue alone meanwhile
     // asynchronous groups run on the slot's own host thread (launches, stream sync, cluster write-back), so the host
     // work of one slot overlaps that of the others
     struct Async {
@@ -243,7 +244,7 @@ struct fslic_engine {
     int pipe_batch_frames = 0;       // 0: one submission per group; otherwise the most frames a group may gather
     bool pipe_gathering = false;     // a slot thread is waiting briefly for a companion of the submission it took
     std::atomic<int> reserve_frames{0};   // arenas are carved for at least this many frames per group
-    int sync_waiters = 0;                    // (mu) synchronous callers waiting for a slot: the slot threads leave the submit queue alone meanwhile
+    int sync_waiters = 0;                    // (mu) synchronous callers waiting for ANY slot (or all of them): the slot threads leave the submit queue alone meanwhile
     std::atomic<int> lab_force_generic{0};   // testing aid (fslic_hip_lab_force_generic): the brute-force gather kernels instead of the tiled ones
 };
 

@@ -23,13 +23,14 @@ int validate(const fslic_params* p, int H, int W, int K, int& S) {
     if (!p) return fail(FSLIC_E_INVALID, "params is NULL");
     static_assert(sizeof(fslic_params) == 64 && offsetof(fslic_params, abi) == 40 && offsetof(fslic_params, variant) == 44, "fslic_params layout (include/fslic_hip.h)");
     if (p->abi != FSLIC_PARAMS_ABI) return fail(FSLIC_E_INVALID, "fslic_params.abi != FSLIC_PARAMS_ABI: the caller was built against another layout of the struct (include/fslic_hip.h)");
+    if (p->reserved[0] | p->reserved[1] | p->reserved[2] | p->reserved[3]) return fail(FSLIC_E_INVALID, "fslic_params.reserved must be 0");
     if (H <= 0 || W <= 0) return fail(FSLIC_E_INVALID, "H and W must be positive");
     if (H > 32767 || W > 32767) return fail(FSLIC_E_INVALID, "H and W must fit int16 (src/context.cpp:262)");
     if ((long long)H * W >= (1ll << 31)) return fail(FSLIC_E_INVALID, "H*W must fit int32");
     if (K <= 0 || K >= 65534) return fail(FSLIC_E_INVALID, "num_components must be in [1, 65533] (cfast_slic.pyx:24-27)");
     if (p->subsample_stride < 1 || p->subsample_stride > 255) return fail(FSLIC_E_INVALID, "subsample_stride must be in [1, 255]");
     if (p->max_iter < 0) return fail(FSLIC_E_INVALID, "max_iter must be >= 0");
-    if (p->preemptive && p->variant != FSLIC_VARIANT_SLIC) return fail(FSLIC_E_UNSUPPORTED, "preemptive=True is implemented for the Slic variant only on hip/gfx950");
+    if (p->preemptive && p->variant == FSLIC_VARIANT_LSC) return fail(FSLIC_E_UNSUPPORTED, "preemptive=True is not implemented for the LSC variant on hip/gfx950");
     if (p->preemptive && !std::isfinite(p->preemptive_thres)) return fail(FSLIC_E_INVALID, "preemptive_thres must be finite");
     if (p->variant < FSLIC_VARIANT_SLIC || p->variant > FSLIC_VARIANT_REALDIST_NOQ) return fail(FSLIC_E_UNSUPPORTED, "unknown variant");
     if (!(p->compactness > 0.0f) || !std::isfinite(p->compactness)) return fail(FSLIC_E_INVALID, "compactness must be a positive finite number");
@@ -254,6 +255,7 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     float noq_coef = 1.0f / ((float)S / p->compactness);        // src/context.cpp:463-464
     noq_coef *= (1 << (p->convert_to_lab ? 1 : 0));
     const bool noq_manhattan = p->manhattan_spatial_dist != 0;
+    const float pre_l1_thres = std::max(roundf(2 * S * p->preemptive_thres), 1.0f);      // src/preemptive.h:129
     for (int it = 0; rd && it < p->max_iter; it++) {            // src/context.cpp:158-175, BaseContext<float>
         const bool tme = timed && s.launch_timing && it < Slot::kMaxTimedIters;
         f.cl_yx = yx_cur; f.cl_yx_out = (yx_cur == yx_a) ? yx_b : yx_a;
@@ -264,11 +266,11 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
         launch_member_sums(f, n, rem, stride, it & 1, noq ? 1 : 0, s.st);
         f.gen_off++;
         pg = PassGeom{};
-        launch_bin_clusters(f, n, 1, (it + 1) & 1, it & 1, pg, s.st);
+        if (pre) launch_preempt_update(f, n, (it + 1) & 1, it & 1, false, pre_l1_thres, s.st);      // update() + set_new_clusters(), src/context.cpp:356-387
+        else launch_bin_clusters(f, n, 1, (it + 1) & 1, it & 1, pg, s.st);
         yx_cur = f.cl_yx_out;
         rem = (rem + 1) % stride;
     }
-    const float pre_l1_thres = std::max(roundf(2 * S * p->preemptive_thres), 1.0f);      // src/preemptive.h:129
     for (int it = 0; lsc && it < p->max_iter; it++) {           // src/context.cpp:158-175 with ContextLSC's hooks
         const bool tme = timed && s.launch_timing && it < Slot::kMaxTimedIters;
         f.cl_yx = yx_cur; f.cl_yx_out = (yx_cur == yx_a) ? yx_b : yx_a;
@@ -336,8 +338,8 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     if (timed) HIPCHK(hipEventRecord(s.ev[2], s.st));
     // full_assign: stride 1, rem 0, no update afterwards (src/context.cpp:246-256)
     if (lsc) { f.cl_yx = yx_cur; launch_lsc_assign(f, l, n, 0, 1, p->max_iter & 1, 0, false, s.st); }
-    else if (noq) { f.cl_yx = yx_cur; launch_noq_assign(f, noq_coef, noq_manhattan, n, 0, 1, p->max_iter & 1, 0, false, s.st); }
-    else if (rd) { f.cl_yx = yx_cur; launch_rd_assign(f, s.d_patchf, rd_l2, n, 0, 1, p->max_iter & 1, 0, false, s.st); }
+    else if (noq) { f.cl_yx = yx_cur; launch_noq_assign(f, noq_coef, noq_manhattan, n, 0, 1, full_buf, 0, false, s.st); }
+    else if (rd) { f.cl_yx = yx_cur; launch_rd_assign(f, s.d_patchf, rd_l2, n, 0, 1, full_buf, 0, false, s.st); }
     else if (generic) launch_assign_generic(f, n, 0, 1, full_buf, 0, false, s.st);
     else (void)launch_assign(f, n, 0, 1, p->max_iter & 1, 0, false, s.st, full_obuf);
     if (timed) HIPCHK(hipEventRecord(s.ev[3], s.st));

@@ -108,6 +108,10 @@ struct FrameDev {
                                // |dx| = tab_xout.  `tab` serves the full (stride 1) pass, `tabs` the subsampled passes
     const uint16_t* tabs;
     int tabs_words, tabs_dyoff, tabs_nrpad;
+    // tab_vmode == 1 only: `tab` is built for 32 rows per wavefront when that fits (tab_rows32); `tabv16` is the same stride-1 table
+    // for at most 16 rows (tabv16_words == 0: `tab` itself is the 16-row table)
+    const uint16_t* tabv16;
+    int tabv16_words, tabv16_dyoff, tab_rows32;
     // tab_vmode == 0 only: the subsampled stride's 2-D table built for 16 rows per wavefront (tabs16_words == 0: too large to keep six
     // blocks per CU resident, the 16-row fused pass is then not used)
     const uint16_t* tabs16;

@@ -507,7 +507,7 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
                 if (slot[u] == kLscNoSlot || (u == 1 && both)) continue;
                 unsigned long long* a = s_accx + ((slot[u] << cshift) + copy) * kLscAccW;
                 auto fixed = [&](int q) { return (uint32_t)(int)__builtin_rintf(Fr[u][q] * l.blk_fix_f); };
-#if !(FSLIC_EXP & 8)      // (knock-out build 8, scripts/gpu_r04_knock.sh: what the block accumulators' LDS atomics cost; results wrong on purpose)
+#if !(FSLIC_EXP & 8)      // (knock-out build 8, scripts/gpu_knock.sh: what the block accumulators' LDS atomics cost; results wrong on purpose)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) atomicAdd(a + q, (unsigned long long)fixed(q) | ((unsigned long long)fixed(6 + q) << 32));
                 atomicAdd(a + 4, (unsigned long long)fixed(4) | ((unsigned long long)fixed(5) << 32));

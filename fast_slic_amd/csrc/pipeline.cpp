@@ -65,9 +65,9 @@ int acquire_slot(fslic_engine* e, int want, int& slot) {
     std::unique_lock<std::mutex> lk(e->mu);
     const int ns = (int)e->slots.size();
     if (want >= ns) return fail(FSLIC_E_INVALID, "slot out of range");
-    // A caller that has to wait is counted (sync_waiters): while the count is non-zero the slot threads leave the submit queue alone,
-    // so the slot that frees next goes to the waiting caller instead of straight back to the queue (under a continuous
-    // pipeline_submit load a synchronous call could otherwise wait indefinitely).
+    // A caller that has to wait is counted (sync_waiters, or Slot::wanted when it asked for one slot): while the count is non-zero the
+    // slot threads concerned leave the submit queue alone, so the slot that frees next goes to the waiting caller instead of straight
+    // back to the queue (under a continuous pipeline_submit load a synchronous call could otherwise wait indefinitely).
     auto got = [&](int i) { e->slots[i].busy = true; slot = i; return FSLIC_OK; };
     for (;;) {
         // A slot serving the submit / drain queue collects its group itself: it is busy for a while, not lost.  Only a
@@ -86,9 +86,12 @@ int acquire_slot(fslic_engine* e, int want, int& slot) {
             }
             if (!any_usable) return fail(FSLIC_E_INVALID, "every slot owns an unfinished asynchronous group");
         }
-        e->sync_waiters++;
+        // counted where it matters: a caller that wants ONE slot holds back that slot's thread only (the others keep serving the
+        // submit queue); a caller that takes any slot holds back whichever thread becomes idle next
+        int& waiting = want >= 0 ? e->slots[want].wanted : e->sync_waiters;
+        waiting++;
         e->cv.wait(lk);
-        e->sync_waiters--;
+        waiting--;
         wake.armed = true;
     }
 }
@@ -154,7 +157,7 @@ void slot_worker(fslic_engine* e, Slot* s) {
         bool took = false;
         {
             std::unique_lock<std::mutex> lk(e->mu);
-            e->cv_work.wait(lk, [&] { return a.has_job || a.quit || (!e->pipe_q.empty() && !e->pipe_gathering && !s->busy && !s->pending && e->sync_waiters == 0); });
+            e->cv_work.wait(lk, [&] { return a.has_job || a.quit || (!e->pipe_q.empty() && !e->pipe_gathering && !s->busy && !s->pending && e->sync_waiters == 0 && s->wanted == 0); });
             if (a.quit) return;
             if (!a.has_job) {
                 // the submit queue's head, plus -- with batching on -- the submissions behind it that ask for the same work,

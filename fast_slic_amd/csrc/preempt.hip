@@ -13,7 +13,9 @@
 //   D  all_active = every cluster active
 //   E  the active clusters are binned for the next assignment pass
 // K^2 / 1024 neighbour tests per thread: O(10 us) for K = 1600.  The mode is an approximation meant to save CPU time;
-// here it is served for interface completeness and takes the generic (one thread per pixel) assign kernel.
+// here it is served for interface completeness: the Slic variant takes the generic (one thread per pixel) assign kernel, the
+// float-distance variants (src/context.h:100-125: BaseContext<float>::iterate is the same template, src/context.cpp:152-181) their
+// own assign kernels on the bins of the active clusters, with the member sums restricted to the active cells.
 #include "device_common.h"
 
 namespace fslic {
@@ -34,16 +36,33 @@ __global__ __launch_bounds__(1024) void k_preempt_update(FrameDev f, int rebin_a
             if (upd) {
                 const int32_t n = (int32_t)s[0];
                 f.cl_n[k] = (uint32_t)n;
+                // |old.x - new.x| + |old.y - new.y| as the reference build evaluates it (src/preemptive.h:131-133): the FLOAT
+                // differences truncated to int (cvttss2si), integer abs -- the same thing as below for the quantised centroids,
+                // not the same for the float centroids of the 'noq' variant
+                int l1 = 0;
                 if (n != 0) {
                     const int32_t h = n / 2;
-                    const int y = min(max(((int32_t)s[1] + h) / n, 0), f.H - 1);
-                    const int x = min(max(((int32_t)s[2] + h) / n, 0), f.W - 1);
+                    int y = min(max(((int32_t)s[1] + h) / n, 0), f.H - 1);
+                    int x = min(max(((int32_t)s[2] + h) / n, 0), f.W - 1);
                     const int32_t L = ((int32_t)s[3] + h) / n, a = ((int32_t)s[4] + h) / n, b = ((int32_t)s[5] + h) / n;
+                    if (f.cl_f) {
+                        // centroid_quantization_enabled() == false (src/context.cpp:374-380): (float)sum / n per component; bins,
+                        // windows and the activity grid use the integer parts
+                        float* c = f.cl_f + 8 * (size_t)k;
+                        const float fn = (float)n, oy = c[0], ox = c[1];
+                        const float fy = (float)(int32_t)s[1] / fn, fx = (float)(int32_t)s[2] / fn;
+                        c[0] = fy; c[1] = fx;
+                        c[2] = (float)(int32_t)s[3] / fn; c[3] = (float)(int32_t)s[4] / fn; c[4] = (float)(int32_t)s[5] / fn;
+                        y = min(max((int)fy, 0), f.H - 1);
+                        x = min(max((int)fx, 0), f.W - 1);
+                        l1 = abs((int)(ox - fx)) + abs((int)(oy - fy));
+                    } else {
+                        l1 = abs((int)(yx_old & 0xFFFFu) - x) + abs((int)(yx_old >> 16) - y);
+                    }
                     yx = ((uint32_t)y << 16) | (uint32_t)x;
                     f.cl_lab[k] = (uint32_t)(L & 255) | ((uint32_t)(a & 255) << 8) | ((uint32_t)(b & 255) << 16);
                     f.cl_moved[k] = 1;
                 }
-                const int l1 = abs((int)(yx_old & 0xFFFFu) - (int)(yx & 0xFFFFu)) + abs((int)(yx_old >> 16) - (int)(yx >> 16));
                 upd = ((float)l1 < l1_thres) ? upd - 1u : 2u;
                 f.cl_upd[k] = upd;
             }
@@ -83,9 +102,12 @@ __global__ __launch_bounds__(1024) void k_preempt_update(FrameDev f, int rebin_a
         const uint32_t phase = (uint32_t)(2 * ((y / f.T) & 1) + ((x / f.T) & 1));
         ClusterRec rec;
         rec.yx = yx; rec.lab = f.cl_lab[k]; rec.tag = (phase << 16) | (uint32_t)k; rec.pad = gen;
-        f.cl_tag[k] = rec.tag;
+        const bool out = !rebin_all && !f.cl_act[k];       // src/context.cpp:218
+        // (the kernels that fall back to a walk over ALL clusters when a block sees more than 64 -- realdist.hip, lsc.hip -- select by
+        // the tag's phase: an inactive cluster carries a phase no walk asks for)
+        f.cl_tag[k] = out ? (0xFFFF0000u | (uint32_t)k) : rec.tag;
         f.cl_shadow[k] = 0u;
-        if (!rebin_all && !f.cl_act[k]) continue;          // src/context.cpp:218
+        if (out) continue;
         const int cell = (y >> f.cs_shift) * f.ncx + (x >> f.cs_shift);
         const uint32_t slot = atomicAdd(&f.cell_cnt[0][cell], 1u);
         if (slot < (uint32_t)kCellCap) f.cell_items[0][(size_t)cell * kCellCap + slot] = rec;

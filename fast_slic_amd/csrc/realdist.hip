@@ -12,6 +12,11 @@
 
 namespace fslic {
 
+// preemptive mode (src/context.cpp:304-343): unless every cluster is active, only pixels of active (2S x 2S) cells take part in update()
+static __device__ __forceinline__ bool in_update(const FrameDev& f, int y, int x) {
+    return !f.cell_act || f.pre_flags[0] || f.cell_act[(y / (2 * f.S)) * f.pre_cw + x / (2 * f.S)];
+}
+
 constexpr int kRdRows = 4;                              // visited rows per wavefront
 constexpr int kRdBH = kWavesPerBlock * kRdRows;
 
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(256) void k_rd_assign(FrameDev f, const float* __re
             const uint32_t old = f.labels[p];
             if (old != 0xFFFFu) {
                 const uint32_t oyx = f.cl_yx[old];
-                if (abs(yr[r] - (int)(oyx >> 16)) > S || abs(x - (int)(oyx & 0xFFFFu)) > S)
+                if ((abs(yr[r] - (int)(oyx >> 16)) > S || abs(x - (int)(oyx & 0xFFFFu)) > S) && in_update(f, yr[r], x))
                     global_accumulate(f.sums[0], old, (uint32_t)yr[r], (uint32_t)x, pix[r]);
             }
         }
@@ -147,6 +152,7 @@ __global__ __launch_bounds__(256) void k_member_sums(FrameDev f, int rem, int st
     const int v_first = t <= 0 ? 0 : (t + stride - 1) / stride;
     uint32_t pre_sum = 0;
     if (lane < 6) pre_sum = f.sums[0][6 * (size_t)k + lane];
+    const bool restricted = f.cell_act && !f.pre_flags[0];      // preemptive mode with inactive cells (in_update)
     uint32_t in[6] = {0u, 0u, 0u, 0u, 0u, 0u};
     constexpr int kRows = 6;
     const size_t p_first = (size_t)min(rem + stride * v_first, f.H - 1) * W + x_lo;
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(256) void k_member_sums(FrameDev f, int rem, int st
 #pragma unroll
             for (int u = 0; u < kRows; ++u) {
                 const int y = y0 + u * stride;
-                m[u] = y <= y_hi && x <= x_hi && lb[u] == (uint32_t)k;
+                m[u] = y <= y_hi && x <= x_hi && lb[u] == (uint32_t)k && (!restricted || f.cell_act[(y / (2 * f.S)) * f.pre_cw + x / (2 * f.S)]);
                 pix[u] = f.lab[m[u] ? p[u] : p_first];
             }
 #pragma unroll
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(256) void k_noq_assign(FrameDev f, float coef, int 
             const uint32_t old = f.labels[p];
             if (old != 0xFFFFu) {
                 const uint32_t oyx = f.cl_yx[old];
-                if (abs(yr[r] - (int)(oyx >> 16)) > S + 1 || abs(x - (int)(oyx & 0xFFFFu)) > S + 1)      // same margin as k_member_sums
+                if ((abs(yr[r] - (int)(oyx >> 16)) > S + 1 || abs(x - (int)(oyx & 0xFFFFu)) > S + 1) && in_update(f, yr[r], x))      // same margin as k_member_sums
                     global_accumulate(f.sums[0], old, (uint32_t)yr[r], (uint32_t)x, pix[r]);
             }
         }

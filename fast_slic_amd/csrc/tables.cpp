@@ -182,6 +182,7 @@ int configure_spatial(Slot& s, int S, const fslic_params* p) {
     constexpr size_t vtab_min = 12288;
     f.tabs = s.d_tab + kTabMaxBytes / 2; f.tabs_words = 0; f.tabs_dyoff = 0;
     f.tabs16 = s.d_tab + kTabMaxBytes; f.tabs16_words = 0; f.tabs16_dyoff = 0; f.tabs16_nrpad = 0;
+    f.tabv16 = s.d_tab + kTabMaxBytes; f.tabv16_words = 0; f.tabv16_dyoff = 0; f.tab_rows32 = 0;      // (the third slot serves one table mode or the other)
     if (manhattan && tab2d_bytes > vtab_min && S >= 8 && max_sp + 765u < 1024u) {
         // Row-vector V tables (the Manhattan patch depends on |di| + |dj| only): one for the full pass (stride 1, up to
         // 32 rows per wavefront) and one for the subsampled passes (stride_it, up to 16 rows per wavefront).
@@ -202,11 +203,15 @@ int configure_spatial(Slot& s, int S, const fslic_params* p) {
             words = tlen * 4; cc = Cc;
             return true;
         };
-        int w1 = 0, c1 = 0, ws = 0, cs = 0;
+        int w1 = 0, c1 = 0, ws = 0, cs = 0, w16 = 0, c16 = 0;
         const int st3 = std::min(stride_it, 3);
-        if (build(1, 32, s.h_tab, w1, c1) && build(st3, 16, s.h_tab + kTabMaxBytes / 2, ws, cs)) {
-            f.tab_words = w1; f.tab_dyoff = c1; f.tab_vmode = 1; f.tab_xout = xout;
+        // the full pass's table for 32 rows per wavefront where it fits the LDS budget (S <= 411), else for 16 (S <= 419); next to a
+        // 32-row table the 16-row one is kept too: launches of at most 16 rows per wavefront reserve 768 bytes of LDS per block less
+        const bool rows32 = build(1, 32, s.h_tab, w1, c1);
+        if ((rows32 || build(1, 16, s.h_tab, w1, c1)) && build(st3, 16, s.h_tab + kTabMaxBytes / 2, ws, cs)) {
+            f.tab_words = w1; f.tab_dyoff = c1; f.tab_vmode = 1; f.tab_xout = xout; f.tab_rows32 = rows32 ? 1 : 0;
             f.tabs_words = ws; f.tabs_dyoff = cs;
+            if (rows32 && build(1, 16, s.h_tab + kTabMaxBytes, w16, c16)) { f.tabv16_words = w16; f.tabv16_dyoff = c16; }
             tiled_ok = true;
         }
     }
@@ -256,6 +261,8 @@ int configure_spatial(Slot& s, int S, const fslic_params* p) {
         HIPCHK(hipMemcpyAsync(const_cast<uint16_t*>(f.tabs), s.h_tab + kTabMaxBytes / 2, (size_t)f.tabs_words * 4, hipMemcpyHostToDevice, s.st));
     if (f.tabs16_words > 0)
         HIPCHK(hipMemcpyAsync(const_cast<uint16_t*>(f.tabs16), s.h_tab + kTabMaxBytes, (size_t)f.tabs16_words * 4, hipMemcpyHostToDevice, s.st));
+    if (f.tabv16_words > 0)
+        HIPCHK(hipMemcpyAsync(const_cast<uint16_t*>(f.tabv16), s.h_tab + kTabMaxBytes, (size_t)f.tabv16_words * 4, hipMemcpyHostToDevice, s.st));
     if (f.lut_words > 0)
         HIPCHK(hipMemcpyAsync(s.d_lut, s.h_lut, (size_t)f.lut_words * 4, hipMemcpyHostToDevice, s.st));
     s.sp_tiled_ok = tiled_ok;

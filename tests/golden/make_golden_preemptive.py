@@ -1,5 +1,5 @@
-"""Generate the preemptive-mode fixtures from the UNMODIFIED reference (oracle/_ref): Slic(preemptive=True),
-src/preemptive.h.
+"""Generate the preemptive-mode fixtures from the UNMODIFIED reference (oracle/_ref): Slic(preemptive=True) and the
+float-distance variants SlicRealDist / SlicRealDistL2 / SlicRealDistNoQ with preemptive=True, src/preemptive.h.
 
     make -C oracle ref && python tests/golden/make_golden_preemptive.py      (build container only: needs /root/reference)
 
@@ -33,8 +33,50 @@ CASES = [
 ]
 
 
+# the float-distance variants in preemptive mode (BaseContext<float>::iterate is the same template, src/context.cpp:152-181):
+# name, kind, synthetic variant, H, W, K, preemptive_thres, kwargs
+RD_CASES = [
+    ("rd_std_A_120x160_k40", "standard", "A", 120, 160, 40, 0.05, {}),
+    ("rd_std_B_200x150_k30_stride2", "standard", "B", 200, 150, 30, 0.05, dict(subsample_stride=2, compactness=20.0)),
+    ("rd_std_A_240x320_k150_thres02", "standard", "A", 240, 320, 150, 0.2, {}),
+    ("rd_std_A_480x640_k3000_pileup", "standard", "A", 480, 640, 3000, 0.05, {}),
+    ("rd_l2_C_240x320_k150", "l2", "C", 240, 320, 150, 0.05, {}),
+    ("rd_l2_A_480x640_k200_iter20", "l2", "A", 480, 640, 200, 0.05, dict(max_iter=20)),
+    ("rd_noq_A_120x160_k40", "noq", "A", 120, 160, 40, 0.05, {}),
+    ("rd_noq_B_200x150_k30_stride2", "noq", "B", 200, 150, 30, 0.05, dict(subsample_stride=2, compactness=20.0)),
+    ("rd_noq_A_240x320_k150_thres02", "noq", "A", 240, 320, 150, 0.2, {}),
+    ("rd_noq_A_200x264_k120_euclid", "noq", "A", 200, 264, 120, 0.1, dict(manhattan=False)),
+    ("rd_noq_A_480x640_k200_iter20", "noq", "A", 480, 640, 200, 0.05, dict(max_iter=20)),
+    ("rd_std_A_720x1280_k1600", "standard", "A", 720, 1280, 1600, 0.05, {}),
+    ("rd_noq_A_720x1280_k1600", "noq", "A", 720, 1280, 1600, 0.05, {}),
+]
+
+
+def realdist_cases(out):
+    for name, kind, var, H, W, K, thres, kw in RD_CASES:
+        img = variant(var, H, W)
+        cl0 = ref.initialize_clusters(img, K)
+        ref.set_preemptive(True, thres)
+        try:
+            labels, cl, pre = ref.realdist_iterate(img, cl0, kind, num_threads=1, **kw)
+            l8, c8, _ = ref.realdist_iterate(img, cl0, kind, num_threads=8, **kw)
+        finally:
+            ref.set_preemptive(False)
+        assert np.array_equal(labels, l8) and cl.tobytes() == c8.tobytes(), "reference not thread-count invariant at " + name
+        out[name + "/kind"] = np.array(kind)
+        out[name + "/variant"] = np.array(var)
+        out[name + "/shape"] = np.array([H, W, K], np.int32)
+        out[name + "/thres"] = np.float32(thres)
+        out[name + "/labels"] = labels
+        out[name + "/clusters"] = cl
+        out[name + "/prelabels"] = pre
+        out[name + "/kwargs"] = np.array(json.dumps(kw))
+        print(name, "segments", len(np.unique(labels)), "is_updatable", np.unique(cl["is_updatable"], return_counts=True))
+
+
 def main():
     out = {}
+    realdist_cases(out)
     for name, var, H, W, K, thres, kw in CASES:
         img = variant(var, H, W)
         cl0 = ref.initialize_clusters(img, K)
