@@ -921,9 +921,43 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
                 for (int q = 0; q < NQ; ++q) min_in_place(best[Q0 + q], key[q]);
             }
         };
-        walk(todo_b, std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * HQ>{});
-        walk(todo_u, std::integral_constant<int, 0>{}, std::integral_constant<int, HQ>{});
-        walk(todo_l, std::integral_constant<int, HQ>{}, std::integral_constant<int, HQ>{});
+        if constexpr (R == 16 && FUSE) {
+            // 16 rows per wavefront (the fused passes of launches that fill the chip: 46 image rows at stride 3 against a window of
+            // 2S + 1 = 49): QUARTERS of four visited rows.  A candidate's window is an interval of rows, so it reaches a contiguous range
+            // of quarters -- ten ranges, ten loops with straight-line bodies, the masks of the ranges from four pairs of comparisons.
+            // At S = 24 a candidate of the list reaches 2.5 of the four quarters on average, 3.0 when it can only be switched by halves:
+            // a sixth of the distance / key / min instructions and of the table reads of these passes.
+            (void)todo_b; (void)todo_u; (void)todo_l;
+            unsigned long long cov[4];
+            {
+                const int cyj = (int)(yx_j >> 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ylo = yw_lo + q * (R / 4) * STRIDE, yhi = ylo + (R / 4 - 1) * STRIDE;
+                    cov[q] = todo & ballot(cyj >= ylo - S) & ballot(cyj <= yhi + S);
+                }
+            }
+            constexpr int P = R / 8;                         // row pairs per quarter
+            auto quarters = [&](unsigned long long m, auto q0, auto nq) {
+                walk(m, std::integral_constant<int, decltype(q0)::value * P>{}, std::integral_constant<int, decltype(nq)::value * P>{});
+            };
+            using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+            using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>;
+            quarters(cov[0] & cov[3], I0{}, I4{});
+            quarters(cov[0] & cov[2] & ~cov[3], I0{}, I3{});
+            quarters(cov[1] & cov[3] & ~cov[0], I1{}, I3{});
+            quarters(cov[0] & cov[1] & ~cov[2], I0{}, I2{});
+            quarters(cov[1] & cov[2] & ~cov[0] & ~cov[3], I1{}, I2{});
+            quarters(cov[2] & cov[3] & ~cov[1], I2{}, I2{});
+            quarters(cov[0] & ~cov[1], I0{}, I1{});
+            quarters(cov[1] & ~cov[0] & ~cov[2], I1{}, I1{});
+            quarters(cov[2] & ~cov[1] & ~cov[3], I2{}, I1{});
+            quarters(cov[3] & ~cov[2], I3{}, I1{});
+        } else {
+            walk(todo_b, std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * HQ>{});
+            walk(todo_u, std::integral_constant<int, 0>{}, std::integral_constant<int, HQ>{});
+            walk(todo_l, std::integral_constant<int, HQ>{}, std::integral_constant<int, HQ>{});
+        }
     }
 
     ASG_STAMP(4, wave == 0);

@@ -808,31 +808,20 @@ static __device__ __forceinline__ void tie_heap_select(const CcaDev& c, uint32_t
         const int last_parent = (len - 2) / 2;
         int d = 0;
         while (((2 << d) - 1) <= last_parent) d++;           // depth of the deepest parent
-        // The deep levels (depth > kTieWaveLevels) subtree by subtree: the 2^(kTieWaveLevels+1) subtrees rooted one level below the
-        // wavefront-sifted levels are independent of each other, so a wavefront takes whole subtrees and walks their levels bottom-up
-        // with nothing but its own LDS ordering between two levels -- one thread per parent, as before, but no block barrier per level
-        // (a barrier among sixteen wavefronts plus the LDS round trips behind it was ~0.55 us per level, six to eight levels).
-        constexpr int DS = kTieWaveLevels + 1;                  // depth of the subtree roots
-        if (d >= DS) {
-            const int wave = (int)rfl((uint32_t)(tid >> 6));
-            for (int t = d - DS; t >= 0; --t) {                 // relative depth of the parents handled in this step
-                for (int sub = wave; sub < (1 << DS); sub += 16) {
-                    const int r = (1 << DS) - 1 + sub;          // the subtree's root
-                    for (int j = lane; j < (1 << t); j += 64) {
-                        const int p = ((r + 1) << t) - 1 + j;
-                        if (p <= last_parent) tie_adjust_heap(heap, p, len, hp_ld(heap + p), true, astar);
-                    }
-                }
-                wave_lds_sync();
-            }
-            __syncthreads();
-            d = DS - 1;
-        }
+        // (the deep levels subtree by subtree inside one wavefront each -- no block barrier between two levels -- were measured in
+        // round 5: 9.9 instead of 6.3 us for K = 1600; the barrier is not what a level costs, the dependent LDS round trips of the
+        // walks are, and a wavefront that takes two subtrees runs them one after the other)
         for (; d >= 0; --d) {
-            // the upper levels: at most one parent per wavefront, walks of several levels -- five levels per LDS round trip
             const int lo = (1 << d) - 1, hi = min((2 << d) - 2, last_parent);
-            for (int p = lo + (int)rfl((uint32_t)(tid >> 6)); p <= hi; p += 16)
-                tie_wave_sift(heap, len, p, hp_ld(heap + p), lane, astar);
+            if (d > kTieWaveLevels) {
+                // deep parents: many of them, short walks -- one thread each
+                for (int p = lo + tid; p <= hi; p += 1024)
+                    tie_adjust_heap(heap, p, len, hp_ld(heap + p), true, astar);
+            } else {
+                // the upper levels: at most one parent per wavefront, walks of several levels -- five levels per LDS round trip
+                for (int p = lo + (int)rfl((uint32_t)(tid >> 6)); p <= hi; p += 16)
+                    tie_wave_sift(heap, len, p, hp_ld(heap + p), lane, astar);
+            }
             __syncthreads();
         }
     }

@@ -32,14 +32,28 @@ template <int NB> static __device__ __forceinline__ void request_entries(const F
         L.v[u][0] = p[0]; L.v[u][1] = p[1]; L.v[u][2] = p[2];
     }
 }
-template <int NB> static __device__ __forceinline__ void add_live_entries(const FrameDev& f, const SlotGeom& g, bool take, uint32_t e0, uint32_t ne, uint32_t ymask, const EntryLoads<NB>& L, uint32_t* out) {
+// the entry of grid position e is live when its block lies inside the window's block range (offsets modulo the grid)
+static __device__ __forceinline__ bool entry_live(const FrameDev& f, const SlotGeom& g, uint32_t e, uint32_t ne, uint32_t ymask) {
     const uint32_t nbx = (uint32_t)f.nbx, xsh = 31u - (uint32_t)__clz((int)nbx);
-    const uint32_t dy = (uint32_t)(g.by1 - g.by0), dx = (uint32_t)(g.bx1 - g.bx0);
+    const uint32_t ry = ((e >> xsh) - (uint32_t)g.by0) & ymask, rx = (e - (uint32_t)g.bx0) & (nbx - 1u);
+    return e < ne && ry <= (uint32_t)(g.by1 - g.by0) && rx <= (uint32_t)(g.bx1 - g.bx0);
+}
+template <int NB> static __device__ __forceinline__ void request_live_entries(const FrameDev& f, const SlotGeom& g, bool take, int k, uint32_t e0, uint32_t ne, uint32_t ymask, EntryLoads<NB>& L) {
+    const char* cp = reinterpret_cast<const char*>(f.cpart + (size_t)k * f.cpart_ns * 6);
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         const uint32_t e = e0 + (uint32_t)u;
-        const uint32_t ry = ((e >> xsh) - (uint32_t)g.by0) & ymask, rx = (e - (uint32_t)g.bx0) & (nbx - 1u);     // offset of the entry's block from the window's first
-        const bool livee = take && e < ne && ry <= dy && rx <= dx;
+        L.v[u][0] = L.v[u][1] = L.v[u][2] = make_uint2(0u, 0u);
+        if (take && entry_live(f, g, e, ne, ymask)) {
+            const uint2* p = reinterpret_cast<const uint2*>(cp + __umul24(e, 24u));
+            L.v[u][0] = p[0]; L.v[u][1] = p[1]; L.v[u][2] = p[2];
+        }
+    }
+}
+template <int NB> static __device__ __forceinline__ void add_live_entries(const FrameDev& f, const SlotGeom& g, bool take, uint32_t e0, uint32_t ne, uint32_t ymask, const EntryLoads<NB>& L, uint32_t* out) {
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const bool livee = take && entry_live(f, g, e0 + (uint32_t)u, ne, ymask);
         out[0] += livee ? L.v[u][0].x : 0u; out[1] += livee ? L.v[u][0].y : 0u; out[2] += livee ? L.v[u][1].x : 0u;
         out[3] += livee ? L.v[u][1].y : 0u; out[4] += livee ? L.v[u][2].x : 0u; out[5] += livee ? L.v[u][2].y : 0u;
     }
@@ -88,20 +102,26 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg, c
         const uint2* const sp = reinterpret_cast<const uint2*>(f.sums[0] + 6 * (size_t)kc);
         const uint2 s01 = sp[0], s23 = sp[1], s45 = sp[2];
         const uint32_t ymask = cpart_rows_mask(f.S, pg.stride, max(pg.BH, 1)), ne = pg.use_slots ? (ymask + 1u) * (uint32_t)f.nbx : 0u;
-        // (NB = entries per trip, chosen by the launcher: four for grids of four -- 1280x720 K=1600 --, else eight; larger grids --
-        // wide windows on 8-row blocks -- take further trips)
+        // NB == 4 (grids of four entries: 1280x720 K=1600): the entries are requested before the position is known (above).  Larger
+        // grids (NB == 8): only the LIVE entries are requested, after the geometry -- measured both ways in round 5
+        // (profiles/r05_cluster_pass.txt): requesting a whole grid of eight costs more than the dependent round trip saves (the pass
+        // is bound by its scattered 24-byte loads, not by the length of its chain: 7.25 -> 7.89 us at 3840x2160 K=6000), a grid of
+        // four gains a little (5.38 -> 5.14 us for 2 x 8 frames of 1280x720).
         EntryLoads<NB> L;
-        if (pg.use_slots) request_entries<NB>(f, kc, 0u, ne, L);
+        if (NB == 4 && pg.use_slots) request_entries<NB>(f, kc, 0u, ne, L);
         // a shadowed cluster is in no candidate list: it received nothing and its entries are stale
         const bool take = live && !(pg.use_slots && shadow_word);
         uint32_t s[6] = {0u, 0u, 0u, 0u, 0u, 0u};
         if (take) { s[0] = s01.x; s[1] = s01.y; s[2] = s23.x; s[3] = s23.y; s[4] = s45.x; s[5] = s45.y; }
         if (pg.use_slots) {
             const SlotGeom g = slot_geom((int)(yx >> 16), (int)(yx & 0xFFFFu), f.S, f.H, f.W, pg.rem, pg.stride, pg.BH, pg.Hv);
-            add_live_entries<NB>(f, g, take && g.any, 0u, ne, ymask, L, s);
-            for (uint32_t e0 = (uint32_t)NB; e0 < ne; e0 += (uint32_t)NB) {
-                request_entries<NB>(f, kc, e0, ne, L);
-                add_live_entries<NB>(f, g, take && g.any, e0, ne, ymask, L, s);
+            if (NB == 4) {
+                add_live_entries<NB>(f, g, take && g.any, 0u, ne, ymask, L, s);
+            } else {
+                for (uint32_t e0 = 0u; e0 < ne; e0 += (uint32_t)NB) {
+                    request_live_entries<NB>(f, g, take && g.any, kc, e0, ne, ymask, L);
+                    add_live_entries<NB>(f, g, take && g.any, e0, ne, ymask, L, s);
+                }
             }
         }
         // member count of cluster k-1 (needed below): the previous thread's
