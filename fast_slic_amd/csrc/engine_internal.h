@@ -243,6 +243,7 @@ struct fslic_engine {
     int pipe_inflight = 0;           // groups taken from the queue and not yet collected
     int pipe_batch_frames = 0;       // 0: one submission per group; otherwise the most frames a group may gather
     bool pipe_gathering = false;     // a slot thread is waiting briefly for a companion of the submission it took
+    double pipe_last_submit_us = 0;  // (mu) when the last submission arrived: a companion is only waited for while submissions are arriving
     std::atomic<int> reserve_frames{0};   // arenas are carved for at least this many frames per group
     int sync_waiters = 0;                    // (mu) synchronous callers waiting for ANY slot (or all of them): the slot threads leave the submit queue alone meanwhile
     std::atomic<int> lab_force_generic{0};   // testing aid (fslic_hip_lab_force_generic): the brute-force gather kernels instead of the tiled ones

@@ -166,8 +166,8 @@ void slot_worker(fslic_engine* e, Slot* s) {
                 a.p = j0.p; a.H = j0.H; a.W = j0.W; a.K = j0.K; a.n = 0; a.jobs = 0;
                 const int limit = std::min(e->pipe_batch_frames, (int)kMaxGroup);
                 const int unit = j0.n;
-                auto gather = [&]() {
-                    while (!e->pipe_q.empty()) {
+                auto gather = [&](int max_jobs) {
+                    while (!e->pipe_q.empty() && a.jobs < max_jobs) {
                         const fslic_engine::PipeJob& j = e->pipe_q.front();
                         if (a.jobs > 0 && (!same_work(j, a) || a.n + j.n > limit)) break;
                         for (int i = 0; i < j.n; i++) { a.d_rgb[a.n + i] = j.d_rgb[i]; a.clusters[a.n + i] = j.clusters[i]; a.d_out[a.n + i] = j.d_out[i]; }
@@ -175,7 +175,11 @@ void slot_worker(fslic_engine* e, Slot* s) {
                         e->pipe_q.pop_front();
                     }
                 };
-                gather();
+                // (Guided self-scheduling -- a slot takes ceil(waiting / slots) submissions, so that the last submissions of a burst spread
+                // over the slots -- was measured in round 5 and not kept: the driver's 20 steps 45.6 against 46.7 GP/s, mean of four runs each,
+                // profiles/r05_burst_schedule.txt: 8-frame groups cost more per frame than the balance gains, and which slots share a
+                // hardware queue -- the runtime's choice: two of four queues carry two streams each with six slots -- decides the tail.)
+                gather(kMaxGroup);
                 // the slot is taken and the group counted BEFORE the wait below: a drain must not take the queue for served
                 // meanwhile, nor a synchronous call this slot for free
                 s->pending = true;
@@ -184,11 +188,13 @@ void slot_worker(fslic_engine* e, Slot* s) {
                 // Room for another submission of this size and nothing waiting: a caller in the middle of a burst delivers the
                 // next one within microseconds.  This thread waits for it briefly (the other idle threads leave the queue alone
                 // meanwhile), so that the first groups of a burst are as full as the later ones.
-                if (a.n + unit <= limit && e->pipe_q.empty() && !e->pipe_gathering) {
+                // (only while the caller IS in the middle of a burst -- its last submission is a few microseconds old: the slot that takes
+                // the last submission of a burst would otherwise wait 100 us for a companion that never comes, 3 % of the driver's region)
+                if (a.n + unit <= limit && e->pipe_q.empty() && !e->pipe_gathering && now_us() - e->pipe_last_submit_us < 50.0) {
                     e->pipe_gathering = true;
                     e->cv_work.wait_for(lk, std::chrono::microseconds(100), [&] { return !e->pipe_q.empty() || a.quit; });
                     e->pipe_gathering = false;
-                    gather();
+                    gather(kMaxGroup);
                 }
                 s->launch_timing = e->launch_timing;
                 a.has_job = true;
@@ -335,6 +341,7 @@ int fslic_hip_pipeline_submit(fslic_engine* e, const fslic_params* p, int H, int
         if (e->pipe_rc != FSLIC_OK) { set_last_error(e->pipe_err); return e->pipe_rc; }   // reported once more by drain
         e->pipe_q.emplace_back();
         fslic_engine::PipeJob& j = e->pipe_q.back();
+        e->pipe_last_submit_us = now_us();
         j.p = *p; j.H = H; j.W = W; j.K = K; j.n = n_frames;
         for (int i = 0; i < n_frames; i++) { j.d_rgb[i] = d_rgb[i]; j.clusters[i] = clusters[i]; j.d_out[i] = d_labels[i]; }
     }
