@@ -615,7 +615,7 @@ def main():
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u8/u16/i32 (integer SLIC)", "data": "synthetic",
             "config": {"workload": cfg["name"], "frames_per_gpu": fpg, "global_frames": fpg * world,
-                       "slots_per_gpu": eng.n_slots, "hw_queue_of_slot": eng.slot_hw_queues(), "submissions_per_launch_group": "up to %d (dynamic batching of the pipeline)" % merged_max,
+                       "slots_per_gpu": eng.n_slots, "submissions_per_launch_group": "up to %d (dynamic batching of the pipeline)" % merged_max,
                        "inputs": "device-resident uint8 RGB, device int16 labels",
                        "parallelism": "frames sharded across GPUs, no collective",
                        "host_cpus_of_this_rank": len(pinned) if pinned else None},

@@ -44,7 +44,7 @@ EXPORTS = [
     "fslic_hip_last_device_times", "fslic_hip_set_launch_timing", "fslic_hip_last_assign_loop", "fslic_hip_last_group_frames", "fslic_hip_last_path", "fslic_hip_last_launch_mode", "fslic_hip_group_done", "fslic_hip_last_error", "fslic_hip_version",
     "fslic_hip_get_connectivity", "fslic_hip_knn_connectivity", "fslic_hip_get_mask_density", "fslic_hip_cluster_density_to_mask",
     "fslic_hip_pipeline_submit", "fslic_hip_pipeline_drain", "fslic_hip_pipeline_batching", "fslic_hip_last_host_topk_frames",
-    "fslic_hip_separate_pass_redos", "fslic_hip_copy_bandwidth", "fslic_hip_slot_hw_queue",
+    "fslic_hip_separate_pass_redos", "fslic_hip_copy_bandwidth",
 ]
 
 _lib = None
@@ -287,14 +287,6 @@ class Engine(object):
     def separate_pass_redos(self):
         """Frames (all slots, since the engine was created) redone with the separate cluster pass because of a stale pixel."""
         return sum(int(load_library().fslic_hip_separate_pass_redos(self._h, s)) for s in range(self.n_slots))
-
-    def slot_hw_queues(self):
-        """Per slot the hardware queue (a class number found by probing when the engine was created) its stream runs on; -1: unknown."""
-        lib = load_library()
-        if not hasattr(lib, "fslic_hip_slot_hw_queue"):
-            return [-1] * self.n_slots
-        lib.fslic_hip_slot_hw_queue.argtypes = [C.c_void_p, C.c_int]
-        return [int(lib.fslic_hip_slot_hw_queue(self._h, s)) for s in range(self.n_slots)]
 
     def copy_bandwidth(self, nbytes=1 << 30, reps=5):
         """Measured HBM rate of this GPU in GB/s: bytes read + written per second of a plain streaming copy of `nbytes`."""

@@ -7,84 +7,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <vector>
 
 using namespace fslic;
 
 static_assert(sizeof(fslic_cluster) == 32, "Cluster ABI (src/fast-slic-common.h:10-23)");
-
-namespace {
-
-// The slots' streams, chosen so that they spread evenly over the runtime's hardware queues.
-// The runtime multiplexes HIP streams onto a few hardware queues (four by default) and decides the mapping itself -- six streams
-// created in a row landed as 1 + 1 + 2 + 2, eight as 2 + 1 + 2 + 3, four as 1 + 0 + 1 + 2 (profiles/r05_burst_schedule.txt) -- and
-// streams that share a queue do not overlap: their groups run one after the other.  With an uneven mapping two queues carry most of a
-// burst while the others run dry (the driver's 20 steps: two of four queues idle for the last fifth of the timed region).  So: create
-// more streams than slots, find out which of them share a queue (a wavefront holds stream A for 60 us; a stamp taken on stream B before
-// it ended means B runs beside A), and keep the streams round-robin over the queues: slot i and slot i + (number of queues) share a
-// queue, no queue carries two slots before every queue carries one.  Any doubt (probe failure, a single class) keeps the first n.
-#if !(FSLIC_EXP & 16)
-int pick_streams(int n_slots, std::vector<hipStream_t>& picked, std::vector<int>& queue_of) {
-    const int n_cand = std::min(std::max(2 * n_slots, n_slots + 8), 24);
-    std::vector<hipStream_t> cand(n_cand, nullptr);
-    unsigned long long* h = nullptr;
-    auto cleanup = [&](int keep_first) {
-        for (int i = keep_first; i < n_cand; i++) if (cand[i]) hipStreamDestroy(cand[i]);
-        if (h) hipHostFree(h);
-        (void)hipGetLastError();
-    };
-    for (auto& c : cand)
-        if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) { cleanup(0); return FSLIC_E_HIP; }
-    auto fallback = [&]() {
-        picked.assign(cand.begin(), cand.begin() + n_slots);
-        queue_of.assign(n_slots, -1);
-        cleanup(n_slots);
-        return FSLIC_OK;
-    };
-    if (n_slots < 2 || hipHostMalloc((void**)&h, 64) != hipSuccess) { h = nullptr; return fallback(); }
-    bool failed = false;
-    auto same_queue = [&](hipStream_t a, hipStream_t b) -> bool {
-        int votes = 0;
-        for (int rep = 0; rep < 2 && !failed; rep++) {      // "same" needs both runs to say so (a late launch of the stamp looks like a shared queue)
-            h[0] = h[1] = h[2] = 0;
-            launch_probe_hold(h, 6000u, a);
-            launch_probe_stamp(h + 2, b);
-            if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess || !h[1] || !h[2]) { failed = true; break; }
-            if (h[2] >= h[1]) votes++; else return false;
-        }
-        return votes == 2;
-    };
-    std::vector<int> cls(n_cand, -1), rep_of;        // class of every candidate; representative stream of every class
-    for (int i = 0; i < n_cand && !failed; i++) {
-        for (size_t c = 0; c < rep_of.size() && cls[i] < 0 && !failed; c++)
-            if (same_queue(cand[rep_of[c]], cand[i])) cls[i] = (int)c;
-        if (cls[i] < 0) { cls[i] = (int)rep_of.size(); rep_of.push_back(i); }
-        if (rep_of.size() > 16) failed = true;
-    }
-    if (failed || rep_of.size() < 2) return fallback();
-    // round-robin over the classes
-    const int nc = (int)rep_of.size();
-    std::vector<std::vector<int>> members(nc);
-    for (int i = 0; i < n_cand; i++) members[cls[i]].push_back(i);
-    std::vector<char> used(n_cand, 0);
-    picked.clear(); queue_of.clear();
-    for (size_t round = 0; (int)picked.size() < n_slots && round < (size_t)n_cand; round++)
-        for (int c = 0; c < nc && (int)picked.size() < n_slots; c++)
-            if (round < members[c].size()) { const int i = members[c][round]; used[i] = 1; picked.push_back(cand[i]); queue_of.push_back(c); }
-    for (int i = 0; i < n_cand; i++) if (!used[i]) hipStreamDestroy(cand[i]);
-    hipHostFree(h);
-    (void)hipGetLastError();
-    return FSLIC_OK;
-}
-#else
-int pick_streams(int n_slots, std::vector<hipStream_t>& picked, std::vector<int>& queue_of) {      // (experiment build: the first n streams, as until round 4)
-    picked.assign(n_slots, nullptr); queue_of.assign(n_slots, -1);
-    for (auto& c : picked) if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) return FSLIC_E_HIP;
-    return FSLIC_OK;
-}
-#endif
-
-}  // namespace
 
 extern "C" {
 
@@ -110,14 +36,8 @@ int fslic_hip_create(int device, int n_slots, fslic_engine** out) {
     e->device = device;
     e->group_size = knobs().group_size;
     e->slots.resize(n_slots);
-    {
-        std::vector<hipStream_t> streams;
-        std::vector<int> queue_of;
-        if (pick_streams(n_slots, streams, queue_of) != FSLIC_OK) { fslic_hip_destroy(e); return fail(FSLIC_E_HIP, "hipStreamCreate failed"); }
-        for (int i = 0; i < n_slots; i++) { e->slots[i].st = streams[i]; e->slots[i].hw_queue = queue_of[i]; }
-        e->queues_known = n_slots >= 2 && queue_of[0] >= 0;
-    }
     for (auto& s : e->slots) {
+        if (hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) { fslic_hip_destroy(e); return fail(FSLIC_E_HIP, "hipStreamCreate failed"); }
         for (auto& ev : s.ev)
             if (hipEventCreate(&ev) != hipSuccess) { fslic_hip_destroy(e); return fail(FSLIC_E_HIP, "hipEventCreate failed"); }
         for (auto& ev : s.ev_it)
@@ -135,11 +55,6 @@ int fslic_hip_create(int device, int n_slots, fslic_engine** out) {
     for (int i = 0; i < 9; i++) e->tables.cb[i] = ht.cb[i];
     *out = e;
     return FSLIC_OK;
-}
-
-int fslic_hip_slot_hw_queue(fslic_engine* e, int slot) {
-    if (!e || slot < 0 || slot >= (int)e->slots.size()) return -1;
-    return e->slots[slot].hw_queue;
 }
 
 void fslic_hip_destroy(fslic_engine* e) {

@@ -74,7 +74,6 @@ const HostTables& host_tables();
 
 struct Slot {
     hipStream_t st = nullptr;
-    int hw_queue = -1;               // which of the runtime's hardware queues the stream runs on (a class number found by probing, capi.cpp pick_streams; -1: unknown)
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // HIP events bracketing every subsampled assign launch of the loop (the roofline figure of bench.py sums them)
     static constexpr int kMaxTimedIters = 16;
@@ -246,7 +245,6 @@ struct fslic_engine {
     bool pipe_gathering = false;     // a slot thread is waiting briefly for a companion of the submission it took
     double pipe_last_submit_us = 0;  // (mu) when the last submission arrived: a companion is only waited for while submissions are arriving
     std::atomic<int> reserve_frames{0};   // arenas are carved for at least this many frames per group
-    bool queues_known = false;       // the slots' streams were spread over the hardware queues by probing (Slot::hw_queue)
     int sync_waiters = 0;                    // (mu) synchronous callers waiting for ANY slot (or all of them): the slot threads leave the submit queue alone meanwhile
     std::atomic<int> lab_force_generic{0};   // testing aid (fslic_hip_lab_force_generic): the brute-force gather kernels instead of the tiled ones
 };

@@ -159,19 +159,4 @@ void launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t st) {
     launch(k_copy16, dim3((unsigned)((n16 + 1023) / 1024)), dim3(256), 0, st, reinterpret_cast<const copy_u4*>(src), reinterpret_cast<copy_u4*>(dst), n16);
 }
 
-// ---- which streams share a hardware queue (capi.cpp, pick_streams) ------------------------------------------------------------------
-// One wavefront that holds its queue for `ticks` of the 100 MHz clock and says when it started and ended; one that only says when it
-// started.  A stamp taken on another stream BEFORE the holder ended means the two streams run side by side: different hardware queues.
-__global__ void k_probe_hold(unsigned long long* out, unsigned ticks) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0) out[0] = t0;
-    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
-    if (threadIdx.x == 0) out[1] = __builtin_amdgcn_s_memrealtime();
-}
-__global__ void k_probe_stamp(unsigned long long* out) {
-    if (threadIdx.x == 0) out[0] = __builtin_amdgcn_s_memrealtime();
-}
-void launch_probe_hold(unsigned long long* out, unsigned ticks, hipStream_t st) { launch(k_probe_hold, dim3(1), dim3(64), 0, st, out, ticks); }
-void launch_probe_stamp(unsigned long long* out, hipStream_t st) { launch(k_probe_stamp, dim3(1), dim3(64), 0, st, out); }
-
 }  // namespace fslic

@@ -297,9 +297,4 @@ void launch_adjacent_pairs(const uint16_t* labels, int H, int W, int K, uint32_t
 // streaming copy of `bytes` (a multiple of 16) for the measured HBM rate bench.py prints (fslic_hip_copy_bandwidth)
 void launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t st);
 
-// stream probes (capi.cpp, pick_streams): a wavefront that holds its stream for `ticks` of the 100 MHz clock and writes its start and end
-// times to out[0], out[1]; a wavefront that writes its start time to out[0]
-void launch_probe_hold(unsigned long long* out, unsigned ticks, hipStream_t st);
-void launch_probe_stamp(unsigned long long* out, hipStream_t st);
-
 }  // namespace fslic

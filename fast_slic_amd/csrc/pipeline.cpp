@@ -175,17 +175,11 @@ void slot_worker(fslic_engine* e, Slot* s) {
                         e->pipe_q.pop_front();
                     }
                 };
-                // How many of the waiting submissions this slot takes: its share, ceil(waiting / slots) (guided self-scheduling).  While
-                // the caller keeps the queue full that is "as many as fit a group"; when a burst runs out it is one -- the last
-                // submissions then spread over the slots, i.e. over the hardware queues, instead of going two at a time to the first
-                // slots that become free.  Only with the slots' streams spread evenly over the queues (capi.cpp, pick_streams): with the
-                // runtime's own mapping the rule was measured and lost (8-frame groups cost more per frame than the balance gained while
-                // two queues carried most of the burst anyway: profiles/r05_burst_schedule.txt).
-                int share = kMaxGroup;
-#if !(FSLIC_EXP & 32)
-                if (e->queues_known) { const int ns = (int)e->slots.size(); share = std::max(1, ((int)e->pipe_q.size() + ns - 1) / ns); }
-#endif
-                gather(share);
+                // (Guided self-scheduling -- a slot takes ceil(waiting / slots) submissions, so that the last submissions of a burst spread
+                // over the slots -- was measured in round 5 and not kept: the driver's 20 steps 45.6 against 46.7 GP/s, mean of four runs each,
+                // profiles/r05_burst_schedule.txt: 8-frame groups cost more per frame than the balance gains, and which slots share a
+                // hardware queue -- the runtime's choice: two of four queues carry two streams each with six slots -- decides the tail.)
+                gather(kMaxGroup);
                 // the slot is taken and the group counted BEFORE the wait below: a drain must not take the queue for served
                 // meanwhile, nor a synchronous call this slot for free
                 s->pending = true;

@@ -236,11 +236,6 @@ int fslic_hip_last_host_topk_frames(fslic_engine* e, int slot);
  * FSLIC_FUSEBIN=0 (the separate cluster pass everywhere: +8 % latency per one-frame call, no redo).  Diagnostics aid. */
 int fslic_hip_separate_pass_redos(fslic_engine* e, int slot);
 
-/* Which of the runtime's hardware queues the stream of `slot` runs on: a class number 0, 1, .. found when the engine was created (the
- * engine creates more streams than slots, finds out which share a queue and keeps them round-robin over the queues, so that slot i and
- * slot i + number-of-queues share one), or -1 when that is not known.  Diagnostics aid. */
-int fslic_hip_slot_hw_queue(fslic_engine* e, int slot);
-
 /* Measurement aid (no counterpart in the reference): bytes read + written per second, in GB/s, of a plain streaming copy of
  * `bytes` on the engine's GPU (best of `reps` launches, HIP events) -- the measured HBM rate that bench.py prints next to the 8 TB/s of
  * the specification.  Allocates and frees 2 x `bytes` of device memory. */
