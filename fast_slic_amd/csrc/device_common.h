@@ -151,6 +151,11 @@ static __device__ __forceinline__ void global_accumulate(uint32_t* sums, uint32_
     atomicAdd(s + 5, (pix >> 16) & 255u);
 }
 
+// preemptive mode (src/context.cpp:304-343): unless every cluster is active, only pixels of active (2S x 2S) cells take part in update()
+static __device__ __forceinline__ bool in_update(const FrameDev& f, int y, int x) {
+    return !f.cell_act || f.pre_flags[0] || f.cell_act[(y / (2 * f.S)) * f.pre_cw + x / (2 * f.S)];
+}
+
 // pixel window of a tile widened by S: a cluster whose centre lies inside can own a pixel of the tile
 struct TileWindow { int wy_lo, wy_hi, wx_lo, wx_hi; };
 static __device__ __forceinline__ bool in_window(const ClusterRec& r, const TileWindow& w) {

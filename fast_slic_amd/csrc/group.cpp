@@ -30,7 +30,6 @@ int validate(const fslic_params* p, int H, int W, int K, int& S) {
     if (K <= 0 || K >= 65534) return fail(FSLIC_E_INVALID, "num_components must be in [1, 65533] (cfast_slic.pyx:24-27)");
     if (p->subsample_stride < 1 || p->subsample_stride > 255) return fail(FSLIC_E_INVALID, "subsample_stride must be in [1, 255]");
     if (p->max_iter < 0) return fail(FSLIC_E_INVALID, "max_iter must be >= 0");
-    if (p->preemptive && p->variant == FSLIC_VARIANT_LSC) return fail(FSLIC_E_UNSUPPORTED, "preemptive=True is not implemented for the LSC variant on hip/gfx950");
     if (p->preemptive && !std::isfinite(p->preemptive_thres)) return fail(FSLIC_E_INVALID, "preemptive_thres must be finite");
     if (p->variant < FSLIC_VARIANT_SLIC || p->variant > FSLIC_VARIANT_REALDIST_NOQ) return fail(FSLIC_E_UNSUPPORTED, "unknown variant");
     if (!(p->compactness > 0.0f) || !std::isfinite(p->compactness)) return fail(FSLIC_E_INVALID, "compactness must be a positive finite number");
@@ -275,12 +274,21 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
         const bool tme = timed && s.launch_timing && it < Slot::kMaxTimedIters;
         f.cl_yx = yx_cur; f.cl_yx_out = (yx_cur == yx_a) ? yx_b : yx_a;
         if (tme) HIPCHK(hipEventRecord(s.ev_it[2 * it], s.st));
-        launch_lsc_assign(f, l, n, rem, stride, it & 1, it & 1, true, s.st);
+        launch_lsc_assign(f, l, n, rem, stride, it & 1, it & 1, !pre, s.st);      // (preemptive: the assignment alone, the sums follow)
         if (tme) HIPCHK(hipEventRecord(s.ev_it[2 * it + 1], s.st));
-        launch_lsc_update(f, l, n, rem, stride, it & 1, s.st);   // update() sums + after_update()
-        f.gen_off++;
-        pg = PassGeom{};                                          // use_slots = 0: everything is in FrameDev::sums
-        launch_bin_clusters(f, n, 1, (it + 1) & 1, it & 1, pg, s.st);
+        if (pre) {
+            // update() under the activity state the pass started with, set_new_clusters(), then after_update() under the new one
+            // (src/context.cpp:301-387, src/preemptive.h:114-178, src/lsc.cpp:226-307): lsc.hip, "preemptive mode"
+            launch_lsc_pre_sums(f, n, rem, stride, it & 1, s.st);
+            f.gen_off++;
+            launch_preempt_update(f, n, (it + 1) & 1, it & 1, false, pre_l1_thres, s.st);
+            launch_lsc_pre_feats(f, l, n, rem, stride, s.st);
+        } else {
+            launch_lsc_update(f, l, n, rem, stride, it & 1, s.st);   // update() sums + after_update()
+            f.gen_off++;
+            pg = PassGeom{};                                          // use_slots = 0: everything is in FrameDev::sums
+            launch_bin_clusters(f, n, 1, (it + 1) & 1, it & 1, pg, s.st);
+        }
         yx_cur = f.cl_yx_out;
         rem = (rem + 1) % stride;
     }
@@ -337,7 +345,7 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     }
     if (timed) HIPCHK(hipEventRecord(s.ev[2], s.st));
     // full_assign: stride 1, rem 0, no update afterwards (src/context.cpp:246-256)
-    if (lsc) { f.cl_yx = yx_cur; launch_lsc_assign(f, l, n, 0, 1, p->max_iter & 1, 0, false, s.st); }
+    if (lsc) { f.cl_yx = yx_cur; launch_lsc_assign(f, l, n, 0, 1, full_buf, 0, false, s.st); }
     else if (noq) { f.cl_yx = yx_cur; launch_noq_assign(f, noq_coef, noq_manhattan, n, 0, 1, full_buf, 0, false, s.st); }
     else if (rd) { f.cl_yx = yx_cur; launch_rd_assign(f, s.d_patchf, rd_l2, n, 0, 1, full_buf, 0, false, s.st); }
     else if (generic) launch_assign_generic(f, n, 0, 1, full_buf, 0, false, s.st);

@@ -254,6 +254,10 @@ void launch_lsc_prepare(const FrameDev& f, const LscDev& l, int nframes, hipStre
 void launch_lsc_assign(const FrameDev& f, const LscDev& l, int nframes, int rem, int stride, int buf, int sbuf, bool stale_sums, hipStream_t st);
 // per-cluster gather of the integer sums (into FrameDev::sums) and the weighted feature means (src/lsc.cpp:226-307)
 void launch_lsc_update(const FrameDev& f, const LscDev& l, int nframes, int rem, int stride, int sbuf, hipStream_t st);
+// LSC in preemptive mode (lsc.hip): the integer sums of update() over the visited pixels of the active cells (before
+// launch_preempt_update); the weighted feature sums and the centroids of after_update() under the NEW activity state (after it)
+void launch_lsc_pre_sums(const FrameDev& f, int nframes, int rem, int stride, int sbuf, hipStream_t st);
+void launch_lsc_pre_feats(const FrameDev& f, const LscDev& l, int nframes, int rem, int stride, hipStream_t st);
 // Float-distance variants (realdist.hip): patchf = (2S+1)^2 f32 spatial patch; l2: squared colour / spatial terms
 void launch_rd_assign(const FrameDev& f, const float* patchf, bool l2, int nframes, int rem, int stride, int buf, int sbuf, bool stale_sums, hipStream_t st);
 // integer member sums per cluster (gather over the cluster window) into FrameDev::sums, for the variants whose assign

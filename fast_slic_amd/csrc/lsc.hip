@@ -597,6 +597,79 @@ __global__ __launch_bounds__(256) void k_lsc_update(FrameDev f, LscDev l) {
     if (q <= kLscFeat) e[q] = 0;
 }
 
+// ---- preemptive mode (src/preemptive.h with ContextLSC's hooks) ------------------------------------------------------------------
+// The reference's update() sums the visited pixels of the ACTIVE cells as they stood before the pass (src/context.cpp:304-343), then
+// PreemptiveGrid::set_new_clusters recomputes the updatable counters, the active clusters and the active cells (src/preemptive.h:114-178),
+// and only then ContextLSC::after_update accumulates w * F -- over every visited pixel when all clusters are active, otherwise over the
+// pixels of the NEW active cells whose cluster is still updatable (src/lsc.cpp:226-307).  Two different masks around one state change:
+// the fused sums of k_lsc_assign_sums cannot serve, so this mode runs the assignment alone (k_lsc_assign) and three small kernels, one
+// thread per visited pixel / 16 threads per cluster.  The mode is an approximation meant to save CPU time; here it is served for
+// interface completeness, not accelerated.
+__global__ __launch_bounds__(256) void k_lsc_pre_sums(FrameDev f, int rem, int stride, int Hv) {
+    f.select(blockIdx.y);
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)Hv * f.W) return;
+    const int v = (int)(i / f.W), x = (int)(i - (size_t)v * f.W), y = rem + v * stride;
+    const size_t p = (size_t)y * f.W + x;
+    const uint32_t lbl = f.labels[p];
+    if (lbl != 0xFFFFu && in_update(f, y, x)) global_accumulate(f.sums[0], lbl, (uint32_t)y, (uint32_t)x, f.lab[p]);
+}
+__global__ __launch_bounds__(256) void k_lsc_pre_feats(FrameDev f, LscDev l, int rem, int stride, int Hv) {
+    f.select(blockIdx.y);
+    l.select(blockIdx.y);
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)Hv * f.W) return;
+    const int v = (int)(i / f.W), x = (int)(i - (size_t)v * f.W), y = rem + v * stride;
+    const size_t p = (size_t)y * f.W + x;
+    const uint32_t lbl = f.labels[p];
+    if (lbl == 0xFFFFu) return;
+    // (after k_preempt_update: pre_flags / cell_act / cl_upd are the NEW state)
+    if (!f.pre_flags[0] && !(f.cell_act[(y / (2 * f.S)) * f.pre_cw + x / (2 * f.S)] && f.cl_upd[lbl])) return;
+    const uint32_t px = f.lab[p];
+    const uint32_t L = px & 255u, A = (px >> 8) & 255u, B = (px >> 16) & 255u;
+    const float F[kLscFeat] = {l.lut_color[L], l.lut_color[256 + L], l.lut_color[512 + A], l.lut_color[768 + A], l.lut_color[512 + B],
+                               l.lut_color[768 + B], l.lut_x[x], l.lut_x[f.W + x], l.lut_y[y], l.lut_y[f.H + y]};
+    float w = 0.0f;
+#pragma unroll
+    for (int q = 0; q < kLscFeat; ++q) w = __builtin_fmaf(l.means[q], F[q], w);
+    // w * (F / w) = F up to an ulp (as the fused sums take it, see the header of this file)
+    unsigned long long* e = reinterpret_cast<unsigned long long*>(l.extra + (size_t)lbl * kLscExPitch);
+#pragma unroll
+    for (int q = 0; q < kLscFeat; ++q) atomicAdd(e + q, (unsigned long long)(long long)__float2ll_rn(F[q] * kLscFixF));
+    atomicAdd(e + kLscFeat, (unsigned long long)(long long)__float2ll_rn(w * kLscFixW));
+}
+// C_f of the clusters that are still updatable: sum w F / sum w (0 / 0 = NaN without members, as the reference); of the others: their
+// old value with weight 1 plus whatever the pass added -- nothing unless all clusters are active, src/lsc.cpp:234-246, :302-306
+__global__ __launch_bounds__(256) void k_lsc_pre_update(FrameDev f, LscDev l) {
+    f.select(blockIdx.y);
+    l.select(blockIdx.y);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = t >> 4, q = t & 15;
+    if (k >= f.K) return;
+    long long* e = l.extra + (size_t)k * kLscExPitch;
+    const long long mine = q <= kLscFeat ? e[q] : 0ll;
+    const long long wsum = e[kLscFeat];
+    const float acc = (float)((double)mine / (double)kLscFixF), tot_w = (float)((double)wsum / (double)kLscFixW);
+    if (q < kLscFeat) {
+        float* c = l.cfeat + (size_t)k * kLscCfPitch + q;
+        *c = f.cl_upd[k] ? acc / tot_w : (*c + acc) / (1.0f + tot_w);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (q <= kLscFeat) e[q] = 0;
+}
+void launch_lsc_pre_sums(const FrameDev& f_, int nframes, int rem, int stride, int sbuf, hipStream_t st) {
+    const FrameDev f = rotated(f_, 0, sbuf);
+    const int Hv = (f.H - rem + stride - 1) / stride;
+    if (Hv <= 0) return;
+    launch(k_lsc_pre_sums, dim3((unsigned)(((size_t)Hv * f.W + 255) / 256), nframes), dim3(256), 0, st, f, rem, stride, Hv);
+}
+void launch_lsc_pre_feats(const FrameDev& f, const LscDev& l, int nframes, int rem, int stride, hipStream_t st) {
+    const int Hv = (f.H - rem + stride - 1) / stride;
+    if (Hv <= 0) return;
+    launch(k_lsc_pre_feats, dim3((unsigned)(((size_t)Hv * f.W + 255) / 256), nframes), dim3(256), 0, st, f, l, rem, stride, Hv);
+    launch(k_lsc_pre_update, dim3((f.K * 16 + 255) / 256, nframes), dim3(256), 0, st, f, l);
+}
+
 // ---- launches -------------------------------------------------------------------------------
 void launch_lsc_prepare(const FrameDev& f, const LscDev& l, int nframes, hipStream_t st) {
     const unsigned N = (unsigned)f.N;

@@ -12,11 +12,6 @@
 
 namespace fslic {
 
-// preemptive mode (src/context.cpp:304-343): unless every cluster is active, only pixels of active (2S x 2S) cells take part in update()
-static __device__ __forceinline__ bool in_update(const FrameDev& f, int y, int x) {
-    return !f.cell_act || f.pre_flags[0] || f.cell_act[(y / (2 * f.S)) * f.pre_cw + x / (2 * f.S)];
-}
-
 constexpr int kRdRows = 4;                              // visited rows per wavefront
 constexpr int kRdBH = kWavesPerBlock * kRdRows;
 

@@ -56,7 +56,7 @@ typedef struct fslic_params {
     int32_t subsample_stride;      /* subsample_stride_config, src/context.h:26 (>= 1) */
     int32_t convert_to_lab;        /* src/context.h:30 */
     int32_t manhattan_spatial_dist;/* src/context.h:35; 0 (hypotf patch) takes the generic kernel */
-    int32_t preemptive;            /* src/context.h:32, src/preemptive.h; every variant but LSC (FSLIC_E_UNSUPPORTED there) */
+    int32_t preemptive;            /* src/context.h:32, src/preemptive.h; every variant (BaseContext<DistType>::iterate, src/context.cpp:152-181) */
     float preemptive_thres;        /* src/context.h:33; ignored while preemptive == 0 */
     int32_t num_threads;           /* src/context.h:27; ignored on the GPU */
     int32_t debug_mode;            /* src/context.h:36; ignored (no recorder report) */

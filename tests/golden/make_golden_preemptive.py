@@ -74,9 +74,42 @@ def realdist_cases(out):
         print(name, "segments", len(np.unique(labels)), "is_updatable", np.unique(cl["is_updatable"], return_counts=True))
 
 
+# the LSC variant in preemptive mode (f32, order-dependent sums: tolerance-based like tests/golden/make_golden_lsc.py; one thread)
+LSC_CASES = [
+    ("lsc_A_120x160_k40", "A", 120, 160, 40, 0.05, {}),
+    ("lsc_C_240x320_k150", "C", 240, 320, 150, 0.05, {}),
+    ("lsc_B_200x150_k30_stride2_c20", "B", 200, 150, 30, 0.05, dict(subsample_stride=2, compactness=20.0)),
+    ("lsc_A_240x320_k150_thres02", "A", 240, 320, 150, 0.2, {}),
+    ("lsc_A_480x640_k200_iter20", "A", 480, 640, 200, 0.05, dict(max_iter=20)),
+    ("lsc_A_720x1280_k1600", "A", 720, 1280, 1600, 0.05, {}),
+]
+
+
+def lsc_cases(out):
+    for name, var, H, W, K, thres, kw in LSC_CASES:
+        img = variant(var, H, W)
+        cl0 = ref.initialize_clusters(img, K)
+        ref.set_preemptive(True, thres)
+        try:
+            labels, cl, pre = ref.lsc_iterate(img, cl0, num_threads=1, arch="standard", **kw)
+            again, _, _ = ref.lsc_iterate(img, cl0, num_threads=1, arch="standard", **kw)
+        finally:
+            ref.set_preemptive(False)
+        assert np.array_equal(labels, again), "reference LSC (preemptive) not repeatable at " + name
+        out[name + "/variant"] = np.array(var)
+        out[name + "/shape"] = np.array([H, W, K], np.int32)
+        out[name + "/thres"] = np.float32(thres)
+        out[name + "/labels"] = labels
+        out[name + "/clusters"] = cl
+        out[name + "/prelabels"] = pre
+        out[name + "/kwargs"] = np.array(json.dumps(kw))
+        print(name, "segments", len(np.unique(labels)), "is_updatable", np.unique(cl["is_updatable"], return_counts=True))
+
+
 def main():
     out = {}
     realdist_cases(out)
+    lsc_cases(out)
     for name, var, H, W, K, thres, kw in CASES:
         img = variant(var, H, W)
         cl0 = ref.initialize_clusters(img, K)
