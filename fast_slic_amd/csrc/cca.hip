@@ -97,8 +97,15 @@ static __device__ __forceinline__ uint32_t ldsb_find(uint32_t* par, uint32_t x) 
 }
 static __device__ __forceinline__ void ldsb_union(uint32_t* par, uint32_t a, uint32_t b) {
     for (;;) {
-        a = ldsb_find(par, a);
-        b = ldsb_find(par, b);
+        // both walks to the roots in LOCKSTEP -- one LDS round trip per step for the two of them (one after the other, with path
+        // halving, a union was five dependent round trips; the knock-out study of round 5 prices the unions of this kernel at a
+        // fifth of its duration, profiles/r05_cca_local_knockout.txt).  No halving stores: the trees of a strip are a few levels
+        // deep, and the flatten of phase C walks them once more anyway.
+        for (;;) {
+            const uint32_t pa = lds_ld(lds_at(par, a)), pb = lds_ld(lds_at(par, b));
+            if (pa == a && pb == b) break;
+            a = pa; b = pb;
+        }
         if (a == b) return;
         if (a < b) { const uint32_t t = a; a = b; b = t; }
         const uint32_t old = atomicMin(lds_at(par, a), b);
@@ -181,7 +188,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cc
     uint32_t up_root = 0, pend_a = 0, pend_b = 0;
     u64 pending = 0;
     auto run_pending = [&]() {
+#if !(FSLIC_EXP & 128)     // (knock-out build 128: no unions, neither the pending pairs of the row loop nor the strip seams)
         if (lanes(pending)) ldsb_union(s_par, pend_a, pend_b);
+#endif
         pending = 0;
     };
 #pragma unroll
@@ -197,8 +206,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cc
             const u64 same = ballot(lbl[i - 1] == l);                           // same label above
             const u64 other = ballot(lane_left0(up_root) != up_root);           // the left neighbour carries another root
             const u64 rep = same & (m | other | ~(same << 1));
+#if !(FSLIC_EXP & 64)      // (knock-out build 64, scripts/gpu_knock.sh: the row loop without its fold + dependent read; results wrong on purpose)
             if (lanes(rep)) __hip_atomic_fetch_min(lds_at(s_par, node), up_root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             cur_root = lds_ld(lds_at(s_par, node));
+#endif
             const u64 need = rep & ballot(up_root != cur_root);
             if (need & pending) run_pending();
             const bool nd = lanes(need);
@@ -218,7 +229,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cc
         const u64 m = ballot(l != lane_left0(l)) | 1ull;
         const u64 same = ballot((prev & 0x1FFFFu) == l);
         const u64 first = same & (m | ~(same << 1));                            // one lane per (run, run above) contact
+#if !(FSLIC_EXP & 128)
         if (lanes(first)) ldsb_union(s_par, nodev[0], prev >> 17);
+#endif
     }
     lds_barrier();
     LOC_STAMP(2);
@@ -251,7 +264,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_cc
         const u64 m = ballot(l != lane_left0(l)) | 1ull;                        // (as in A: two instructions, cheaper than keeping eight masks)
         const u64 e = (m >> 1) | (1ull << 63);                                  // last pixels of the runs
         const uint32_t len_part = (lanes(e) ? lane_p1 : 0u) - (lanes(m) ? (uint32_t)lane : 0u);
+#if !(FSLIC_EXP & 512)     // (knock-out build 512: no run-length atomics; every node then reports the area 2048 and no adopted neighbour, which the later passes survive)
         if (lanes((m | e) & ok)) atomicAdd(lds_at(s_area, root[i]), len_part);
+#endif
         const u64 mr = m & ok & ballot(root[i] == nodev[i]);                    // the first pixel of a root run
         pos[i] = lanes(mr) ? wcount + rank_in(mr) : 0xFFFFFFFFu;
         wcount += (uint32_t)__popcll(mr);

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_preemptive_bit_equal_to_reference_fixtures(engine):
     cases = np.load(os.path.join(ROOT, "tests", "golden", "preemptive_cases.npz"), allow_pickle=False)
-    names = sorted({k.split("/")[0] for k in cases.files if k.endswith("/shape") and not k.startswith("rd_")})
+    names = sorted({k.split("/")[0] for k in cases.files if k.endswith("/shape") and not k.startswith(("rd_", "lsc_"))})
     assert len(names) >= 9
     for name in names:
         H, W, K = (int(v) for v in cases[name + "/shape"])
@@ -63,7 +63,7 @@ def test_preemptive_realdist_variants_bit_equal_to_reference_fixtures(engine):
 # LSC in preemptive mode: f32 with order-dependent sums in the reference, so tolerance-based like tests/test_gpu_lsc.py (SURVEY.md 8 a13:
 # best overlap >= 0.90 and boundary IoU >= 0.75 is the contract; the floors below are what this implementation reaches, rounded down).
 # The is_updatable counters are integers driven by float centroids: they may differ where a centre moved by a pixel.
-LSC_PRE_FLOORS = (0.97, 0.97, 0.90)      # pre-connectivity pixel agreement, best overlap both ways, boundary IoU
+LSC_PRE_FLOORS = (0.99, 0.99, 0.95)      # pre-connectivity pixel agreement, best overlap both ways, boundary IoU (measured: 1.0000 on five fixtures, 0.9989 / 0.9982 / 0.9914 at 1280x720 K=1600)
 
 
 def test_preemptive_lsc_agrees_with_reference_fixtures(engine):
