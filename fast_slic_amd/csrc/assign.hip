@@ -535,9 +535,14 @@ static inline BlkMap blk_map(dim3 g) { BlkMap m; m.gx = g.x; m.gy = g.y; return 
 // pipelined rates unchanged.
 static inline dim3 blk_grid(dim3 g) { return dim3(g.x, g.z, g.y); }
 
-template <int R, bool FUSE, int STRIDE, bool VT, bool FBIN = false>
+// PRE: preemptive mode (src/preemptive.h).  The bins hold the ACTIVE clusters only (k_preempt_update), so the gather is the reference's
+// scatter over the active clusters (src/context.cpp:218); unless every cluster is active the fused sums take only the pixels of active
+// (2S x 2S) cells (src/context.cpp:304-343: the row-by-row epilogue with the cell test), and the block's sums leave through global
+// atomics into FrameDev::sums, where k_preempt_update reads them (no partial-sum entries, no slot geometry).
+template <int R, bool FUSE, int STRIDE, bool VT, bool FBIN = false, bool PRE = false>
 static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, int Hv, const BlkMap& bm) {
     static_assert(!FBIN || FUSE, "the cluster pass rides on the fused centroid sums");
+    static_assert(!PRE || (FUSE && !FBIN), "preemptive mode: the fused pass with its own flush");
     const uint32_t bxi = blockIdx.x, byi = blockIdx.z, bzi = blockIdx.y;      // (tile column, tile row, frame): see blk_grid
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];   // spatial table (u16), whole KB (LDS-DMA lands 1 KB per wavefront instruction); 16-byte aligned: the row-vector reads are ds_read_b128
     __shared__ __attribute__((aligned(16))) uint4 s_raw[kWavesPerBlock][64];       // every wavefront's kept records {yx, lab, tag, -}
@@ -729,7 +734,9 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
     }
     if (lane < bn) s_klab[(int)rank_j] = (uint16_t)(mine.z & 0xFFFFu);
     uint32_t fin_nx = 0, fin_ny = 0, fin_b0 = 0; // FBIN, wavefront 0, lane j: blocks that deliver sums of candidate j (0: not this block), the first of them (row << 16 | column)
-    if (FUSE && wave == 0) {
+    if (PRE && wave == 0) {
+        if (lane < bn) s_entry[rank_j] = mine.z & 0xFFFFu;
+    } else if (FUSE && wave == 0) {
         uint32_t entry = kNoSlot;
         const SlotGeom g = slot_geom((int)(mine.x >> 16), (int)(mine.x & 0xFFFFu), S, f.H, W, rem, STRIDE, BH, Hv);
         const int by = (int)byi;
@@ -974,7 +981,9 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
 #pragma unroll
         for (int q = 1; q < R / 2; ++q) worst = __builtin_elementwise_max(worst, best[q]);
         const bool all_found = (ballot(worst.x == 0xFFFF) | ballot(worst.y == 0xFFFF)) == 0ull;
-        if (all_found && nrows == R) {          // interior wavefront with every pixel assigned: the rule, by far
+        bool fast_ok = all_found && nrows == R;
+        if constexpr (PRE) fast_ok = fast_ok && rfl(f.pre_flags[0]) != 0u;      // (inactive cells: the row-by-row form below applies the cell test)
+        if (fast_ok) {          // interior wavefront with every pixel assigned: the rule, by far
             epilogue_done = true;
             if (okx) {
                 uint32_t kk[R];
@@ -1057,7 +1066,9 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
             const bool found = key != 0xFFFFu;
             slot[r] = kNoSlot;
             if (ok && found) st_stream(rowp + xo, s_klab[key & 63u]);
-            if (FUSE && ok) {
+            bool summed = FUSE && ok;
+            if constexpr (PRE) summed = summed && in_update(f, yw_lo + r * STRIDE, x);
+            if (summed) {
                 if (found) slot[r] = key & 63u;
                 else {
                     const uint32_t old = rowp[xo];     // stale label still takes part in update()
@@ -1118,9 +1129,14 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
                 const uint2 q01 = make_uint2(cnt, ((uint32_t)(B >> 20) & 0xFFFFFu) + __umul24(yb0, cnt));
                 const uint2 q23 = make_uint2(((uint32_t)B & 0xFFFFFu) + __umul24((uint32_t)x0, cnt), (uint32_t)A & 0xFFFFFu);
                 const uint2 q45 = make_uint2((uint32_t)(A >> 20) & 0xFFFFFu, (uint32_t)(A >> 40));
-                uint2* const dst = reinterpret_cast<uint2*>(f.cpart + (size_t)entry);      // (entries are 24 bytes apart in an 8-byte aligned array)
-                if (FBIN) { st_stream(dst, q01); st_stream(dst + 1, q23); st_stream(dst + 2, q45); }      // written through: another block's lane reads it
-                else { dst[0] = q01; dst[1] = q23; dst[2] = q45; }
+                if constexpr (PRE) {                   // (`entry` is the cluster number here)
+                    uint32_t* const sm = f.sums[0] + 6 * (size_t)entry;
+                    if (cnt) { atomicAdd(sm, q01.x); atomicAdd(sm + 1, q01.y); atomicAdd(sm + 2, q23.x); atomicAdd(sm + 3, q23.y); atomicAdd(sm + 4, q45.x); atomicAdd(sm + 5, q45.y); }
+                } else {
+                    uint2* const dst = reinterpret_cast<uint2*>(f.cpart + (size_t)entry);      // (entries are 24 bytes apart in an 8-byte aligned array)
+                    if (FBIN) { st_stream(dst, q01); st_stream(dst + 1, q23); st_stream(dst + 2, q45); }      // written through: another block's lane reads it
+                    else { dst[0] = q01; dst[1] = q23; dst[2] = q45; }
+                }
             }
         }
         if (FBIN) {
@@ -1161,6 +1177,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_wav
     assign_blk2_body<R, true, STRIDE, VT, true>(f, rem, Hv, bm);
 }
 
+template <int R, int STRIDE, bool VT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(7, 8))) void k_assign_pre(FrameDev f, int rem, int Hv, BlkMap bm) {
+    assign_blk2_body<R, true, STRIDE, VT, false, true>(f, rem, Hv, bm);
+}
+
 template <int R, bool FUSE, int STRIDE>
 static void launch_assign_blk_t(const FrameDev& f_, int nframes, int rem, int Hv, hipStream_t st) {
     FrameDev f = f_;
@@ -1199,6 +1220,28 @@ static void launch_assign_bin_t(const FrameDev& f_, int nframes, int rem, int Hv
         if (f.tab_vmode) launch((k_assign_bin<R, STRIDE, true>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
         else launch((k_assign_bin<R, STRIDE, false>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
     }
+}
+
+template <int STRIDE>
+static void launch_assign_pre_t(const FrameDev& f_, int nframes, int rem, int Hv, hipStream_t st) {
+    FrameDev f = f_;
+    f.tab = f.tabs; f.tab_words = f.tabs_words; f.tab_dyoff = f.tabs_dyoff; f.tab_nrpad = f.tabs_nrpad;     // table of the subsampled stride
+    dim3 grid((f.W + kTileW - 1) / kTileW, (Hv + kWavesPerBlock * 8 - 1) / (kWavesPerBlock * 8), nframes);
+    const size_t lds2 = ((size_t)f.tab_words * sizeof(uint32_t) + 1023) / 1024 * 1024;
+    if (f.tab_vmode) launch((k_assign_pre<8, STRIDE, true>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
+    else launch((k_assign_pre<8, STRIDE, false>), blk_grid(grid), dim3(256), lds2, st, f, rem, Hv, blk_map(grid));
+}
+// preemptive mode: the fused pass of the block kernel on the bins of the active clusters (see assign_blk2_body, PRE); false: the
+// geometry does not take the block kernel (the caller uses the generic kernel)
+bool launch_assign_pre(const FrameDev& f_, int nframes, int rem, int stride, int buf, int sbuf, hipStream_t st) {
+    const FrameDev f = rotated(f_, buf, sbuf);
+    const int Hv = (f.H - rem + stride - 1) / stride;
+    if (!(f.tab_words > 0 && stride >= 1 && stride <= 3 && (unsigned long long)f.N * 4ull < 0x7FFFFFFFull)) return false;
+    if (Hv <= 0) return true;
+    if (stride == 1) launch_assign_pre_t<1>(f, nframes, rem, Hv, st);
+    else if (stride == 2) launch_assign_pre_t<2>(f, nframes, rem, Hv, st);
+    else launch_assign_pre_t<3>(f, nframes, rem, Hv, st);
+    return true;
 }
 
 static bool blk_kernel_applies(const FrameDev& f, int stride) {

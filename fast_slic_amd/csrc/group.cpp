@@ -326,8 +326,10 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
         pg = PassGeom{};
         const bool tme = timed && s.launch_timing && it < Slot::kMaxTimedIters;
         if (tme) HIPCHK(hipEventRecord(s.ev_it[2 * it], s.st));
-        if (generic) launch_assign_generic(f, n, rem, stride, it & 1, it & 1, true, s.st);
-        else pg = launch_assign(f, n, rem, stride, it & 1, it & 1, true, s.st);
+        // (preemptive mode: the block kernel on the bins of the active clusters where the geometry takes it, round 5; until then the
+        // generic kernel served every preemptive frame)
+        if (generic || (pre && !launch_assign_pre(f, n, rem, stride, it & 1, it & 1, s.st))) launch_assign_generic(f, n, rem, stride, it & 1, it & 1, true, s.st);
+        else if (!pre) pg = launch_assign(f, n, rem, stride, it & 1, it & 1, true, s.st);
         if (tme) HIPCHK(hipEventRecord(s.ev_it[2 * it + 1], s.st));
         f.gen_off++;
         f.cl_yx = yx_cur; f.cl_yx_out = (yx_cur == yx_a) ? yx_b : yx_a;
@@ -349,7 +351,7 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     else if (noq) { f.cl_yx = yx_cur; launch_noq_assign(f, noq_coef, noq_manhattan, n, 0, 1, full_buf, 0, false, s.st); }
     else if (rd) { f.cl_yx = yx_cur; launch_rd_assign(f, s.d_patchf, rd_l2, n, 0, 1, full_buf, 0, false, s.st); }
     else if (generic) launch_assign_generic(f, n, 0, 1, full_buf, 0, false, s.st);
-    else (void)launch_assign(f, n, 0, 1, p->max_iter & 1, 0, false, s.st, full_obuf);
+    else (void)launch_assign(f, n, 0, 1, full_buf, 0, false, s.st, full_obuf);      // (full_buf: the bins of all clusters; max_iter & 1 unless preemptive)
     if (timed) HIPCHK(hipEventRecord(s.ev[3], s.st));
     // enforce_connectivity, src/context.cpp:14-20
     const int thres = (int)round((double)(S * S) * (double)p->min_size_factor);
@@ -472,7 +474,7 @@ int group_begin(fslic_engine* e, Slot& s, const fslic_params* p, int H, int W, i
     }
     rc = upload_ptrs(s, n, d_rgb, d_out);
     if (rc) return rc;
-    s.generic = p->variant == FSLIC_VARIANT_SLIC && (e->lab_force_generic.load() != 0 || !s.sp_tiled_ok || p->preemptive);
+    s.generic = p->variant == FSLIC_VARIANT_SLIC && (e->lab_force_generic.load() != 0 || !s.sp_tiled_ok);
     if (p->preemptive && s.h_upd_words < (size_t)s.cap_frames * K) {
         if (s.h_upd) hipHostFree(s.h_upd);
         s.h_upd = nullptr; s.h_upd_words = 0;

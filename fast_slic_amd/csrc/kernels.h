@@ -248,6 +248,9 @@ PassGeom launch_assign(const FrameDev& f, int nframes, int rem, int stride, int 
 bool assign_fuses_cluster_pass(const FrameDev& f, int stride);
 void launch_assign_fused_bin(const FrameDev& f, int nframes, int rem, int stride, int it, hipStream_t st);
 void launch_assign_generic(const FrameDev& f, int nframes, int rem, int stride, int buf, int sbuf, bool fuse_update, hipStream_t st);
+// preemptive mode (src/preemptive.h), Slic variant: the fused pass of the block kernel on the bins of the ACTIVE clusters, sums of the
+// pixels of active cells into FrameDev::sums (global atomics per block and cluster); false: geometry outside the block kernel
+bool launch_assign_pre(const FrameDev& f, int nframes, int rem, int stride, int buf, int sbuf, hipStream_t st);
 // LSC variant (lsc.hip).  prepare: feature means + seed centroids (src/lsc.cpp:12-15), after LAB and the mode-0 cluster pass.
 void launch_lsc_prepare(const FrameDev& f, const LscDev& l, int nframes, hipStream_t st);
 // 10-D assignment of rows == rem (mod stride) (src/lsc.cpp:197-224); stale_sums: an update follows

@@ -13,7 +13,8 @@
 //   D  all_active = every cluster active
 //   E  the active clusters are binned for the next assignment pass
 // K^2 / 1024 neighbour tests per thread: O(10 us) for K = 1600.  The mode is an approximation meant to save CPU time;
-// here it is served for interface completeness: the Slic variant takes the generic (one thread per pixel) assign kernel, the
+// the Slic variant takes the block assign kernel on the bins of the active clusters (assign.hip, PRE; the generic kernel where the
+// geometry is outside it), the
 // float-distance variants (src/context.h:100-125: BaseContext<float>::iterate is the same template, src/context.cpp:152-181) their
 // own assign kernels on the bins of the active clusters, with the member sums restricted to the active cells.
 #include "device_common.h"
