@@ -21,13 +21,30 @@
 
 namespace fslic {
 
+// LISTS: the activity marking (C) through per-cell lists of the updatable clusters in LDS -- the structure the reference itself uses
+// (cluster_grid, src/preemptive.h:118-123, :141-163): a cluster can only be activated from the 3 x 3 cells of side 2S around its own,
+// so it tests the handful of updatable clusters listed there instead of all K (K^2 / 1024 tests per thread were 470 us per call at
+// K = 1600: 93 % of a preemptive group once the assignment ran on the block kernel).  Positions (4 B), lists (2 B) and cell offsets in
+// dynamic LDS: K <= 8192 and at most 4096 cells; larger problems keep the all-pairs form.
+template <bool LISTS>
 __global__ __launch_bounds__(1024) void k_preempt_update(FrameDev f, int rebin_all, float l1_thres) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    const int ncell2 = f.pre_cw * f.pre_ch;
+    uint32_t* const s_pos = s_dyn;                                     // K: new positions
+    uint32_t* const s_start = s_dyn + (LISTS ? f.K : 0);               // ncell2 + 1: first list entry of every cell
+    uint32_t* const s_fill = s_start + (LISTS ? ncell2 + 1 : 0);       // ncell2
+    uint16_t* const s_list = reinterpret_cast<uint16_t*>(s_fill + (LISTS ? ncell2 : 0));      // K: updatable clusters, cell by cell
     f.select(blockIdx.x);
     const int tid = threadIdx.x, K = f.K, S2 = 2 * f.S;
     for (int gi = tid; gi < f.ncell; gi += 1024) f.cell_cnt[1][gi] = 0;
     if (tid == 0) *f.ovf_cnt[1] = 0;
     const uint32_t* __restrict__ pos = rebin_all ? f.cl_yx : f.cl_yx_out;
     if (!rebin_all) {
+        if (LISTS) {
+            for (int c = tid; c <= ncell2; c += 1024) s_start[c] = 0u;
+            for (int c = tid; c < ncell2; c += 1024) s_fill[c] = 0u;
+            __syncthreads();
+        }
         for (int k = tid; k < K; k += 1024) {
             const uint32_t yx_old = f.cl_yx[k];
             const uint32_t* s = f.sums[0] + 6 * (size_t)k;
@@ -69,10 +86,55 @@ __global__ __launch_bounds__(1024) void k_preempt_update(FrameDev f, int rebin_a
             }
             f.cl_yx_out[k] = yx;
             f.cl_act[k] = 0u;
+            if (LISTS) {
+                s_pos[k] = yx;
+                if (upd) atomicAdd(&s_start[1 + ((int)(yx >> 16) / S2) * f.pre_cw + (int)(yx & 0xFFFFu) / S2], 1u);
+            }
             z0[0] = 0; z0[1] = 0; z0[2] = 0; z0[3] = 0; z0[4] = 0; z0[5] = 0;
         }
         for (int c = tid; c < f.pre_cw * f.pre_ch; c += 1024) f.cell_act[c] = 0u;
         __syncthreads();
+        if (LISTS) {
+            // inclusive scan of the per-cell counts by one wavefront (a lane sums its chunk of cells, the 64 chunk totals are scanned
+            // across the lanes, the lane writes its chunk's running totals), then the lists
+            if (tid < 64) {
+                const int chunk = (ncell2 + 63) / 64;
+                const int lo = 1 + tid * chunk, hi = min(lo + chunk, ncell2 + 1);
+                uint32_t sum = 0;
+                for (int c = lo; c < hi; ++c) sum += s_start[c];
+                uint32_t inc = sum;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t u = __shfl_up(inc, off);
+                    if (tid >= off) inc += u;
+                }
+                uint32_t run = inc - sum;
+                for (int c = lo; c < hi; ++c) { run += s_start[c]; s_start[c] = run; }
+            }
+            __syncthreads();
+            for (int k = tid; k < K; k += 1024) {
+                if (!f.cl_upd[k]) continue;
+                const uint32_t yx = s_pos[k];
+                const int cell = ((int)(yx >> 16) / S2) * f.pre_cw + (int)(yx & 0xFFFFu) / S2;
+                s_list[s_start[cell] + atomicAdd(&s_fill[cell], 1u)] = (uint16_t)k;
+            }
+            __syncthreads();
+            for (int j = tid; j < K; j += 1024) {
+                const uint32_t yxj = s_pos[j];
+                const int yj = (int)(yxj >> 16), xj = (int)(yxj & 0xFFFFu);
+                const int cy = yj / S2, cx = xj / S2;
+                bool act = false;
+                for (int ny = max(cy - 1, 0); ny <= min(cy + 1, f.pre_ch - 1) && !act; ++ny)
+                    for (int nx = max(cx - 1, 0); nx <= min(cx + 1, f.pre_cw - 1) && !act; ++nx) {
+                        const int c = ny * f.pre_cw + nx;
+                        for (uint32_t q = s_start[c]; q < s_start[c + 1] && !act; ++q) {
+                            const uint32_t yxk = s_pos[s_list[q]];
+                            act = abs(yj - (int)(yxk >> 16)) <= S2 && abs(xj - (int)(yxk & 0xFFFFu)) <= S2;
+                        }
+                    }
+                if (act) { f.cl_act[j] = 1u; f.cell_act[cy * f.pre_cw + cx] = 1u; }
+            }
+        } else {
         for (int k = tid; k < K; k += 1024) {
             if (!f.cl_upd[k]) continue;
             const uint32_t yxk = f.cl_yx_out[k];
@@ -85,6 +147,7 @@ __global__ __launch_bounds__(1024) void k_preempt_update(FrameDev f, int rebin_a
                     f.cell_act[(yj / S2) * f.pre_cw + xj / S2] = 1u;
                 }
             }
+        }
         }
         __syncthreads();
         __shared__ int s_cnt;
@@ -118,7 +181,16 @@ __global__ __launch_bounds__(1024) void k_preempt_update(FrameDev f, int rebin_a
 
 void launch_preempt_update(const FrameDev& f_, int nframes, int buf, int sbuf, bool rebin_all, float l1_thres, hipStream_t st) {
     const FrameDev f = rotated(f_, buf, sbuf);
-    launch(k_preempt_update, dim3(nframes), dim3(1024), 0, st, f, rebin_all ? 1 : 0, l1_thres);
+    const int ncell2 = f.pre_cw * f.pre_ch;
+    if (f.K <= 8192 && ncell2 <= 4096) {
+        const size_t lds = ((size_t)f.K + 2 * (size_t)ncell2 + 1) * 4 + (size_t)f.K * 2 + 16;
+        static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(k_preempt_update<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                               (int)((8192 + 2 * 4096 + 1) * 4 + 8192 * 2 + 16));
+        (void)attr_once;
+        launch(k_preempt_update<true>, dim3(nframes), dim3(1024), lds, st, f, rebin_all ? 1 : 0, l1_thres);
+    } else {
+        launch(k_preempt_update<false>, dim3(nframes), dim3(1024), 0, st, f, rebin_all ? 1 : 0, l1_thres);
+    }
 }
 
 }  // namespace fslic

@@ -1,5 +1,5 @@
 """Profiling workload: n single-stream steps of G frames of H x W, K clusters, device-resident, through the C ABI.
-   python scripts/frames.py H W K [n] [slic|lsc] [G]    """
+   python scripts/frames.py H W K [n] [slic|lsc|pre] [G]    """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -21,7 +21,7 @@ for im in imgs:
     B.load_library().fslic_hip_initialize_clusters(H, W, K, im.ctypes.data, cl.ctypes.data)
     cl0.append(cl)
 torch.cuda.synchronize()
-p = make_params(10, 10.0, 0.25, 3, variant=var)
+p = make_params(10, 10.0, 0.25, 3, variant=var, preemptive=len(sys.argv) > 5 and sys.argv[5] == "pre", preemptive_thres=0.05)      # "pre": Slic(preemptive=True)
 for i in range(n):
     e.iterate_batch([t.data_ptr() for t in d], [c.copy() for c in cl0], [t.data_ptr() for t in l], H, W, p, True)
 print(H, W, K, G, e.last_device_times(), e.last_timing_report())
