@@ -12,7 +12,7 @@ for cfg in "${CFGS[@]}"; do
   timeout 300 rocprofv3 --kernel-trace -d $OUT/p -o t -- python $R/scripts/frames.py $cfg > /dev/null 2>&1
   DB=$(find $OUT/p -name '*_results.db' | head -1)
   python $R/scripts/rocpd_stats.py timeline $DB | cut -c1-170 > $OUT/timeline_$tag.txt
-  python $R/scripts/rocpd_stats.py stats $DB | cut -c1-150 > $OUT/kernel_stats_$tag.csv
+  python $R/scripts/rocpd_stats.py stats $DB > $OUT/kernel_stats_$tag.csv
   echo "== $tag"; cat $OUT/kernel_stats_$tag.csv
   rm -rf $OUT/p
 done

@@ -28,7 +28,7 @@ for cfg in "720 1280 1600 6 slic 8" "720 1280 1600 6 slic 16" "720 1280 1600 6 s
   FSLIC_GROUP=$6 timeout 300 rocprofv3 --kernel-trace -d $OUT/p -o t -- python $R/scripts/frames.py $cfg > /dev/null 2>&1      # (one launch group of all G frames)
   DB=$(find $OUT/p -name '*_results.db' | head -1)
   python $R/scripts/rocpd_stats.py timeline $DB | cut -c1-170 > $OUT/timeline_$tag.txt
-  python $R/scripts/rocpd_stats.py stats $DB | cut -c1-170 > $OUT/kernel_stats_$tag.csv
+  python $R/scripts/rocpd_stats.py stats $DB > $OUT/kernel_stats_$tag.csv
   rm -rf $OUT/p
 done
 # 3. HBM traffic of the assign launches (separate --pmc passes, as the MI355X guide prescribes)
@@ -45,7 +45,8 @@ for cfg in "720 1280 1600 3 slic 8" "720 1280 1600 3 slic 16" "2160 3840 1600 3 
 done
 cd $R
 # 4. in-kernel time stamps (lab builds of the same sources: make -C fast_slic_amd/csrc LAB=1 / LAB=2)
-[ -f fast_slic_amd/libfslic_hip_lab1.so ] && FSLIC_LIB=$R/fast_slic_amd/libfslic_hip_lab1.so timeout 200 python scripts/lab_select_stamps.py > $OUT/lab_select_stamps.txt 2>&1
+[ -f fast_slic_amd/libfslic_hip_lab1.so ] && FSLIC_LIB=$R/fast_slic_amd/libfslic_hip_lab1.so timeout 200 python scripts/lab_select_stamps.py 2>/dev/null > $OUT/lab_select_stamps.txt
+[ -f fast_slic_amd/libfslic_hip_lab1.so ] && { echo "== 3840x2160 K=6000, 4 frames" >> $OUT/lab_select_stamps.txt; FSLIC_LIB=$R/fast_slic_amd/libfslic_hip_lab1.so timeout 200 python scripts/lab_select_stamps.py 2160 3840 6000 4 2>/dev/null >> $OUT/lab_select_stamps.txt; }
 [ -f fast_slic_amd/libfslic_hip_lab2.so ] && FSLIC_LIB=$R/fast_slic_amd/libfslic_hip_lab2.so timeout 200 python scripts/lab_local_phases.py 720 1280 1600 8 > $OUT/lab_tile_ccl_phases_720p.txt 2>&1
 [ -f fast_slic_amd/libfslic_hip_lab2.so ] && FSLIC_LIB=$R/fast_slic_amd/libfslic_hip_lab2.so timeout 200 python scripts/lab_local_phases.py 2160 3840 1600 8 > $OUT/lab_tile_ccl_phases_4k.txt 2>&1
 [ -f fast_slic_amd/libfslic_hip_lab4.so ] && for cfg in "720 1280 1600 8" "720 1280 1600 1" "2160 3840 1600 8" "2160 3840 6000 4"; do
@@ -53,9 +54,15 @@ cd $R
   FSLIC_LIB=$R/fast_slic_amd/libfslic_hip_lab4.so timeout 200 python scripts/lab_assign_phases.py $cfg 2>&1 | grep -v amdgpu.ids >> $OUT/lab_assign_phases.txt
 done
 # 4b. instruction mix of every kernel of an 8 x 1280x720 group (SQ counters, separate --pmc passes)
-PMC_G=8 bash scripts/gpu_pmc_group.sh > /dev/null 2>&1; cp $R/gpurun_out/pmc_group.txt $OUT/pmc_group_instruction_mix_720p_x8.txt
+PMC_G=8 bash scripts/gpu_pmc_group.sh > /dev/null 2>&1; cp $R/gpurun_out/pmc_group.txt $OUT/pmc_group_instruction_mix_720p_x8.txt; cd $R
+FSLIC_GROUP=16 PMC_G=16 bash scripts/gpu_pmc_group.sh > /dev/null 2>&1; cp $R/gpurun_out/pmc_group.txt $OUT/pmc_group_instruction_mix_720p_x16.txt; cd $R
+PMC_H=2160 PMC_W=3840 PMC_G=8 bash scripts/gpu_pmc_group.sh > /dev/null 2>&1; cp $R/gpurun_out/pmc_group.txt $OUT/pmc_group_instruction_mix_4k_x8.txt; cd $R
 # 5. microbenchmarks
-for m in ${MICROBENCH:-frame_barrier kernel_rate}; do
+for m in ${MICROBENCH:-copy_rate}; do
   [ -x scripts/microbench/$m.out ] && timeout 200 scripts/microbench/$m.out > $OUT/microbench_$m.txt 2>&1
 done
+# 6. the driver's command line under rocprofv3: what every stream does during the timed burst
+BURST_REPS=1 bash scripts/gpu_burst.sh > /dev/null 2>&1; cp $R/gpurun_out/burst_product_1.txt $OUT/burst_driver_cmdline.txt 2>/dev/null
+cd $R
+python scripts/pmc_traffic_json.py $OUT/ > /dev/null 2>&1
 ls $OUT

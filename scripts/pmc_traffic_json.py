@@ -19,9 +19,10 @@ def read(path):
 out = {"note": "bytes per launch = FETCH_SIZE*1024*2 + WRITE_SIZE*1024 (gfx950 correction on the read side only); mean over the "
                "dispatches of separate rocprofv3 --pmc passes (profiles/%s_pmc_fetch_write_*.csv)" % os.path.basename(prefix)}
 for key, (tag, px, stride) in SETS.items():
-    if not os.path.exists("%s_pmc_fetch_write_%s.csv" % (prefix, tag)):
+    path = "%s%spmc_fetch_write_%s.csv" % (prefix, "" if prefix.endswith("/") else "_", tag)      # (a directory prefix: files without the round tag)
+    if not os.path.exists(path):
         continue
-    d = read("%s_pmc_fetch_write_%s.csv" % (prefix, tag))
+    d = read(path)
     ent = {}
     for name, fused in (("full_assign", False), ("fused_assign_update", True)):
         sel = [k for k in d if "k_assign_blk" in k[0] and (", true," in k[0]) == fused]
@@ -32,5 +33,5 @@ for key, (tag, px, stride) in SETS.items():
         ent[name] = {"fetch_kib": round(f[0], 1), "write_kib": round(w[0], 1), "bytes": round(f[0] * 1024 * 2 + w[0] * 1024, 1),
                      "algorithmic_bytes": 6 * px // (stride if fused else 1)}
     out[key] = ent
-json.dump(out, open(prefix + "_pmc_assign_traffic.json", "w"), indent=1)
+json.dump(out, open(prefix + ("" if prefix.endswith("/") else "_") + "pmc_assign_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))

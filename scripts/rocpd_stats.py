@@ -17,6 +17,7 @@ def stats(db, out=None):
     tot = sum(r[2] for r in rows) or 1
     lines = ["Name,Calls,TotalDurationUs,AverageUs,MinUs,MaxUs,Percentage"]
     for n, cnt, s, a, mn, mx in rows:
+        n = n.split("(")[0]          # the kernel with its template arguments, without the parameter list (a long list pushed the numbers out of the clipped lines of round 4)
         lines.append('"%s",%d,%.3f,%.3f,%.3f,%.3f,%.2f' % (n, cnt, s / 1e3, a / 1e3, mn / 1e3, mx / 1e3, 100.0 * s / tot))
     text = "\n".join(lines) + "\n"
     if out:
