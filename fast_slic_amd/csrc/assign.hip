@@ -860,23 +860,83 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
             fetch(c, clab, uxc, k0, idx01, std::false_type{});
             if (uxc <= (uint32_t)S) pass(clab, k0 + uxc, idx01, nullptr);
         }
+        if constexpr (R == 16 && FUSE) {
+            // 16 rows per wavefront (the fused passes at 3840x2160): the masked candidates by HALVES of eight rows, i.e. by the 16-byte
+            // table entries.  The rows a masked pass has to look at are a prefix or a suffix of the wavefront's rows -- above the centre:
+            // rows [.., rs), at / below it: [rs, ..], cut by the window -- so they lie in one half more often than not, and a candidate
+            // whose centre row is inside the wavefront's rows (walked twice) needs three halves on average instead of four: a tenth of
+            // the kernel's vector work at S = 72.
+            auto pass_half = [&](auto half_tag, uint32_t clab, uint32_t base, uint32_t idx01, const uint32_t* mq4) {
+                constexpr int HF = decltype(half_tag)::value;
+                const uint4 e0 = s_rv[base + 8 * HF * STRIDE];
+                const uint32_t spw[4] = {e0.x, e0.y, e0.z, e0.w};
+                uint32_t t[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t s0 = __builtin_amdgcn_sad_u8(pix[2 * (4 * HF + q)], clab, spw[q]);
+                    t[q] = __builtin_amdgcn_sad_hi_u8(pix[2 * (4 * HF + q) + 1], clab, s0);
+                }
+                us2 key[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) key[q] = key_pair(t[q], mq4[q] | idx01);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) min_in_place(best[4 * HF + q], key[q]);
+            };
+            // (sign: -1 the rows above the centre, index k0 - |dx|; +1 the rows at / below it, k0 + |dx|)
+            auto masked = [&](unsigned long long m, const uint32_t rows_j, auto sign_tag) {
+                constexpr int SG = decltype(sign_tag)::value;
+                unsigned long long m_lo = m & ballot((rows_j & 0xFF00u) == 0u);         // every row in the upper half of the wavefront's rows
+                unsigned long long m_hi = m & ballot((rows_j & 0x00FFu) == 0u) & ~m_lo;
+                unsigned long long m_both = m & ~m_lo & ~m_hi;
 #pragma unroll 1
-        while (todo_above) {
-            const int c = __builtin_ctzll(todo_above);
-            todo_above &= todo_above - 1ull;
-            uint32_t clab, uxc, k0, idx01, mq[R / 2];
-            fetch(c, clab, uxc, k0, idx01, std::true_type{});
-            row_masks<R>(~__builtin_amdgcn_readlane(va_j, c) & full, mq);
-            pass(clab, k0 - uxc, idx01, mq);
-        }
+                while (m_lo) {
+                    const int c = __builtin_ctzll(m_lo);
+                    m_lo &= m_lo - 1ull;
+                    uint32_t clab, uxc, k0, idx01, mq[4];
+                    fetch(c, clab, uxc, k0, idx01, std::true_type{});
+                    row_masks<8>(~__builtin_amdgcn_readlane(rows_j, c) & 0xFFu, mq);
+                    pass_half(std::integral_constant<int, 0>{}, clab, SG < 0 ? k0 - uxc : k0 + uxc, idx01, mq);
+                }
 #pragma unroll 1
-        while (todo_below) {
-            const int c = __builtin_ctzll(todo_below);
-            todo_below &= todo_below - 1ull;
-            uint32_t clab, uxc, k0, idx01, mq[R / 2];
-            fetch(c, clab, uxc, k0, idx01, std::true_type{});
-            row_masks<R>(~__builtin_amdgcn_readlane(vb_j, c) & full, mq);
-            pass(clab, k0 + uxc, idx01, mq);
+                while (m_hi) {
+                    const int c = __builtin_ctzll(m_hi);
+                    m_hi &= m_hi - 1ull;
+                    uint32_t clab, uxc, k0, idx01, mq[4];
+                    fetch(c, clab, uxc, k0, idx01, std::true_type{});
+                    row_masks<8>(~(__builtin_amdgcn_readlane(rows_j, c) >> 8) & 0xFFu, mq);
+                    pass_half(std::integral_constant<int, 1>{}, clab, SG < 0 ? k0 - uxc : k0 + uxc, idx01, mq);
+                }
+#pragma unroll 1
+                while (m_both) {
+                    const int c = __builtin_ctzll(m_both);
+                    m_both &= m_both - 1ull;
+                    uint32_t clab, uxc, k0, idx01, mq[R / 2];
+                    fetch(c, clab, uxc, k0, idx01, std::true_type{});
+                    row_masks<R>(~__builtin_amdgcn_readlane(rows_j, c) & full, mq);
+                    pass(clab, SG < 0 ? k0 - uxc : k0 + uxc, idx01, mq);
+                }
+            };
+            masked(todo_above, va_j, std::integral_constant<int, -1>{});
+            masked(todo_below, vb_j, std::integral_constant<int, 1>{});
+        } else {
+#pragma unroll 1
+            while (todo_above) {
+                const int c = __builtin_ctzll(todo_above);
+                todo_above &= todo_above - 1ull;
+                uint32_t clab, uxc, k0, idx01, mq[R / 2];
+                fetch(c, clab, uxc, k0, idx01, std::true_type{});
+                row_masks<R>(~__builtin_amdgcn_readlane(va_j, c) & full, mq);
+                pass(clab, k0 - uxc, idx01, mq);
+            }
+#pragma unroll 1
+            while (todo_below) {
+                const int c = __builtin_ctzll(todo_below);
+                todo_below &= todo_below - 1ull;
+                uint32_t clab, uxc, k0, idx01, mq[R / 2];
+                fetch(c, clab, uxc, k0, idx01, std::true_type{});
+                row_masks<R>(~__builtin_amdgcn_readlane(vb_j, c) & full, mq);
+                pass(clab, k0 + uxc, idx01, mq);
+            }
         }
     } else {
         // 2-D table.  The wavefront's rows in two halves (R/2 visited rows each): a candidate whose window reaches only one half is

@@ -200,8 +200,11 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     const size_t fb = s.frame_bytes;
 
     // copies the graph recorder has no node for (launch.h): such a group is always enqueued directly
-    if ((p->preemptive != 0 || p->variant == FSLIC_VARIANT_REALDIST_NOQ || (generic && !s.sp_patch_uploaded)) && recording_unsupported()) return FSLIC_OK;
-    if (generic && !s.sp_patch_uploaded) {
+    // the (2S+1)^2 patch of the generic kernel: also where a preemptive Slic group falls back to that kernel for its subsampled passes
+    // (geometries outside the block kernel: launch_assign_pre returns false)
+    const bool need_patch = generic || (p->preemptive != 0 && p->variant == FSLIC_VARIANT_SLIC && !assign_fuses_cluster_pass(f, p->subsample_stride));
+    if ((p->preemptive != 0 || p->variant == FSLIC_VARIANT_REALDIST_NOQ || (need_patch && !s.sp_patch_uploaded)) && recording_unsupported()) return FSLIC_OK;
+    if (need_patch && !s.sp_patch_uploaded) {
         HIPCHK(hipMemcpyAsync(s.d_patch, s.h_patch, (size_t)(2 * S + 1) * (2 * S + 1) * sizeof(uint16_t), hipMemcpyHostToDevice, s.st));
         s.sp_patch_uploaded = true;
     }

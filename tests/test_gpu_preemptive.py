@@ -101,3 +101,27 @@ def test_preemptive_facade_on_every_variant(engine):
     for cls_ in (Slic, SlicRealDist, LSC):
         out = cls_(num_components=40, compactness=10, preemptive=True, preemptive_thres=0.05).iterate(img)
         assert out.dtype == np.int16 and out.shape == (120, 160) and out.min() >= 0
+
+
+def test_preemptive_group_equals_single_runs(engine):
+    # frames of a group share every launch (k_preempt_update: one block per frame; the per-pixel kernels of LSC: the frame is a grid dimension)
+    H, W, K = 240, 320, 150
+    imgs = [np.ascontiguousarray(variant(v, H, W, seed=i)) for i, v in enumerate("ABCA")]
+    for var in (B.VARIANT_SLIC, B.VARIANT_REALDIST, B.VARIANT_REALDIST_NOQ, B.VARIANT_LSC):
+        p = make_params(10, 10.0, 0.25, 3, True, True, preemptive=True, preemptive_thres=0.05, variant=var)
+        singles = []
+        for im in imgs:
+            cl = np.zeros(K, B.CLUSTER_DTYPE)
+            B._check(B.load_library().fslic_hip_initialize_clusters(H, W, K, im.ctypes.data, cl.ctypes.data))
+            singles.append((engine.iterate(im, cl, p), cl))
+        cls = []
+        for im in imgs:
+            cl = np.zeros(K, B.CLUSTER_DTYPE)
+            B._check(B.load_library().fslic_hip_initialize_clusters(H, W, K, im.ctypes.data, cl.ctypes.data))
+            cls.append(cl)
+        out = [np.zeros((H, W), np.uint16) for _ in imgs]
+        engine.iterate_batch([im.ctypes.data for im in imgs], cls, [o.ctypes.data for o in out], H, W, p, False)
+        for z in range(len(imgs)):
+            assert np.array_equal(out[z], singles[z][0]), (var, z)
+            assert cls[z].tobytes() == singles[z][1].tobytes(), (var, z)
+
