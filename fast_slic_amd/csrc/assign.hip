@@ -737,14 +737,17 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
     if (PRE && wave == 0) {
         if (lane < bn) s_entry[rank_j] = mine.z & 0xFFFFu;
     } else if (FUSE && wave == 0) {
-        uint32_t entry = kNoSlot;
-        const SlotGeom g = slot_geom((int)(mine.x >> 16), (int)(mine.x & 0xFFFFu), S, f.H, W, rem, STRIDE, BH, Hv);
-        const int by = (int)byi;
-        if (g.any && by >= g.by0 && by <= g.by1) {
-            // (the entry by the block's own coordinates modulo the entry grid: the reader needs no geometry to find it; 24-bit factors, full-rate multiplies)
-            const uint32_t e1 = __umul24(mine.z & 0xFFFFu, (uint32_t)f.cpart_ns) + cpart_slot(byi, bxi, cpart_rows_mask(S, STRIDE, BH), (uint32_t)f.nbx);
-            entry = (e1 << 2) + (e1 << 1);
-            if (FBIN && lane < bn) { fin_nx = (uint32_t)(g.bx1 - g.bx0 + 1); fin_ny = (uint32_t)(g.by1 - g.by0 + 1); fin_b0 = ((uint32_t)g.by0 << 16) | (uint32_t)g.bx0; }
+        // The entry of (cluster, this block): by the block's own coordinates modulo the entry grid (device_common.h, cpart_slot) -- no
+        // geometry of the cluster's window needed.  Every candidate of the list has visited rows in this block: the list's window is
+        // the block's first .. last VISITED row +- S (and its columns +- S), and a cluster window of 2S + 1 >= stride rows that meets
+        // that extent contains one of its visited rows, so the block is always one of the blocks the cluster pass expects an entry
+        // from (until round 5 this was re-derived per candidate from slot_geom by wavefront 0, ~50 vector instructions on the block's
+        // critical path).  The fused cluster pass (FBIN) still needs the window's block range: how many blocks deliver.
+        const uint32_t e1 = __umul24(mine.z & 0xFFFFu, (uint32_t)f.cpart_ns) + cpart_slot(byi, bxi, cpart_rows_mask(S, STRIDE, BH), (uint32_t)f.nbx);
+        const uint32_t entry = (e1 << 2) + (e1 << 1);
+        if constexpr (FBIN) {
+            const SlotGeom g = slot_geom((int)(mine.x >> 16), (int)(mine.x & 0xFFFFu), S, f.H, W, rem, STRIDE, BH, Hv);
+            if (lane < bn) { fin_nx = (uint32_t)(g.bx1 - g.bx0 + 1); fin_ny = (uint32_t)(g.by1 - g.by0 + 1); fin_b0 = ((uint32_t)g.by0 << 16) | (uint32_t)g.bx0; }
         }
         if (lane < bn) s_entry[rank_j] = entry;
     }
