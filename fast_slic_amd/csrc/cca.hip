@@ -85,16 +85,6 @@ static __device__ __forceinline__ uint32_t lane_left_or(uint32_t old, uint32_t v
 static __device__ __forceinline__ uint32_t rank_in(u64 m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 // LDS word at a BYTE offset (the tile kernel's union-find names its nodes by byte offset: no shift per dependent look-up)
 static __device__ __forceinline__ uint32_t* lds_at(uint32_t* base, uint32_t off) { return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(base) + off); }
-static __device__ __forceinline__ uint32_t ldsb_find(uint32_t* par, uint32_t x) {
-    for (;;) {
-        const uint32_t p = lds_ld(lds_at(par, x));
-        if (p == x) return x;
-        const uint32_t gp = lds_ld(lds_at(par, p));
-        if (gp == p) return p;
-        lds_st(lds_at(par, x), gp);
-        x = gp;
-    }
-}
 static __device__ __forceinline__ void ldsb_union(uint32_t* par, uint32_t a, uint32_t b) {
     for (;;) {
         // both walks to the roots in LOCKSTEP -- one LDS round trip per step for the two of them (one after the other, with path
