@@ -162,7 +162,11 @@ constexpr int kLscAccEntries = 64 << kLscCopyShift;
 // the spatial features (cos / sin of any angle) wrap in two's complement -- and the two packed integer words.  8 LDS atomics per
 // flush instead of 13.
 //   word 0..3: F0..F3 | F6..F9 << 32      word 4: F4 | F5 << 32      word 5: w      word 6, 7: integers
+// Word-major: word q of record r = (candidate, copy) lies at q * kLscAccEntries + r.  One atomic instruction adds word q of every
+// lane's record, so the lanes of an instruction hit neighbouring 8-byte words; record-major (records 64 bytes apart) put word q of
+// ANY record on one of two bank pairs and queued a wavefront's 16 quad leaders 8 deep (profiles/r05_lsc_knockout.txt).
 constexpr int kLscAccW = 8;
+static __device__ __forceinline__ int lsc_acc_index(int word, uint32_t record) { return word * kLscAccEntries + (int)record; }
 constexpr uint32_t kLscNoSlot = 0xFFFFFFFFu;
 constexpr int kDppQuadSwap1 = 0xB1, kDppQuadSwap2 = 0x4E;     // quad_perm [1,0,3,2] and [2,3,0,1]
 
@@ -343,7 +347,13 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
             const float4* po = reinterpret_cast<const float4*>(s_org);
             const float4 o0 = po[0], o1 = po[1], o2 = po[2];
             const float org[kLscFeat] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w, o2.x, o2.y};
+#if !(FSLIC_EXP & 32)     // (knock-out build 32: no feature rebuild -- six table reads, the weight chain and the twenty quotients of a row pair)
             lsc_pair_features(s_lut, pix[r0], pix[r1], xcos, xsin, ycos, ysin, mean, org, G, wv);
+#else
+#pragma unroll
+            for (int q = 0; q < kLscFeat; ++q) G[q] = (f2){__uint_as_float(pix[r0] + q) - org[q], __uint_as_float(pix[r1] + q) - org[q]};
+            wv = (f2){1.0f, 1.0f};
+#endif
         }
         f2 best = {FLT_MAX, FLT_MAX};
         uint32_t bk0 = 0xFFFFu, bk1 = 0xFFFFu;
@@ -352,8 +362,12 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
             const bool inx = abs(x - cx) <= S;
             f2 d = {0.0f, 0.0f};
             if (dot_form) {
+#if !(FSLIC_EXP & 16)     // (knock-out build 16, scripts/gpu_knock.sh: the walk without its ten packed FMAs per candidate; results wrong on purpose)
 #pragma unroll
                 for (int q = 0; q < kLscFeat; ++q) d = __builtin_elementwise_fma(G[q], (f2){cf[q], cf[q]}, d);
+#else
+                d = G[0] + (f2){cf[0], cf[9]};
+#endif
                 d = __builtin_elementwise_fma(d, (f2){-2.0f, -2.0f}, (f2){nrm, nrm});
             } else {
 #pragma unroll
@@ -505,15 +519,17 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 if (slot[u] == kLscNoSlot || (u == 1 && both)) continue;
-                unsigned long long* a = s_accx + ((slot[u] << cshift) + copy) * kLscAccW;
+                                // the copy: by quad for a quad's first lane that speaks for the four, by lane inside a quad a label boundary runs
+                // through (its lanes of one label would otherwise meet on one address: 37.7 -> 36.1 us per launch of 8 x 1280x720)
+                unsigned long long* a = s_accx + ((slot[u] << cshift) + (quad ? copy : ((uint32_t)lane & ((1u << cshift) - 1u))));
                 auto fixed = [&](int q) { return (uint32_t)(int)__builtin_rintf(Fr[u][q] * l.blk_fix_f); };
 #if !(FSLIC_EXP & 8)      // (knock-out build 8, scripts/gpu_knock.sh: what the block accumulators' LDS atomics cost; results wrong on purpose)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) atomicAdd(a + q, (unsigned long long)fixed(q) | ((unsigned long long)fixed(6 + q) << 32));
-                atomicAdd(a + 4, (unsigned long long)fixed(4) | ((unsigned long long)fixed(5) << 32));
-                atomicAdd(a + 5, (unsigned long long)(uint32_t)(int)__builtin_rintf(Fr[u][kLscFeat] * l.blk_fix_w));
-                atomicAdd(a + 6, (unsigned long long)ia[u][0] | ((unsigned long long)ia[u][1] << 32));
-                atomicAdd(a + 7, (unsigned long long)ia[u][2] | ((unsigned long long)ia[u][3] << 32));
+                for (int q = 0; q < 4; ++q) atomicAdd(a + lsc_acc_index(q, 0), (unsigned long long)fixed(q) | ((unsigned long long)fixed(6 + q) << 32));
+                atomicAdd(a + lsc_acc_index(4, 0), (unsigned long long)fixed(4) | ((unsigned long long)fixed(5) << 32));
+                atomicAdd(a + lsc_acc_index(5, 0), (unsigned long long)(uint32_t)(int)__builtin_rintf(Fr[u][kLscFeat] * l.blk_fix_w));
+                atomicAdd(a + lsc_acc_index(6, 0), (unsigned long long)ia[u][0] | ((unsigned long long)ia[u][1] << 32));
+                atomicAdd(a + lsc_acc_index(7, 0), (unsigned long long)ia[u][2] | ((unsigned long long)ia[u][3] << 32));
 #else
                 asm volatile("" :: "v"(a), "v"(fixed(0)), "v"(fixed(1)), "v"(fixed(2)), "v"(fixed(3)), "v"(fixed(4)), "v"(fixed(5)), "v"(fixed(6)), "v"(fixed(7)), "v"(fixed(8)), "v"(fixed(9)),
                              "v"(ia[u][0]), "v"(ia[u][1]), "v"(ia[u][2]), "v"(ia[u][3]));
@@ -532,9 +548,9 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
     const uint32_t yb0 = (uint32_t)(rem + stride * v0);
     for (int i = threadIdx.x; i < cnt * (kLscFeat + 1 + 6) && listed; i += 256) {
         const int c = i / (kLscFeat + 1 + 6), q = i - c * (kLscFeat + 1 + 6);
-        const unsigned long long* a = s_accx + ((size_t)c << cshift) * kLscAccW;
+        const unsigned long long* a = s_accx + ((size_t)c << cshift);
         unsigned long long B = 0;
-        for (int cpy = 0; cpy < (1 << cshift); ++cpy) B += a[cpy * kLscAccW + 7];
+        for (int cpy = 0; cpy < (1 << cshift); ++cpy) B += a[lsc_acc_index(7, cpy)];
         const uint32_t n = (uint32_t)(B >> 20) & 0xFFFu;
         if (n == 0u) continue;                                              // nothing for this cluster
         const uint32_t k = s_k[c];
@@ -543,13 +559,13 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
             const int word = q < 4 ? q : q < 6 ? 4 : q < kLscFeat ? q - 6 : 5;
             const bool high = q == 5 || (q >= 6 && q < kLscFeat);
             unsigned long long w = 0;
-            for (int cpy = 0; cpy < (1 << cshift); ++cpy) w += a[cpy * kLscAccW + word];
+            for (int cpy = 0; cpy < (1 << cshift); ++cpy) w += a[lsc_acc_index(word, cpy)];
             const long long field = high ? (long long)(int)(uint32_t)(w >> 32) : (long long)(uint32_t)w;
             const long long v = field << (q < kLscFeat ? l.blk_shift_f : l.blk_shift_w);      // to the fixed point of the global accumulators
             atomicAdd(reinterpret_cast<unsigned long long*>(l.extra + (size_t)k * kLscExPitch) + q, (unsigned long long)v);
         } else {
             unsigned long long A = 0;
-            for (int cpy = 0; cpy < (1 << cshift); ++cpy) A += a[cpy * kLscAccW + 6];
+            for (int cpy = 0; cpy < (1 << cshift); ++cpy) A += a[lsc_acc_index(6, cpy)];
             const int u = q - kLscFeat - 1;
             uint32_t v;
             if (u == 0) v = n;

@@ -4,7 +4,7 @@
 # Round 4, fused assign kernel at 8 x 3840x2160: the guards were FSLIC_EXP 1 (no LDS atomics in the fast epilogue), 2 (no whole-column atomics), 4
 # (no label look-ups); they found the label table's bank conflicts and were removed with the fix (profiles/r04_assign_experiments.txt; the
 # guarded source is in commit 7126983's tree of experiments: `git log -S"FSLIC_EXP & 4"`).  LSC: FSLIC_EXP 8 (no block-accumulator atomics in
-# k_lsc_assign_sums) is in lsc.hip, not yet run:  make -C fast_slic_amd/csrc VAR=k8 DEFS=-DFSLIC_EXP=8
+# k_lsc_assign_sums), 16 (no packed FMAs in its walk), 32 (no feature rebuild) are in lsc.hip: profiles/r05_lsc_knockout.txt.  make -C fast_slic_amd/csrc VAR=k8 DEFS=-DFSLIC_EXP=8
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 KERNEL=${KNOCK_KERNEL:-k_lsc_assign_sums}
