@@ -502,8 +502,9 @@ def main():
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 1000 if args.workload == "720p" else 200
-    if args.launch_frames is not None and not 1 <= args.launch_frames <= 16:
-        ap.error("--launch-frames must be in 1..16 (the library's group limit, FSLIC_MAX_GROUP)")
+    group_limit = int(os.environ.get("FSLIC_BENCH_MAX_GROUP", "16"))      # the library's group limit (FSLIC_MAX_GROUP of its build)
+    if args.launch_frames is not None and not 1 <= args.launch_frames <= group_limit:
+        ap.error("--launch-frames must be in 1..%d (the library's group limit, FSLIC_MAX_GROUP)" % group_limit)
 
     from fast_slic_amd import batch
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

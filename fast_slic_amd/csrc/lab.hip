@@ -44,24 +44,11 @@ __global__ __launch_bounds__(1024) void k_rgb_to_lab(FrameDev f, const uint16_t*
     // first kernel of a group: new generation of bin stamps (nothing in this kernel reads them; the stream orders the rest)
     if (gen_step && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *f.gen_base += gen_step;
     f.select(blockIdx.y);
-    {   // the group's accumulators, bin counters and flags of this frame (nothing reads them before the next kernel)
-        const size_t fo = (size_t)blockIdx.y * f.frame_bytes;
-        const unsigned t0 = blockIdx.x * blockDim.x + threadIdx.x, ts = gridDim.x * blockDim.x;
-        if (zero_a) { uint4* za = reinterpret_cast<uint4*>(zero_a + fo); for (unsigned i = t0; i < zero_a_quads; i += ts) za[i] = make_uint4(0u, 0u, 0u, 0u); }
-        if (zero_b) { uint32_t* zb = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(zero_b) + fo); for (unsigned i = t0; i < zero_b_words; i += ts) zb[i] = 0u; }
-    }
     const uint8_t* __restrict__ rgb = f.rgb;
     uint32_t* __restrict__ lab = f.lab;
     uint16_t* __restrict__ labels_init = init_labels ? f.labels : nullptr;
     const int N = f.N;
     const int aligned4 = ((reinterpret_cast<uintptr_t>(rgb) & 3) == 0) ? 1 : 0;
-    if (CONVERT) {
-        for (int i = threadIdx.x; i < 128; i += blockDim.x)
-            reinterpret_cast<uint32_t*>(s_gamma)[i] = reinterpret_cast<const uint32_t*>(g_gamma)[i];
-        for (int i = threadIdx.x; i < 4097; i += blockDim.x)   // 8194 entries (last one padding)
-            reinterpret_cast<uint32_t*>(s_lab)[i] = reinterpret_cast<const uint32_t*>(g_labtbl)[i];
-        __syncthreads();
-    }
     const int nquad = aligned4 ? (N >> 2) : 0;
     const int gstride = gridDim.x * blockDim.x;
     // Software-pipelined over the thread's quads: the next quad's loads are issued BEFORE this quad's stores, so that
@@ -72,6 +59,22 @@ __global__ __launch_bounds__(1024) void k_rgb_to_lab(FrameDev f, const uint16_t*
     if (q < nquad) {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(rgb) + 3 * (size_t)q;
         w0 = src[0]; w1 = src[1]; w2 = src[2];
+    }
+    // The tables are requested with the first quad's loads in flight (a one-frame launch is 225 blocks of one quad per thread: the
+    // two round trips were one after the other).  1024 threads per block (the launcher).
+    uint32_t tg = 0, tl0 = 0, tl1 = 0, tl2 = 0, tl3 = 0, tl4 = 0;
+    if (CONVERT) {
+        const uint32_t* gt = reinterpret_cast<const uint32_t*>(g_labtbl);   // 8194 entries (last one padding) = 4097 words
+        if (threadIdx.x < 128) tg = reinterpret_cast<const uint32_t*>(g_gamma)[threadIdx.x];
+        tl0 = gt[threadIdx.x]; tl1 = gt[1024 + threadIdx.x]; tl2 = gt[2048 + threadIdx.x]; tl3 = gt[3072 + threadIdx.x];
+        if (threadIdx.x == 0) tl4 = gt[4096];
+    }
+    if (CONVERT) {
+        uint32_t* sl = reinterpret_cast<uint32_t*>(s_lab);
+        if (threadIdx.x < 128) reinterpret_cast<uint32_t*>(s_gamma)[threadIdx.x] = tg;
+        sl[threadIdx.x] = tl0; sl[1024 + threadIdx.x] = tl1; sl[2048 + threadIdx.x] = tl2; sl[3072 + threadIdx.x] = tl3;
+        if (threadIdx.x == 0) sl[4096] = tl4;
+        __syncthreads();
     }
     while (q < nquad) {
         const int qn = q + gstride;
@@ -107,6 +110,15 @@ __global__ __launch_bounds__(1024) void k_rgb_to_lab(FrameDev f, const uint16_t*
         const uint32_t r = rgb[3 * (size_t)p], g = rgb[3 * (size_t)p + 1], b = rgb[3 * (size_t)p + 2];
         st_stream(lab + p, CONVERT ? lab_px(r, g, b, s_gamma, s_lab, kc) : (r | (g << 8) | (b << 16)));
         if (labels_init) st_stream(labels_init + p, (uint16_t)0xFFFFu);
+    }
+    // Last, the zeroing of the group's accumulators, bin counters and flags of this frame (nothing reads them before the next
+    // kernel): the one vector-memory counter is in order, so a wait for a load also waits for every store issued before it --
+    // at the top of the kernel these stores sat in front of the first quad's loads.
+    {
+        const size_t fo = (size_t)blockIdx.y * f.frame_bytes;
+        const unsigned t0 = blockIdx.x * blockDim.x + threadIdx.x, ts = gridDim.x * blockDim.x;
+        if (zero_a) { uint4* za = reinterpret_cast<uint4*>(zero_a + fo); for (unsigned i = t0; i < zero_a_quads; i += ts) za[i] = make_uint4(0u, 0u, 0u, 0u); }
+        if (zero_b) { uint32_t* zb = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(zero_b) + fo); for (unsigned i = t0; i < zero_b_words; i += ts) zb[i] = 0u; }
     }
 }
 
