@@ -59,8 +59,8 @@ template <int NB> static __device__ __forceinline__ void add_live_entries(const 
     }
 }
 
-template <int MODE, int NB = 8>
-__global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg, const uint32_t* __restrict__ src_yx, size_t src_stride) {
+template <int MODE, int NB>
+static __device__ __forceinline__ void bin_clusters_body(FrameDev& f, const PassGeom& pg, const uint32_t* __restrict__ src_yx, size_t src_stride) {
     f.select(blockIdx.y);
     // mode 0: the centres of a group start are read where the host staged them (pinned memory), no upload command
     const uint32_t* __restrict__ yx_in = (MODE == 0 && src_yx) ? src_yx + (size_t)blockIdx.y * src_stride : f.cl_yx;
@@ -186,6 +186,35 @@ __global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg, c
     }
 }
 
+template <int MODE, int NB = 8>
+__global__ __launch_bounds__(256) void k_bin_clusters(FrameDev f, PassGeom pg, const uint32_t* __restrict__ src_yx, size_t src_stride) {
+    bin_clusters_body<MODE, NB>(f, pg, src_yx, src_stride);
+}
+
+// LSC: the cluster pass (blocks 0 .. nbin-1) and, in the blocks behind them, the second half of the variant's update --
+// C_f = sum w*F / sum w per cluster (src/lsc.cpp:256-269 then :309-316; 0/0 = NaN for a memberless cluster exactly as the
+// reference produces it) from the fixed-point accumulators the assign pass filled, which are cleared for the next pass.
+// The integer sums of the shared centroid update are in FrameDev::sums, where the cluster pass reads them: the two halves
+// touch different data.  16 threads per cluster: 10 features, the weight, 5 idle.
+__global__ __launch_bounds__(256) void k_bin_clusters_lsc(FrameDev f, PassGeom pg, LscDev l, int nbin) {
+    if ((int)blockIdx.x < nbin) {
+        bin_clusters_body<1, 8>(f, pg, nullptr, (size_t)0);
+        return;
+    }
+    l.select(blockIdx.y);
+    const int t = ((int)blockIdx.x - nbin) * (int)blockDim.x + (int)threadIdx.x;
+    const int k = t >> 4, q = t & 15;
+    if (k >= f.K) return;
+    long long* e = l.extra + (size_t)k * kLscExPitch;
+    const long long mine = q <= kLscFeat ? e[q] : 0ll;
+    const long long wsum = e[kLscFeat];
+    const float acc = (float)((double)mine / (double)kLscFixF), tot_w = (float)((double)wsum / (double)kLscFixW);
+    if (q < kLscFeat) l.cfeat[(size_t)k * kLscCfPitch + q] = acc / tot_w;
+    // every thread of the cluster has read what it needs before any of them clears (same wavefront: 16 consecutive lanes)
+    __builtin_amdgcn_wave_barrier();
+    if (q <= kLscFeat) e[q] = 0;
+}
+
 void launch_bin_clusters(const FrameDev& f_, int nframes, int mode, int buf, int sbuf, const PassGeom& pg, hipStream_t st,
                          const uint32_t* src_yx, size_t src_stride) {
     const FrameDev f = rotated(f_, buf, sbuf);
@@ -205,6 +234,13 @@ void launch_bin_clusters(const FrameDev& f_, int nframes, int mode, int buf, int
         if (ne > 0 && ne <= 4) launch((k_bin_clusters<1, 4>), dim3(bk > bc ? bk : bc, nframes), dim3(256), 0, st, f, pg, nullptr, (size_t)0);
         else launch((k_bin_clusters<1, 8>), dim3(bk > bc ? bk : bc, nframes), dim3(256), 0, st, f, pg, nullptr, (size_t)0);
     }
+}
+
+void launch_bin_clusters_lsc(const FrameDev& f_, const LscDev& l, int nframes, int buf, int sbuf, hipStream_t st) {
+    const FrameDev f = rotated(f_, buf, sbuf);
+    const int bk = (f.K + 254) / 255, bc = (f.ncell + 255) / 256;
+    const int nbin = bk > bc ? bk : bc;
+    launch(k_bin_clusters_lsc, dim3(nbin + (f.K * 16 + 255) / 256, nframes), dim3(256), 0, st, f, PassGeom{}, l, nbin);
 }
 
 }  // namespace fslic

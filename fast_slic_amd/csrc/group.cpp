@@ -287,10 +287,9 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
             launch_preempt_update(f, n, (it + 1) & 1, it & 1, false, pre_l1_thres, s.st);
             launch_lsc_pre_feats(f, l, n, rem, stride, s.st);
         } else {
-            launch_lsc_update(f, l, n, rem, stride, it & 1, s.st);   // update() sums + after_update()
             f.gen_off++;
             pg = PassGeom{};                                          // use_slots = 0: everything is in FrameDev::sums
-            launch_bin_clusters(f, n, 1, (it + 1) & 1, it & 1, pg, s.st);
+            launch_bin_clusters_lsc(f, l, n, (it + 1) & 1, it & 1, s.st);   // update() sums + after_update(), re-binning: one launch
         }
         yx_cur = f.cl_yx_out;
         rem = (rem + 1) % stride;

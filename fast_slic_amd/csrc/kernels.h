@@ -196,6 +196,9 @@ struct CcaDev {
 constexpr int kLscFeat = 10;        // l1, l2, a1, a2, b1, b2, x1, x2, y1, y2 (src/lsc.h:12)
 constexpr int kLscCfPitch = 16;     // floats per centroid record (10 features, padded to 64 bytes)
 constexpr int kLscExPitch = 12;     // int64 per cluster of the stale-pixel accumulators (10 features, weight, pad)
+// fixed point of the global accumulators of the fused update (LscDev::extra, 64-bit: a cluster that owned a whole 4K frame
+// would reach 4.4e14 in a feature sum and 7.8e14 in the weight sum)
+constexpr float kLscFixF = 1048576.0f, kLscFixW = 4096.0f;
 struct LscDev {
     size_t frame_bytes;
     uint32_t* hist;      // 768: histograms of the L, a, b planes (feature means of the colour half, src/lsc.cpp:143-149)
@@ -236,6 +239,10 @@ void launch_rgb_to_lab(const FrameDev& f, int nframes, int convert, const LabTab
 // src_yx + z * src_stride words) instead of FrameDev::cl_yx.
 void launch_bin_clusters(const FrameDev& f, int nframes, int mode, int buf, int sbuf, const PassGeom& pg, hipStream_t st,
                          const uint32_t* src_yx = nullptr, size_t src_stride = 0);
+// The cluster pass of the LSC variant: the same launch also turns the fused update's accumulators into the feature-space centroids
+// (src/lsc.cpp:256-269, 309-316) in blocks of its own -- the two passes are independent, and as two launches they were two latency-bound
+// kernels back to back in every iteration.  Mode 1 with PassGeom{} (everything is in FrameDev::sums).
+void launch_bin_clusters_lsc(const FrameDev& f, const LscDev& l, int nframes, int buf, int sbuf, hipStream_t st);
 
 // One assign pass over rows == rem (mod stride); fuse_update also accumulates the centroid sums
 // of src/context.cpp:301-354 for the same rows.  Returns the geometry the following cluster pass needs.
@@ -256,7 +263,6 @@ void launch_lsc_prepare(const FrameDev& f, const LscDev& l, int nframes, hipStre
 // 10-D assignment of rows == rem (mod stride) (src/lsc.cpp:197-224); stale_sums: an update follows
 void launch_lsc_assign(const FrameDev& f, const LscDev& l, int nframes, int rem, int stride, int buf, int sbuf, bool stale_sums, hipStream_t st);
 // per-cluster gather of the integer sums (into FrameDev::sums) and the weighted feature means (src/lsc.cpp:226-307)
-void launch_lsc_update(const FrameDev& f, const LscDev& l, int nframes, int rem, int stride, int sbuf, hipStream_t st);
 // LSC in preemptive mode (lsc.hip): the integer sums of update() over the visited pixels of the active cells (before
 // launch_preempt_update); the weighted feature sums and the centroids of after_update() under the NEW activity state (after it)
 void launch_lsc_pre_sums(const FrameDev& f, int nframes, int rem, int stride, int sbuf, hipStream_t st);

@@ -148,24 +148,25 @@ static __device__ __forceinline__ void lsc_pixel_features(const LscDev& l, uint3
 }
 
 static __device__ __forceinline__ float wave_sum(float v) { return wave_reduce_add(v); }
-// fixed point of the global accumulators of the fused update (LscDev::extra, 64-bit: a cluster that owned a whole 4K frame
-// would reach 4.4e14 in a feature sum and 7.8e14 in the weight sum)
-constexpr float kLscFixF = 1048576.0f, kLscFixW = 4096.0f;
 // 4 privatised copies of every accumulator (by quad): lanes of a run of columns with one label meet on the same words, and
 // same-address LDS atomics are served one lane after the other (2 copies 45.5, 4 copies 44.1 us per launch of 8 x 1280x720; 8 copies
 // for lists of up to 32 candidates, chosen at run time: 45.4)
 constexpr int kLscCopyShift = 2;
 constexpr int kLscAccEntries = 64 << kLscCopyShift;
-// A block's accumulators (LDS), per (candidate, copy) eight 64-bit words: the eleven float sums in a coarser fixed point that keeps a
+// A block's accumulators (LDS), per (candidate, copy) seven 64-bit words: the eleven float sums in a coarser fixed point that keeps a
 // block's total (1024 pixels) inside 32 bits (LscDev::blk_fix_*: 2^-15 and 2^-8 for the default constants), two to a word -- the low
 // half always one of the colour features or the weight, which are never negative, so no borrow crosses into the high half, where
-// the spatial features (cos / sin of any angle) wrap in two's complement -- and the two packed integer words.  8 LDS atomics per
-// flush instead of 13.
-//   word 0..3: F0..F3 | F6..F9 << 32      word 4: F4 | F5 << 32      word 5: w      word 6, 7: integers
+// the spatial features (cos / sin of any angle) wrap in two's complement -- and the six integer sums in the bits that leaves:
+//   word 0..3: F0..F3 | F6..F9 << 32      word 4: F4 | F5 << 32
+//   word 5: sum L | sum a << 18 | sum b << 36 | count << 54      (255 * 1024 < 2^18; the count has the ten bits that are left: a block
+//           of 1024 pixels that is ONE cluster's wraps to 0 and is told from an empty one by its column sum, 16 * (0 + ... + 63))
+//   word 6: w | sum (x - x0) << 32 | sum (row inside the block) << 48      (63 * 1024 < 2^16, 15 * 1024 < 2^14)
+// 7 LDS atomics per flush instead of 13 (8 until the weight moved in with the positions: an LDS atomic costs its issue whatever the
+// number of lanes that take part, profiles/r05_lsc_knockout.txt).
 // Word-major: word q of record r = (candidate, copy) lies at q * kLscAccEntries + r.  One atomic instruction adds word q of every
 // lane's record, so the lanes of an instruction hit neighbouring 8-byte words; record-major (records 64 bytes apart) put word q of
 // ANY record on one of two bank pairs and queued a wavefront's 16 quad leaders 8 deep (profiles/r05_lsc_knockout.txt).
-constexpr int kLscAccW = 8;
+constexpr int kLscAccW = 7;
 static __device__ __forceinline__ int lsc_acc_index(int word, uint32_t record) { return word * kLscAccEntries + (int)record; }
 constexpr uint32_t kLscNoSlot = 0xFFFFFFFFu;
 constexpr int kDppQuadSwap1 = 0xB1, kDppQuadSwap2 = 0x4E;     // quad_perm [1,0,3,2] and [2,3,0,1]
@@ -228,8 +229,7 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
     __shared__ __attribute__((aligned(8))) float s_lut[1024];
     __shared__ int s_cnt;
     // block-level accumulators of the fused update: per candidate of the block's list (and privatised copy) 11 feature sums
-    // in fixed point and the 6 integer sums packed into two words (sum L | sum a << 20 | sum b << 40 and sum (x - x0) |
-    // sum (y - y0) << 20 | count << 40, as the SLIC block kernel packs them: 1024 pixels per block, no field reaches 2^20);
+    // in fixed point and the 6 integer sums packed beside them (kLscAccW above: 1024 pixels per block bound every field);
     // LDS atomics, flushed with ONE set of global atomics per (block, cluster)
     __shared__ unsigned long long s_accx[stale_sums ? kLscAccEntries * kLscAccW : 1];
     const int wave = threadIdx.x >> 6, lane = LANE();
@@ -457,7 +457,7 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
             // 87 us, 16-lane row sums 172 us; the kernel that re-scanned every cluster's window for its members 64 of 100 us per
             // iteration.  Column runs + LDS atomics: 49 us, profiles/r03_lsc_sums_ablation.txt.)
             float Fr[2][kLscFeat + 1];
-            uint32_t ia[2][4];
+            uint32_t ia[2][3];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int r = 2 * h + u;
@@ -465,10 +465,9 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
                 const float2 Lr = tl[px & 255u], Ar = tl[256u + ((px >> 8) & 255u)], Br = tl[256u + ((px >> 16) & 255u)];
                 Fr[u][0] = Lr.x; Fr[u][1] = Lr.y; Fr[u][2] = Ar.x; Fr[u][3] = Ar.y; Fr[u][4] = Br.x; Fr[u][5] = Br.y;
                 Fr[u][6] = xcos; Fr[u][7] = xsin; Fr[u][8] = ycos[u]; Fr[u][9] = ysin[u]; Fr[u][kLscFeat] = wv[u];
-                ia[u][0] = (px & 255u) | ((px & 0xFF00u) << 12);                 // L | a << 20
-                ia[u][1] = (px >> 8) & 0xFF00u;                                 // b << 40
-                ia[u][2] = (uint32_t)lane | (1u << 20);                         // x - x0 | count << 20
-                ia[u][3] = (uint32_t)(wave * kLscRows + r);                     // the row's number inside the block << 32
+                ia[u][0] = (px & 255u) | ((px & 0xFF00u) << 10);                 // L | a << 18
+                ia[u][1] = ((px >> 12) & 0xFF0u) | (1u << 22);                  // (b << 36 | count << 54) >> 32
+                ia[u][2] = (uint32_t)lane | ((uint32_t)(wave * kLscRows + r) << 16);      // (x - x0 | the row's number inside the block << 16), the high half of the weight's word
                 if (lbl[u] != 0xFFFFu && slot[u] == kLscNoSlot) {
                     // its label is not on the block's list (it kept a label whose window has left it, or the block walks
                     // every cluster): straight to the global accumulators.  Rare.
@@ -484,7 +483,7 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
 #pragma unroll
                 for (int q = 0; q <= kLscFeat; ++q) Fr[0][q] += Fr[1][q];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) ia[0][q] += ia[1][q];
+                for (int q = 0; q < 3; ++q) ia[0][q] += ia[1][q];
             }
             // Lanes of one label hit the same words, and same-address LDS atomics are served one lane after the other (a
             // 24-column superpixel: a dozen lanes per copy).  Four neighbouring columns mostly agree, so a quad whose lanes all
@@ -497,14 +496,14 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
             const bool quad = ((bq >> (lane & ~3)) & 0xFull) == 0xFull && slot[0] == sa && slot[0] == sb && slot[0] == sc && slot[0] != kLscNoSlot;
             if (__ballot(quad)) {                     // uniform
                 float t[kLscFeat + 1];
-                uint32_t it[4];
+                uint32_t it[3];
 #pragma unroll
                 for (int q = 0; q <= kLscFeat; ++q) {
                     t[q] = Fr[0][q] + __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(Fr[0][q]), kDppQuadSwap1, 0xF, 0xF, true));
                     t[q] = t[q] + __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(t[q]), kDppQuadSwap2, 0xF, 0xF, true));
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < 3; ++q) {
                     it[q] = ia[0][q] + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ia[0][q], kDppQuadSwap1, 0xF, 0xF, true);
                     it[q] = it[q] + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)it[q], kDppQuadSwap2, 0xF, 0xF, true);
                 }
@@ -512,7 +511,7 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
 #pragma unroll
                     for (int q = 0; q <= kLscFeat; ++q) Fr[0][q] = t[q];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) ia[0][q] = it[q];
+                    for (int q = 0; q < 3; ++q) ia[0][q] = it[q];
                     if (lane & 3) slot[0] = kLscNoSlot;          // the quad's first lane speaks for it
                 }
             }
@@ -527,12 +526,11 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
 #pragma unroll
                 for (int q = 0; q < 4; ++q) atomicAdd(a + lsc_acc_index(q, 0), (unsigned long long)fixed(q) | ((unsigned long long)fixed(6 + q) << 32));
                 atomicAdd(a + lsc_acc_index(4, 0), (unsigned long long)fixed(4) | ((unsigned long long)fixed(5) << 32));
-                atomicAdd(a + lsc_acc_index(5, 0), (unsigned long long)(uint32_t)(int)__builtin_rintf(Fr[u][kLscFeat] * l.blk_fix_w));
-                atomicAdd(a + lsc_acc_index(6, 0), (unsigned long long)ia[u][0] | ((unsigned long long)ia[u][1] << 32));
-                atomicAdd(a + lsc_acc_index(7, 0), (unsigned long long)ia[u][2] | ((unsigned long long)ia[u][3] << 32));
+                atomicAdd(a + lsc_acc_index(5, 0), (unsigned long long)ia[u][0] | ((unsigned long long)ia[u][1] << 32));
+                atomicAdd(a + lsc_acc_index(6, 0), (unsigned long long)(uint32_t)(int)__builtin_rintf(Fr[u][kLscFeat] * l.blk_fix_w) | ((unsigned long long)ia[u][2] << 32));
 #else
                 asm volatile("" :: "v"(a), "v"(fixed(0)), "v"(fixed(1)), "v"(fixed(2)), "v"(fixed(3)), "v"(fixed(4)), "v"(fixed(5)), "v"(fixed(6)), "v"(fixed(7)), "v"(fixed(8)), "v"(fixed(9)),
-                             "v"(ia[u][0]), "v"(ia[u][1]), "v"(ia[u][2]), "v"(ia[u][3]));
+                             "v"(ia[u][0]), "v"(ia[u][1]), "v"(ia[u][2]));
 #endif
             }
         }
@@ -543,20 +541,21 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
     lds_barrier();      // LDS contents only pass between the wavefronts here: pixel loads / label stores stay in flight (device_common.h)
     LSC_STAMP(9, wave == 1);
     // one set of global atomics per (block, cluster that received pixels here).  (Plain stores into per-(cluster, block) entries
-    // summed by k_lsc_update, as the SLIC block kernel delivers its sums, were built and measured: 48.6 against 47.1 us per launch
+    // summed by the cluster pass, as the SLIC block kernel delivers its sums, were built and measured: 48.6 against 47.1 us per launch
     // of 8 x 1280x720 -- the window arithmetic in the prologue costs what the atomics cost at the end.)
     const uint32_t yb0 = (uint32_t)(rem + stride * v0);
     for (int i = threadIdx.x; i < cnt * (kLscFeat + 1 + 6) && listed; i += 256) {
         const int c = i / (kLscFeat + 1 + 6), q = i - c * (kLscFeat + 1 + 6);
         const unsigned long long* a = s_accx + ((size_t)c << cshift);
-        unsigned long long B = 0;
-        for (int cpy = 0; cpy < (1 << cshift); ++cpy) B += a[lsc_acc_index(7, cpy)];
-        const uint32_t n = (uint32_t)(B >> 20) & 0xFFFu;
+        unsigned long long A = 0, B = 0;                                      // words 5 and 6 (the copies' words add up field by field)
+        for (int cpy = 0; cpy < (1 << cshift); ++cpy) { A += a[lsc_acc_index(5, cpy)]; B += a[lsc_acc_index(6, cpy)]; }
+        const uint32_t xs = (uint32_t)(B >> 32) & 0xFFFFu, n10 = (uint32_t)(A >> 54);
+        const uint32_t n = n10 ? n10 : (xs ? 1024u : 0u);                     // (ten bits of count: see kLscAccW)
         if (n == 0u) continue;                                              // nothing for this cluster
         const uint32_t k = s_k[c];
         if (q <= kLscFeat) {
             // the value's half of its word (the copies' words add up without a carry between the halves: a block's total fits its half)
-            const int word = q < 4 ? q : q < 6 ? 4 : q < kLscFeat ? q - 6 : 5;
+            const int word = q < 4 ? q : q < 6 ? 4 : q < kLscFeat ? q - 6 : 6;
             const bool high = q == 5 || (q >= 6 && q < kLscFeat);
             unsigned long long w = 0;
             for (int cpy = 0; cpy < (1 << cshift); ++cpy) w += a[lsc_acc_index(word, cpy)];
@@ -564,16 +563,14 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
             const long long v = field << (q < kLscFeat ? l.blk_shift_f : l.blk_shift_w);      // to the fixed point of the global accumulators
             atomicAdd(reinterpret_cast<unsigned long long*>(l.extra + (size_t)k * kLscExPitch) + q, (unsigned long long)v);
         } else {
-            unsigned long long A = 0;
-            for (int cpy = 0; cpy < (1 << cshift); ++cpy) A += a[lsc_acc_index(6, cpy)];
             const int u = q - kLscFeat - 1;
             uint32_t v;
             if (u == 0) v = n;
-            else if (u == 1) v = yb0 * n + (uint32_t)stride * (uint32_t)(B >> 32);
-            else if (u == 2) v = (uint32_t)x0 * n + ((uint32_t)B & 0xFFFFFu);
-            else if (u == 3) v = (uint32_t)A & 0xFFFFFu;
-            else if (u == 4) v = (uint32_t)(A >> 20) & 0xFFFFFu;
-            else v = (uint32_t)(A >> 40);
+            else if (u == 1) v = yb0 * n + (uint32_t)stride * ((uint32_t)(B >> 48) & 0x3FFFu);
+            else if (u == 2) v = (uint32_t)x0 * n + xs;
+            else if (u == 3) v = (uint32_t)A & 0x3FFFFu;
+            else if (u == 4) v = (uint32_t)(A >> 18) & 0x3FFFFu;
+            else v = (uint32_t)(A >> 36) & 0x3FFFFu;
             atomicAdd(f.sums[0] + 6 * (size_t)k + u, v);
         }
     }
@@ -591,26 +588,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_lsc_assign_sums(FrameDev f, LscDev l, int rem, int stride, int Hv) {
     lsc_assign_body<true>(f, l, rem, stride, Hv);
-}
-
-// ---- update, second half ----------------------------------------------------------------------
-// C_f = sum w*F / sum w per cluster (src/lsc.cpp:256-269 then :309-316; 0/0 = NaN for a memberless cluster exactly as the
-// reference produces it) from the fixed-point accumulators the assign pass filled, which are cleared for the next pass.
-// The integer sums of the shared centroid update are in FrameDev::sums, where the cluster pass reads them.
-__global__ __launch_bounds__(256) void k_lsc_update(FrameDev f, LscDev l) {
-    f.select(blockIdx.y);
-    l.select(blockIdx.y);
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int k = t >> 4, q = t & 15;                       // 16 threads per cluster: 10 features, the weight, 5 idle
-    if (k >= f.K) return;
-    long long* e = l.extra + (size_t)k * kLscExPitch;
-    const long long mine = q <= kLscFeat ? e[q] : 0ll;
-    const long long wsum = e[kLscFeat];
-    const float acc = (float)((double)mine / (double)kLscFixF), tot_w = (float)((double)wsum / (double)kLscFixW);
-    if (q < kLscFeat) l.cfeat[(size_t)k * kLscCfPitch + q] = acc / tot_w;
-    // every thread of the cluster has read what it needs before any of them clears (same wavefront: 16 consecutive lanes)
-    __builtin_amdgcn_wave_barrier();
-    if (q <= kLscFeat) e[q] = 0;
 }
 
 // ---- preemptive mode (src/preemptive.h with ContextLSC's hooks) ------------------------------------------------------------------
@@ -701,12 +678,6 @@ void launch_lsc_assign(const FrameDev& f_, const LscDev& l, int nframes, int rem
     const dim3 grid((f.W + 63) / 64, (Hv + kLscBH - 1) / kLscBH, nframes);
     if (stale_sums) launch(k_lsc_assign_sums, grid, dim3(256), 0, st, f, l, rem, stride, Hv);
     else launch(k_lsc_assign, grid, dim3(256), 0, st, f, l, rem, stride, Hv);
-}
-
-void launch_lsc_update(const FrameDev& f_, const LscDev& l, int nframes, int rem, int stride, int sbuf, hipStream_t st) {
-    (void)rem; (void)stride;
-    const FrameDev f = rotated(f_, 0, sbuf);
-    launch(k_lsc_update, dim3((f.K * 16 + 255) / 256, nframes), dim3(256), 0, st, f, l);
 }
 
 }  // namespace fslic

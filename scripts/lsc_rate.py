@@ -11,6 +11,8 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 torch.cuda.set_device(0)
 eng = Engine(0, 6)                     # bench.py's default slot count
+bench.Workload.merged_max = 2          # as bench.py's default run: two submissions of 8 frames per launch group
+eng.pipeline_batching(16)
 w = bench.Workload(eng, 720, 1280, 1600, list(range(8)), variant_id=1)
 for _ in range(reps):
     print("LSC 720p pipelined, %d steps: %.0f MP/s" % (steps, w.throughput(steps)[0]))

@@ -31,6 +31,9 @@ CASES = [
     ("A_480x640_k200", "A", 480, 640, 200, {}),
     ("A_720x1280_k1600", "A", 720, 1280, 1600, {}),        # BASELINE.json configs[4]
     ("A_96x128_k300_small_S", "A", 96, 128, 300, {}),      # S = 6: more than 64 clusters reach a block (no block list: every cluster is walked)
+    # S = 202 on an all-zero raw frame: blocks of 64 x 16 pixels that are ONE cluster's (a count of 1024 wraps the ten bits it has in the
+    # block accumulators, and L = a = b = 0 leaves only the column sum to tell such a block from an empty one: lsc.hip, kLscAccW)
+    ("D_256x320_k2_whole_blocks", "D", 256, 320, 2, dict(subsample_stride=1, convert_to_lab=False, max_iter=4)),
 ]
 
 
