@@ -64,19 +64,7 @@ done
 # 6. the driver's command line under rocprofv3: what every stream does during the timed burst
 BURST_REPS=1 bash scripts/gpu_burst.sh > /dev/null 2>&1; cp $R/gpurun_out/burst_product_1.txt $OUT/burst_driver_cmdline.txt 2>/dev/null
 cd $R
-# 7. engine clock while the pipelined region runs (the fractions of a pipe's peak assume the 2.4 GHz of rocminfo)
-( timeout 120 python bench.py --timed-only --steps 6000 > $OUT/clock_bench.json 2>/dev/null & BP=$!
-  sleep 12
-  for i in 1 2 3 4 5 6 7 8; do
-    kill -0 $BP 2>/dev/null || break
-    rocm-smi --showclocks 2>/dev/null | grep -E "sclk|mclk|fclk" | tr -s ' ' | sed "s/^/sample $i (bench running): /"
-    rocm-smi --showpower 2>/dev/null | grep -iE "power" | tr -s ' ' | sed "s/^/sample $i (bench running): /"
-    sleep 0.5
-  done
-  wait $BP
-  sleep 2
-  rocm-smi --showclocks 2>/dev/null | grep -E "sclk|mclk|fclk" | tr -s ' ' | sed "s/^/idle: /" ) > $OUT/clocks_under_load.txt 2>&1
-# 8. the LSC group: SQ counters of every kernel (vector ALU / LDS time, bank conflicts of k_lsc_assign_sums)
+# 7. the LSC group: SQ counters of every kernel (vector ALU / LDS time, bank conflicts of k_lsc_assign_sums)
 PMC_VAR=lsc PMC_G=8 bash scripts/gpu_pmc_group.sh > /dev/null 2>&1; cp $R/gpurun_out/pmc_group.txt $OUT/lsc_pmc_instruction_mix.txt; cd $R
 python scripts/pmc_traffic_json.py $OUT/ > /dev/null 2>&1
 ls $OUT
