@@ -1,6 +1,8 @@
 // lab.hip -- RGB -> CIELAB prepass (src/cielab.h)
 // Hand-written gfx950 (CDNA4, wave64) kernels of the SLIC hot path; see kernels.h for the launch interface and
 // DESIGN.md for the design.  All arithmetic on this path is integer, so results are bit-identical to the reference.
+#include <cstdio>
+#include <cstdlib>
 #include "device_common.h"
 
 namespace fslic {
@@ -8,20 +10,28 @@ namespace fslic {
 // =============================================================================================
 // RGB -> CIELAB prepass.  Restates FastCIELabCvt::convert (src/cielab.h:309-325) with both lookup
 // tables staged in LDS (16.5 KB); 4 pixels per thread: 3 dword loads in, one 16-byte store out.
-// Algorithmic traffic: 3 B read + 4 B written per pixel.
+// Algorithmic traffic: 3 B read + 4 B written per pixel, + 2 B written per pixel where the kernel also fills the label plane (the
+// first kernel of every group): 9 B per pixel.  8 x 3840x2160 take 99 - 102 us = 5.9 TB/s, the rate of a plain streaming copy on this
+// part (6.2 TB/s, k_copy16): HBM-bound there.  16 x 1280x720: 29 - 31 us = 4.3 TB/s (512 blocks, ramp and tail).  Measured without
+// effect on either (round 5, profiles/r05_experiments.txt): 12 % fewer vector instructions (the dot2 rows below), two quads in
+// flight per thread.
 // =============================================================================================
-struct LabConst { int cb[9]; };
+struct LabConst { uint32_t c01[3], c2[3]; };      // per matrix row: coefficient 0 | coefficient 1 << 16, coefficient 2 (all below 2^16: launch_rgb_to_lab)
+typedef unsigned short lab_us2 __attribute__((ext_vector_type(2)));
 
 static __device__ __forceinline__ uint32_t lab_px(uint32_t R, uint32_t G, uint32_t B,
                                                   const uint16_t* sg, const uint16_t* sl, const LabConst& k) {
-    // (24-bit multiply-adds: the gamma values are below 2^14, the matrix coefficients below 2^16 and a row's sum below 2^30, so the
-    // results are the reference's ints; a 32-bit v_mul_lo_u32 issues at a quarter of the rate, and nine of them per pixel were more
-    // than half of this kernel's vector time)
+    // A matrix row is c0 * r + c1 * g + c2 * b with the gamma values below 2^14, the coefficients below 2^16 and the sum below 2^30, so
+    // the results are the reference's ints whichever way the products are formed: one v_dot2_u32_u16 on (r | g << 16) with the 24-bit
+    // product of the blue term as its addend -- 7 instructions per pixel for the three rows instead of 12 (three 24-bit products and a
+    // three-operand add per row; 32-bit v_mul_lo_u32, a quarter of the rate, before that: nine of them were more than half of this
+    // kernel's vector time).
     const uint32_t sr = sg[R], sgv = sg[G], sb = sg[B];
+    const lab_us2 rg = __builtin_bit_cast(lab_us2, sr | (sgv << 16));
     auto row = [&](int i) -> int {
-        return (int)((__umul24((uint32_t)k.cb[i], sr) + __umul24((uint32_t)k.cb[i + 1], sgv) + __umul24((uint32_t)k.cb[i + 2], sb)) >> 16);
+        return (int)(__builtin_amdgcn_udot2(rg, __builtin_bit_cast(lab_us2, k.c01[i]), __umul24(k.c2[i], sb), false) >> 16);
     };
-    const int xr = row(0), yr = row(3), zr = row(6);
+    const int xr = row(0), yr = row(1), zr = row(2);
     const int fx = sl[xr], fy = sl[yr], fz = sl[zr];
     const int ciel = 116 * fy - (16 << 13);
     const int ciea = 500 * (fx - fy) + (128 << 13);
@@ -125,7 +135,12 @@ __global__ __launch_bounds__(1024) void k_rgb_to_lab(FrameDev f, const uint16_t*
 void launch_rgb_to_lab(const FrameDev& f, int nframes, int convert, const LabTables& t, bool init_labels, hipStream_t st, uint32_t gen_step,
                        void* zero_a, size_t zero_a_bytes, uint32_t* zero_b, size_t zero_b_words) {
     LabConst kc;
-    for (int i = 0; i < 9; i++) kc.cb[i] = t.cb[i];
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++)
+            if (t.cb[3 * i + j] < 0 || t.cb[3 * i + j] > 0xFFFF) { fprintf(stderr, "fslic: RGB->XYZ coefficient outside 16 bits\n"); abort(); }      // (src/cielab.h:300-301: all below 1.0 * 65536)
+        kc.c01[i] = (uint32_t)t.cb[3 * i] | ((uint32_t)t.cb[3 * i + 1] << 16);
+        kc.c2[i] = (uint32_t)t.cb[3 * i + 2];
+    }
     int blocks = (f.N / 4 + 1023) / 1024;
     const int cap = (512 + nframes - 1) / nframes;   // about two resident blocks per CU over the whole group, grid-stride
     if (blocks > cap) blocks = cap;
