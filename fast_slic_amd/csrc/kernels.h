@@ -18,7 +18,10 @@ constexpr int kRowsPerWave = 8;     // visited rows per wavefront
 constexpr int kCellCap = 8;         // cluster records per coarse cell before spilling to overflow
 constexpr int kAccSlots = 16;       // candidates per wavefront with LDS-privatised centroid sums
 constexpr int kAccCopies = 8;       // privatised copies per (slot, quantity)
-constexpr int kBlkCopies = 4;       // block-level kernel: privatised copies per (candidate, quantity)
+#ifndef FSLIC_BLK_COPIES
+#define FSLIC_BLK_COPIES 4
+#endif
+constexpr int kBlkCopies = FSLIC_BLK_COPIES;       // block-level kernel: privatised copies per (candidate, quantity)
 constexpr uint32_t kHuge = 0x40000000u;   // out-of-window marker added to the distance key
 constexpr int kCcaTile = 64;        // connectivity tile width  (one wavefront of columns)
 constexpr int kCcaTileH = 32;       // connectivity tile height (4 wavefronts x 8 rows), one block of 256 threads

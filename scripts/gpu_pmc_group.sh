@@ -22,7 +22,7 @@ for r in csv.reader(open("$OUT/pmc_group.csv")):
     d[r[0]][r[1][3:]] = float(r[2]); calls[r[0]] = int(r[3]) / 3.0
 SIMDS, CUS, GHZ = 1024.0, 256.0, 2.4
 print("per GROUP (calls x mean), in us at %.1f GHz if that unit alone were the limit: VALU = INSTS_VALU x 4 cycles / %d SIMDs; LDS = LDS_IDX_ACTIVE / %d CUs" % (GHZ, SIMDS, CUS))
-print("%-52s %6s %9s %9s %9s %9s %9s %9s" % ("kernel", "calls", "VALU us", "SALU us", "LDS us", "VMEM/wave", "waves", "busyCU us"))
+print("%-52s %6s %9s %9s %9s %9s %9s %9s %9s" % ("kernel", "calls", "VALU us", "SALU us", "LDS us", "VMEM/wave", "waves", "busyCU us", "bank-cf"))      # bank-cf: LDS_BANK_CONFLICT / LDS_IDX_ACTIVE
 tot = collections.Counter()
 for k, v in sorted(d.items(), key=lambda kv: -kv[1].get("INSTS_VALU", 0) * calls[kv[0]]):
     n = calls[k]
@@ -32,7 +32,7 @@ for k, v in sorted(d.items(), key=lambda kv: -kv[1].get("INSTS_VALU", 0) * calls
     vm = (v.get("INSTS_VMEM_RD", 0) + v.get("INSTS_VMEM_WR", 0)) / max(v.get("WAVES", 1), 1)
     busy = n * v.get("BUSY_CU_CYCLES", 0) / CUS / GHZ / 1e3
     tot.update({"valu": valu, "salu": salu, "lds": lds, "busy": busy})
-    print("%-52s %6.1f %9.2f %9.2f %9.2f %9.1f %9.0f %9.2f" % (k[:52], n, valu, salu, lds, vm, v.get("WAVES", 0), busy))
+    print("%-52s %6.1f %9.2f %9.2f %9.2f %9.1f %9.0f %9.2f %9.2f" % (k[:52], n, valu, salu, lds, vm, v.get("WAVES", 0), busy, v.get("LDS_BANK_CONFLICT", 0) / max(v.get("LDS_IDX_ACTIVE", 0), 1)))
 print("%-52s %6s %9.2f %9.2f %9.2f %9s %9s %9.2f" % ("group total", "", tot["valu"], tot["salu"], tot["lds"], "", "", tot["busy"]))
 PY
 cat $OUT/pmc_group.txt
