@@ -167,6 +167,8 @@ constexpr int kLscAccEntries = 64 << kLscCopyShift;
 // lane's record, so the lanes of an instruction hit neighbouring 8-byte words; record-major (records 64 bytes apart) put word q of
 // ANY record on one of two bank pairs and queued a wavefront's 16 quad leaders 8 deep (profiles/r05_lsc_knockout.txt).
 constexpr int kLscAccW = 7;
+static_assert(kLscBH == 16 && kTileW == 64, "the integer fields of words 5 and 6 are sized for blocks of 64 x 16 pixels: count <= 1024 (ten bits + the wrap rule), "
+                                            "column sum <= 16 * 2016 < 2^16, row sum <= 64 * 120 < 2^14, colour sums <= 255 * 1024 < 2^18");
 static __device__ __forceinline__ int lsc_acc_index(int word, uint32_t record) { return word * kLscAccEntries + (int)record; }
 constexpr uint32_t kLscNoSlot = 0xFFFFFFFFu;
 constexpr int kDppQuadSwap1 = 0xB1, kDppQuadSwap2 = 0x4E;     // quad_perm [1,0,3,2] and [2,3,0,1]
