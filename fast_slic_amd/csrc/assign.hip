@@ -1064,13 +1064,20 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
                     __builtin_amdgcn_raw_buffer_store_b16((uint16_t)kk[r], ws, (int)((uint32_t)x * 2u), (int)(so0 + (uint32_t)r * pitch2), kAuxSc1);
                 ASG_STAMP(5, wave == 0);
                 if (FUSE) {
-                    // Sums of update() (src/context.cpp:301-354), second form.  A lane keeps the PREFIX sums of its column (three
-                    // v_dot4 per row, nothing else: count, sum x and sum y of a prefix are constants of the row number).  Where the
-                    // label changes between rows r and r+1 the prefix goes to the upper run's accumulator with + and to the lower
-                    // run's with -, the whole column at the end to the last run's with +: every run receives (prefix at its end) -
-                    // (prefix at its start) in two pieces, and the 64-bit words (three 20-bit-spaced fields each, see s_acc) are added
-                    // modulo 2^64, so the transient negative pieces cost nothing.  No per-run state, no resets, no comparisons of
-                    // accumulated values: 4.5 vector instructions per row plus 9 per row gap in which some lane changes its label.
+                    // Sums of update() (src/context.cpp:301-354), third form.  A lane keeps the PREFIX sums of its column (three v_dot4 per
+                    // row, nothing else: count, sum x and sum y of a prefix are constants of the row number).  Where the label changes
+                    // between rows r and r+1 the run that ends there is (prefix now) - (prefix at the lane's previous change): two packed
+                    // 64-bit differences (three 20-bit-spaced fields each, see s_acc; field by field non-negative, so no borrow crosses a
+                    // field), added to that run's accumulator; the column's last run at the end.  TWO 64-bit LDS atomics and ~14 vector
+                    // instructions per row gap in which some lane changes its label; the second form (+ prefix to the upper run, - prefix
+                    // to the lower run, no per-lane state) issued four atomics for the same vector work.
+                    // What this epilogue costs, measured in round 5 (profiles/r05_experiments.txt): without the work at the label changes
+                    // the launch of 16 x 1280x720 takes 12.3 instead of 16.2 us (knock-out build 1) -- but halving the atomics (this form)
+                    // gave 16.66 -> 16.54 us, so it is the ~14 vector instructions a wavefront executes per gap for a handful of lanes,
+                    // 15 gaps per wavefront of 16 rows, not the LDS pipe (a 64-bit LDS atomic occupies it for 6.5 clk whatever the number
+                    // of lanes, profiles/r05_microbench_valu_lds_overlap.txt).  Lanes HOLDING their finished run until a common flush
+                    // point every five rows (8 - 12 atomics per wavefront instead of 32): 18.3 us -- columns that run along a jagged
+                    // boundary change label at nearly every gap and force the flush there and then, on top of the capture.
                     const uint32_t copy16 = ((uint32_t)lane & (kBlkCopies - 1)) * 16u;
                     const uint32_t dyw = (uint32_t)(wave * R * STRIDE);
                     char* const accb = reinterpret_cast<char*>(s_acc);
@@ -1085,6 +1092,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
                         A = (unsigned long long)a_lo | ((unsigned long long)a_hi << 32);
                         B = (unsigned long long)b_lo | ((unsigned long long)b_hi << 32);
                     };
+                    unsigned long long prevA = 0ull, prevB = 0ull;      // the packed prefixes at the lane's last label change
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const uint32_t p = pix[r];
@@ -1094,23 +1102,25 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
                         if (r == R - 1) break;
                         const uint32_t cur = (r & 1) ? (wq[r / 2] >> 16) : (wq[r / 2] & 0xFFFFu);
                         const uint32_t nxt = (r & 1) ? (wq[r / 2 + 1] & 0xFFFFu) : (wq[r / 2] >> 16);
+#if FSLIC_EXP & 1      // (knock-out build 1: no accumulator updates at the label changes -- sums wrong on purpose)
+                        if (false) {
+#else
                         if (cur != nxt) {
+#endif
                             unsigned long long A, B;
                             words(r + 1, A, B);
-                            unsigned long long* const up = reinterpret_cast<unsigned long long*>(accb + (cur * (uint32_t)(kBlkCopies * 16) + copy16));
-                            unsigned long long* const dn = reinterpret_cast<unsigned long long*>(accb + (nxt * (uint32_t)(kBlkCopies * 16) + copy16));
-                            atomicAdd(up, A);
-                            atomicAdd(up + 1, B);
-                            __hip_atomic_fetch_sub(dn, A, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            __hip_atomic_fetch_sub(dn + 1, B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            unsigned long long* const run = reinterpret_cast<unsigned long long*>(accb + (cur * (uint32_t)(kBlkCopies * 16) + copy16));
+                            atomicAdd(run, A - prevA);
+                            atomicAdd(run + 1, B - prevB);
+                            prevA = A; prevB = B;
                         }
                     }
                     {
                         unsigned long long A, B;
                         words(R, A, B);
                         unsigned long long* const last = reinterpret_cast<unsigned long long*>(accb + ((wq[R / 2 - 1] >> 16) * (uint32_t)(kBlkCopies * 16) + copy16));
-                        atomicAdd(last, A);
-                        atomicAdd(last + 1, B);
+                        atomicAdd(last, A - prevA);
+                        atomicAdd(last + 1, B - prevB);
                     }
                 }
             }
