@@ -529,7 +529,11 @@ __global__ __launch_bounds__(256) void k_cca_compress(CcaDev c, int nframes) {
         __syncthreads();
         if (threadIdx.x == 0 && s_app[0]) s_app[1] = atomicAdd(&c.counters[1], s_app[0]);
         __syncthreads();
-        if (cand) c.cand_leader[s_app[1] + wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = leader;
+        if (cand) {     // the leader and, beside it, its node (the component's root): k_cca_select then reaches the area in two dependent loads, not three
+            const uint32_t at = s_app[1] + wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            c.cand_leader[at] = leader;
+            c.cand_area[at] = g;
+        }
     }
 }
 
@@ -937,16 +941,14 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int cap) {
         if (tid == 0) c.counters[3] = 2u;
         return;
     }
-    // leader -> component number of its pixel -> area of that node: three dependent global loads per candidate.  Four candidates per
-    // thread and trip with the loads of each stage in flight together (one candidate after the other the chain was paid per candidate:
-    // 18 of the 25 us this step took for the 6 060 candidates of a 3840x2160 K=6000 frame)
+    // (leader, node) -> area of that node: two dependent global loads per candidate (three until k_cca_compress wrote the node beside the
+    // leader).  Four candidates per thread and trip with the loads of each stage in flight together (one candidate after the other the
+    // chain was paid per candidate: 18 of the 25 us this step took for the 6 060 candidates of a 3840x2160 K=6000 frame)
     uint32_t amax = 0;
     for (uint32_t i0 = tid; i0 < M; i0 += 4096) {
         uint32_t l[4], nd[4], a[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) l[u] = (uint32_t)c.cand_leader[min(i0 + 1024u * u, M - 1u)];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) nd[u] = node_of(c, l[u]);
+        for (int u = 0; u < 4; ++u) { l[u] = (uint32_t)c.cand_leader[min(i0 + 1024u * u, M - 1u)]; nd[u] = c.cand_area[min(i0 + 1024u * u, M - 1u)]; }      // (the node: written by k_cca_compress)
 #pragma unroll
         for (int u = 0; u < 4; ++u) a[u] = c.narea[nd[u]];      // (a leader's node is its component's root)
 #pragma unroll
@@ -1026,6 +1028,8 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int cap) {
         uint32_t me[4], r[4], nd[4];
         bool kept[4];
 #pragma unroll
+        for (int u = 0; u < 4; ++u) nd[u] = c.cand_area[min(i0 + 1024u * u, M - 1u)];      // the candidates' nodes (k_cca_compress), requested before the ranks are counted
+#pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t i = i0 + 1024u * u;
             kept[u] = i < M && s_area[i] >= astar;
@@ -1038,8 +1042,6 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int cap) {
                 for (uint32_t j = lo; j < hi; ++j) r[u] += (uint32_t)(s_key[j] < me[u]);
             }
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) nd[u] = node_of(c, me[u]);
 #pragma unroll
         for (int u = 0; u < 4; ++u) if (kept[u]) c.nfinal[nd[u]] = (uint16_t)r[u];
     }
