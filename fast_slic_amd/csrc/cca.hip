@@ -485,6 +485,7 @@ __global__ __launch_bounds__(256) void k_cca_compress(CcaDev c, int nframes) {
     // go to different frames' counters
     const uint32_t bx = blockIdx.x / (unsigned)nframes, nbx = gridDim.x / (unsigned)nframes;
     c.select((int)(blockIdx.x % (unsigned)nframes));
+    const uint32_t r_first = c.roots[bx * blockDim.x + threadIdx.x];      // requested together with the count (capacity: see k_cca_chain)
     const uint32_t n = c.counters[0];
     const int lane = LANE();
     const uint32_t gstride = nbx * blockDim.x;
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(256) void k_cca_compress(CcaDev c, int nframes) {
         if (threadIdx.x == 0) s_app[0] = 0u;
         __syncthreads();
         const bool live = i < n;
-        const uint32_t r = c.roots[min(i, n - 1)];
+        const uint32_t r = (b0 == bx * blockDim.x && live) ? r_first : c.roots[min(i, n - 1)];
         const uint32_t a = n_local(c, r);
         // READ-ONLY walk: a path-halving store of another thread (parent[r] = some ancestor) could land after this
         // thread's parent[r] = g and leave r one level short of flat, and chain / relabel rely on parent[node]
@@ -933,7 +934,12 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int cap) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int K = c.K;
-    // 1. the frame's candidates -> LDS
+    // 1. the frame's candidates -> LDS.  The first trip's (leader, node) pairs are requested together with the count: the lists hold
+    // one entry per pixel of whole 64 x 32 tiles, i.e. at least max(N, 2048), and entries past the count are not used.
+    const uint32_t cand_last = (uint32_t)max(c.N, 2048) - 1u;
+    uint32_t l_first[4], nd_first[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { l_first[u] = (uint32_t)c.cand_leader[min((uint32_t)threadIdx.x + 1024u * u, cand_last)]; nd_first[u] = c.cand_area[min((uint32_t)threadIdx.x + 1024u * u, cand_last)]; }
     const uint32_t M = c.counters[1];
     if (tid < 8) s_v[tid] = 0;
     if (tid == 0) c.counters[2] = M;
@@ -948,7 +954,10 @@ __global__ __launch_bounds__(1024) void k_cca_select(CcaDev c, int cap) {
     for (uint32_t i0 = tid; i0 < M; i0 += 4096) {
         uint32_t l[4], nd[4], a[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { l[u] = (uint32_t)c.cand_leader[min(i0 + 1024u * u, M - 1u)]; nd[u] = c.cand_area[min(i0 + 1024u * u, M - 1u)]; }      // (the node: written by k_cca_compress)
+        for (int u = 0; u < 4; ++u) {      // (the node: written by k_cca_compress)
+            if (i0 == (uint32_t)tid) { l[u] = l_first[u]; nd[u] = i0 + 1024u * u < M ? nd_first[u] : 0u; }      // (an entry past the count may hold anything: node 0 is read instead, and not used)
+            else { l[u] = (uint32_t)c.cand_leader[min(i0 + 1024u * u, M - 1u)]; nd[u] = c.cand_area[min(i0 + 1024u * u, M - 1u)]; }
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) a[u] = c.narea[nd[u]];      // (a leader's node is its component's root)
 #pragma unroll
@@ -1130,10 +1139,14 @@ static __device__ __forceinline__ uint32_t chase_final(const CcaDev& c, uint32_t
 
 __global__ __launch_bounds__(256) void k_cca_chain(CcaDev c) {
     c.select(blockIdx.y);
+    // the first root is requested together with the count (the list's capacity covers the grid: root_pass_blocks): one dependent
+    // round trip less at the head of a kernel that is a chain of them
+    const uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r0 = c.roots[i0];
     const uint32_t n = c.counters[0];
     const uint32_t gstride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gstride) {
-        const uint32_t r = c.roots[i];
+    for (uint32_t i = i0; i < n; i += gstride) {
+        const uint32_t r = i == i0 ? r0 : c.roots[i];
         const uint32_t g = *n_parent(c, r);
         // the component's final label: set already when it was kept, or when its own thread got here first; otherwise
         // chased from its leader (whoever computes it finds the same value)

@@ -232,7 +232,7 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     // + labels <- 0xFFFF (src/context.cpp:138-145); + a fresh range of bin generation stamps for this group's passes
     f.gen_base = s.d_gen;
     launch_rgb_to_lab(f, n, p->convert_to_lab, e->tables, true, s.st, s.gen_step,
-                      s.at(s.zero_block, i0), s.zero_bytes, f.cl_n, 2 * (size_t)K);
+                      s.at(s.zero_block, i0), s.zero_bytes, f.cl_n, 2 * (size_t)K, s.h_cl + (size_t)i0 * 4 * K, 4 * (size_t)K);      // (+ the staged centres -> cl_yx)
     if (timed) HIPCHK(hipEventRecord(s.ev[1], s.st));
     f.gen_off = 1;
     PassGeom pg{};
@@ -243,7 +243,7 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     f.cl_yx = yx_up; f.cl_yx_out = yx_a;
     const int stride = p->subsample_stride;
     const bool lsc = p->variant == FSLIC_VARIANT_LSC;
-    launch_bin_clusters(f, n, 0, 0, 0, pg, s.st, s.h_cl + (size_t)i0 * 4 * K, 4 * (size_t)K);
+    launch_bin_clusters(f, n, 0, 0, 0, pg, s.st);      // (the centres are in cl_yx: copied from the host's staging block by the LAB kernel)
     uint32_t* yx_cur = yx_a;
     int rem = 0;
     LscDev l = s.l;

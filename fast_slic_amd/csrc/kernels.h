@@ -234,8 +234,11 @@ struct LabTables {
 // gen_step != 0: first kernel of a group, advances FrameDev::gen_base by gen_step (more than the group's bin passes)
 // zero_a / zero_b: optional per-frame regions (frame 0's address; zero_a_bytes a multiple of 16, zero_b_words dwords) the
 // kernel clears as well -- the accumulators, bin counters and flags a group starts from (no separate memset launches)
+// stage_yx != nullptr: the group's cluster centres as the host staged them (pinned memory, stage_stride words per frame): blocks of their own
+// copy them into FrameDev::cl_yx beside the conversion, and the first cluster pass reads device memory
 void launch_rgb_to_lab(const FrameDev& f, int nframes, int convert, const LabTables& t, bool init_labels, hipStream_t st, uint32_t gen_step = 0,
-                       void* zero_a = nullptr, size_t zero_a_bytes = 0, uint32_t* zero_b = nullptr, size_t zero_b_words = 0);
+                       void* zero_a = nullptr, size_t zero_a_bytes = 0, uint32_t* zero_b = nullptr, size_t zero_b_words = 0,
+                       const uint32_t* stage_yx = nullptr, size_t stage_stride = 0);
 // mode 0: resample colours at the current centres (src/context.cpp:128-135) and bin;
 // mode 1: integer centroid update from `sums` (src/context.cpp:356-373), zero sums, and bin.
 // mode 0 with src_yx != nullptr: the centres come from there (the engine's pinned staging block, read in place; frame z at

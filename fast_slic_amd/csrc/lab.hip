@@ -48,19 +48,28 @@ static __device__ __forceinline__ uint32_t lab_px(uint32_t R, uint32_t G, uint32
 template <bool CONVERT>
 __global__ __launch_bounds__(1024) void k_rgb_to_lab(FrameDev f, const uint16_t* __restrict__ g_gamma,
                                                      const uint16_t* __restrict__ g_labtbl, LabConst kc, int init_labels, uint32_t gen_step,
-                                                     char* zero_a, unsigned zero_a_quads, uint32_t* zero_b, unsigned zero_b_words) {
+                                                     char* zero_a, unsigned zero_a_quads, uint32_t* zero_b, unsigned zero_b_words,
+                                                     const uint32_t* __restrict__ stage_yx, size_t stage_stride, int stage_K, int conv_blocks) {
     __shared__ uint16_t s_gamma[256];
     __shared__ uint16_t s_lab[8194];
     // first kernel of a group: new generation of bin stamps (nothing in this kernel reads them; the stream orders the rest)
     if (gen_step && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *f.gen_base += gen_step;
     f.select(blockIdx.y);
+    if ((int)blockIdx.x >= conv_blocks) {
+        // blocks behind the conversion's: the group's cluster centres from where the host staged them (pinned memory) into device memory
+        // -- the read over the bus (~2 us) runs beside the conversion instead of at the head of the first cluster pass
+        const uint32_t* src = stage_yx + (size_t)blockIdx.y * stage_stride;
+        for (int i = ((int)blockIdx.x - conv_blocks) * (int)blockDim.x + (int)threadIdx.x; i < stage_K; i += ((int)gridDim.x - conv_blocks) * (int)blockDim.x)
+            f.cl_yx[i] = src[i];
+        return;
+    }
     const uint8_t* __restrict__ rgb = f.rgb;
     uint32_t* __restrict__ lab = f.lab;
     uint16_t* __restrict__ labels_init = init_labels ? f.labels : nullptr;
     const int N = f.N;
     const int aligned4 = ((reinterpret_cast<uintptr_t>(rgb) & 3) == 0) ? 1 : 0;
     const int nquad = aligned4 ? (N >> 2) : 0;
-    const int gstride = gridDim.x * blockDim.x;
+    const int gstride = conv_blocks * blockDim.x;
     // Software-pipelined over the thread's quads: the next quad's loads are issued BEFORE this quad's stores, so that
     // waiting for them does not also wait for the acknowledgement of the written-through stores (one vector-memory
     // counter covers both; a load issued after a store cannot be waited for without the store).
@@ -126,14 +135,14 @@ __global__ __launch_bounds__(1024) void k_rgb_to_lab(FrameDev f, const uint16_t*
     // at the top of the kernel these stores sat in front of the first quad's loads.
     {
         const size_t fo = (size_t)blockIdx.y * f.frame_bytes;
-        const unsigned t0 = blockIdx.x * blockDim.x + threadIdx.x, ts = gridDim.x * blockDim.x;
+        const unsigned t0 = blockIdx.x * blockDim.x + threadIdx.x, ts = (unsigned)conv_blocks * blockDim.x;
         if (zero_a) { uint4* za = reinterpret_cast<uint4*>(zero_a + fo); for (unsigned i = t0; i < zero_a_quads; i += ts) za[i] = make_uint4(0u, 0u, 0u, 0u); }
         if (zero_b) { uint32_t* zb = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(zero_b) + fo); for (unsigned i = t0; i < zero_b_words; i += ts) zb[i] = 0u; }
     }
 }
 
 void launch_rgb_to_lab(const FrameDev& f, int nframes, int convert, const LabTables& t, bool init_labels, hipStream_t st, uint32_t gen_step,
-                       void* zero_a, size_t zero_a_bytes, uint32_t* zero_b, size_t zero_b_words) {
+                       void* zero_a, size_t zero_a_bytes, uint32_t* zero_b, size_t zero_b_words, const uint32_t* stage_yx, size_t stage_stride) {
     LabConst kc;
     for (int i = 0; i < 3; i++) {
         for (int j = 0; j < 3; j++)
@@ -145,10 +154,13 @@ void launch_rgb_to_lab(const FrameDev& f, int nframes, int convert, const LabTab
     const int cap = (512 + nframes - 1) / nframes;   // about two resident blocks per CU over the whole group, grid-stride
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
+    const int stage_blocks = stage_yx ? (f.K + 1023) / 1024 : 0;      // the centres' prefetch (see the kernel)
     if (convert)
-        launch(k_rgb_to_lab<true>, dim3(blocks, nframes), dim3(1024), 0, st, f, t.gamma, t.labtbl, kc, init_labels ? 1 : 0, gen_step, (char*)zero_a, (unsigned)(zero_a_bytes / 16), zero_b, (unsigned)zero_b_words);
+        launch(k_rgb_to_lab<true>, dim3(blocks + stage_blocks, nframes), dim3(1024), 0, st, f, t.gamma, t.labtbl, kc, init_labels ? 1 : 0, gen_step, (char*)zero_a, (unsigned)(zero_a_bytes / 16), zero_b, (unsigned)zero_b_words,
+               stage_yx, stage_stride, f.K, blocks);
     else
-        launch(k_rgb_to_lab<false>, dim3(blocks, nframes), dim3(1024), 0, st, f, t.gamma, t.labtbl, kc, init_labels ? 1 : 0, gen_step, (char*)zero_a, (unsigned)(zero_a_bytes / 16), zero_b, (unsigned)zero_b_words);
+        launch(k_rgb_to_lab<false>, dim3(blocks + stage_blocks, nframes), dim3(1024), 0, st, f, t.gamma, t.labtbl, kc, init_labels ? 1 : 0, gen_step, (char*)zero_a, (unsigned)(zero_a_bytes / 16), zero_b, (unsigned)zero_b_words,
+               stage_yx, stage_stride, f.K, blocks);
 }
 
 }  // namespace fslic
