@@ -375,9 +375,9 @@ def single_frame_latency(eng, wl, reps=24):
 
 def end_to_end_ref_binding(H, W, K, budget_s=3.0, threads=4):
     """The same through the drop-in itself: the REFERENCE's Cython binding with the arch "hip/gfx950" patched in
-    (integration/_build, built by integration/build_ref_binding.sh), driven through its own fast_slic.hip.SlicHip facade when the
-    compiled package travelled with it, else through cfast_slic.SlicModel the way fast_slic/base_slic.py:18-52 drives it.  Runs in
-    a separate interpreter (the patched module links libfslic_hip.so itself).  None when integration/_build is absent."""
+    (integration/_build, built by integration/build_ref_binding.sh): cfast_slic.SlicModel(K, "hip/gfx950") driven the way
+    fast_slic/base_slic.py:18-52 drives it (only the compiled extension travels to the GPU box, not the reference's Python
+    package).  Runs in a separate interpreter (the patched module links libfslic_hip.so itself).  None when integration/_build is absent."""
     import glob
     import subprocess
     build = os.path.join(ROOT, "integration", "_build")
@@ -390,26 +390,20 @@ sys.path.insert(0, %(build)r); sys.path.insert(1, %(root)r)
 from fast_slic_amd.synth import variant
 H, W, K, budget, threads = %(H)d, %(W)d, %(K)d, %(budget)f, %(threads)d
 imgs = [variant("A", H, W, seed=s) for s in range(4)]
-try:
-    from fast_slic.hip import SlicHip
-    facade = "fast_slic.hip.SlicHip"
-    def make():
-        return SlicHip(num_components=K, compactness=10)
-except ImportError:
-    import cfast_slic
-    facade = "cfast_slic.SlicModel('hip/gfx950') driven like fast_slic/base_slic.py"
-    class _M(object):
-        def __init__(self):
-            m = cfast_slic.SlicModel(K, "hip/gfx950")
-            m.convert_to_lab = True; m.preemptive = False; m.preemptive_thres = 0.05
-            m.manhattan_spatial_dist = True; m.num_threads = -1; m.debug_mode = False
-            self.slic_model = m
-        def iterate(self, image, max_iter=10):
-            if not self.slic_model.initialized:
-                self.slic_model.initialize(image)
-            return self.slic_model.iterate(image, max_iter, 10, 0.25, 3)
-    def make():
-        return _M()
+import cfast_slic
+facade = "cfast_slic.SlicModel('hip/gfx950') driven like fast_slic/base_slic.py"
+class _M(object):
+    def __init__(self):
+        m = cfast_slic.SlicModel(K, "hip/gfx950")
+        m.convert_to_lab = True; m.preemptive = False; m.preemptive_thres = 0.05
+        m.manhattan_spatial_dist = True; m.num_threads = -1; m.debug_mode = False
+        self.slic_model = m
+    def iterate(self, image, max_iter=10):
+        if not self.slic_model.initialized:
+            self.slic_model.initialize(image)
+        return self.slic_model.iterate(image, max_iter, 10, 0.25, 3)
+def make():
+    return _M()
 def run(nt):
     counts = [0] * nt
     stop = time.perf_counter() + budget / 2

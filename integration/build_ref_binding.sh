@@ -20,7 +20,7 @@ if [ ! -d "$REF" ]; then
   fi
   exit 0
 fi
-if [ -f "$STAMP" ] && [ "$(cat $STAMP)" = "$NEW" ] && ls $B/cfast_slic*.so >/dev/null 2>&1 && [ -f $B/fast_slic/hip.pyc ]; then exit 0; fi
+if [ -f "$STAMP" ] && [ "$(cat $STAMP)" = "$NEW" ] && ls $B/cfast_slic*.so >/dev/null 2>&1; then exit 0; fi
 rm -rf "$B"; mkdir -p "$B"
 T=$(mktemp -d /tmp/fslic_refbuild.XXXXXX)
 trap 'rm -rf "$T"' EXIT
@@ -33,10 +33,9 @@ export FSLIC_HIP_LIBDIR=$ROOT/fast_slic_amd
 export FSLIC_HIP_RPATH='$ORIGIN/../../fast_slic_amd'
 python3 setup.py -q build_ext --inplace > "$B/build.log" 2>&1 || { tail -30 "$B/build.log"; exit 1; }
 cp cfast_slic*.so "$B/"
-# the facade package as the reference ships it plus fast_slic/hip.py from the patch, COMPILED (sourceless .pyc, like the .so: a
-# built form of the patched reference, git-ignored): lets the GPU box import fast_slic.hip.SlicHip / LSCHip
-python3 -m compileall -q -b fast_slic > /dev/null
-mkdir -p "$B/fast_slic"
-cp fast_slic/*.pyc "$B/fast_slic/"
+# Only the compiled extension travels.  The reference's Python facade (fast_slic/*.py) stays where it is: neither source nor
+# bytecode of it enters this repository or the GPU box.  Where /root/reference exists (this container) the facade hunk of the
+# patch, fast_slic/hip.py, is imported against the scratch copy right here and the outcome kept in the build directory:
+PYTHONPATH="$B:$T/fast-slic" python3 "$HERE/facade_check.py" > "$B/facade_import.log" 2>&1 || true
 echo "$NEW" > "$STAMP"
 echo "[integration] built $(ls $B/cfast_slic*.so)"
