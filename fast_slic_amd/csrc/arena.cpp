@@ -264,7 +264,9 @@ int prepare_lsc(Slot& s, int H, int W, int K, int S, int G, float compactness) {
         const double w_max = 2.0 * C_color * C_color + 4.0 * (C_color * 2.55) * (C_color * 2.55) + 4.0 * (double)C_spatial * C_spatial;
         int bits_f = 20, bits_w = 12;                  // never finer than the global accumulators (2^-20, 2^-12: lsc.hip kLscFixF / kLscFixW)
         while (bits_f > 0 && 1024.0 * f_max * ldexp(1.0, bits_f) >= 2147483648.0) bits_f--;
-        while (bits_w > 0 && 1024.0 * w_max * ldexp(1.0, bits_w) >= 4294967296.0) bits_w--;
+        const double w_bias = ceil(4.0 * (double)C_spatial * C_spatial);      // LscDev::blk_bias_w: the stored weight is never negative
+        while (bits_w > 0 && 1024.0 * (w_max + w_bias) * ldexp(1.0, bits_w) >= 4294967296.0) bits_w--;
+        s.l.blk_bias_w = (float)w_bias;
         s.l.blk_fix_f = (float)ldexp(1.0, bits_f); s.l.blk_fix_w = (float)ldexp(1.0, bits_w);
         s.l.blk_shift_f = 20 - bits_f; s.l.blk_shift_w = 12 - bits_w;
         s.lsc_S = S; s.lsc_compactness = compactness;

@@ -419,6 +419,14 @@ static __device__ __forceinline__ void row_masks(uint32_t inv, uint32_t (&m)[R /
 #define ASG_STAMP(i_, cond_) do { } while (0)
 #define ASG_PUT(i_, cond_, v_) do { } while (0)
 #endif
+// Analysis listing only (scripts/isa_budget.py compiles this file with -DFSLIC_MARKS -S): a comment line in the assembly at every
+// phase boundary of the block kernel, so that the static instruction count of each phase can be read off the ISA.  The product build
+// emits nothing here.
+#ifdef FSLIC_MARKS
+#define ASG_MARK(name_) asm volatile("; @@MARK " name_ ::: "memory")
+#else
+#define ASG_MARK(name_) do { } while (0)
+#endif
 // =============================================================================================
 // The block assign kernel's body (second form, round 3; the first form -- one wavefront builds and sorts the list while three
 // stage the table through registers -- is in the history and in profiles/r02_*).  The phase stamps of lab build 4
@@ -564,10 +572,12 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
     constexpr int BH = kWavesPerBlock * R;
     static_assert(!FUSE || (BH * 64 * 255 < (1 << 20) && (BH - 1) * STRIDE * BH * 64 < (1 << 20)), "accumulator fields overflow");
 
+    ASG_MARK("entry");
     f.select((int)bzi);
     const uint32_t gen = f.generation();
     const int tid = threadIdx.x;
     if (FBIN) {
+
         // housekeeping the separate cluster pass used to do: the counters of the bins this pass READS (nobody looks at them
         // while the records are stamped) are cleared for the pass after next; likewise the spill counter nobody uses in this pass
         const uint32_t gi = (byi * bm.gx + bxi) * 256u + (uint32_t)tid;
@@ -619,6 +629,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
     // block's pixels can see: 240 at 1280x720 K=1600, i.e. one trip), keeps the live records inside the window and appends them
     // to its wavefront's part of s_raw (ballot compaction, no atomics).  Meanwhile the spatial table arrives by LDS-DMA and the
     // pixel loads are in flight.
+    ASG_MARK("gather");
     const int sh = f.cs_shift;
     TileWindow win;
     {
@@ -692,6 +703,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
         if (lane == 0) s_wcnt[wave] = (uint32_t)cnt;
     }
     ASG_STAMP(1, wave == 0);
+    ASG_MARK("wait_table");
     // The table has landed once at most R loads are outstanding (the compiler's counters do not include the LDS-DMA pieces): the R pixel
     // loads were issued after them and loads return in order; whatever the gather issued later has been waited for by the compiler at
     // its use.  The pixels themselves stay in flight across both barriers of the prologue (LDS-only barriers, see lds_barrier).
@@ -702,6 +714,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
 #endif
     lds_barrier();
     ASG_STAMP(2, wave == 0);
+    ASG_MARK("list_rank");
     // lane j = candidate j of the block (raw order: wavefront 0's records, then wavefront 1's, ...)
     int bn;
     uint4 mine;
@@ -752,6 +765,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
         if (lane < bn) s_entry[rank_j] = entry;
     }
     ASG_STAMP(3, wave == 0);
+    ASG_MARK("masks");
 
     // 3. the block list in registers: lane j = candidate j; candidates whose window reaches this wavefront's rows
     // (the rank travels in the top byte of the colour word: one v_readlane fetches both)
@@ -1030,6 +1044,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
         }
     }
 
+    ASG_MARK("after_walk");
     ASG_STAMP(4, wave == 0);
     ASG_PUT(9, wave == 0, __popcll(todo));
     ASG_PUT(10, wave == 0, bn);
@@ -1047,6 +1062,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
         bool fast_ok = all_found && nrows == R;
         if constexpr (PRE) fast_ok = fast_ok && rfl(f.pre_flags[0]) != 0u;      // (inactive cells: the row-by-row form below applies the cell test)
         if (fast_ok) {          // interior wavefront with every pixel assigned: the rule, by far
+            ASG_MARK("labels");
             epilogue_done = true;
             if (okx) {
                 uint32_t kk[R];
@@ -1063,6 +1079,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
                 for (int r = 0; r < R; ++r)
                     __builtin_amdgcn_raw_buffer_store_b16((uint16_t)kk[r], ws, (int)((uint32_t)x * 2u), (int)(so0 + (uint32_t)r * pitch2), kAuxSc1);
                 ASG_STAMP(5, wave == 0);
+                ASG_MARK("sums");
                 if (FUSE) {
                     // Sums of update() (src/context.cpp:301-354), third form.  A lane keeps the PREFIX sums of its column (three v_dot4 per
                     // row, nothing else: count, sum x and sum y of a prefix are constants of the row number).  Where the label changes
@@ -1126,6 +1143,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
             }
         }
     }
+    ASG_MARK("slow_epilogue");
     if (!epilogue_done) {
         // The exception: bottom rows missing, or a pixel no window reached (it keeps its label and still takes part in the update,
         // src/context.cpp:138-145): row by row with the full rules, sums per run of equal slot.
@@ -1182,6 +1200,7 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
             flush();
         }
     }
+    ASG_MARK("block_flush");
     if (FUSE) {
         ASG_STAMP(6, wave == 0);
         lds_barrier();

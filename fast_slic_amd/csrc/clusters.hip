@@ -101,10 +101,10 @@ static __device__ __forceinline__ void bin_clusters_body(FrameDev& f, const Pass
         const uint32_t shadow_word = f.cl_shadow[kc];        // (loaded whatever the pass geometry: a load inside a branch is waited for at the branch's end)
         const uint2* const sp = reinterpret_cast<const uint2*>(f.sums[0] + 6 * (size_t)kc);
         const uint2 s01 = sp[0], s23 = sp[1], s45 = sp[2];
-        const uint32_t ymask = cpart_rows_mask(f.S, pg.stride, max(pg.BH, 1)), ne = pg.use_slots ? (ymask + 1u) * (uint32_t)f.nbx : 0u;
+        const uint32_t ymask = pg.use_slots ? cpart_rows_mask(f.S, pg.stride, max(pg.BH, 1)) : 0u, ne = pg.use_slots ? (ymask + 1u) * (uint32_t)f.nbx : 0u;
         // NB == 4 (grids of four entries: 1280x720 K=1600): the entries are requested before the position is known (above).  Larger
         // grids (NB == 8): only the LIVE entries are requested, after the geometry -- measured both ways in round 5
-        // (profiles/r05_cluster_pass.txt): requesting a whole grid of eight costs more than the dependent round trip saves (the pass
+        // (profiles/r05_experiments.txt, section `Cluster pass k_bin_clusters<1>`): requesting a whole grid of eight costs more than the dependent round trip saves (the pass
         // is bound by its scattered 24-byte loads, not by the length of its chain: 7.25 -> 7.89 us at 3840x2160 K=6000), a grid of
         // four gains a little (5.38 -> 5.14 us for 2 x 8 frames of 1280x720).
         EntryLoads<NB> L;

@@ -145,6 +145,7 @@ struct Slot {
     bool nap_wait = false;           // set for groups served by the slot thread
     double recent_wait_us[4] = {1e30, 1e30, 1e30, 1e30};   // its last four waits (1e30: none yet)
     unsigned recent_wait_i = 0;
+    unsigned long long recent_wait_key = 0;   // the workload those waits belong to (geometry, group size, iterations, variant): another one starts a new history
     // per-call state
     int H = 0, W = 0, K = 0, S = 0;
     int nframes = 0;

@@ -503,6 +503,15 @@ int group_begin(fslic_engine* e, Slot& s, const fslic_params* p, int H, int W, i
 static int nap_wait(Slot& s) {
     const double t0 = now_us();
     HIPCHK(hipEventRecord(s.ev[5], s.st));
+    // The history belongs to ONE workload: after a switch from long groups (16 x 4K: ~10 ms) to short ones (0.15 ms) the first short
+    // groups would otherwise sleep 5, 2.5, 1.25 .. ms before the minimum converged.
+    const unsigned long long key = ((unsigned long long)(uint32_t)s.H << 48) ^ ((unsigned long long)(uint32_t)s.W << 32) ^ ((unsigned long long)(uint32_t)s.K << 16) ^
+                                   ((unsigned long long)(uint32_t)s.nframes << 8) ^ ((unsigned long long)(uint32_t)s.p.max_iter << 4) ^ (unsigned long long)(uint32_t)s.p.variant ^
+                                   ((unsigned long long)(uint32_t)s.p.preemptive << 60) ^ ((unsigned long long)(uint32_t)s.p.subsample_stride << 56);
+    if (key != s.recent_wait_key) {
+        s.recent_wait_key = key;
+        for (double& w : s.recent_wait_us) w = 1e30;
+    }
     double shortest = 1e30;
     for (double w : s.recent_wait_us) shortest = std::min(shortest, w);
     auto nap = [](double us) { struct timespec ts; ts.tv_sec = 0; ts.tv_nsec = (long)(us * 1000.0); nanosleep(&ts, nullptr); };

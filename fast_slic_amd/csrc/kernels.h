@@ -216,6 +216,11 @@ struct LscDev {
     // inside 31 bits and of the weight inside 32; shifts from there to the 2^-20 / 2^-12 of the global accumulators
     float blk_fix_f, blk_fix_w;
     int blk_shift_f, blk_shift_w;
+    // The weight w = sum_q mean_q * F_q holds four spatial products of either sign (each >= -C_spatial^2), so with a large compactness
+    // it can be negative -- and it shares a 64-bit block accumulator word with the position sums, where a negative addend would borrow
+    // from them.  Every pixel's weight is therefore stored with the bias ceil(4 C_spatial^2) (an integer: exact in the block's fixed
+    // point), which the block's flush takes out again as count * bias.
+    float blk_bias_w;
     __host__ __device__ __forceinline__ void select(int z) {
         const size_t d = (size_t)z * frame_bytes;
         FrameDev::adv(hist, d); FrameDev::adv(means, d);

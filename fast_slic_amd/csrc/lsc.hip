@@ -155,7 +155,7 @@ constexpr int kLscCopyShift = 2;
 constexpr int kLscAccEntries = 64 << kLscCopyShift;
 // A block's accumulators (LDS), per (candidate, copy) seven 64-bit words: the eleven float sums in a coarser fixed point that keeps a
 // block's total (1024 pixels) inside 32 bits (LscDev::blk_fix_*: 2^-15 and 2^-8 for the default constants), two to a word -- the low
-// half always one of the colour features or the weight, which are never negative, so no borrow crosses into the high half, where
+// half always one of the colour features or the BIASED weight (LscDev::blk_bias_w), which are never negative, so no borrow crosses into the high half, where
 // the spatial features (cos / sin of any angle) wrap in two's complement -- and the six integer sums in the bits that leaves:
 //   word 0..3: F0..F3 | F6..F9 << 32      word 4: F4 | F5 << 32
 //   word 5: sum L | sum a << 18 | sum b << 36 | count << 54      (255 * 1024 < 2^18; the count has the ten bits that are left: a block
@@ -466,7 +466,7 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
                 const uint32_t px = pix[r];
                 const float2 Lr = tl[px & 255u], Ar = tl[256u + ((px >> 8) & 255u)], Br = tl[256u + ((px >> 16) & 255u)];
                 Fr[u][0] = Lr.x; Fr[u][1] = Lr.y; Fr[u][2] = Ar.x; Fr[u][3] = Ar.y; Fr[u][4] = Br.x; Fr[u][5] = Br.y;
-                Fr[u][6] = xcos; Fr[u][7] = xsin; Fr[u][8] = ycos[u]; Fr[u][9] = ysin[u]; Fr[u][kLscFeat] = wv[u];
+                Fr[u][6] = xcos; Fr[u][7] = xsin; Fr[u][8] = ycos[u]; Fr[u][9] = ysin[u]; Fr[u][kLscFeat] = wv[u] + l.blk_bias_w;      // (biased: never negative, LscDev::blk_bias_w)
                 ia[u][0] = (px & 255u) | ((px & 0xFF00u) << 10);                 // L | a << 18
                 ia[u][1] = ((px >> 12) & 0xFF0u) | (1u << 22);                  // (b << 36 | count << 54) >> 32
                 ia[u][2] = (uint32_t)lane | ((uint32_t)(wave * kLscRows + r) << 16);      // (x - x0 | the row's number inside the block << 16), the high half of the weight's word
@@ -476,7 +476,7 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
                     unsigned long long* e = reinterpret_cast<unsigned long long*>(l.extra + (size_t)lbl[u] * kLscExPitch);
 #pragma unroll
                     for (int q = 0; q < kLscFeat; ++q) atomicAdd(e + q, (unsigned long long)(long long)(int)__builtin_rintf(Fr[u][q] * kLscFixF));
-                    atomicAdd(e + kLscFeat, (unsigned long long)(long long)(int)__builtin_rintf(Fr[u][kLscFeat] * kLscFixW));
+                    atomicAdd(e + kLscFeat, (unsigned long long)(long long)(int)__builtin_rintf(wv[u] * kLscFixW));
                     global_accumulate(f.sums[0], lbl[u], (uint32_t)yr[r], (uint32_t)x, px);
                 }
             }
@@ -561,7 +561,8 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
             const bool high = q == 5 || (q >= 6 && q < kLscFeat);
             unsigned long long w = 0;
             for (int cpy = 0; cpy < (1 << cshift); ++cpy) w += a[lsc_acc_index(word, cpy)];
-            const long long field = high ? (long long)(int)(uint32_t)(w >> 32) : (long long)(uint32_t)w;
+            long long field = high ? (long long)(int)(uint32_t)(w >> 32) : (long long)(uint32_t)w;
+            if (q == kLscFeat) field -= (long long)n * (long long)(l.blk_bias_w * l.blk_fix_w);      // the bias of n pixels' weights (an integer in this fixed point)
             const long long v = field << (q < kLscFeat ? l.blk_shift_f : l.blk_shift_w);      // to the fixed point of the global accumulators
             atomicAdd(reinterpret_cast<unsigned long long*>(l.extra + (size_t)k * kLscExPitch) + q, (unsigned long long)v);
         } else {
@@ -660,8 +661,9 @@ void launch_lsc_pre_sums(const FrameDev& f_, int nframes, int rem, int stride, i
 }
 void launch_lsc_pre_feats(const FrameDev& f, const LscDev& l, int nframes, int rem, int stride, hipStream_t st) {
     const int Hv = (f.H - rem + stride - 1) / stride;
-    if (Hv <= 0) return;
-    launch(k_lsc_pre_feats, dim3((unsigned)(((size_t)Hv * f.W + 255) / 256), nframes), dim3(256), 0, st, f, l, rem, stride, Hv);
+    // a pass without visited rows (H <= rem) still recomputes the centroids of the updatable clusters: 0 / 0 = NaN, as
+    // ContextLSC::after_update leaves them (src/lsc.cpp:256-269)
+    if (Hv > 0) launch(k_lsc_pre_feats, dim3((unsigned)(((size_t)Hv * f.W + 255) / 256), nframes), dim3(256), 0, st, f, l, rem, stride, Hv);
     launch(k_lsc_pre_update, dim3((f.K * 16 + 255) / 256, nframes), dim3(256), 0, st, f, l);
 }
 

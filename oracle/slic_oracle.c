@@ -10,7 +10,7 @@
  *
  * PARITY PIN: the reference's own golden PNGs are stale so parity is pinned
  * against the reference itself, compiled unmodified into oracle/_ref/libfslic_ref.so by
- * oracle/Makefile and compared stage by stage in tests/test_oracle_vs_ref.py, plus the committed
+ * oracle/Makefile and compared stage by stage in tests/test_oracle.py, plus the committed
  * fixtures under tests/golden/ (generated from that library by tests/golden/make_golden.py).
  *
  * Third-party algorithm on the path: std::partial_sort (src/cca.cpp:226) from libstdc++
