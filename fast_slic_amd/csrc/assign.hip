@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
             const size_t p = (size_t)y * W + x;
             uint32_t lbl;
             if (bw[r] < kHuge) { lbl = bt[r] & 0xFFFFu; f.labels[p] = (uint16_t)lbl; }
+            else if (f.first_visit(y)) { lbl = 0xFFFFu; f.labels[p] = (uint16_t)0xFFFFu; }      // (lazy reset of the plane, FrameDev::fv_mod)
             else lbl = f.labels[p];
             if (FUSE && lbl != 0xFFFFu) global_accumulate(f.sums[0], lbl, (uint32_t)y, (uint32_t)x, pix[r]);
         }
@@ -272,6 +273,8 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
                     if (idx < (uint32_t)kAccSlots) slot[r] = idx;
                     else global_accumulate(f.sums[0], k, (uint32_t)y, (uint32_t)x, pix[r]);
                 }
+            } else if (f.first_visit(y)) {
+                f.labels[p] = (uint16_t)0xFFFFu;      // nobody has looked at this row in this call yet: unlabelled (lazy reset, FrameDev::fv_mod)
             } else if (FUSE) {
                 const uint32_t old = f.labels[p];     // stale label still takes part in update()
                 if (old != 0xFFFFu) global_accumulate(f.sums[0], old, (uint32_t)y, (uint32_t)x, pix[r]);
@@ -1157,7 +1160,10 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
             const bool found = key != 0xFFFFu;
             slot[r] = kNoSlot;
             if (ok && found) st_stream(rowp + xo, s_klab[key & 63u]);
-            bool summed = FUSE && ok;
+            // lazy reset of the plane (FrameDev::fv_mod): the first pass to look at a row stores the 0xFFFF of pixels no window covers
+            const bool unlabelled = ok && !found && f.first_visit(yw_lo + r * STRIDE);
+            if (unlabelled) st_stream(rowp + xo, (uint16_t)0xFFFFu);
+            bool summed = FUSE && ok && !unlabelled;
             if constexpr (PRE) summed = summed && in_update(f, yw_lo + r * STRIDE, x);
             if (summed) {
                 if (found) slot[r] = key & 63u;

@@ -231,7 +231,10 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     if (timed) HIPCHK(hipEventRecord(s.ev[0], s.st));
     // + labels <- 0xFFFF (src/context.cpp:138-145); + a fresh range of bin generation stamps for this group's passes
     f.gen_base = s.d_gen;
-    launch_rgb_to_lab(f, n, p->convert_to_lab, e->tables, true, s.st, s.gen_step,
+    // (the integer SLIC path on the block / 32-bit kernels resets the assignment plane lazily, FrameDev::fv_mod: the LAB kernel then writes
+    // 4 B/px instead of 6; every other path -- variants, generic kernel, preemptive mode -- has the plane filled here)
+    const bool lazy_labels = p->variant == FSLIC_VARIANT_SLIC && !generic && p->preemptive == 0;
+    launch_rgb_to_lab(f, n, p->convert_to_lab, e->tables, !lazy_labels, s.st, s.gen_step,
                       s.at(s.zero_block, i0), s.zero_bytes, f.cl_n, 2 * (size_t)K, s.h_cl + (size_t)i0 * 4 * K, 4 * (size_t)K);      // (+ the staged centres -> cl_yx)
     if (timed) HIPCHK(hipEventRecord(s.ev[1], s.st));
     f.gen_off = 1;
@@ -315,6 +318,7 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     for (int it = 0; fusebin && it < p->max_iter; it++) {
         const bool tme = timed && s.launch_timing && it < Slot::kMaxTimedIters;
         f.cl_yx = yx_a; f.cl_yx_out = yx_a;
+        f.fv_mod = lazy_labels && it < stride ? 1 : 0; f.fv_from = 0;
         if (tme) HIPCHK(hipEventRecord(s.ev_it[2 * it], s.st));
         launch_assign_fused_bin(f, n, rem, stride, it, s.st);
         if (tme) HIPCHK(hipEventRecord(s.ev_it[2 * it + 1], s.st));
@@ -330,6 +334,7 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
         if (tme) HIPCHK(hipEventRecord(s.ev_it[2 * it], s.st));
         // (preemptive mode: the block kernel on the bins of the active clusters where the geometry takes it, round 5; until then the
         // generic kernel served every preemptive frame)
+        f.fv_mod = lazy_labels && it < stride ? 1 : 0; f.fv_from = 0;
         if (generic || (pre && !launch_assign_pre(f, n, rem, stride, it & 1, it & 1, s.st))) launch_assign_generic(f, n, rem, stride, it & 1, it & 1, true, s.st);
         else if (!pre) pg = launch_assign(f, n, rem, stride, it & 1, it & 1, true, s.st);
         if (tme) HIPCHK(hipEventRecord(s.ev_it[2 * it + 1], s.st));
@@ -348,6 +353,9 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
         full_buf = (p->max_iter + 1) & 1;
     }
     if (timed) HIPCHK(hipEventRecord(s.ev[2], s.st));
+    // (lazy reset: the rows of the residues no subsampled pass came to are first looked at by the full pass)
+    f.fv_mod = lazy_labels && p->max_iter < stride ? stride : 0; f.fv_from = p->max_iter < stride ? std::max(p->max_iter, 0) : 0;
+    f.fv_rcp = f.fv_mod > 1 ? 0xFFFFFFFFu / (uint32_t)f.fv_mod : 0u;
     // full_assign: stride 1, rem 0, no update afterwards (src/context.cpp:246-256)
     if (lsc) { f.cl_yx = yx_cur; launch_lsc_assign(f, l, n, 0, 1, full_buf, 0, false, s.st); }
     else if (noq) { f.cl_yx = yx_cur; launch_noq_assign(f, noq_coef, noq_manhattan, n, 0, 1, full_buf, 0, false, s.st); }

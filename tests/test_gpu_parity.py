@@ -501,3 +501,30 @@ def test_warm_starts_with_stale_pixels_under_the_fused_cluster_pass():
         assert n_stale_cases >= 5
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("stride", [1, 2, 3, 5])
+def test_lazy_label_reset_scattered_centres_every_iteration_count(engine, stride):
+    """Round 6: the assignment plane is no longer filled with 0xFFFF by the LAB kernel on the integer SLIC path (src/context.cpp:138-145
+    resets it once per call); the first pass that looks at a row stores the 0xFFFF of the pixels no window covers (FrameDev::fv_mod).
+    Scattered centres leave such pixels in every pass; with max_iter below the stride the rows of the residues no subsampled pass came
+    to are first looked at by the full pass.  Consecutive calls on one engine, different images and shapes of one size class: what the
+    previous call left in the plane (every label a valid cluster number) must never be read as a label of this call."""
+    rng = np.random.RandomState(100 + stride)
+    uncovered_cases = 0
+    for trial in range(14):
+        H, W = int(rng.choice([120, 160, 200])), int(rng.choice([128, 176, 240]))
+        K = int(rng.choice([10, 16, 24, 40]))
+        if orc.S_of(H, W, K) < 8:
+            continue
+        max_iter = trial % 7          # 0 .. 6: below, at and above every stride here
+        img = variant("ABC"[trial % 3], H, W, seed=200 + trial)
+        cl0 = orc.initialize_clusters(img, K)
+        cl0["y"] = rng.randint(0, H, K).astype(np.float32)
+        cl0["x"] = rng.randint(0, W, K).astype(np.float32)
+        kw = dict(max_iter=max_iter, subsample_stride=stride)
+        labels, cl, pre, path = run_hip(engine, img, cl0, **kw)
+        o_labels, o_cl, o_lab, o_pre = orc.slic_iterate(img, cl0, stages=True, **kw)
+        uncovered_cases += int((o_pre == 0xFFFF).any())
+        assert_same("trial %d %dx%d K=%d max_iter=%d stride=%d path=%d" % (trial, W, H, K, max_iter, stride, path), (labels, cl, pre), (o_labels, o_cl, o_pre))
+    assert uncovered_cases >= 3, "the inputs were meant to leave uncovered pixels"
