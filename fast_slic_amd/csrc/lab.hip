@@ -20,13 +20,17 @@ struct LabConst { uint32_t c01[3], c2[3]; };      // per matrix row: coefficient
 typedef unsigned short lab_us2 __attribute__((ext_vector_type(2)));
 
 static __device__ __forceinline__ uint32_t lab_px(uint32_t R, uint32_t G, uint32_t B,
-                                                  const uint16_t* sg, const uint16_t* sl, const LabConst& k) {
+                                                  const uint32_t* sg, const uint16_t* sl, const LabConst& k) {
     // A matrix row is c0 * r + c1 * g + c2 * b with the gamma values below 2^14, the coefficients below 2^16 and the sum below 2^30, so
     // the results are the reference's ints whichever way the products are formed: one v_dot2_u32_u16 on (r | g << 16) with the 24-bit
     // product of the blue term as its addend -- 7 instructions per pixel for the three rows instead of 12 (three 24-bit products and a
     // three-operand add per row; 32-bit v_mul_lo_u32, a quarter of the rate, before that: nine of them were more than half of this
     // kernel's vector time).
-    const uint32_t sr = sg[R], sgv = sg[G], sb = sg[B];
+    // gamma table: entry e of the lane's own copy, (e * 32 + lane % 32) dwords into the array -- copy c lies entirely in LDS bank c, and
+    // the two lanes that share a copy (i, i + 32) are served in different halves of the instruction: no bank conflicts, where the 128
+    // dwords of a single copy met ~3.5 lanes per bank for arbitrary pixel values (63 % of this kernel's LDS time were conflicts,
+    // profiles/r06_pipeline_stalls.txt).  `sg` is the lane's base (copy offset applied), one v_lshl_add per look-up.
+    const uint32_t sr = sg[R << 5], sgv = sg[G << 5], sb = sg[B << 5];
     const lab_us2 rg = __builtin_bit_cast(lab_us2, sr | (sgv << 16));
     auto row = [&](int i) -> int {
         return (int)(__builtin_amdgcn_udot2(rg, __builtin_bit_cast(lab_us2, k.c01[i]), __umul24(k.c2[i], sb), false) >> 16);
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(1024) void k_rgb_to_lab(FrameDev f, const uint16_t*
                                                      const uint16_t* __restrict__ g_labtbl, LabConst kc, int init_labels, uint32_t gen_step,
                                                      char* zero_a, unsigned zero_a_quads, uint32_t* zero_b, unsigned zero_b_words,
                                                      const uint32_t* __restrict__ stage_yx, size_t stage_stride, int stage_K, int conv_blocks) {
-    __shared__ uint16_t s_gamma[256];
+    __shared__ uint32_t s_gamma32[CONVERT ? 256 * 32 : 1];      // 32 copies of the gamma table, one per LDS bank (see lab_px): 32 KB
     __shared__ uint16_t s_lab[8194];
     // first kernel of a group: new generation of bin stamps (nothing in this kernel reads them; the stream orders the rest)
     if (gen_step && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *f.gen_base += gen_step;
@@ -81,16 +85,21 @@ __global__ __launch_bounds__(1024) void k_rgb_to_lab(FrameDev f, const uint16_t*
     }
     // The tables are requested with the first quad's loads in flight (a one-frame launch is 225 blocks of one quad per thread: the
     // two round trips were one after the other).  1024 threads per block (the launcher).
-    uint32_t tg = 0, tl0 = 0, tl1 = 0, tl2 = 0, tl3 = 0, tl4 = 0;
+    uint32_t tg0 = 0, tg1 = 0, tg2 = 0, tg3 = 0, tl0 = 0, tl1 = 0, tl2 = 0, tl3 = 0, tl4 = 0;
     if (CONVERT) {
         const uint32_t* gt = reinterpret_cast<const uint32_t*>(g_labtbl);   // 8194 entries (last one padding) = 4097 words
-        if (threadIdx.x < 128) tg = reinterpret_cast<const uint32_t*>(g_gamma)[threadIdx.x];
+        // thread t fills copy t % 32 of the gamma entries 8 * (t / 32) .. + 7 (four dwords of the source)
+        const uint32_t* gg = reinterpret_cast<const uint32_t*>(g_gamma) + 4 * (threadIdx.x >> 5);
+        tg0 = gg[0]; tg1 = gg[1]; tg2 = gg[2]; tg3 = gg[3];
         tl0 = gt[threadIdx.x]; tl1 = gt[1024 + threadIdx.x]; tl2 = gt[2048 + threadIdx.x]; tl3 = gt[3072 + threadIdx.x];
         if (threadIdx.x == 0) tl4 = gt[4096];
     }
+    const uint32_t* const s_gamma = s_gamma32 + (CONVERT ? (threadIdx.x & 31) : 0);      // the lane's copy
     if (CONVERT) {
         uint32_t* sl = reinterpret_cast<uint32_t*>(s_lab);
-        if (threadIdx.x < 128) reinterpret_cast<uint32_t*>(s_gamma)[threadIdx.x] = tg;
+        uint32_t* const gd = s_gamma32 + ((threadIdx.x >> 5) * 8) * 32 + (threadIdx.x & 31);
+        gd[0 * 32] = tg0 & 0xFFFFu; gd[1 * 32] = tg0 >> 16; gd[2 * 32] = tg1 & 0xFFFFu; gd[3 * 32] = tg1 >> 16;
+        gd[4 * 32] = tg2 & 0xFFFFu; gd[5 * 32] = tg2 >> 16; gd[6 * 32] = tg3 & 0xFFFFu; gd[7 * 32] = tg3 >> 16;
         sl[threadIdx.x] = tl0; sl[1024 + threadIdx.x] = tl1; sl[2048 + threadIdx.x] = tl2; sl[3072 + threadIdx.x] = tl3;
         if (threadIdx.x == 0) sl[4096] = tl4;
         __syncthreads();
