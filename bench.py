@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 ASSIGN_BYTES_PER_PX = 6.0      # 4 B LAB read + 2 B label write per visited pixel
 LSC_ASSIGN_BYTES_PER_PX = 6.0  # 4 B LAB word + 2 B label: the features are rebuilt from the LAB word (SURVEY.md 8d's recompute design; the materialised one moved 46 B)
-PROFILE_TAG = "r05"
+PROFILE_TAG = "r06"
 
 WORKLOADS = {
     "720p": dict(H=720, W=1280, K=1600, fpg=8, name="1280x720 RGB, K=1600, 10 iters (configs[1]), 8 frames/GPU"),
@@ -75,10 +75,11 @@ def path_roofline(mp_per_s, what):
 def pmc_traffic(key):
     """HBM bytes per launch of the assign kernels from the committed rocprofv3 --pmc passes of this workload
     (profiles/<round>_pmc_assign_traffic.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE); None when absent."""
-    for tag in (PROFILE_TAG, "r04", "r03", "r02", "r01"):
+    for tag in (PROFILE_TAG, "r05", "r04", "r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", "%s_pmc_assign_traffic.json" % tag)) as f:
-                return json.load(f)[key], "profiles/%s_pmc_assign_traffic.json" % tag
+                d = json.load(f)
+                return d[key], "profiles/%s_pmc_assign_traffic.json (counters of build %s)" % (tag, d.get("build_commit") or "unrecorded")
         except (OSError, KeyError, ValueError):
             continue
     return None, None
@@ -87,7 +88,7 @@ def pmc_traffic(key):
 def rocprof_avg_us(csv_name, *needles):
     """Average duration (us) of the first kernel whose name contains every one of `needles` in a committed rocprofv3 summary
     (profiles/<round>_kernel_stats_*.csv, written by scripts/gpu_profiles.sh from a --kernel-trace run); None when absent."""
-    for tag in (PROFILE_TAG, "r04"):
+    for tag in (PROFILE_TAG, "r05", "r04"):
         try:
             with open(os.path.join(ROOT, "profiles", "%s_%s" % (tag, csv_name))) as f:
                 for line in f:

@@ -7,6 +7,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/r
 rm -rf $OUT; mkdir -p $OUT
 cd $R
+# the commit this tree was built from (the GPU box has no .git: the caller passes it, scripts/pmc_traffic_json.py stamps the traffic json with it)
+echo "${BUILD_COMMIT:-unrecorded}" > $OUT/build_commit.txt
 rocminfo 2>/dev/null | grep -E 'Marketing Name|Compute Unit|Max Clock' | head -8 > $OUT/rocminfo.txt
 nproc >> $OUT/rocminfo.txt; grep -m1 'model name' /proc/cpuinfo >> $OUT/rocminfo.txt
 timeout 900 python bench.py 2> $OUT/bench.err > $OUT/bench.json; echo "bench rc=$?"
@@ -66,5 +68,8 @@ BURST_REPS=1 bash scripts/gpu_burst.sh > /dev/null 2>&1; cp $R/gpurun_out/burst_
 cd $R
 # 7. the LSC group: SQ counters of every kernel (vector ALU / LDS time, bank conflicts of k_lsc_assign_sums)
 PMC_VAR=lsc PMC_G=8 bash scripts/gpu_pmc_group.sh > /dev/null 2>&1; cp $R/gpurun_out/pmc_group.txt $OUT/lsc_pmc_instruction_mix.txt; cd $R
+# 8. occupancy / stall counters of every kernel of the benched group shape (scripts/gpu_stalls.sh, round 6)
+FSLIC_GROUP=16 STALL_CFG="720 1280 1600 16" bash scripts/gpu_stalls.sh > /dev/null 2>&1; cp $R/gpurun_out/stalls/pmc_stalls_1280x720_k1600_x16.txt $OUT/ 2>/dev/null; cd $R
+FSLIC_GROUP=8 STALL_CFG="2160 3840 1600 8" bash scripts/gpu_stalls.sh > /dev/null 2>&1; cp $R/gpurun_out/stalls/pmc_stalls_3840x2160_k1600_x8.txt $OUT/ 2>/dev/null; cd $R
 python scripts/pmc_traffic_json.py $OUT/ > /dev/null 2>&1
 ls $OUT
