@@ -40,6 +40,7 @@ def main():
     BH = 4 * R
     nbx, nby = (W + 63) // 64, (Hv + BH - 1) // BH
     rows = rem + stride * np.arange(Hv)
+    ys_all = np.concatenate([rows, rows[-1] + stride * np.arange(1, 4 * 64)])      # (rows past the bottom edge: never used for full wavefronts)
     lab_rows = pre[rows]                       # labels of the visited rows
     acc = {k: 0.0 for k in ("waves", "bn", "todo", "q1", "q2", "q3", "q4", "pairs", "gaps", "fast", "half1", "half2", "covered_px_cand", "change_lanes")}
     for by in range(nby):
@@ -86,6 +87,23 @@ def main():
                     acc["half2"] += int(both.sum())
                     acc["half1"] += int((up ^ lo).sum())
                     acc["pairs"] += int(both.sum()) * (R // 2) + int((up ^ lo).sum()) * (R // 4)
+                # the row-vector form (VT, 3840x2160 K=1600): rows above the centre use table index k0 - |dx|, rows at / below it k0 + |dx|; a
+                # candidate whose rows of one side are all sixteen and inside the window takes a mask-free loop, the others the masked
+                # loops by halves of eight rows (assign_blk2_body, `masked`)
+                if R == 16:
+                    for c_y in tcy:
+                        dy = ys_all[v0:v0 + R] - c_y if nrows == R else None
+                        if dy is None:
+                            continue
+                        inwin = np.abs(dy) <= S
+                        va, vb = inwin & (dy < 0), inwin & (dy >= 0)
+                        for side, v in (("a", va), ("b", vb)):
+                            if v.all():
+                                acc["vt_whole_" + side] = acc.get("vt_whole_" + side, 0) + 1
+                            elif v.any():
+                                lo, hi = v[:8].any(), v[8:].any()
+                                kind = "both" if (lo and hi) else ("lo" if lo else "hi")
+                                acc["vt_%s_%s" % (side, kind)] = acc.get("vt_%s_%s" % (side, kind), 0) + 1
                 # exact pixel-candidate pairs of the wavefront (what an ideal machine would evaluate)
                 xs = np.arange(x0, min(x0 + 64, W))
                 ys = rows[v0:v0 + nrows]
@@ -104,6 +122,9 @@ def main():
             acc["q1"] / n, acc["q2"] / n, acc["q3"] / n, acc["q4"] / n, acc["pairs"] / n, acc["pairs"] / 2 / max(acc["todo"], 1)))
     else:
         print("  walk iterations: both halves %.2f, one half %.2f (row pairs evaluated %.1f)" % (acc["half2"] / n, acc["half1"] / n, acc["pairs"] / n))
+    if R == 16:
+        keys = ["vt_whole_a", "vt_whole_b", "vt_a_lo", "vt_a_hi", "vt_a_both", "vt_b_lo", "vt_b_hi", "vt_b_both"]
+        print("  row-vector form, walk iterations per wavefront (interior wavefronts): " + "  ".join("%s %.2f" % (k[3:], acc.get(k, 0) / n) for k in keys))
     print("  pixel-candidate pairs inside a window %.0f of %.0f evaluated lane-slots (%.1f %%): %.2f candidates per pixel" % (
         acc["covered_px_cand"] / n, acc["pairs"] / n * 128, 100.0 * acc["covered_px_cand"] / max(acc["pairs"] * 128, 1), acc["covered_px_cand"] / n / (64.0 * R)))
     print("  row gaps with a label change in some lane %.2f of %d; lanes changing per such gap %.1f; wavefronts on the fast epilogue %.3f" % (
