@@ -1161,7 +1161,10 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
             slot[r] = kNoSlot;
             if (ok && found) st_stream(rowp + xo, s_klab[key & 63u]);
             // lazy reset of the plane (FrameDev::fv_mod): the first pass to look at a row stores the 0xFFFF of pixels no window covers
-            const bool unlabelled = ok && !found && f.first_visit(yw_lo + r * STRIDE);
+            // (a fused pass is a subsampled pass: ALL of its rows are first visits or none is, one scalar test; only the full pass
+            // has to look at the row's residue)
+            // (the launches that carry the cluster pass -- FBIN -- belong to groups whose plane the LAB kernel still fills, group.cpp: compiled out there)
+            const bool unlabelled = !FBIN && ok && !found && (FUSE ? f.fv_mod == 1 : f.first_visit(yw_lo + r * STRIDE));
             if (unlabelled) st_stream(rowp + xo, (uint16_t)0xFFFFu);
             bool summed = FUSE && ok && !unlabelled;
             if constexpr (PRE) summed = summed && in_update(f, yw_lo + r * STRIDE, x);

@@ -185,6 +185,23 @@ void stage_group(fslic_engine* e, Slot& s, int i0, int n, bool timed) {
     }
 }
 
+// Whether a group's cluster passes run inside its assign launches (the per-cluster fused form, assign.hip: k_assign_bin): the integer
+// SLIC path on the block kernel, launches that do not fill the chip (FSLIC_FUSEBIN=1, the default) or all of them (=2).
+static bool cluster_pass_fused(const FrameDev& f, const fslic_params& p, int n, int W, int H, bool generic, bool separate_cluster_pass) {
+    const int stride = p.subsample_stride;
+    const int assign_blocks = n * ((W + kTileW - 1) / kTileW) * (((H + stride - 1) / stride + 31) / 32);
+#if defined(FSLIC_LAB) && FSLIC_LAB == 3
+    // lab build 3 turns st_stream into plain stores; the fused cluster pass hands partial sums from block to block through
+    // written-through (sc1) stores and agent-scope loads and would read stale lines of another XCD's L2: never fused there
+    const bool fuse_wanted = false;
+    (void)assign_blocks;
+#else
+    const bool fuse_wanted = knobs().fuse_bin == 2 || (knobs().fuse_bin == 1 && assign_blocks <= 640);
+#endif
+    const bool plain_slic = p.variant == FSLIC_VARIANT_SLIC && p.preemptive == 0;
+    return fuse_wanted && !separate_cluster_pass && plain_slic && !generic && assign_fuses_cluster_pass(f, stride);
+}
+
 // Device half: everything of iterate() for frames [i0, i0+n) of the slot's current group, enqueued asynchronously on
 // the slot's stream: LAB, the first cluster pass (reads the staged centres), the assign/update loop, full assign,
 // connectivity, export of the cluster state.  Pure
@@ -233,7 +250,12 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     f.gen_base = s.d_gen;
     // (the integer SLIC path on the block / 32-bit kernels resets the assignment plane lazily, FrameDev::fv_mod: the LAB kernel then writes
     // 4 B/px instead of 6; every other path -- variants, generic kernel, preemptive mode -- has the plane filled here)
-    const bool lazy_labels = p->variant == FSLIC_VARIANT_SLIC && !generic && p->preemptive == 0;
+    // ... except where the cluster pass is fused into the assign kernel (launches that do not fill the chip: one or two frames per group):
+    // there every block drains its label stores before it counts itself in, and stores into a plane the LAB kernel has just written
+    // find their lines in the memory-side cache -- without the fill each of the ten launches of a one-frame group takes 0.35 us longer
+    // (8.54 against 8.18 us, same-box A/B, profiles/r06_experiments.txt) for the 0.6 us the LAB kernel saves once.
+    const bool lazy_labels = p->variant == FSLIC_VARIANT_SLIC && !generic && p->preemptive == 0 &&
+                             !cluster_pass_fused(f, *p, n, s.W, s.H, generic, separate_cluster_pass);
     launch_rgb_to_lab(f, n, p->convert_to_lab, e->tables, !lazy_labels, s.st, s.gen_step,
                       s.at(s.zero_block, i0), s.zero_bytes, f.cl_n, 2 * (size_t)K, s.h_cl + (size_t)i0 * 4 * K, 4 * (size_t)K);      // (+ the staged centres -> cl_yx)
     if (timed) HIPCHK(hipEventRecord(s.ev[1], s.st));
@@ -305,15 +327,7 @@ int enqueue_frames(fslic_engine* e, Slot& s, int i0, int n, bool generic, bool t
     // drops from 51.8 to 45.3 GP/s: the finaliser is a chain of dependent memory round trips at the end of every block and
     // vector work a 1600-thread cluster pass does once.  So: fused where a launch does not fill the chip (latency-bound: the
     // reference's own one-frame-per-call pattern), separate where it does.  FSLIC_FUSEBIN=0 / 2: never / always.
-    const int assign_blocks = n * ((s.W + kTileW - 1) / kTileW) * (((s.H + stride - 1) / stride + 31) / 32);
-#if defined(FSLIC_LAB) && FSLIC_LAB == 3
-    // lab build 3 turns st_stream into plain stores; the fused cluster pass hands partial sums from block to block through
-    // written-through (sc1) stores and agent-scope loads and would read stale lines of another XCD's L2: never fused there
-    const bool fuse_wanted = false;
-#else
-    const bool fuse_wanted = knobs().fuse_bin == 2 || (knobs().fuse_bin == 1 && assign_blocks <= 640);
-#endif
-    const bool fusebin = fuse_wanted && !separate_cluster_pass && !lsc && !rd && !generic && !pre && assign_fuses_cluster_pass(f, stride);
+    const bool fusebin = cluster_pass_fused(f, *p, n, s.W, s.H, generic, separate_cluster_pass);
     int full_obuf = -1;
     for (int it = 0; fusebin && it < p->max_iter; it++) {
         const bool tme = timed && s.launch_timing && it < Slot::kMaxTimedIters;

@@ -67,21 +67,6 @@ struct FrameDev {
     const uint8_t* rgb;  // N*3 (set by select)
     uint32_t* lab;       // N, L|a<<8|b<<16
     uint16_t* labels;    // N, pre-connectivity assignment (persists across iterations)
-    // Lazy reset of the assignment plane (round 6).  The reference fills it with 0xFFFF once per call (src/context.cpp:138-145); a row's
-    // labels are first looked at by the first pass that visits the row, so that pass can treat "no window covers this pixel" as
-    // "unlabelled" and store the 0xFFFF itself -- the LAB kernel then moves 7 B/px instead of 9.  A launch's visited row y is a FIRST visit
-    // iff fv_mod != 0 && y % fv_mod >= fv_from: subsampled pass it < stride: (1, 0), i.e. all of its rows; later subsampled passes:
-    // (0, -); the full pass: (stride, min(max_iter, stride)), i.e. the residues no subsampled pass came to.  fv_mod == 0 everywhere
-    // (and the plane filled by the LAB kernel) for the kernels that do not implement it: the variants, the generic kernel, preemptive mode.
-    int fv_mod, fv_from;
-    uint32_t fv_rcp;     // floor((2^32 - 1) / fv_mod) (fv_mod > 1): y % fv_mod without a division (the test sits in the kernels' rare paths, but a 32-bit division is ~40 instructions each time it is inlined)
-    __device__ __forceinline__ bool first_visit(int y) const {
-        if (fv_mod <= 1) return fv_mod == 1;
-        uint32_t q = __umulhi((uint32_t)y, fv_rcp), rest = (uint32_t)y - q * (uint32_t)fv_mod;      // (device_common.h, div_by: the estimate is at most two short)
-        if (rest >= (uint32_t)fv_mod) rest -= (uint32_t)fv_mod;
-        if (rest >= (uint32_t)fv_mod) rest -= (uint32_t)fv_mod;
-        return (int)rest >= fv_from;
-    }
     // cluster state (SoA)
     uint32_t* cl_yx;     // K  positions the cluster pass READS (pre-update; also the uploaded centres)
     uint32_t* cl_yx_out; // K  positions the cluster pass WRITES (the two alternate per iteration: a pass may still be
@@ -141,6 +126,22 @@ struct FrameDev {
 #if defined(FSLIC_LAB) && FSLIC_LAB == 4
     uint32_t* lab_stamps;      // lab build 4: phase time stamps of the block assign kernel (the idle candidate-area array of the connectivity pass)
 #endif
+    // (at the END of the struct: the kernels' scalar loads of every older member keep their offsets and their grouping)
+    // Lazy reset of the assignment plane (round 6).  The reference fills it with 0xFFFF once per call (src/context.cpp:138-145); a row's
+    // labels are first looked at by the first pass that visits the row, so that pass can treat "no window covers this pixel" as
+    // "unlabelled" and store the 0xFFFF itself -- the LAB kernel then moves 7 B/px instead of 9.  A launch's visited row y is a FIRST visit
+    // iff fv_mod != 0 && y % fv_mod >= fv_from: subsampled pass it < stride: (1, 0), i.e. all of its rows; later subsampled passes:
+    // (0, -); the full pass: (stride, min(max_iter, stride)), i.e. the residues no subsampled pass came to.  fv_mod == 0 everywhere
+    // (and the plane filled by the LAB kernel) for the kernels that do not implement it: the variants, the generic kernel, preemptive mode.
+    int fv_mod, fv_from;
+    uint32_t fv_rcp;     // floor((2^32 - 1) / fv_mod) (fv_mod > 1): y % fv_mod without a division (the test sits in the kernels' rare paths, but a 32-bit division is ~40 instructions each time it is inlined)
+    __device__ __forceinline__ bool first_visit(int y) const {
+        if (fv_mod <= 1) return fv_mod == 1;
+        uint32_t q = __umulhi((uint32_t)y, fv_rcp), rest = (uint32_t)y - q * (uint32_t)fv_mod;      // (device_common.h, div_by: the estimate is at most two short)
+        if (rest >= (uint32_t)fv_mod) rest -= (uint32_t)fv_mod;
+        if (rest >= (uint32_t)fv_mod) rest -= (uint32_t)fv_mod;
+        return (int)rest >= fv_from;
+    }
 
     // byte offset by POINTER arithmetic (not through an integer): the compiler then still knows the pointer came from a
     // kernel argument, i.e. points to global memory, and emits global_load / global_store instead of FLAT instructions
