@@ -1082,9 +1082,15 @@ void launch_cca_select(const CcaDev& c, int nframes, hipStream_t st) {
     if (cap > kSelCap) cap = kSelCap;
     const size_t lds = (3 * (size_t)cap + 3 * (size_t)kSelBuckets) * sizeof(uint32_t);
     static_assert(kSelBins <= 3 * kSelBuckets, "the selection histogram reuses the ranking buckets");
-    static const hipError_t attr_once = hipFuncSetAttribute(reinterpret_cast<const void*>(k_cca_select), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                           (int)((3 * (size_t)kSelCap + 3 * (size_t)kSelBuckets) * sizeof(uint32_t)));
-    (void)attr_once;
+    // (per device: a process may drive several GPUs.  A device that refuses the attribute gets a capacity that fits 64 KB; frames with more
+    // candidates than that take the host's top-K step, as frames beyond kSelCap do)
+    static std::atomic<int> attr_state[64];
+    if (!max_dynamic_lds_on_this_device(k_cca_select, (int)((3 * (size_t)kSelCap + 3 * (size_t)kSelBuckets) * sizeof(uint32_t)), attr_state)) {
+        while (cap > 1024 && (3 * (size_t)cap + 3 * (size_t)kSelBuckets) * sizeof(uint32_t) > 64 * 1024) cap >>= 1;
+        const size_t lds_small = (3 * (size_t)cap + 3 * (size_t)kSelBuckets) * sizeof(uint32_t);
+        launch(k_cca_select, dim3(nframes), dim3(1024), lds_small, st, c, cap);
+        return;
+    }
     launch(k_cca_select, dim3(nframes), dim3(1024), lds, st, c, cap);
 }
 

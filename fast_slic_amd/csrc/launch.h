@@ -6,6 +6,7 @@
 // synchronising, allocating) fail with "operation not permitted when stream is capturing", whatever the capture mode.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <tuple>
 #include <type_traits>
 #include <utility>
@@ -58,6 +59,21 @@ static inline hipError_t clear_rows(void* dst, size_t pitch, size_t width_bytes,
     if (e != hipSuccess) { r->err = e; return hipSuccess; }
     r->chain(node);
     return hipSuccess;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the DEVICE that is current when it is set, and a process may hold an engine per
+// GPU (the patched reference binding: arch "hip/gfx950:N"): set once per device and call site, result kept (`state`: 64 zero-initialised
+// words of the call site; 1 set, -1 refused).  false: the kernel must not be launched with more than 64 KB of dynamic LDS on this device.
+template <class F> static inline bool max_dynamic_lds_on_this_device(F* kernel, int bytes, std::atomic<int>* state) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = dev < 0 || dev >= 64 ? 0 : dev;
+    int s = state[dev].load(std::memory_order_acquire);
+    if (s == 0) {
+        s = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 1 : -1;
+        state[dev].store(s, std::memory_order_release);
+    }
+    return s > 0;
 }
 
 // A stream operation the recorder has no node for: direct launches only for such a group.

@@ -224,7 +224,6 @@ template <bool stale_sums>
 static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, int rem, int stride, int Hv) {
     f.select(blockIdx.z);
     l.select(blockIdx.z);
-    __shared__ uint32_t s_raw[192];
     __shared__ uint32_t s_yx[64], s_k[64];
     __shared__ __attribute__((aligned(16))) float s_cf[64 * 12];      // per candidate: centroid - origin (10), its squared norm, pad
     __shared__ __attribute__((aligned(16))) float s_org[12];          // the origin
@@ -246,71 +245,152 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
     if (stale_sums)
         for (int i = threadIdx.x; i < kLscAccEntries * kLscAccW; i += 256) s_accx[i] = 0ull;
     lsc_stage_lut(l, s_lut);
-    if (wave == 0) {
-        const int v_last = min(v0 + kLscBH, Hv) - 1;
-        TileWindow win;
-        win.wy_lo = rem + stride * v0 - S; win.wy_hi = rem + stride * v_last + S;
-        win.wx_lo = x0 - S; win.wx_hi = min(x0 + 63, W - 1) + S;
-        const int cnt = gather_candidates(f, win, s_raw, lane);
-        wave_lds_sync();
-        if (cnt <= 64) {
-            const uint32_t mytag = lane < cnt ? s_raw[128 + lane] : 0xFFFFFFFFu;
-            int rank = 0;
-            for (int j = 0; j < cnt; ++j) rank += (uint32_t)__builtin_amdgcn_readlane((int)mytag, j) < mytag ? 1 : 0;
-            // The distance is evaluated as |C - O|^2 - 2 (G - O) . (C - O) (+ |G - O|^2, the same for every candidate of a pixel)
-            // around an origin O of the block's own neighbourhood -- the first finite centroid of the list -- instead of
-            // sum (G - C)^2 (src/lsc.cpp:212-215): 11 FMAs per candidate instead of 10 subtractions + 10 FMAs.  Around O every
-            // term is of the size of the distances themselves, so the rounding stays at a few f32 ulps of them (measured on the
-            // reference fixtures: the same agreement as the subtract-and-square form, profiles/r03_lsc_recompute.txt).
-            const uint32_t k = lane < cnt ? (mytag & 0xFFFFu) : 0u;
-            const float4* src = reinterpret_cast<const float4*>(l.cfeat + (size_t)k * kLscCfPitch);
-            const float4 q0 = src[0], q1 = src[1], q2 = src[2];
-            float cf[kLscFeat] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y};
-            float tot = 0.0f;
-#pragma unroll
-            for (int q = 0; q < kLscFeat; ++q) tot += cf[q];
-            // (the first in VISIT order: the lanes hold the list in the order the bin pass happened to insert it, which varies
-            // from run to run -- an origin picked by lane would move the rounding with it)
-            const bool finite = lane < cnt && (tot - tot) == 0.0f;                          // (NaN centroid of a memberless cluster: never the origin)
-            const uint32_t first = lsc_wave_min(finite ? (uint32_t)rank : 64u);
-            const unsigned long long fin = __ballot(finite && (uint32_t)rank == first);
-            const int o = fin ? __builtin_ctzll(fin) : 0;
-            float nrm = 0.0f;
-#pragma unroll
-            for (int q = 0; q < kLscFeat; ++q) {
-                const float org = fin ? __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(cf[q]), o)) : 0.0f;
-                if (lane == 0) s_org[q] = org;
-                cf[q] -= org;
-                nrm = __builtin_fmaf(cf[q], cf[q], nrm);
-            }
-            if (lane < cnt) {
-                s_yx[rank] = s_raw[lane];
-                s_k[rank] = k;
-                float4* dst = reinterpret_cast<float4*>(s_cf + rank * 12);
-                dst[0] = make_float4(cf[0], cf[1], cf[2], cf[3]); dst[1] = make_float4(cf[4], cf[5], cf[6], cf[7]);
-                dst[2] = make_float4(cf[8], cf[9], nrm, 0.0f);
-            }
-        } else if (lane < 12) {
-            s_org[lane] = 0.0f;        // the walk over every cluster subtracts and squares, around no origin
-        }
-        if (lane == 0) s_cnt = cnt;
-        LSC_STAMP(1, true);                     // list built and staged (wave 0)
-    }
-    // this wavefront's pixels: column x0 + lane of kLscRows visited rows (clamped addresses, masked results), taken two rows
-    // (r, r+1) at a time: the feature and distance chains run on packed f32 (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, two
-    // rows per instruction; each half is the same IEEE operation as the scalar form), and a pair's twenty quotients are dead
-    // before the next pair's are formed -- all four rows at once cost 104 VGPRs (4 wavefronts per SIMD) with the sums below.
     const int x = x0 + lane;
     const bool xok = x < W;
     const int vw = (int)rfl((uint32_t)(v0 + wave * kLscRows));
     int yr[kLscRows];
     uint32_t pix[kLscRows];
     const int xc = min(x, W - 1);
+    // ---- the block's candidate list, second form (round 6).  Until then wavefront 0 built it alone -- six bin slots per lane and trip, the
+    // (phase, k) ranks, then the centroid records of the listed clusters in a dependent round trip -- while the other three waited at
+    // the barrier: 6.2 of a block's 22 us (profiles/r03_lab_lsc_phases.txt).  Now, as in the SLIC block kernel (assign.hip, second form):
+    //   A  every thread takes ONE 16-byte slot of the cells the block's window can see (all of them in one trip at S >= 16), keeps the
+    //      live records inside the window, and REQUESTS THE CENTROID RECORD of a kept cluster at once (three 16-byte loads that stay in
+    //      flight across the first barrier); positions inside the wavefront by ballot, the counts meet in LDS
+    //   B  kept records go to their arrival index (wavefront 0's first, ...): {yx, tag} and the ten centroid features
+    //   C  wavefront 0, lane j = arrival j: ranks by (phase, k), the origin (first finite centroid in VISIT order, so the rounding does
+    //      not depend on the arrival order), centroid - origin and its squared norm staged by rank -- from LDS, no memory round trip
+    __shared__ __attribute__((aligned(16))) float s_cfraw[64 * 12];      // centroid records by arrival index
+    __shared__ uint2 s_arr[64];                                           // {yx, tag} by arrival index
+    __shared__ uint32_t s_wc[kWavesPerBlock];
+    {
+        const int v_last = min(v0 + kLscBH, Hv) - 1;
+        TileWindow win;
+        win.wy_lo = rem + stride * v0 - S; win.wy_hi = rem + stride * v_last + S;
+        win.wx_lo = x0 - S; win.wx_hi = min(x0 + 63, W - 1) + S;
+        const uint32_t gen = f.generation();
+        const int sh = f.cs_shift;
+        const int cxa = max(win.wx_lo, 0) >> sh, cxb = min(win.wx_hi, W - 1) >> sh;
+        const int cya = max(win.wy_lo, 0) >> sh, cyb = min(win.wy_hi, f.H - 1) >> sh;
+        const uint32_t ncxr = (uint32_t)(cxb - cxa + 1);
+        const uint32_t nslots = ncxr * (uint32_t)(cyb - cya + 1) * (uint32_t)kCellCap;
+        const uint32_t novf = *f.ovf_cnt[0];
+        uint32_t my_yx = 0, my_tag = 0, my_pos = 0;
+        bool mine_kept = false;
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+        int cntw = 0;
+        // (a thread keeps at most one record: its own slot of the first trip that yields one; a second kept record of the same thread --
+        // more than 256 slots, i.e. S < 16, or the spill list -- is counted as an overflow of the list, which takes the walk over every
+        // cluster: exact either way)
+        bool lost = false;
+        auto visit = [&](const ClusterRec& rec, bool keep) {
+            const unsigned long long m = ballot(keep);
+            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)cntw));
+            if (keep) {
+                if (mine_kept) lost = true;
+                else {
+                    mine_kept = true; my_yx = rec.yx; my_tag = rec.tag; my_pos = pos;
+                    const float4* src = reinterpret_cast<const float4*>(l.cfeat + (size_t)(rec.tag & 0xFFFFu) * kLscCfPitch);
+                    q0 = src[0]; q1 = src[1]; q2 = src[2];
+                }
+            }
+            cntw += __popcll(m);
+        };
+        auto slot_rec = [&](uint32_t e) -> ClusterRec {
+            const uint32_t cell = e < nslots ? e >> 3 : 0u;
+            const uint32_t cyi = cell / ncxr, cxi = cell - cyi * ncxr;
+            return f.cell_items[0][((size_t)(cya + (int)cyi) * f.ncx + cxa + (int)cxi) * kCellCap + (e & 7u)];
+        };
+        const ClusterRec rec_first = slot_rec((uint32_t)threadIdx.x);
+        // the wavefront's pixel loads, issued BEHIND the slot load the list waits for (the vector-memory counter is in order: a wait for
+        // the slot then leaves these in flight, and they stay in flight across the list's barriers; nothing needs them until the walk)
 #pragma unroll
-    for (int r = 0; r < kLscRows; ++r) {
-        yr[r] = rem + stride * min(vw + r, Hv - 1);
-        pix[r] = f.lab[(size_t)yr[r] * W + xc];
+        for (int r = 0; r < kLscRows; ++r) {
+            yr[r] = rem + stride * min(vw + r, Hv - 1);
+            pix[r] = f.lab[(size_t)yr[r] * W + xc];
+        }
+        visit(rec_first, (uint32_t)threadIdx.x < nslots && rec_first.pad == gen && in_window(rec_first, win));
+        for (uint32_t e0 = 256u; e0 < nslots; e0 += 256u) {
+            const uint32_t e = e0 + (uint32_t)threadIdx.x;
+            const ClusterRec rec = slot_rec(e);
+            visit(rec, e < nslots && rec.pad == gen && in_window(rec, win));
+        }
+        if (wave == kWavesPerBlock - 1) {
+            for (uint32_t i0 = 0; i0 < novf; i0 += 64) {
+                const uint32_t i = i0 + (uint32_t)lane;
+                ClusterRec rec;
+                rec.yx = 0; rec.lab = 0; rec.tag = 0; rec.pad = 0;
+                if (i < novf) rec = f.ovf_items[0][i];
+                visit(rec, i < novf && in_window(rec, win));
+            }
+        }
+        const bool any_lost = ballot(lost) != 0ull;
+        if (lane == 0) s_wc[wave] = (uint32_t)cntw | (any_lost ? 0x10000u : 0u);      // (bit 16: this wavefront lost a record: the list counts as overflowed)
+        LSC_STAMP(1, wave == 0);                // wave 0: its slots visited, centroid records requested
+        lds_barrier();
+        const uint32_t c0 = s_wc[0], c1 = s_wc[1], c2 = s_wc[2], c3 = s_wc[3];
+        const bool overflow = ((c0 | c1 | c2 | c3) & 0x10000u) != 0u;
+        const uint32_t n0 = c0 & 0xFFFFu, n1 = c1 & 0xFFFFu, n2 = c2 & 0xFFFFu, n3 = c3 & 0xFFFFu;
+        const uint32_t bn = overflow ? 65u : n0 + n1 + n2 + n3;
+        const uint32_t off = wave == 0 ? 0u : wave == 1 ? n0 : wave == 2 ? n0 + n1 : n0 + n1 + n2;
+        if (mine_kept && bn <= 64u) {
+            const uint32_t idx = off + my_pos;
+            s_arr[idx] = make_uint2(my_yx, my_tag);
+            float4* dst = reinterpret_cast<float4*>(s_cfraw + idx * 12);
+            dst[0] = q0; dst[1] = q1; dst[2] = q2;
+        }
+        lds_barrier();
+        if (wave == 0) {
+            const int cnt = (int)bn;
+            if (cnt <= 64) {
+                const bool act = lane < cnt;
+                const uint2 at = act ? s_arr[lane] : make_uint2(0u, 0xFFFFFFFFu);
+                const uint32_t mytag = at.y;
+                int rank = 0;
+                for (int jn = 0; jn < cnt; ++jn) rank += (uint32_t)__builtin_amdgcn_readlane((int)mytag, jn) < mytag ? 1 : 0;
+                // The distance is evaluated as |C - O|^2 - 2 (G - O) . (C - O) (+ |G - O|^2, the same for every candidate of a pixel)
+                // around an origin O of the block's own neighbourhood -- the first finite centroid of the list -- instead of
+                // sum (G - C)^2 (src/lsc.cpp:212-215): 11 FMAs per candidate instead of 10 subtractions + 10 FMAs.  Around O every
+                // term is of the size of the distances themselves, so the rounding stays at a few f32 ulps of them (measured on the
+                // reference fixtures: the same agreement as the subtract-and-square form, profiles/r03_lsc_recompute.txt).
+                const uint32_t k = act ? (mytag & 0xFFFFu) : 0u;
+                const float4* src = reinterpret_cast<const float4*>(s_cfraw + (act ? lane : 0) * 12);
+                const float4 r0 = src[0], r1 = src[1], r2 = src[2];
+                float cf[kLscFeat] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y};
+                float tot = 0.0f;
+#pragma unroll
+                for (int q = 0; q < kLscFeat; ++q) tot += cf[q];
+                // (the first in VISIT order: the lanes hold the list in the order the bin pass happened to insert it, which varies
+                // from run to run -- an origin picked by lane would move the rounding with it)
+                const bool finite = act && (tot - tot) == 0.0f;                                 // (NaN centroid of a memberless cluster: never the origin)
+                const uint32_t first = lsc_wave_min(finite ? (uint32_t)rank : 64u);
+                const unsigned long long fin = __ballot(finite && (uint32_t)rank == first);
+                const int o = fin ? __builtin_ctzll(fin) : 0;
+                float nrm = 0.0f;
+#pragma unroll
+                for (int q = 0; q < kLscFeat; ++q) {
+                    const float org = fin ? __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(cf[q]), o)) : 0.0f;
+                    if (lane == 0) s_org[q] = org;
+                    cf[q] -= org;
+                    nrm = __builtin_fmaf(cf[q], cf[q], nrm);
+                }
+                if (act) {
+                    s_yx[rank] = at.x;
+                    s_k[rank] = k;
+                    float4* dst = reinterpret_cast<float4*>(s_cf + rank * 12);
+                    dst[0] = make_float4(cf[0], cf[1], cf[2], cf[3]); dst[1] = make_float4(cf[4], cf[5], cf[6], cf[7]);
+                    dst[2] = make_float4(cf[8], cf[9], nrm, 0.0f);
+                }
+            } else if (lane < 12) {
+                s_org[lane] = 0.0f;        // the walk over every cluster subtracts and squares, around no origin
+            }
+            if (lane == 0) s_cnt = cnt;
+        }
     }
+    // this wavefront's pixels: column x0 + lane of kLscRows visited rows (clamped addresses, masked results), taken two rows
+    // (r, r+1) at a time: the feature and distance chains run on packed f32 (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, two
+    // rows per instruction; each half is the same IEEE operation as the scalar form), and a pair's twenty quotients are dead
+    // before the next pair's are formed -- all four rows at once cost 104 VGPRs (4 wavefronts per SIMD) with the sums below.
     const float xcos = l.lut_x[xc], xsin = l.lut_x[W + xc];
     float mean[kLscFeat];
 #pragma unroll

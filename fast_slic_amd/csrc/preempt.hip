@@ -185,19 +185,11 @@ void launch_preempt_update(const FrameDev& f_, int nframes, int buf, int sbuf, b
     const int ncell2 = f.pre_cw * f.pre_ch;
     if (f.K <= 8192 && ncell2 <= 4096) {
         const size_t lds = ((size_t)f.K + 2 * (size_t)ncell2 + 1) * 4 + (size_t)f.K * 2 + 16;
-        // the attribute belongs to the device that is current when it is set: once per DEVICE (an engine per GPU in one process), and a
-        // device on which it could not be set takes the all-pairs kernel instead of failing the launch
+        // the attribute belongs to the device that is current when it is set: once per DEVICE (launch.h), and a device on which it could
+        // not be set takes the all-pairs kernel instead of failing the launch
         constexpr int kMaxLds = (8192 + 2 * 4096 + 1) * 4 + 8192 * 2 + 16;
-        static std::atomic<int> attr_state[64];          // per device: 0 unknown, 1 set, -1 refused
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        dev = dev < 0 || dev >= 64 ? 0 : dev;
-        int stt = attr_state[dev].load(std::memory_order_acquire);
-        if (stt == 0) {
-            stt = hipFuncSetAttribute(reinterpret_cast<const void*>(k_preempt_update<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) == hipSuccess ? 1 : -1;
-            attr_state[dev].store(stt, std::memory_order_release);
-        }
-        if (stt < 0 && lds > 64 * 1024) {
+        static std::atomic<int> attr_state[64];
+        if (!max_dynamic_lds_on_this_device(k_preempt_update<true>, kMaxLds, attr_state) && lds > 64 * 1024) {
             launch(k_preempt_update<false>, dim3(nframes), dim3(1024), 0, st, f, rebin_all ? 1 : 0, l1_thres);
             return;
         }
