@@ -251,6 +251,7 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
     int yr[kLscRows];
     uint32_t pix[kLscRows];
     const int xc = min(x, W - 1);
+    float xcos, xsin, yf_mine = 0.0f, mean_raw[kLscFeat];
     // ---- the block's candidate list, second form (round 6).  Until then wavefront 0 built it alone -- six bin slots per lane and trip, the
     // (phase, k) ranks, then the centroid records of the listed clusters in a dependent round trip -- while the other three waited at
     // the barrier: 6.2 of a block's 22 us (profiles/r03_lab_lsc_phases.txt).  Now, as in the SLIC block kernel (assign.hip, second form):
@@ -308,6 +309,16 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
         for (int r = 0; r < kLscRows; ++r) {
             yr[r] = rem + stride * min(vw + r, Hv - 1);
             pix[r] = f.lab[(size_t)yr[r] * W + xc];
+        }
+        // ... and with them everything else the walk needs from memory (the column's x features, the feature means, this lane's y feature):
+        // requested after the list's barriers (until this round) they were what the first row pair waited for -- its walk took 4.5 us,
+        // the second pair's 2.4 (lab build 4 stamps)
+        xcos = l.lut_x[xc]; xsin = l.lut_x[W + xc];
+#pragma unroll
+        for (int q = 0; q < kLscFeat; ++q) mean_raw[q] = l.means[q];
+        if (lane < 2 * kLscRows) {
+            const int r = (lane >> 2) * 2 + (lane & 1);
+            yf_mine = l.lut_y[((lane >> 1) & 1) * f.H + rem + stride * min(vw + r, Hv - 1)];
         }
         visit(rec_first, (uint32_t)threadIdx.x < nslots && rec_first.pad == gen && in_window(rec_first, win));
         for (uint32_t e0 = 256u; e0 < nslots; e0 += 256u) {
@@ -391,19 +402,15 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
     // (r, r+1) at a time: the feature and distance chains run on packed f32 (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, two
     // rows per instruction; each half is the same IEEE operation as the scalar form), and a pair's twenty quotients are dead
     // before the next pair's are formed -- all four rows at once cost 104 VGPRs (4 wavefronts per SIMD) with the sums below.
-    const float xcos = l.lut_x[xc], xsin = l.lut_x[W + xc];
-    float mean[kLscFeat];
-#pragma unroll
-    for (int q = 0; q < kLscFeat; ++q) mean[q] = lsc_uniform(l.means[q]);
     // the rows' y features, all of them now: fetched pair by pair inside the loop below, the second pair's loads sat behind the first
     // pair's label stores in the vector-memory queue and their s_waitcnt exposed the stores' (written-through) acknowledgements
     // (through LDS: eight more scalar registers spill, eight vector registers cost a wavefront per SIMD)
+    float mean[kLscFeat];
+#pragma unroll
+    for (int q = 0; q < kLscFeat; ++q) mean[q] = lsc_uniform(mean_raw[q]);
     __shared__ __attribute__((aligned(16))) float s_yf[4][2 * kLscRows];      // per wavefront and row pair: cos r0, cos r1, sin r0, sin r1
     static_assert(kLscRows == 4, "two row pairs per wavefront");
-    if (lane < 2 * kLscRows) {
-        const int r = (lane >> 2) * 2 + (lane & 1);
-        s_yf[wave][lane] = l.lut_y[((lane >> 1) & 1) * f.H + rem + stride * min(vw + r, Hv - 1)];
-    }
+    if (lane < 2 * kLscRows) s_yf[wave][lane] = yf_mine;      // (requested with the pixel loads, above)
     LSC_STAMP(2, wave == 1);                    // wave 1: its pixel loads issued
     lds_barrier();      // LDS contents only pass between the wavefronts here: pixel loads / label stores stay in flight (device_common.h)
     LSC_STAMP(3, wave == 1);                    // barrier passed
