@@ -122,3 +122,39 @@ def test_lsc_full_size_4k_agrees(engine):
     bo = min(best_overlap(labels, r_labels), best_overlap(r_labels, labels))
     print("LSC 3840x2160 K=1600: pre-connectivity agreement %.4f, best-overlap %.4f" % (agree, bo))
     assert agree >= 0.97 and bo >= 0.95
+
+
+@pytest.mark.parametrize("arch", ["standard", "x64/avx2"])
+def test_integer_slic_against_the_live_reference_on_the_gpu_box(engine, arch):
+    """VERDICT r05, soft spot: the GPU parity tests compare the integer path with oracle/slic_oracle.c, whose equality with the
+    reference is established on the CPU box (tests/test_oracle.py) and by digests.  Here the HIP path meets the UNMODIFIED reference
+    itself (oracle/_ref, both of its archs) on the GPU box: BASELINE configs[1] (1280x720 K=1600), the 4K tie case of configs[2]
+    (3840x2160 K=6000: the area tie at the top-K cut), warm start from the reference's own cluster block, and random shapes /
+    options -- labels, pre-connectivity labels and every Cluster byte."""
+    rng = np.random.RandomState(77)
+    cases = [("A", 720, 1280, 1600, {}), ("A", 2160, 3840, 6000, {})]
+    for trial in range(10):
+        H, W = int(rng.randint(40, 420)), int(rng.randint(64, 520))
+        K = int(rng.randint(1, max(2, H * W // 300)))
+        kw = dict(max_iter=int(rng.randint(0, 12)), compactness=float(rng.choice([1.0, 10.0, 40.0])), min_size_factor=float(rng.choice([0.0, 0.25, 0.6])),
+                  subsample_stride=int(rng.randint(1, 5)), convert_to_lab=bool(rng.randint(0, 2)), manhattan=bool(rng.randint(0, 4) > 0))
+        cases.append(("ABC"[trial % 3], H, W, K, kw))
+    for kind, H, W, K, kw in cases:
+        img = variant(kind, H, W, seed=H + K)
+        cl0 = ref.initialize_clusters(img, K, arch=arch)
+        r_labels, r_cl, r_lab, r_pre = ref.slic_iterate(img, cl0, stages=True, num_threads=16 if H >= 720 else 2, arch=arch, **kw)
+        cl = cl0.copy().view(B.CLUSTER_DTYPE)
+        p = make_params(kw.get("max_iter", 10), kw.get("compactness", 10.0), kw.get("min_size_factor", 0.25), kw.get("subsample_stride", 3),
+                        kw.get("convert_to_lab", True), kw.get("manhattan", True))
+        labels = engine.iterate(np.ascontiguousarray(img), cl, p)
+        pre = engine.last_prelabels(H, W)
+        tag = "%s %dx%d K=%d %s arch=%s" % (kind, W, H, K, kw, arch)
+        assert np.array_equal(pre, r_pre), tag + " (pre-connectivity labels)"
+        assert np.array_equal(labels, r_labels), tag + " (labels)"
+        assert cl.tobytes() == r_cl.tobytes(), tag + " (clusters)"
+        if H == 720:      # warm start: the next frame from the block the reference left
+            img2 = variant("A", H, W, seed=9)
+            r2_labels, r2_cl = ref.slic_iterate(img2, r_cl, num_threads=16, arch=arch)
+            cl2 = r_cl.copy().view(B.CLUSTER_DTYPE)
+            labels2 = engine.iterate(np.ascontiguousarray(img2), cl2, make_params(10, 10.0, 0.25, 3))
+            assert np.array_equal(labels2, r2_labels) and cl2.tobytes() == r2_cl.tobytes(), tag + " (warm start)"
