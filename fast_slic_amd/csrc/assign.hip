@@ -727,6 +727,16 @@ static __device__ __forceinline__ void assign_blk2_body(FrameDev& f, int rem, in
         bn = c0 + c1 + c2 + c3;
         if (bn > 64) {                        // more live candidates than idx bits: the host redoes the frame generically
             if (tid == 0) atomicOr(f.err_flag, 1u);
+            // The plane is reset lazily (FrameDev::fv_mod): rows this launch is the first to look at hold whatever the arena's previous
+            // geometry left there.  The frame is redone, but a later pass of THIS run whose list fits again would take that for the
+            // pixels' old labels (sums of a cluster number beyond K), and the connectivity pass runs before the host sees the flag.
+            if constexpr (!FBIN) {
+                if (okx) {
+                    uint16_t* rowp = f.labels + (size_t)yw_lo * W + (uint32_t)x;
+                    for (int r = 0; r < nrows; ++r, rowp += (size_t)STRIDE * W)
+                        if (FUSE ? f.fv_mod == 1 : f.first_visit(yw_lo + r * STRIDE)) st_stream(rowp, (uint16_t)0xFFFFu);
+                }
+            }
             return;
         }
         const int p1 = c0, p2 = c0 + c1, p3 = c0 + c1 + c2;

@@ -1,0 +1,93 @@
+#!/usr/bin/env python
+"""Parity sweep on the GPU box (longer than the suite's randomized test; same bar: bit-exact against the oracle).
+    python tests/fuzz_parity.py [seed=1] [seconds=600]          FUZZ_SKIP=N: start at case N of the seed's sequence; FUZZ_CASES=M: stop after M cases
+ONE engine serves the whole sequence on purpose: every case re-carves the arena over what the previous geometries left there (round 6:
+a block that bailed out on a candidate-list overflow left the lazily reset label plane undefined, and a later pass summed pixels under
+the cluster numbers of an earlier, larger frame -- a memory fault at case 141 of seed 1; tests/test_gpu_parity.py replays that stretch).
+Random MID-SIZE shapes (the suite's randomized test stays below 300 px, where the generic kernels run; here the block kernels with
+their ragged right / bottom edges, every row count per wavefront and both table forms get random geometry), random options, and every
+frame both alone (Engine.iterate) and as one of a group of 2 .. 16 frames of one launch sequence (Engine.iterate_batch, host pointers).
+The oracle is the checker; prints two lines per case and a summary, exit code 1 at the first mismatch."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from fast_slic_amd import Engine, make_params      # noqa: E402
+from fast_slic_amd.synth import variant            # noqa: E402
+from oracle import oracle as orc                   # noqa: E402
+from util import cluster_fields_equal, describe_mismatch      # noqa: E402
+
+
+def main():
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    budget = float(sys.argv[2]) if len(sys.argv) > 2 else 600.0
+    rng = np.random.default_rng(seed)
+    e = Engine(0, 1)
+    t0 = time.time()
+    n_cases = n_frames = n_drawn = 0
+    skip = int(os.environ.get("FUZZ_SKIP", "0"))
+    max_cases = int(os.environ.get("FUZZ_CASES", "0"))
+    only_alone = os.environ.get("FUZZ_ONLY", "") == "alone"
+    only_group = os.environ.get("FUZZ_ONLY", "") == "group"
+    paths = {}
+    while time.time() - t0 < budget and (max_cases == 0 or n_cases < max_cases):
+        H, W = int(rng.integers(120, 1300)), int(rng.integers(120, 2000))
+        # superpixel side between ~6 and ~60 pixels: both table forms, every rows-per-wavefront choice
+        side = float(rng.choice([6, 8, 10, 13, 16, 20, 24, 32, 40, 48, 60]))
+        K = max(1, min(60000, int(H * W / (side * side))))
+        kw = dict(max_iter=int(rng.integers(0, 12)), compactness=float(rng.choice([1.0, 5.0, 10.0, 20.0, 40.0, 80.0])),
+                  min_size_factor=float(rng.choice([0.0, 0.1, 0.25, 0.5])), subsample_stride=int(rng.choice([1, 2, 3, 3, 3, 4, 5, 7])),
+                  convert_to_lab=bool(rng.integers(0, 4)), manhattan=True)
+        n = int(rng.choice([1, 2, 3, 5, 8, 16]))
+        if H * W * n > 12_000_000:
+            n = max(1, 12_000_000 // (H * W))
+        kinds = [("ABCD"[int(rng.integers(0, 4))]) for _ in range(n)]
+        seeds = [int(rng.integers(0, 1 << 30)) for _ in kinds]
+        n_drawn += 1
+        if n_drawn <= skip:                     # (FUZZ_SKIP=N: replay from case N of the same seed, e.g. the one a fault interrupted)
+            continue
+        tag = "%dx%d K=%d n=%d %s %s" % (W, H, K, n, "".join(kinds), kw)
+        print("run case %d %s" % (n_drawn - 1, tag), flush=True)
+        frames = [np.ascontiguousarray(variant(k, H, W, seed=sd)) for k, sd in zip(kinds, seeds)]
+        p = make_params(kw["max_iter"], kw["compactness"], kw["min_size_factor"], kw["subsample_stride"], kw["convert_to_lab"], kw["manhattan"])
+        exp = []
+        for f in frames:
+            cl0 = orc.initialize_clusters(f, K)
+            exp.append(orc.slic_iterate(f, cl0, **kw))
+        # alone
+        cl = orc.initialize_clusters(frames[0], K)
+        labels = e.iterate(frames[0], cl, p) if not only_group else exp[0][0]
+        if only_group:
+            cl = exp[0][1]
+        path = e.last_path() if not only_group else -1
+        paths[path] = paths.get(path, 0) + 1
+        bad = []
+        if not np.array_equal(labels, exp[0][0]):
+            bad.append(describe_mismatch("alone/labels", labels, exp[0][0]))
+        bad += cluster_fields_equal(cl, exp[0][1])
+        # as a group
+        if n > 1 and not only_alone:
+            cls = [orc.initialize_clusters(f, K) for f in frames]
+            outs = [np.empty((H, W), np.uint16) for _ in frames]
+            e.iterate_batch([f.ctypes.data for f in frames], cls, [o.ctypes.data for o in outs], H, W, p, device_ptrs=False)
+            for i in range(n):
+                if not np.array_equal(outs[i], exp[i][0]):
+                    bad.append(describe_mismatch("group frame %d/labels" % i, outs[i], exp[i][0]))
+                bad += ["group frame %d: %s" % (i, m) for m in cluster_fields_equal(cls[i], exp[i][1])]
+        n_cases += 1
+        n_frames += n
+        print("  %s path=%d" % ("ok" if not bad else "BAD", path), flush=True)
+        if bad:
+            print("\n".join(bad[:10]))
+            sys.exit(1)
+    print("fuzz_parity seed %d: %d cases, %d frames, all bit-exact; paths %s; %.0f s" % (seed, n_cases, n_frames, paths, time.time() - t0))
+    e.close()
+
+
+if __name__ == "__main__":
+    main()
