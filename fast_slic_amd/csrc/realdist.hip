@@ -10,6 +10,14 @@
 #include "device_common.h"
 #include <cfloat>
 
+// Every rounding of this file is stated: a product that is added is fused only where __builtin_fmaf says so.  hipcc's default for device
+// code (-ffp-contract=fast) fuses a * b + c wherever it finds one -- __fmul_rn / __fadd_rn are inline functions of the HIP headers, compiled
+// under that default whatever the pragma below says, so the operators are written out here -- and whether it
+// found the last addition of the 'noq' Euclidean distance depended on the unrolling around it: t + dy * dy became fma(dy, dy, t), one
+// rounding fewer than the reference makes, and on a constant frame (every pixel between two grid centres is a tie decided by the last
+// bit) 26 of 647 878 pixels of a 1078x601 K=1124 frame went to the other neighbour (tests/fuzz_parity.py, variants mode, seed 1 case 140).
+#pragma clang fp contract(off)
+
 namespace fslic {
 
 constexpr int kRdRows = 4;                              // visited rows per wavefront
@@ -203,7 +211,9 @@ void launch_member_sums(const FrameDev& f_, int nframes, int rem, int stride, in
 // Float centroids; per pixel-candidate the reference evaluates, in this order and with these roundings (checked against
 // the disassembly of the reference built with its own flags):
 //   manhattan:  ((|dr| + |dg|) + |db|) + |coef*(j - cx)|, then + |coef*(i - cy)|
-//   otherwise:  t = dr*dr; t = fma(dg,dg,t); t = fma(db,db,t); t = fma(dx,dx,t); t + (dy*dy)
+//   otherwise:  t = dg*dg; t = fma(dr,dr,t); t = fma(db,db,t); t = fma(dx,dx,t); t + (dy*dy)
+//               (vmulss dg,dg; vfmadd132ss dr,t,dr; .. db ..; .. dx ..; vaddss dy2 -- the square that is rounded on its own is dg's, not dr's:
+//               until round 6 this kernel had the two the other way round, one pixel in ~10^5 of a noise frame on the wrong side of a tie)
 // and the window [ (int)(cy - S), (int)((cy + S) + 1) ) x [ (int)(cx - S), (int)((cx + S) + 1) ) clipped to the image.
 // The candidate list is gathered with one pixel of slack around the integer window (the float expression can round up
 // across an integer); the exact test decides.
@@ -276,11 +286,12 @@ __global__ __launch_bounds__(256) void k_noq_assign(FrameDev f, float coef, int 
                 d = ((__builtin_fabsf(dr) + __builtin_fabsf(dg)) + __builtin_fabsf(db)) + __builtin_fabsf(dx);
                 d = d + __builtin_fabsf(dy);
             } else {
-                float t = __fmul_rn(dr, dr);
-                t = __builtin_fmaf(dg, dg, t);
+                float t = dg * dg;
+                t = __builtin_fmaf(dr, dr, t);
                 t = __builtin_fmaf(db, db, t);
                 t = __builtin_fmaf(dx, dx, t);
-                d = __fadd_rn(t, __fmul_rn(dy, dy));
+                const float dy2 = dy * dy;         // (its own rounding: plain operators under `fp contract(off)`, see the top of the file)
+                d = t + dy2;
             }
             if (inx && d < best[r]) { best[r] = d; bk[r] = k; }
         }

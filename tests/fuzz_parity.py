@@ -23,7 +23,88 @@ from oracle import oracle as orc                   # noqa: E402
 from util import cluster_fields_equal, describe_mismatch      # noqa: E402
 
 
+def variants_main(seed, budget):
+    """Mode `variants` (python tests/fuzz_parity.py SEED SECONDS variants): the same sweep for the paths the plain-C oracle does not restate --
+    SlicRealDist / L2 / NoQ, the preemptive mode (Slic and the float family) and the Euclidean spatial table -- against the UNMODIFIED
+    reference run live (oracle/_ref, travels as a built library), bit for bit, alone and in groups."""
+    from fast_slic_amd import _binding as B
+    from oracle import ref
+    if not ref.available():
+        print("oracle/_ref is not present: nothing to compare with")
+        sys.exit(2)
+    KIND = {"standard": B.VARIANT_REALDIST, "l2": B.VARIANT_REALDIST_L2, "noq": B.VARIANT_REALDIST_NOQ}
+    rng = np.random.default_rng(seed)
+    e = Engine(0, 1)
+    t0 = time.time()
+    n_cases = n_frames = n_drawn = 0
+    skip = int(os.environ.get("FUZZ_SKIP", "0"))
+    max_cases = int(os.environ.get("FUZZ_CASES", "0"))
+    while time.time() - t0 < budget and (max_cases == 0 or n_cases < max_cases):
+        H, W = int(rng.integers(60, 900)), int(rng.integers(60, 1300))
+        side = float(rng.choice([6, 8, 10, 13, 16, 20, 24, 32, 40, 60]))
+        K = max(1, min(60000, int(H * W / (side * side))))
+        kind = str(rng.choice(["slic", "slic", "standard", "l2", "noq"]))
+        pre = bool(rng.integers(0, 2))
+        thres = float(rng.choice([0.0, 0.02, 0.05, 0.1, 0.3]))
+        kw = dict(max_iter=int(rng.integers(0, 12)), compactness=float(rng.choice([1.0, 5.0, 10.0, 20.0, 40.0, 80.0])),
+                  min_size_factor=float(rng.choice([0.0, 0.1, 0.25, 0.5])), subsample_stride=int(rng.choice([1, 2, 3, 3, 3, 4, 5])),
+                  convert_to_lab=bool(rng.integers(0, 4)), manhattan=bool(rng.integers(0, 3)))
+        if kind == "slic" and not pre and kw["manhattan"]:
+            pre = True                                  # (plain Manhattan Slic is the default mode's sweep)
+        n = int(rng.choice([1, 2, 3, 5, 8, 16]))
+        if H * W * n > 6_000_000:
+            n = max(1, 6_000_000 // (H * W))
+        kinds = [("ABCD"[int(rng.integers(0, 4))]) for _ in range(n)]
+        seeds = [int(rng.integers(0, 1 << 30)) for _ in kinds]
+        n_drawn += 1
+        if n_drawn <= skip:
+            continue
+        tag = "%dx%d K=%d n=%d %s kind=%s preemptive=%s(%.2f) %s" % (W, H, K, n, "".join(kinds), kind, pre, thres, kw)
+        print("run case %d %s" % (n_drawn - 1, tag), flush=True)
+        frames = [np.ascontiguousarray(variant(k, H, W, seed=sd)) for k, sd in zip(kinds, seeds)]
+        p = make_params(kw["max_iter"], kw["compactness"], kw["min_size_factor"], kw["subsample_stride"], kw["convert_to_lab"], kw["manhattan"],
+                        preemptive=pre, preemptive_thres=thres, variant=(B.VARIANT_SLIC if kind == "slic" else KIND[kind]))
+        exp = []
+        ref.set_preemptive(pre, thres)
+        try:
+            for f in frames:
+                cl0 = ref.initialize_clusters(f, K)
+                if kind == "slic":
+                    r = ref.slic_iterate(f, cl0, num_threads=1, arch="standard", **kw)
+                    exp.append((r[0], r[1]))
+                else:
+                    r = ref.realdist_iterate(f, cl0, kind, num_threads=1, **kw)
+                    exp.append((r[0], r[1]))
+        finally:
+            ref.set_preemptive(False)
+        bad = []
+        ai = int(os.environ.get("FUZZ_ALONE_INDEX", "0")) % n          # (which frame of the case also runs alone)
+        cl = ref.initialize_clusters(frames[ai], K)
+        labels = e.iterate(frames[ai], cl, p)
+        if not np.array_equal(labels, exp[ai][0]):
+            bad.append(describe_mismatch("alone (frame %d)/labels" % ai, labels, exp[ai][0]))
+        bad += ["alone (frame %d): %s" % (ai, m) for m in cluster_fields_equal(cl, exp[ai][1])]
+        if n > 1:
+            cls = [ref.initialize_clusters(f, K) for f in frames]
+            outs = [np.empty((H, W), np.uint16) for _ in frames]
+            e.iterate_batch([f.ctypes.data for f in frames], cls, [o.ctypes.data for o in outs], H, W, p, device_ptrs=False)
+            for i in range(n):
+                if not np.array_equal(outs[i], exp[i][0]):
+                    bad.append(describe_mismatch("group frame %d/labels" % i, outs[i], exp[i][0]))
+                bad += ["group frame %d: %s" % (i, m) for m in cluster_fields_equal(cls[i], exp[i][1])]
+        n_cases += 1
+        n_frames += n
+        print("  %s" % ("ok" if not bad else "BAD"), flush=True)
+        if bad:
+            print("\n".join(bad[:10]))
+            sys.exit(1)
+    print("fuzz_parity variants seed %d: %d cases, %d frames, all bit-exact; %.0f s" % (seed, n_cases, n_frames, time.time() - t0))
+    e.close()
+
+
 def main():
+    if len(sys.argv) > 3 and sys.argv[3] == "variants":
+        return variants_main(int(sys.argv[1]), float(sys.argv[2]))
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     budget = float(sys.argv[2]) if len(sys.argv) > 2 else 600.0
     rng = np.random.default_rng(seed)

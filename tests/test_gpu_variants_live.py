@@ -184,3 +184,23 @@ def test_lsc_large_compactness_against_the_live_reference(engine, compactness):
             assert np.abs(np.stack([cl["y"] - r_cl["y"], cl["x"] - r_cl["x"]])).max() <= 2.0
         else:
             assert agree >= 0.90 and ov >= 0.90, (compactness, H, W, K, agree, ov)
+
+
+def test_noq_euclidean_distance_roundings_on_ties(engine):
+    # SlicRealDistNoQ with manhattan_spatial_dist=False: the reference build evaluates dg*dg first, then fma(dr,dr,.), fma(db,db,.),
+    # fma(dx,dx,.) and ADDS the row's dy*dy (src/context.cpp:486-492 under -O2 -mfma).  Two frames on which one rounding decides pixels
+    # (found by tests/fuzz_parity.py, variants mode, seed 1 cases 140 and 1022): a constant frame -- every pixel between two grid centres
+    # is an exact tie, and a compiler-fused last addition moved 26 of them -- and a noise frame where the squares of dr and dg had been
+    # taken in the other order (one pixel in 1.4e5 at the third iteration, 71 pixels and 11 centroids at the end).
+    cases = [(np.zeros((601, 1078, 3), np.uint8), 1124, dict(max_iter=3, compactness=5.0, min_size_factor=0.1, subsample_stride=5, convert_to_lab=False, manhattan=False)),
+             (variant("C", 531, 271, seed=700345361), 249, dict(max_iter=5, compactness=80.0, min_size_factor=0.1, subsample_stride=3, convert_to_lab=True, manhattan=False))]
+    for img, K, kw in cases:
+        img = np.ascontiguousarray(img)
+        cl0 = ref.initialize_clusters(img, K)
+        r_labels, r_cl, r_pre = ref.realdist_iterate(img, cl0, "noq", num_threads=1, **kw)
+        labels, cl, pre = run(engine, img, cl0, KIND["noq"], **kw)
+        tag = "noq euclidean %dx%d K=%d" % (img.shape[1], img.shape[0], K)
+        assert np.array_equal(pre, r_pre), describe_mismatch(tag + "/prelabels", pre, r_pre)
+        msgs = cluster_fields_equal(cl, r_cl)
+        assert not msgs, tag + ": " + "; ".join(msgs)
+        assert np.array_equal(labels, r_labels), describe_mismatch(tag + "/labels", labels, r_labels)
