@@ -256,14 +256,20 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
     // (phase, k) ranks, then the centroid records of the listed clusters in a dependent round trip -- while the other three waited at
     // the barrier: 6.2 of a block's 22 us (profiles/r03_lab_lsc_phases.txt).  Now, as in the SLIC block kernel (assign.hip, second form):
     //   A  every thread takes ONE 16-byte slot of the cells the block's window can see (all of them in one trip at S >= 16), keeps the
-    //      live records inside the window, and REQUESTS THE CENTROID RECORD of a kept cluster at once (three 16-byte loads that stay in
-    //      flight across the first barrier); positions inside the wavefront by ballot, the counts meet in LDS
+    //      live records inside the window, and REQUESTS THE CENTROID RECORD of the first cluster it keeps at once (three 16-byte loads that
+    //      stay in flight across the first barrier; further records of the same thread: s_ext, below); positions inside the wavefront by
+    //      ballot, the counts meet in LDS
     //   B  kept records go to their arrival index (wavefront 0's first, ...): {yx, tag} and the ten centroid features
     //   C  wavefront 0, lane j = arrival j: ranks by (phase, k), the origin (first finite centroid in VISIT order, so the rounding does
     //      not depend on the arrival order), centroid - origin and its squared norm staged by rank -- from LDS, no memory round trip
     __shared__ __attribute__((aligned(16))) float s_cfraw[64 * 12];      // centroid records by arrival index
     __shared__ uint2 s_arr[64];                                           // {yx, tag} by arrival index
     __shared__ uint32_t s_wc[kWavesPerBlock];
+    // {yx, tag | position << 20} of the records a thread kept beyond its first, 64 per wavefront: in the bytes of s_cf (3 KB), which is
+    // written only behind the second barrier, when these have been consumed -- an array of its own (2 KB) took the block's LDS from
+    // 25.8 to 27.8 KB, i.e. from six resident blocks per CU to five
+    uint2 (* const s_ext)[64] = reinterpret_cast<uint2 (*)[64]>(s_cf);
+    static_assert(sizeof(s_cf) >= kWavesPerBlock * 64 * sizeof(uint2), "s_ext lives in s_cf");
     {
         const int v_last = min(v0 + kLscBH, Hv) - 1;
         TileWindow win;
@@ -279,21 +285,27 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
         uint32_t my_yx = 0, my_tag = 0, my_pos = 0;
         bool mine_kept = false;
         float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
-        int cntw = 0;
-        // (a thread keeps at most one record: its own slot of the first trip that yields one; a second kept record of the same thread --
-        // more than 256 slots, i.e. S < 16, or the spill list -- is counted as an overflow of the list, which takes the walk over every
-        // cluster: exact either way)
-        bool lost = false;
+        int cntw = 0, cnte = 0;
+        // A thread holds ONE centroid record in registers: that of the first record it keeps.  A further kept record of the same thread
+        // (more than 256 slots, i.e. S < 16, or the spill list) goes to the wavefront's s_ext list with its position, and its centroid
+        // record is fetched after the first barrier, the dependent round trip the first form paid for every record.  Which thread meets
+        // which record is the bin pass's insertion order, i.e. it varies from run to run: the LIST must not (until this was added a second
+        // record made the block walk over every cluster -- exact, but with the roundings of the other distance form, so that ties of
+        // a constant frame fell differently from run to run: tests/fuzz_parity.py, lsc mode, seed 1 case 146).
         auto visit = [&](const ClusterRec& rec, bool keep) {
             const unsigned long long m = ballot(keep);
             const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)cntw));
-            if (keep) {
-                if (mine_kept) lost = true;
-                else {
-                    mine_kept = true; my_yx = rec.yx; my_tag = rec.tag; my_pos = pos;
-                    const float4* src = reinterpret_cast<const float4*>(l.cfeat + (size_t)(rec.tag & 0xFFFFu) * kLscCfPitch);
-                    q0 = src[0]; q1 = src[1]; q2 = src[2];
-                }
+            const bool extra = keep && mine_kept;
+            const unsigned long long me = ballot(extra);
+            if (me) {                                  // (uniform)
+                const uint32_t epos = __builtin_amdgcn_mbcnt_hi((uint32_t)(me >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)me, (uint32_t)cnte));
+                if (extra && epos < 64u && pos < 64u) s_ext[wave][epos] = make_uint2(rec.yx, rec.tag | (pos << 20));
+                cnte += __popcll(me);
+            }
+            if (keep && !mine_kept) {
+                mine_kept = true; my_yx = rec.yx; my_tag = rec.tag; my_pos = pos;
+                const float4* src = reinterpret_cast<const float4*>(l.cfeat + (size_t)(rec.tag & 0xFFFFu) * kLscCfPitch);
+                q0 = src[0]; q1 = src[1]; q2 = src[2];
             }
             cntw += __popcll(m);
         };
@@ -335,20 +347,28 @@ static __device__ __forceinline__ void lsc_assign_body(FrameDev& f, LscDev& l, i
                 visit(rec, i < novf && in_window(rec, win));
             }
         }
-        const bool any_lost = ballot(lost) != 0ull;
-        if (lane == 0) s_wc[wave] = (uint32_t)cntw | (any_lost ? 0x10000u : 0u);      // (bit 16: this wavefront lost a record: the list counts as overflowed)
+        if (lane == 0) s_wc[wave] = (uint32_t)min(cntw, 0xFFFF);
         LSC_STAMP(1, wave == 0);                // wave 0: its slots visited, centroid records requested
         lds_barrier();
-        const uint32_t c0 = s_wc[0], c1 = s_wc[1], c2 = s_wc[2], c3 = s_wc[3];
-        const bool overflow = ((c0 | c1 | c2 | c3) & 0x10000u) != 0u;
-        const uint32_t n0 = c0 & 0xFFFFu, n1 = c1 & 0xFFFFu, n2 = c2 & 0xFFFFu, n3 = c3 & 0xFFFFu;
-        const uint32_t bn = overflow ? 65u : n0 + n1 + n2 + n3;
+        const uint32_t n0 = s_wc[0], n1 = s_wc[1], n2 = s_wc[2], n3 = s_wc[3];
+        const uint32_t bn = n0 + n1 + n2 + n3;                       // (the number of live records inside the window: the same in every run)
         const uint32_t off = wave == 0 ? 0u : wave == 1 ? n0 : wave == 2 ? n0 + n1 : n0 + n1 + n2;
-        if (mine_kept && bn <= 64u) {
-            const uint32_t idx = off + my_pos;
-            s_arr[idx] = make_uint2(my_yx, my_tag);
-            float4* dst = reinterpret_cast<float4*>(s_cfraw + idx * 12);
-            dst[0] = q0; dst[1] = q1; dst[2] = q2;
+        if (bn <= 64u) {
+            if (mine_kept) {
+                const uint32_t idx = off + my_pos;
+                s_arr[idx] = make_uint2(my_yx, my_tag);
+                float4* dst = reinterpret_cast<float4*>(s_cfraw + idx * 12);
+                dst[0] = q0; dst[1] = q1; dst[2] = q2;
+            }
+            if (cnte > 0 && lane < cnte) {             // this wavefront's further records (cnte <= bn <= 64): fetched now
+                const uint2 ex = s_ext[wave][lane];
+                const uint32_t tag = ex.y & 0xFFFFFu, idx = off + (ex.y >> 20);
+                const float4* src = reinterpret_cast<const float4*>(l.cfeat + (size_t)(tag & 0xFFFFu) * kLscCfPitch);
+                const float4 e0 = src[0], e1 = src[1], e2 = src[2];
+                s_arr[idx] = make_uint2(ex.x, tag);
+                float4* dst = reinterpret_cast<float4*>(s_cfraw + idx * 12);
+                dst[0] = e0; dst[1] = e1; dst[2] = e2;
+            }
         }
         lds_barrier();
         if (wave == 0) {

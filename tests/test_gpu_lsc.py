@@ -167,3 +167,17 @@ def test_lsc_ragged_shapes_run_and_cover(engine, H, W, K, kw):
     labels, cl, pre = run_lsc(engine, img, K, **kw)
     assert labels.shape == (H, W) and (pre != 0xFFFF).all()
     assert np.isfinite(cl["y"]).all() and (cl["y"] >= 0).all() and (cl["y"] <= H - 1).all() and (cl["x"] <= W - 1).all()
+
+
+def test_lsc_small_superpixels_on_a_constant_frame_are_deterministic(engine):
+    # S = 6: a block's window sees more than 256 bin slots, so a thread of the list build can meet two live records -- which two
+    # depends on the order the bin pass inserted them, i.e. it varies from run to run.  Round 6's first parallel list build then fell
+    # back to the walk over every cluster: exact, but with the roundings of the other distance form, and on a constant frame (every pixel
+    # between two seeds is a tie) 6 .. 25 pixels changed sides from run to run (tests/fuzz_parity.py, lsc mode, seed 1 case 146).
+    H, W, K = 287, 687, 5476
+    img = np.zeros((H, W, 3), np.uint8)
+    for max_iter in (1, 3, 11):
+        runs = [run_lsc(engine, img, K, max_iter=max_iter, compactness=20.0, min_size_factor=0.1, subsample_stride=2, convert_to_lab=False) for _ in range(5)]
+        for r in runs[1:]:
+            assert np.array_equal(r[2], runs[0][2]) and np.array_equal(r[0], runs[0][0]), max_iter
+            assert r[1].tobytes() == runs[0][1].tobytes(), max_iter
