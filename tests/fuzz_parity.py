@@ -111,7 +111,8 @@ def cca_main(seed, budget):
     t0 = time.time()
     n_cases = 0
     kinds_seen = {}
-    while time.time() - t0 < budget:
+    max_cases = int(os.environ.get("FUZZ_CASES", "0"))
+    while time.time() - t0 < budget and (max_cases == 0 or n_cases < max_cases):
         H, W = int(rng.integers(1, 1100)), int(rng.integers(1, 1700))
         kind = str(rng.choice(["noise", "blobs", "stripes_v", "stripes_h", "checker", "kron", "ramp", "slic"]))
         K = int(rng.choice([1, 2, 5, 50, 500, 5000, 60000]))
@@ -169,7 +170,8 @@ def lsc_main(seed, budget):
     t0 = time.time()
     n_cases = 0
     worst = 1.0
-    while time.time() - t0 < budget:
+    max_cases = int(os.environ.get("FUZZ_CASES", "0"))
+    while time.time() - t0 < budget and (max_cases == 0 or n_cases < max_cases):
         H, W = int(rng.integers(40, 1100)), int(rng.integers(40, 1700))
         side = float(rng.choice([6, 8, 10, 13, 16, 20, 24, 32, 40, 60]))
         K = max(1, min(60000, int(H * W / (side * side))))
@@ -219,7 +221,209 @@ def lsc_main(seed, budget):
     e.close()
 
 
+def warm_main(seed, budget):
+    """Mode `warm`: arbitrary cluster states as INPUT (the reference accepts whatever SlicModel.clusters was set to, cfast_slic.pyx:68-98):
+    random positions (fractional, on the borders, outside the image), piles of identical clusters (bins beyond their eight slots: the
+    spill list; block lists beyond 64 candidates: the generic redo), random colours, and the state a previous frame left (warm start)
+    -- against the oracle, bit for bit, alone and in groups of different states."""
+    rng = np.random.default_rng(seed)
+    e = Engine(0, 1)
+    t0 = time.time()
+    n_cases = 0
+    paths = {}
+    max_cases = int(os.environ.get("FUZZ_CASES", "0"))
+    while time.time() - t0 < budget and (max_cases == 0 or n_cases < max_cases):
+        H, W = int(rng.integers(40, 900)), int(rng.integers(40, 1400))
+        side = float(rng.choice([8, 10, 13, 16, 20, 24, 32, 40, 60]))
+        K = max(1, min(20000, int(H * W / (side * side))))
+        kw = dict(max_iter=int(rng.integers(0, 9)), compactness=float(rng.choice([1.0, 10.0, 40.0])),
+                  min_size_factor=float(rng.choice([0.0, 0.25])), subsample_stride=int(rng.choice([1, 2, 3, 3, 5])),
+                  convert_to_lab=bool(rng.integers(0, 4)), manhattan=bool(rng.integers(0, 4)))
+        n = int(rng.choice([1, 2, 4, 8]))
+        if H * W * n > 5_000_000:
+            n = max(1, 5_000_000 // (H * W))
+        frames = [np.ascontiguousarray(variant("ABCD"[int(rng.integers(0, 4))], H, W, seed=int(rng.integers(0, 1 << 30)))) for _ in range(n)]
+        states = []
+        kinds = []
+        for f in frames:
+            cl = orc.initialize_clusters(f, K)
+            kind = str(rng.choice(["grid", "uniform", "piles", "borders", "warm", "one_cell", "fraction"]))
+            if kind == "uniform":
+                cl["y"] = rng.uniform(0, H, K).astype(np.float32); cl["x"] = rng.uniform(0, W, K).astype(np.float32)
+            elif kind == "piles":
+                m = max(1, K // int(rng.choice([2, 9, 40])))
+                py = rng.integers(0, H, m); px = rng.integers(0, W, m); pick = rng.integers(0, m, K)
+                cl["y"] = py[pick].astype(np.float32); cl["x"] = px[pick].astype(np.float32)
+                if rng.random() < 0.5:
+                    pc = rng.integers(0, 256, (m, 3)); cl["r"], cl["g"], cl["b"] = (pc[pick, q].astype(np.float32) for q in range(3))
+            elif kind == "borders":
+                cl["y"] = rng.choice([-3.0, 0.0, 0.4, H - 1.0, H - 0.5, H + 7.0], K).astype(np.float32)
+                cl["x"] = rng.uniform(-5, W + 5, K).astype(np.float32)
+            elif kind == "warm":
+                other = np.ascontiguousarray(variant("AB"[int(rng.integers(0, 2))], H, W, seed=int(rng.integers(0, 1 << 30))))
+                cl = orc.slic_iterate(other, cl, **kw)[1]
+            elif kind == "one_cell":
+                cl["y"] = rng.integers(0, min(H, 12), K).astype(np.float32); cl["x"] = rng.integers(0, min(W, 12), K).astype(np.float32)
+            elif kind == "fraction":
+                cl["y"] = (cl["y"] + rng.uniform(-0.99, 0.99, K)).astype(np.float32); cl["x"] = (cl["x"] + rng.uniform(-0.99, 0.99, K)).astype(np.float32)
+            if kind not in ("grid", "warm") and rng.random() < 0.5:
+                cl["r"] = rng.integers(0, 256, K).astype(np.float32); cl["g"] = rng.integers(0, 256, K).astype(np.float32); cl["b"] = rng.integers(0, 256, K).astype(np.float32)
+            states.append(cl)
+            kinds.append(kind)
+        tag = "%dx%d K=%d n=%d %s %s" % (W, H, K, n, kinds, kw)
+        print("run case %d %s" % (n_cases, tag), flush=True)
+        p = make_params(kw["max_iter"], kw["compactness"], kw["min_size_factor"], kw["subsample_stride"], kw["convert_to_lab"], kw["manhattan"])
+        exp = [orc.slic_iterate(f, c, **kw) for f, c in zip(frames, states)]
+        bad = []
+        cl = states[0].copy()
+        labels = e.iterate(frames[0], cl, p)
+        path = e.last_path()
+        paths[path] = paths.get(path, 0) + 1
+        if not np.array_equal(labels, exp[0][0]):
+            bad.append(describe_mismatch("alone/labels", labels, exp[0][0]))
+        bad += cluster_fields_equal(cl, exp[0][1])
+        if n > 1:
+            cls = [c.copy() for c in states]
+            outs = [np.empty((H, W), np.uint16) for _ in frames]
+            e.iterate_batch([f.ctypes.data for f in frames], cls, [o.ctypes.data for o in outs], H, W, p, device_ptrs=False)
+            for i in range(n):
+                if not np.array_equal(outs[i], exp[i][0]):
+                    bad.append(describe_mismatch("group frame %d/labels" % i, outs[i], exp[i][0]))
+                bad += ["group frame %d: %s" % (i, m) for m in cluster_fields_equal(cls[i], exp[i][1])]
+        n_cases += 1
+        print("  %s path=%d" % ("ok" if not bad else "BAD", path), flush=True)
+        if bad:
+            print("\n".join(bad[:10]))
+            sys.exit(1)
+    print("fuzz_parity warm seed %d: %d cases, all bit-exact; paths %s; %.0f s" % (seed, n_cases, paths, time.time() - t0))
+    e.close()
+
+
+def pipeline_main(seed, budget):
+    """Mode `pipeline`: the submit / drain pipeline the bench runs in (several slots, recorded launch sequences replayed, dynamic batching)
+    under a RANDOM sequence of submissions drawn from a pool of fourteen geometries / option sets -- more than the eight launch
+    sequences a slot keeps, so entries are recorded, replayed, evicted and recorded again while arenas are re-carved between them --
+    device-resident frames, every frame of every submission against the oracle."""
+    import torch
+    rng = np.random.default_rng(seed)
+    n_slots = int(rng.choice([2, 3, 6]))
+    batching = int(rng.choice([0, 8, 16]))
+    e = Engine(0, n_slots)
+    if batching:
+        e.pipeline_batching(batching)
+    pool = []
+    for _ in range(14):
+        H, W = int(rng.integers(60, 500)), int(rng.integers(60, 700))
+        side = float(rng.choice([8, 10, 16, 24, 40]))
+        K = max(1, int(H * W / (side * side)))
+        kw = dict(max_iter=int(rng.integers(0, 11)), compactness=float(rng.choice([1.0, 10.0, 40.0])), min_size_factor=float(rng.choice([0.0, 0.25])),
+                  subsample_stride=int(rng.choice([1, 2, 3, 3, 4])), convert_to_lab=bool(rng.integers(0, 4)), manhattan=True)
+        pool.append((H, W, K, kw, int(rng.choice([1, 2, 4, 8]))))
+    print("pipeline: %d slots, batching %d" % (n_slots, batching), flush=True)
+    t0 = time.time()
+    n_sub = n_frames = 0
+    max_cases = int(os.environ.get("FUZZ_CASES", "0"))           # (submissions)
+    while time.time() - t0 < budget and (max_cases == 0 or n_sub < max_cases):
+        burst = []                       # submissions between two drains
+        for _ in range(int(rng.integers(1, 25))):
+            H, W, K, kw, n = pool[int(rng.integers(0, len(pool)))] if rng.random() < 0.8 else pool[0]
+            frames = [np.ascontiguousarray(variant("ABCD"[int(rng.integers(0, 4))], H, W, seed=int(rng.integers(0, 1 << 30)))) for _ in range(n)]
+            cls = np.stack([orc.initialize_clusters(f, K) for f in frames])
+            exp = [orc.slic_iterate(f, c, **kw) for f, c in zip(frames, cls)]
+            d_rgb = [torch.from_numpy(f).cuda() for f in frames]
+            d_lab = [torch.empty((H, W), dtype=torch.int16, device="cuda") for _ in frames]
+            torch.cuda.synchronize()
+            a = (e.pointer_array([t.data_ptr() for t in d_rgb]), e.pointer_array([cls[i].ctypes.data for i in range(n)]), e.pointer_array([t.data_ptr() for t in d_lab]))
+            p = make_params(kw["max_iter"], kw["compactness"], kw["min_size_factor"], kw["subsample_stride"], kw["convert_to_lab"], kw["manhattan"])
+            e.pipeline_submit(a[0], a[1], a[2], n, H, W, K, p)
+            burst.append((H, W, K, kw, n, cls, exp, d_rgb, d_lab, a, p))
+        e.pipeline_drain()
+        for (H, W, K, kw, n, cls, exp, d_rgb, d_lab, a, p) in burst:
+            for i in range(n):
+                got = d_lab[i].cpu().numpy().view(np.uint16)
+                msgs = cluster_fields_equal(cls[i], exp[i][1])
+                if not np.array_equal(got, exp[i][0]) or msgs:
+                    print("BAD after %d submissions: %dx%d K=%d n=%d frame %d %s" % (n_sub, W, H, K, n, i, kw))
+                    print(describe_mismatch("labels", got, exp[i][0]))
+                    print("\n".join(msgs))
+                    sys.exit(1)
+            n_sub += 1
+            n_frames += n
+        print("  drained: %d submissions so far" % n_sub, flush=True)
+    print("fuzz_parity pipeline seed %d (%d slots, batching %d): %d submissions, %d frames, all bit-exact; %.0f s" % (seed, n_slots, batching, n_sub, n_frames, time.time() - t0))
+    e.close()
+
+
+def graph_main(seed, budget):
+    """Mode `graph`: the superpixel-graph utilities (src/fast-slic.cpp: get_connectivity with its 12-neighbour cut-off, get_mask_density,
+    cluster_density_to_mask) on random label maps of random size -- SLIC-like blocks with ragged borders, noise, frames around blocks,
+    few labels -- against the unmodified reference run live, bit for bit."""
+    from fast_slic_amd import _binding as B
+    from oracle import ref
+    if not ref.available():
+        print("oracle/_ref is not present: nothing to compare with")
+        sys.exit(2)
+    rng = np.random.default_rng(seed)
+    e = Engine(0, 1)
+    t0 = time.time()
+    n_cases = 0
+    max_cases = int(os.environ.get("FUZZ_CASES", "0"))
+    while time.time() - t0 < budget and (max_cases == 0 or n_cases < max_cases):
+        H, W = int(rng.integers(1, 900)), int(rng.integers(1, 1400))
+        K = int(rng.choice([1, 2, 7, 60, 400, 3000, 20000, 60000]))
+        kind = str(rng.choice(["noise", "blocks", "frames", "few", "slic"]))
+        if kind == "noise":
+            labels = rng.integers(0, K, (H, W))
+        elif kind == "blocks":
+            labels = ((np.arange(H)[:, None] // 7) * 13 + np.arange(W)[None, :] // 9) % K + np.zeros((H, W), int)
+            m = rng.random((H, W)) < 0.1
+            labels[m] = rng.integers(0, K, int(m.sum()))
+        elif kind == "frames":
+            labels = ((np.arange(H)[:, None] // 4) * 50 + np.arange(W)[None, :] // 4) % K + np.zeros((H, W), int)
+            labels[::4] = 0
+            labels[:, ::4] = 0
+        elif kind == "few":
+            labels = rng.integers(0, min(K, 3), (H // 8 + 1, W // 8 + 1)).repeat(8, 0).repeat(8, 1)[:H, :W]
+        else:
+            c = int(rng.choice([6, 10, 16, 24, 40])); gy, gx = H // c + 1, W // c + 1
+            base = np.kron(np.arange(gy * gx).reshape(gy, gx), np.ones((c, c), int))[:H, :W]
+            jit = rng.integers(-c // 2, c // 2 + 1, (H, W)) * (rng.random((H, W)) < 0.15)
+            yy = np.clip(np.arange(H)[:, None] + jit, 0, H - 1); xx = np.clip(np.arange(W)[None, :] + jit, 0, W - 1)
+            labels = base[yy, xx] % K
+        labels = np.ascontiguousarray(labels.astype(np.uint16))
+        cl = np.zeros(K, B.CLUSTER_DTYPE)
+        cl["number"] = np.arange(K)
+        cl["num_members"] = rng.integers(0, 50, K)
+        mask = (rng.integers(0, 256, (H, W)) * (rng.random((H, W)) < float(rng.choice([0.05, 0.6, 1.0])))).astype(np.uint8)
+        tag = "%dx%d %s K=%d" % (W, H, kind, K)
+        print("run case %d %s" % (n_cases, tag), flush=True)
+        num, nb = e.get_connectivity(labels, H, W, K)
+        rnum, rnb = ref.get_connectivity(labels, K)
+        ok = np.array_equal(num, rnum) and np.array_equal(nb, rnb)
+        dens = e.get_mask_density(cl, labels, mask, H, W)
+        ok = ok and np.array_equal(dens, ref.get_mask_density(cl, labels, mask))
+        ok = ok and np.array_equal(e.cluster_density_to_mask(labels, dens, H, W), ref.cluster_density_to_mask(cl, labels, dens))
+        if rng.random() < 0.3:           # unassigned pixels: the density utilities skip them
+            holes = labels.copy()
+            holes[rng.random((H, W)) < 0.1] = 0xFFFF
+            dens = e.get_mask_density(cl, holes, mask, H, W)
+            ok = ok and np.array_equal(dens, ref.get_mask_density(cl, holes, mask))
+            ok = ok and np.array_equal(e.cluster_density_to_mask(holes, dens, H, W), ref.cluster_density_to_mask(cl, holes, dens))
+        if not ok:
+            print("  BAD")
+            sys.exit(1)
+        n_cases += 1
+    print("fuzz_parity graph seed %d: %d maps, all bit-exact; %.0f s" % (seed, n_cases, time.time() - t0))
+    e.close()
+
+
 def main():
+    if len(sys.argv) > 3 and sys.argv[3] == "graph":
+        return graph_main(int(sys.argv[1]), float(sys.argv[2]))
+    if len(sys.argv) > 3 and sys.argv[3] == "warm":
+        return warm_main(int(sys.argv[1]), float(sys.argv[2]))
+    if len(sys.argv) > 3 and sys.argv[3] == "pipeline":
+        return pipeline_main(int(sys.argv[1]), float(sys.argv[2]))
     if len(sys.argv) > 3 and sys.argv[3] == "variants":
         return variants_main(int(sys.argv[1]), float(sys.argv[2]))
     if len(sys.argv) > 3 and sys.argv[3] == "cca":
