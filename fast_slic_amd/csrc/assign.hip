@@ -91,13 +91,17 @@ __global__ __launch_bounds__(256) void k_assign(FrameDev f, int rem, int stride,
     const int cya = max(win.wy_lo, 0) >> sh, cyb = min(win.wy_hi, f.H - 1) >> sh;
     const int ncxr = cxb - cxa + 1, ncyr = cyb - cya + 1;
     const int total = ncxr * ncyr * kCellCap;
-    const uint32_t inv = (uint32_t)(4294967296.0f / (float)ncxr) + 1u;   // exact quotient for the small operands here
+    // exact quotient for the small operands here -- for ncxr >= 2: 2^32 / 1 does not fit (the conversion saturates, + 1 wraps to 0 and every
+    // cell landed in cell row 0).  One cell column is what a tile at the image's left edge sees when 63 + S is less than the cell side,
+    // S = 129 .. 192 or 257 .. 448, on the inputs this kernel serves (spatial term >= 259): candidates of the lower cell rows were
+    // never fetched there until round 6 (tests/fuzz_parity.py, FUZZ_SHAPES=big, seed 5 case 11: 2090x1412 K=131 compactness 80).
+    const uint32_t inv = ncxr > 1 ? (uint32_t)(4294967296.0f / (float)ncxr) + 1u : 0u;
     const ClusterRec* __restrict__ citems = f.cell_items[0];
     const ClusterRec* __restrict__ oitems = f.ovf_items[0];
     const unsigned long long lowmask = (1ull << lane) - 1ull;
     auto cell_slot = [&](int e) -> size_t {
         const uint32_t ce = (uint32_t)e >> 3;
-        uint32_t cyi = __umulhi(ce, inv);
+        uint32_t cyi = ncxr > 1 ? __umulhi(ce, inv) : ce;
         if (cyi * (uint32_t)ncxr > ce) cyi--;                // guard the float reciprocal
         const uint32_t cxi = ce - cyi * (uint32_t)ncxr;
         return ((size_t)(cya + (int)cyi) * f.ncx + cxa + (int)cxi) * kCellCap + (e & 7);

@@ -199,7 +199,11 @@ static bool cluster_pass_fused(const FrameDev& f, const fslic_params& p, int n, 
     const bool fuse_wanted = knobs().fuse_bin == 2 || (knobs().fuse_bin == 1 && assign_blocks <= 640);
 #endif
     const bool plain_slic = p.variant == FSLIC_VARIANT_SLIC && p.preemptive == 0;
-    return fuse_wanted && !separate_cluster_pass && plain_slic && !generic && assign_fuses_cluster_pass(f, stride);
+    // (H < stride: the passes of the residues >= H visit no row at all and launch nothing -- src/context.cpp:158-175 still runs update()
+    // for them: every cluster's num_members becomes 0, positions stay; a cluster pass that rides on the assign blocks would not happen.
+    // Found on a 71x1 frame, tests/fuzz_parity.py FUZZ_SHAPES=tiny seed 5 case 3100.)
+    const bool every_pass_has_rows = H >= stride;
+    return fuse_wanted && !separate_cluster_pass && plain_slic && !generic && every_pass_has_rows && assign_fuses_cluster_pass(f, stride);
 }
 
 // Device half: everything of iterate() for frames [i0, i0+n) of the slot's current group, enqueued asynchronously on

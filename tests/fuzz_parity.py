@@ -186,7 +186,12 @@ def lsc_main(seed, budget):
         tag = "%dx%d K=%d n=%d %s %s" % (W, H, K, n, "".join(kinds), kw)
         print("run case %d %s" % (n_cases, tag), flush=True)
         frames = [np.ascontiguousarray(variant(k, H, W, seed=sd)) for k, sd in zip(kinds, seeds)]
-        p = make_params(kw["max_iter"], kw["compactness"], kw["min_size_factor"], kw["subsample_stride"], kw["convert_to_lab"], True, variant=B.VARIANT_LSC)
+        pre = bool(rng.integers(0, 4) == 0)
+        thres = float(rng.choice([0.0, 0.05, 0.3]))
+        p = make_params(kw["max_iter"], kw["compactness"], kw["min_size_factor"], kw["subsample_stride"], kw["convert_to_lab"], True,
+                        preemptive=pre, preemptive_thres=thres, variant=B.VARIANT_LSC)
+        if pre:
+            print("  (preemptive, threshold %.2f)" % thres, flush=True)
         def init(f):
             cl = np.zeros(K, B.CLUSTER_DTYPE)
             B._check(B.load_library().fslic_hip_initialize_clusters(H, W, K, f.ctypes.data, cl.ctypes.data))
@@ -204,7 +209,7 @@ def lsc_main(seed, budget):
             if not np.array_equal(outs[ai], lab_a) or cls[ai].tobytes() != cl_a.tobytes():
                 bad.append("frame %d inside the group differs from the frame alone (%d pixels)" % (ai, int((outs[ai] != lab_a).sum())))
         note = ""
-        if have_ref and kinds[ai] in "AB" and H * W <= 600_000 and K >= 4:
+        if have_ref and not pre and kinds[ai] in "AB" and H * W <= 600_000 and K >= 4:
             cl0 = ref.initialize_clusters(frames[ai], K)
             r_labels, r_cl, r_pre = ref.lsc_iterate(frames[ai], cl0, num_threads=1, **kw)
             bo = min(best_overlap(lab_a, r_labels), best_overlap(r_labels, lab_a))
@@ -441,17 +446,25 @@ def main():
     only_alone = os.environ.get("FUZZ_ONLY", "") == "alone"
     only_group = os.environ.get("FUZZ_ONLY", "") == "group"
     paths = {}
+    shapes = os.environ.get("FUZZ_SHAPES", "")          # "tiny": 1 .. 80 px, any K up to the pixel count and beyond; "big": up to 2400 x 4000, side up to 150
     while time.time() - t0 < budget and (max_cases == 0 or n_cases < max_cases):
         H, W = int(rng.integers(120, 1300)), int(rng.integers(120, 2000))
         # superpixel side between ~6 and ~60 pixels: both table forms, every rows-per-wavefront choice
         side = float(rng.choice([6, 8, 10, 13, 16, 20, 24, 32, 40, 48, 60]))
         K = max(1, min(60000, int(H * W / (side * side))))
+        if shapes == "tiny":
+            H, W = int(rng.integers(1, 80)), int(rng.integers(1, 80))
+            K = int(rng.integers(1, max(2, int(H * W * float(rng.choice([0.02, 0.2, 0.6, 1.0]))) + 1)))
+        elif shapes == "big":
+            H, W = int(rng.integers(900, 2400)), int(rng.integers(1500, 4000))
+            side = float(rng.choice([8, 16, 24, 40, 72, 100, 150]))
+            K = max(1, min(60000, int(H * W / (side * side))))
         kw = dict(max_iter=int(rng.integers(0, 12)), compactness=float(rng.choice([1.0, 5.0, 10.0, 20.0, 40.0, 80.0])),
                   min_size_factor=float(rng.choice([0.0, 0.1, 0.25, 0.5])), subsample_stride=int(rng.choice([1, 2, 3, 3, 3, 4, 5, 7])),
                   convert_to_lab=bool(rng.integers(0, 4)), manhattan=True)
         n = int(rng.choice([1, 2, 3, 5, 8, 16]))
-        if H * W * n > 12_000_000:
-            n = max(1, 12_000_000 // (H * W))
+        if H * W * n > (40_000_000 if shapes == "big" else 12_000_000):
+            n = max(1, (40_000_000 if shapes == "big" else 12_000_000) // (H * W))
         kinds = [("ABCD"[int(rng.integers(0, 4))]) for _ in range(n)]
         seeds = [int(rng.integers(0, 1 << 30)) for _ in kinds]
         n_drawn += 1

@@ -544,3 +544,32 @@ def test_arena_reuse_after_a_candidate_list_overflow_keeps_the_label_plane_defin
     tail = (r.stdout + r.stderr)[-1500:]
     assert r.returncode == 0, tail
     assert "37 cases" in r.stdout and "all bit-exact" in r.stdout, tail
+
+
+def test_single_cell_column_at_the_left_edge_of_the_32_bit_kernel(engine):
+    # S = 150 (cells of 256 px), compactness 80 (spatial term up to 320: the 32-bit kernel k_assign serves it): the tile column at the image's
+    # left edge sees ONE cell column, and the kernel's reciprocal of the cell-column count wrapped to zero for a count of one -- the cell
+    # rows below the first were never fetched, 28 318 pixels of a 2090x1412 frame took the wrong cluster or none (tests/fuzz_parity.py,
+    # FUZZ_SHAPES=big, seed 5 case 11; every build since round 2).  Smaller frame, same geometry.
+    H, W, K = 900, 700, 28
+    img = variant("A", H, W, seed=3)
+    assert orc.S_of(H, W, K) == 150
+    cl0 = orc.initialize_clusters(img, K)
+    for kw in (dict(max_iter=0, compactness=80.0), dict(max_iter=4, compactness=80.0, subsample_stride=3), dict(max_iter=2, compactness=120.0, subsample_stride=2)):
+        labels, cl, pre, path = run_hip(engine, img, cl0, **kw)
+        o_labels, o_cl, o_lab, o_pre = orc.slic_iterate(img, cl0, stages=True, **kw)
+        assert path == 0, "the tiled kernels were meant to serve this: %s" % kw
+        assert_same("S=150 %s" % kw, (labels, cl, pre), (o_labels, o_cl, o_pre))
+
+
+@pytest.mark.parametrize("H,W,K,stride,max_iter", [(1, 71, 1, 3, 2), (2, 90, 3, 3, 5), (1, 200, 4, 2, 3), (3, 130, 2, 5, 7)])
+def test_frames_shorter_than_the_subsample_stride(engine, H, W, K, stride, max_iter):
+    # H < stride: the passes of the residues >= H visit no row -- src/context.cpp:158-175 still runs update() for them (every cluster's
+    # num_members becomes 0, positions stay).  The cluster pass that rides on the assign blocks did not happen for such a pass: a 71x1
+    # frame came back with the member counts of the pass before (tests/fuzz_parity.py, FUZZ_SHAPES=tiny, seed 5 case 3100).
+    img = variant("A", H, W, seed=H + W)
+    cl0 = orc.initialize_clusters(img, K)
+    kw = dict(max_iter=max_iter, compactness=80.0, min_size_factor=0.1, subsample_stride=stride, convert_to_lab=False)
+    labels, cl, pre, path = run_hip(engine, img, cl0, **kw)
+    o_labels, o_cl, o_lab, o_pre = orc.slic_iterate(img, cl0, stages=True, **kw)
+    assert_same("%dx%d K=%d stride %d max_iter %d path=%d" % (W, H, K, stride, max_iter, path), (labels, cl, pre), (o_labels, o_cl, o_pre))
