@@ -23,6 +23,30 @@ from oracle import oracle as orc                   # noqa: E402
 from util import cluster_fields_equal, describe_mismatch      # noqa: E402
 
 
+def override_shape(rng, H, W, K):
+    """FUZZ_SHAPES=tiny: 1 .. 80 px, any K up to the pixel count; =big: up to 2400 x 4000, superpixel side up to 150 (extra draws only when set:
+    the default sequences stay what they were)."""
+    shapes = os.environ.get("FUZZ_SHAPES", "")
+    if shapes == "tiny":
+        H, W = int(rng.integers(1, 80)), int(rng.integers(1, 80))
+        K = int(rng.integers(1, max(2, int(H * W * float(rng.choice([0.02, 0.2, 0.6, 1.0]))) + 1)))
+    elif shapes == "big":
+        H, W = int(rng.integers(900, 2400)), int(rng.integers(1500, 4000))
+        side = float(rng.choice([8, 16, 24, 40, 72, 100, 150]))
+        K = max(1, min(60000, int(H * W / (side * side))))
+    return H, W, K
+
+
+def extreme_options(rng, kw):
+    """FUZZ_OPTS=extreme: option values far from the defaults (extra draws only when set)."""
+    if os.environ.get("FUZZ_OPTS", "") == "extreme":
+        kw["compactness"] = float(rng.choice([0.01, 0.5, 3.0, 150.0, 400.0, 1000.0]))
+        kw["subsample_stride"] = int(rng.integers(1, 13))
+        kw["max_iter"] = int(rng.choice([0, 1, 2, 13, 25]))
+        kw["min_size_factor"] = float(rng.choice([0.0, 0.01, 0.9, 2.0]))
+    return kw
+
+
 def variants_main(seed, budget):
     """Mode `variants` (python tests/fuzz_parity.py SEED SECONDS variants): the same sweep for the paths the plain-C oracle does not restate --
     SlicRealDist / L2 / NoQ, the preemptive mode (Slic and the float family) and the Euclidean spatial table -- against the UNMODIFIED
@@ -43,17 +67,20 @@ def variants_main(seed, budget):
         H, W = int(rng.integers(60, 900)), int(rng.integers(60, 1300))
         side = float(rng.choice([6, 8, 10, 13, 16, 20, 24, 32, 40, 60]))
         K = max(1, min(60000, int(H * W / (side * side))))
+        H, W, K = override_shape(rng, H, W, K)
         kind = str(rng.choice(["slic", "slic", "standard", "l2", "noq"]))
         pre = bool(rng.integers(0, 2))
         thres = float(rng.choice([0.0, 0.02, 0.05, 0.1, 0.3]))
         kw = dict(max_iter=int(rng.integers(0, 12)), compactness=float(rng.choice([1.0, 5.0, 10.0, 20.0, 40.0, 80.0])),
                   min_size_factor=float(rng.choice([0.0, 0.1, 0.25, 0.5])), subsample_stride=int(rng.choice([1, 2, 3, 3, 3, 4, 5])),
                   convert_to_lab=bool(rng.integers(0, 4)), manhattan=bool(rng.integers(0, 3)))
+        kw = extreme_options(rng, kw)
         if kind == "slic" and not pre and kw["manhattan"]:
             pre = True                                  # (plain Manhattan Slic is the default mode's sweep)
         n = int(rng.choice([1, 2, 3, 5, 8, 16]))
-        if H * W * n > 6_000_000:
-            n = max(1, 6_000_000 // (H * W))
+        cap = 24_000_000 if os.environ.get("FUZZ_SHAPES", "") == "big" else 6_000_000
+        if H * W * n > cap:
+            n = max(1, cap // (H * W))
         kinds = [("ABCD"[int(rng.integers(0, 4))]) for _ in range(n)]
         seeds = [int(rng.integers(0, 1 << 30)) for _ in kinds]
         n_drawn += 1
@@ -175,12 +202,15 @@ def lsc_main(seed, budget):
         H, W = int(rng.integers(40, 1100)), int(rng.integers(40, 1700))
         side = float(rng.choice([6, 8, 10, 13, 16, 20, 24, 32, 40, 60]))
         K = max(1, min(60000, int(H * W / (side * side))))
+        H, W, K = override_shape(rng, H, W, K)
         kw = dict(max_iter=int(rng.integers(0, 12)), compactness=float(rng.choice([1.0, 5.0, 10.0, 20.0, 40.0, 80.0])),
                   min_size_factor=float(rng.choice([0.0, 0.1, 0.25, 0.5])), subsample_stride=int(rng.choice([1, 2, 3, 3, 3, 4, 5])),
                   convert_to_lab=bool(rng.integers(0, 4)))
+        kw = extreme_options(rng, kw)
         n = int(rng.choice([1, 2, 3, 5, 8, 16]))
-        if H * W * n > 8_000_000:
-            n = max(1, 8_000_000 // (H * W))
+        cap = 30_000_000 if os.environ.get("FUZZ_SHAPES", "") == "big" else 8_000_000
+        if H * W * n > cap:
+            n = max(1, cap // (H * W))
         kinds = [("ABCD"[int(rng.integers(0, 4))]) for _ in range(n)]
         seeds = [int(rng.integers(0, 1 << 30)) for _ in kinds]
         tag = "%dx%d K=%d n=%d %s %s" % (W, H, K, n, "".join(kinds), kw)
@@ -215,7 +245,9 @@ def lsc_main(seed, budget):
             bo = min(best_overlap(lab_a, r_labels), best_overlap(r_labels, lab_a))
             worst = min(worst, bo)
             note = " best overlap with the reference %.4f" % bo
-            if bo < 0.97 and kw["compactness"] <= 40.0:
+            # (the floor is asserted where the comparison is meaningful: frames of a few hundred pixels or a compactness near zero leave the
+            # f32, order-dependent sums of the reference to decide most pixels -- 0.87 on a 68x7 frame with K = 97 at compactness 0.01)
+            if bo < 0.97 and 1.0 <= kw["compactness"] <= 40.0 and H * W >= 20000:
                 bad.append("best overlap %.4f" % bo)
         n_cases += 1
         print("  %s%s" % ("ok" if not bad else "BAD", note), flush=True)
@@ -241,12 +273,15 @@ def warm_main(seed, budget):
         H, W = int(rng.integers(40, 900)), int(rng.integers(40, 1400))
         side = float(rng.choice([8, 10, 13, 16, 20, 24, 32, 40, 60]))
         K = max(1, min(20000, int(H * W / (side * side))))
+        H, W, K = override_shape(rng, H, W, K)
         kw = dict(max_iter=int(rng.integers(0, 9)), compactness=float(rng.choice([1.0, 10.0, 40.0])),
                   min_size_factor=float(rng.choice([0.0, 0.25])), subsample_stride=int(rng.choice([1, 2, 3, 3, 5])),
                   convert_to_lab=bool(rng.integers(0, 4)), manhattan=bool(rng.integers(0, 4)))
+        kw = extreme_options(rng, kw)
         n = int(rng.choice([1, 2, 4, 8]))
-        if H * W * n > 5_000_000:
-            n = max(1, 5_000_000 // (H * W))
+        cap = 24_000_000 if os.environ.get("FUZZ_SHAPES", "") == "big" else 5_000_000
+        if H * W * n > cap:
+            n = max(1, cap // (H * W))
         frames = [np.ascontiguousarray(variant("ABCD"[int(rng.integers(0, 4))], H, W, seed=int(rng.integers(0, 1 << 30)))) for _ in range(n)]
         states = []
         kinds = []
@@ -462,6 +497,9 @@ def main():
         kw = dict(max_iter=int(rng.integers(0, 12)), compactness=float(rng.choice([1.0, 5.0, 10.0, 20.0, 40.0, 80.0])),
                   min_size_factor=float(rng.choice([0.0, 0.1, 0.25, 0.5])), subsample_stride=int(rng.choice([1, 2, 3, 3, 3, 4, 5, 7])),
                   convert_to_lab=bool(rng.integers(0, 4)), manhattan=True)
+        kw = extreme_options(rng, kw)
+        if os.environ.get("FUZZ_OPTS", "") == "extreme":
+            kw["manhattan"] = bool(rng.integers(0, 2))
         n = int(rng.choice([1, 2, 3, 5, 8, 16]))
         if H * W * n > (40_000_000 if shapes == "big" else 12_000_000):
             n = max(1, (40_000_000 if shapes == "big" else 12_000_000) // (H * W))
