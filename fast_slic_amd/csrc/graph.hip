@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256) void k_density_to_mask(const uint16_t* __restr
 // Plain pre-reads only ever see values that are not newer than the truth (keys only decrease, a filled slot never
 // changes), so skipping on them is safe; the atomics decide.
 constexpr uint32_t kPairEmpty = 0xFFFFFFFFu;
+constexpr uint32_t kMaxProbe = 255u;          // (linear probing at a load of at most 1/2: runs of a few dozen slots are already rare)
 static __device__ __forceinline__ uint32_t pair_hash(uint32_t v) {
     v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16;
     return v;
@@ -88,6 +89,11 @@ __global__ __launch_bounds__(256) void k_adjacent_pairs(const uint16_t* __restri
     const unsigned long long npx = (unsigned long long)(H - 1) * (unsigned long long)(W - 1);
     const unsigned long long stride = (unsigned long long)gridDim.x * 256ull;
     for (unsigned long long q = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; q < npx; q += stride) {
+        // The table is declared full -- more than half of it taken, or a probe sequence longer than kMaxProbe -- as soon as one thread
+        // finds it so, and every thread leaves at its next pixel: the host doubles the table and starts over.  (Until round 6 a thread
+        // probed the WHOLE table before it gave up, and nobody else stopped: a noise map of 2072x2348 with K = 20 000 -- 14 million distinct
+        // pairs against a first table of a million entries -- did not finish in 13 minutes; tests/fuzz_parity.py, graph mode, big shapes.)
+        if (__hip_atomic_load(&counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
         const unsigned long long i = q / (unsigned long long)(W - 1), j = q - i * (unsigned long long)(W - 1);
         const unsigned long long p = i * (unsigned long long)W + j;
         const uint32_t s = labels[p];
@@ -103,11 +109,14 @@ __global__ __launch_bounds__(256) void k_adjacent_pairs(const uint16_t* __restri
             const unsigned long long key = p * 4ull + (unsigned long long)d;
             uint32_t h = pair_hash(pair) & cap_mask;
             bool done = false;
-            for (uint32_t probe = 0; probe <= cap_mask; ++probe) {
+            for (uint32_t probe = 0; probe <= min(cap_mask, kMaxProbe); ++probe) {
                 uint32_t cur = tab_pair[h];
                 if (cur == kPairEmpty) {
                     cur = atomicCAS(&tab_pair[h], kPairEmpty, pair);
-                    if (cur == kPairEmpty) { atomicAdd(&counters[0], 1u); cur = pair; }      // counters[0]: distinct pairs stored
+                    if (cur == kPairEmpty) {                                                // counters[0]: distinct pairs stored
+                        if (atomicAdd(&counters[0], 1u) >= (cap_mask >> 1)) atomicExch(&counters[1], 1u);      // (the host wants it at most half full)
+                        cur = pair;
+                    }
                 }
                 if (cur == pair) {
                     if (tab_key[h] > key) atomicMin(&tab_key[h], key);

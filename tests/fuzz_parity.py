@@ -141,6 +141,8 @@ def cca_main(seed, budget):
     max_cases = int(os.environ.get("FUZZ_CASES", "0"))
     while time.time() - t0 < budget and (max_cases == 0 or n_cases < max_cases):
         H, W = int(rng.integers(1, 1100)), int(rng.integers(1, 1700))
+        if os.environ.get("FUZZ_SHAPES", "") == "big":
+            H, W = int(rng.integers(900, 2400)), int(rng.integers(1500, 4000))
         kind = str(rng.choice(["noise", "blobs", "stripes_v", "stripes_h", "checker", "kron", "ramp", "slic"]))
         K = int(rng.choice([1, 2, 5, 50, 500, 5000, 60000]))
         if kind == "noise":
@@ -410,6 +412,8 @@ def graph_main(seed, budget):
     max_cases = int(os.environ.get("FUZZ_CASES", "0"))
     while time.time() - t0 < budget and (max_cases == 0 or n_cases < max_cases):
         H, W = int(rng.integers(1, 900)), int(rng.integers(1, 1400))
+        if os.environ.get("FUZZ_SHAPES", "") == "big":
+            H, W = int(rng.integers(900, 2400)), int(rng.integers(1500, 4000))
         K = int(rng.choice([1, 2, 7, 60, 400, 3000, 20000, 60000]))
         kind = str(rng.choice(["noise", "blocks", "frames", "few", "slic"]))
         if kind == "noise":
@@ -437,8 +441,13 @@ def graph_main(seed, budget):
         mask = (rng.integers(0, 256, (H, W)) * (rng.random((H, W)) < float(rng.choice([0.05, 0.6, 1.0])))).astype(np.uint8)
         tag = "%dx%d %s K=%d" % (W, H, kind, K)
         print("run case %d %s" % (n_cases, tag), flush=True)
+        t1 = time.time()
         num, nb = e.get_connectivity(labels, H, W, K)
+        t2 = time.time()
         rnum, rnb = ref.get_connectivity(labels, K)
+        t3 = time.time()
+        if t3 - t1 > 2.0:
+            print("  (get_connectivity: engine %.2f s, reference %.2f s)" % (t2 - t1, t3 - t2), flush=True)
         ok = np.array_equal(num, rnum) and np.array_equal(nb, rnb)
         dens = e.get_mask_density(cl, labels, mask, H, W)
         ok = ok and np.array_equal(dens, ref.get_mask_density(cl, labels, mask))

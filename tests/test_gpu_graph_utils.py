@@ -126,3 +126,21 @@ def test_model_surface_mirrors_the_reference(engine):
         m.get_mask_density(mask[:-1], a)
     with pytest.raises(ValueError):
         m.broadcast_density_to_mask(dens[:-1], a)
+
+
+@needs_ref
+def test_connectivity_of_a_large_noise_map_grows_its_pair_table_quickly(engine):
+    # 700x900 noise over 20 000 labels: ~1.9 million distinct adjacent pairs against a first table of a million entries.  Until round 6 every
+    # thread that found the table full probed ALL of it before giving up and nobody else stopped (a 2072x2348 map did not finish in 13
+    # minutes: tests/fuzz_parity.py, graph mode, FUZZ_SHAPES=big); now the first thread to find it half full ends the launch.
+    import time
+    rng = np.random.default_rng(8)
+    H, W, K = 700, 900, 20000
+    labels = np.ascontiguousarray(rng.integers(0, K, (H, W)).astype(np.uint16))
+    t0 = time.time()
+    num, nb = engine.get_connectivity(labels, H, W, K)
+    took = time.time() - t0
+    rnum, rnb = ref.get_connectivity(labels, K)
+    np.testing.assert_array_equal(num, rnum)
+    np.testing.assert_array_equal(nb, rnb)
+    assert took < 30.0, "get_connectivity took %.1f s" % took
