@@ -466,7 +466,68 @@ def graph_main(seed, budget):
     e.close()
 
 
+def threads_main(seed, budget):
+    """Mode `threads`: ONE engine of four slots shared by six Python threads that call iterate / enforce_connectivity / get_mask_density
+    on random shapes at the same time (what four `Slic.iterate` callers of one process do to the default engine): slot leasing, per-slot
+    arenas and launch-sequence caches under contention; every result against the oracle."""
+    import threading
+    e = Engine(0, 4)
+    t0 = time.time()
+    errors = []
+    counts = [0] * 6
+    def worker(tid):
+        rng = np.random.default_rng(seed * 100 + tid)
+        try:
+            while time.time() - t0 < budget and not errors:
+                H, W = int(rng.integers(20, 500)), int(rng.integers(20, 700))
+                side = float(rng.choice([6, 8, 10, 16, 24, 40]))
+                K = max(1, min(60000, int(H * W / (side * side))))
+                op = int(rng.integers(0, 4))
+                img = np.ascontiguousarray(variant("ABCD"[int(rng.integers(0, 4))], H, W, seed=int(rng.integers(0, 1 << 30))))
+                kw = dict(max_iter=int(rng.integers(0, 11)), compactness=float(rng.choice([1.0, 10.0, 80.0])), min_size_factor=float(rng.choice([0.0, 0.25])),
+                          subsample_stride=int(rng.choice([1, 2, 3, 3, 5])), convert_to_lab=bool(rng.integers(0, 4)), manhattan=True)
+                if op <= 1:
+                    p = make_params(kw["max_iter"], kw["compactness"], kw["min_size_factor"], kw["subsample_stride"], kw["convert_to_lab"], True)
+                    cl = orc.initialize_clusters(img, K)
+                    exp = orc.slic_iterate(img, cl, **kw)
+                    labels = e.iterate(img, cl, p)
+                    if not np.array_equal(labels, exp[0]) or cluster_fields_equal(cl, exp[1]):
+                        errors.append("thread %d: iterate %dx%d K=%d %s" % (tid, W, H, K, kw))
+                elif op == 2:
+                    lab = np.ascontiguousarray(rng.integers(0, min(K, 5), (H, W)).astype(np.uint16))
+                    thr = int(rng.choice([0, 4, 64]))
+                    if not np.array_equal(e.enforce_connectivity(lab, K, thr), orc.enforce_connectivity(lab, K, thr)):
+                        errors.append("thread %d: enforce_connectivity %dx%d K=%d thr=%d" % (tid, W, H, K, thr))
+                else:
+                    from fast_slic_amd import _binding as B
+                    lab = np.ascontiguousarray(rng.integers(0, K, (H, W)).astype(np.uint16))
+                    mask = rng.integers(0, 256, (H, W)).astype(np.uint8)
+                    cl = np.zeros(K, B.CLUSTER_DTYPE); cl["number"] = np.arange(K); cl["num_members"] = np.bincount(lab.ravel(), minlength=K)[:K]
+                    dens = e.get_mask_density(cl, lab, mask, H, W)
+                    sums = np.bincount(lab.ravel(), weights=mask.ravel().astype(np.float64), minlength=K)[:K]
+                    # (src/fast-slic.cpp:141-150: integer mean of the mask over the cluster's pixels, 0 for an empty cluster)
+                    want = np.where(cl["num_members"] > 0, sums // np.maximum(cl["num_members"], 1), 0).astype(dens.dtype)
+                    if not np.array_equal(dens, want):
+                        errors.append("thread %d: get_mask_density %dx%d K=%d" % (tid, W, H, K))
+                counts[tid] += 1
+        except Exception as ex:          # noqa: BLE001
+            errors.append("thread %d: %r" % (tid, ex))
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    if errors:
+        print("BAD")
+        print("\n".join(errors[:10]))
+        sys.exit(1)
+    print("fuzz_parity threads seed %d: %d calls from 6 threads on 4 slots, all bit-exact; %.0f s" % (seed, sum(counts), time.time() - t0))
+    e.close()
+
+
 def main():
+    if len(sys.argv) > 3 and sys.argv[3] == "threads":
+        return threads_main(int(sys.argv[1]), float(sys.argv[2]))
     if len(sys.argv) > 3 and sys.argv[3] == "graph":
         return graph_main(int(sys.argv[1]), float(sys.argv[2]))
     if len(sys.argv) > 3 and sys.argv[3] == "warm":
