@@ -557,6 +557,10 @@ def main():
         # superpixel side between ~6 and ~60 pixels: both table forms, every rows-per-wavefront choice
         side = float(rng.choice([6, 8, 10, 13, 16, 20, 24, 32, 40, 48, 60]))
         K = max(1, min(60000, int(H * W / (side * side))))
+        if os.environ.get("FUZZ_K"):               # FUZZ_K=65533: the largest cluster count the reference accepts (cfast_slic.pyx:24-27), on every shape that holds it
+            K = int(os.environ["FUZZ_K"])
+            if H * W < K:
+                H, W = max(H, 300), max(W, 300)
         if shapes == "tiny":
             H, W = int(rng.integers(1, 80)), int(rng.integers(1, 80))
             K = int(rng.integers(1, max(2, int(H * W * float(rng.choice([0.02, 0.2, 0.6, 1.0]))) + 1)))
