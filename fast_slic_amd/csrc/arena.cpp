@@ -25,8 +25,6 @@ void free_slot(Slot& s) {
     if (s.h_misc) hipHostFree(s.h_misc);
     if (s.h_lut) hipHostFree(s.h_lut);
     if (s.h_tab) hipHostFree(s.h_tab);
-    if (s.h_keep_leader) hipHostFree(s.h_keep_leader);
-    if (s.h_keep_label) hipHostFree(s.h_keep_label);
     if (s.h_patch) hipHostFree(s.h_patch);
     if (s.h_cand_leader) hipHostFree(s.h_cand_leader);
     if (s.h_cand_area) hipHostFree(s.h_cand_area);
@@ -50,14 +48,6 @@ int prepare(fslic_engine* e, Slot& s, int H, int W, int K, int S, int G) {
         s.h_cl = nullptr; s.h_cl_words = 0;
         HIPCHK(hipHostMalloc((void**)&s.h_cl, sizeof(uint32_t) * 4 * (size_t)K * G));
         s.h_cl_words = (size_t)G * 4 * K;
-    }
-    if (s.hKeep < K || s.hKeepFrames < G) {
-        if (s.h_keep_leader) { hipHostFree(s.h_keep_leader); hipHostFree(s.h_keep_label); }
-        s.h_keep_leader = nullptr; s.h_keep_label = nullptr; s.hKeep = 0; s.hKeepFrames = 0;
-        const int kk = std::max(K, s.hKeep), gg = std::max(G, s.hKeepFrames);
-        HIPCHK(hipHostMalloc((void**)&s.h_keep_leader, sizeof(int32_t) * (size_t)kk * gg));
-        HIPCHK(hipHostMalloc((void**)&s.h_keep_label, sizeof(uint16_t) * (size_t)kk * gg));
-        s.hKeep = kk; s.hKeepFrames = gg;
     }
     if (!s.h_misc) HIPCHK(hipHostMalloc((void**)&s.h_misc, 64 * kMaxGroup));
     if (!s.h_lut) HIPCHK(hipHostMalloc((void**)&s.h_lut, kLutMaxWords * 4));

@@ -113,15 +113,11 @@ struct Slot {
     uint32_t* h_cl = nullptr;        // per frame 4K words: in [0,K) yx; out (yx, lab, n, moved)
     size_t h_cl_words = 0;
     uint32_t* h_misc = nullptr;      // per frame 16 words (copy of d_misc)
-    int32_t* h_keep_leader = nullptr;   // per frame hKeep entries
-    uint16_t* h_keep_label = nullptr;
-    int hKeepFrames = 0;
     uint16_t* h_patch = nullptr;
     size_t h_patch_cap = 0;
     int32_t* h_cand_leader = nullptr;
     uint32_t* h_cand_area = nullptr;
     size_t h_cand_cap = 0;
-    int hKeep = 0;
     uint32_t* d_gen = nullptr;       // device word: base of the bin generation stamps (FrameDev::gen_base)
     uint64_t gen_host = 0;           // host mirror of *d_gen
     uint32_t gen_span_prev = 0;      // stamps the previous group used above its base (max_iter + 3): what the next group's first kernel adds to *d_gen
