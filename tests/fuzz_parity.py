@@ -41,7 +41,7 @@ def extreme_options(rng, kw):
     """FUZZ_OPTS=extreme: option values far from the defaults (extra draws only when set)."""
     if os.environ.get("FUZZ_OPTS", "") == "extreme":
         kw["compactness"] = float(rng.choice([0.01, 0.5, 3.0, 150.0, 400.0, 1000.0]))
-        kw["subsample_stride"] = int(rng.integers(1, 13))
+        kw["subsample_stride"] = int(rng.integers(1, int(os.environ.get("FUZZ_STRIDE_MAX", "12")) + 1))
         kw["max_iter"] = int(rng.choice([0, 1, 2, 13, 25]))
         kw["min_size_factor"] = float(rng.choice([0.0, 0.01, 0.9, 2.0]))
     return kw
